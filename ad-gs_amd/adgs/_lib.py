@@ -1,0 +1,80 @@
+"""ctypes loader for libadgs_hip.so (the C ABI declared in include/adgs_rasterizer.h).
+
+There is NO CPU fallback: if the library is missing or cannot be loaded this
+module raises, and every operator built on it raises with it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libadgs_hip.so")
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+
+# symbol -> (restype, argtypes); mirrors include/adgs_rasterizer.h
+SIGNATURES = {
+    "adgs_last_error": (ctypes.c_char_p, []),
+    "adgs_device_check": (c_i, []),
+    "adgs_raster_forward": (c_i, [ALLOC_FN, c_p, ALLOC_FN, c_p, ALLOC_FN, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i,
+                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
+                                  c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "adgs_raster_backward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
+                                   c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                   c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "adgs_mark_visible": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_knn_workspace_bytes": (ctypes.c_size_t, [c_i]),
+    "adgs_knn_dist2": (c_i, [c_i, c_p, c_p, c_p, c_p]),
+    "adgs_get_frame_stats": (None, [c_p]),
+    # include/adgs_testing.h
+    "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
+    "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),
+    "adgs_test_sort_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
+    "adgs_test_sort_pairs_u64": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_size_t, c_i, c_p, c_p]),
+    "adgs_test_sort_pairs_u32": (c_i, [c_p, c_p, c_p, c_p, ctypes.c_size_t, c_i, c_p, c_p]),
+}
+
+
+class FrameStats(ctypes.Structure):
+    _fields_ = [("num_rendered", ctypes.c_int64), ("tiles", ctypes.c_int32), ("sort_bits", ctypes.c_int32),
+                ("sort_passes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libadgs_hip.so not found at %s: build it with `make -C ad-gs_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    msg = lib().adgs_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(code, what):
+    if code < 0:
+        raise RuntimeError("%s failed: %s" % (what, last_error()))
+    return code
+
+
+def frame_stats():
+    st = FrameStats()
+    lib().adgs_get_frame_stats(ctypes.byref(st))
+    return dict(num_rendered=int(st.num_rendered), tiles=int(st.tiles), sort_bits=int(st.sort_bits), sort_passes=int(st.sort_passes))

@@ -1,0 +1,266 @@
+// C ABI of libadgs_hip.so (declared in include/adgs_rasterizer.h): host-side
+// orchestration of the forward / backward kernel sequences.
+//
+// Replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (RAST/cuda_rasterizer/rasterizer_impl.cu:141-153,198-352,356-476).
+#include "common.h"
+#include "kernels.h"
+#include "../../include/adgs_rasterizer.h"
+
+#include <mutex>
+
+namespace adgs {
+
+static thread_local std::string g_last_error;
+static thread_local adgs_frame_stats g_stats = { 0, 0, 0, 0, 0 };
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+// rasterizer_impl.cu:35-50 (next-highest bit of the MSB)
+static uint32_t higher_msb(uint32_t n) {
+	uint32_t msb = sizeof(n) * 4;
+	uint32_t step = msb;
+	while (step > 1) {
+		step /= 2;
+		if (n >> msb) msb += step; else msb -= step;
+	}
+	if (n >> msb) msb++;
+	return msb;
+}
+
+// ---- state carved from the three caller-owned byte buffers (opaque to the caller) ----
+struct GeomState {
+	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched; uint32_t* offsets; char* scan_temp;
+	static GeomState carve(char* chunk, size_t P, size_t* bytes) {
+		Carver c(chunk); GeomState g;
+		g.splats = c.take<Splat>(P);
+		g.cov3D = c.take<float>(P * 6);
+		g.clamped = c.take<uint8_t>(P);
+		g.tiles_touched = c.take<uint32_t>(P + 1);
+		g.offsets = c.take<uint32_t>(P + 1);
+		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
+		if (bytes) *bytes = c.size();
+		return g;
+	}
+};
+struct ImgState {
+	uint32_t* n_contrib; uint2* ranges;
+	static ImgState carve(char* chunk, size_t npix, size_t ntiles, size_t* bytes) {
+		Carver c(chunk); ImgState s;
+		s.n_contrib = c.take<uint32_t>(npix);
+		s.ranges = c.take<uint2>(ntiles);
+		if (bytes) *bytes = c.size();
+		return s;
+	}
+};
+struct BinState {
+	uint64_t* keys_unsorted; uint64_t* keys; uint32_t* list_unsorted; uint32_t* list; char* sort_temp;
+	static BinState carve(char* chunk, size_t R, size_t* bytes) {
+		Carver c(chunk); BinState b;
+		b.list = c.take<uint32_t>(R);
+		b.list_unsorted = c.take<uint32_t>(R);
+		b.keys = c.take<uint64_t>(R);
+		b.keys_unsorted = c.take<uint64_t>(R);
+		b.sort_temp = c.take<char>(sort_temp_bytes(R));
+		if (bytes) *bytes = c.size();
+		return b;
+	}
+};
+
+// pinned host word for the one device->host read-back of num_rendered
+// (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
+static uint32_t* pinned_word() {
+	static thread_local uint32_t* p = nullptr;
+	if (!p) { if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr; }
+	return p;
+}
+
+} // namespace adgs
+
+using namespace adgs;
+
+extern "C" const char* adgs_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_stats; }
+
+extern "C" int adgs_device_check(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { set_error("no HIP device"); return -1; }
+	hipDeviceProp_t prop;
+	int dev = 0;
+	ADGS_HIP_CHECK(hipGetDevice(&dev));
+	ADGS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+	if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+		set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+		return -2;
+	}
+	return 0;
+}
+
+extern "C" int adgs_raster_forward(
+	adgs_alloc_fn geometryBuffer, void* geometryUser,
+	adgs_alloc_fn binningBuffer, void* binningUser,
+	adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S,
+	const float* background, int width, int height,
+	const float* means3D, const float* shs, const float* colors_precomp, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream_) {
+	(void)prefiltered;   // the reference only uses it to trap on an impossible cull (auxiliary.h:156-160)
+	hipStream_t stream = (hipStream_t)stream_;
+	if (P <= 0) return 0;
+	if (D_S > MAX_SEMANTIC) { set_error("D_S exceeds 32 semantic channels"); return -1; }
+	if (!means3D || !opacities || (!cov3D_precomp && (!scales || !rotations)) || !radii) { set_error("missing required input pointer"); return -1; }
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+
+	size_t gbytes = 0, ibytes = 0;
+	GeomState::carve(nullptr, P, &gbytes);
+	char* gchunk = geometryBuffer(geometryUser, gbytes);
+	ImgState::carve(nullptr, npix, ntiles, &ibytes);
+	char* ichunk = imageBuffer(imageUser, ibytes);
+	if (!gchunk || !ichunk) { set_error("buffer allocator returned NULL"); return -1; }
+	GeomState geom = GeomState::carve(gchunk, P, nullptr);
+	ImgState img = ImgState::carve(ichunk, npix, ntiles, nullptr);
+
+	PreprocessArgs pa;
+	pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
+	pa.means3D = means3D; pa.scales = scales; pa.scale_modifier = scale_modifier; pa.rotations = rotations;
+	pa.opacities = opacities; pa.shs = shs; pa.cov3D_precomp = cov3D_precomp; pa.colors_precomp = colors_precomp;
+	pa.flow_points = flow_points; pa.semantic = semantic;
+	pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
+	pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy;
+	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy;
+	pa.focal_y = height / (2.0f * tan_fovy);     // rasterizer_impl.cu:229-230
+	pa.focal_x = width / (2.0f * tan_fovx);
+	pa.inv_depth = inv_depth;
+	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
+	if (launch_preprocess_fwd(pa, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+
+	// tiles_touched[P] = 0 sentinel so that the exclusive scan yields the total at [P]
+	ADGS_HIP_CHECK(hipMemsetAsync(geom.tiles_touched + P, 0, sizeof(uint32_t), stream));
+	if (exclusive_scan_u32(geom.tiles_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+
+	uint32_t* host_word = pinned_word();
+	if (!host_word) { set_error("hipHostMalloc failed"); return -1; }
+	ADGS_HIP_CHECK(hipMemcpyAsync(host_word, geom.offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	ADGS_HIP_CHECK(hipStreamSynchronize(stream));
+	const int num_rendered = (int)*host_word;
+
+	size_t bbytes = 0;
+	BinState::carve(nullptr, (size_t)num_rendered, &bbytes);
+	char* bchunk = binningBuffer(binningUser, bbytes);
+	if (!bchunk) { set_error("binning allocator returned NULL"); return -1; }
+	BinState bin = BinState::carve(bchunk, (size_t)num_rendered, nullptr);
+
+	if (launch_duplicate_keys(P, geom.splats, geom.offsets, radii, bin.keys_unsorted, bin.list_unsorted, gx, gy, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+	const int bit = (int)higher_msb((uint32_t)ntiles);
+	if (radix_sort_pairs_u64(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, (size_t)num_rendered, 32 + bit, bin.sort_temp, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+	ADGS_HIP_CHECK(hipMemsetAsync(img.ranges, 0, ntiles * sizeof(uint2), stream));
+	if (launch_tile_ranges(num_rendered, bin.keys, img.ranges, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+
+	RenderFwdArgs ra;
+	ra.ranges = img.ranges; ra.point_list = bin.list; ra.splats = geom.splats;
+	ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy; ra.D_S = D_S;
+	ra.has_color = (colors_precomp != nullptr) || (shs != nullptr);
+	ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0; ra.inv_depth = inv_depth != 0;
+	ra.semantic = semantic; ra.bg = background;
+	ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
+	ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
+	if (launch_render_fwd(ra, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+
+	g_stats.num_rendered = num_rendered; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
+	return num_rendered;
+}
+
+extern "C" int adgs_raster_backward(
+	int P, int D, int M, int R, int D_S,
+	const float* background, int width, int height,
+	const float* means3D, const float* shs, const float* colors_precomp, const float* flow_points, const float* semantic,
+	const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+	const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+	const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+	const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_flow, const float* dL_dpix_semantic,
+	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+	float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dflow, float* dL_dsemantic,
+	const float* grad_img_opacity, const float* img_opacity, int inv_depth, int debug, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (P <= 0) return 0;
+	if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) { set_error("backward called without forward state buffers"); return -1; }
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	GeomState geom = GeomState::carve(geom_buffer, P, nullptr);
+	ImgState img = ImgState::carve(img_buffer, npix, ntiles, nullptr);
+	BinState bin = BinState::carve(binning_buffer, (size_t)R, nullptr);
+
+	const bool has_color = (colors_precomp != nullptr) || (shs != nullptr);
+	RenderBwdArgs ra;
+	ra.ranges = img.ranges; ra.point_list = bin.list; ra.splats = geom.splats;
+	ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy; ra.D_S = D_S;
+	ra.semantic = semantic; ra.bg = background;
+	ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
+	ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dpix_flow = dL_dpix_flow; ra.dL_dpix_sem = dL_dpix_semantic;
+	ra.dL_dpix_opacity = grad_img_opacity;
+	// gating as in backward.cu:497-506
+	ra.do_color = dL_dpix && has_color;
+	ra.do_flow = dL_dpix_flow && flow_points;
+	ra.do_sem = dL_dpix_semantic && semantic && D_S > 0;
+	ra.do_depth = dL_dpix_depth != nullptr;
+	ra.do_opacity = grad_img_opacity != nullptr;
+	ra.dL_dmean2D = dL_dmean2D; ra.dL_dconic = dL_dconic; ra.dL_dopacity = dL_dopacity; ra.dL_dcolor = dL_dcolor;
+	ra.dL_ddepth = dL_ddepth; ra.dL_dflow = dL_dflow; ra.dL_dsem = dL_dsemantic;
+	if (R > 0) {
+		if (launch_render_bwd(ra, stream) != 0) return -1;
+		ADGS_LAUNCH_CHECK(debug, stream);
+	}
+
+	PreprocessBwdArgs pa;
+	pa.P = P; pa.D = D; pa.M = M;
+	pa.means3D = means3D; pa.radii = radii; pa.shs = shs; pa.clamped = geom.clamped;
+	pa.scales = scales; pa.rotations = rotations; pa.scale_modifier = scale_modifier;
+	pa.cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+	pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = campos;
+	pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
+	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
+	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
+	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
+	if (launch_preprocess_bwd(pa, stream) != 0) return -1;
+	ADGS_LAUNCH_CHECK(debug, stream);
+	return 0;
+}
+
+extern "C" int adgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_) {
+	(void)projmatrix;   // in_frustum only tests the view-space depth (auxiliary.h:154)
+	if (P <= 0) return 0;
+	if (launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_) != 0) return -1;
+	return 0;
+}
+
+extern "C" size_t adgs_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
+
+extern "C" int adgs_knn_dist2(int P, const float* points, float* meanDists, char* workspace, void* stream_) {
+	if (P <= 0) return 0;
+	if (!points || !meanDists || !workspace) { set_error("adgs_knn_dist2: NULL pointer"); return -1; }
+	return knn_run(P, points, meanDists, workspace, (hipStream_t)stream_);
+}
+
+// ---- test-only hooks (include/adgs_testing.h) ----
+#include "../../include/adgs_testing.h"
+extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
+extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {
+	return exclusive_scan_u32(in, out, n, temp, (hipStream_t)stream);
+}
+extern "C" size_t adgs_test_sort_temp_bytes(size_t n) { return sort_temp_bytes(n); }
+extern "C" int adgs_test_sort_pairs_u64(uint64_t* ki, uint64_t* ko, uint32_t* vi, uint32_t* vo, size_t n, int end_bit, char* temp, void* stream) {
+	return radix_sort_pairs_u64(ki, ko, vi, vo, n, end_bit, temp, (hipStream_t)stream);
+}
+extern "C" int adgs_test_sort_pairs_u32(uint32_t* ki, uint32_t* ko, uint32_t* vi, uint32_t* vo, size_t n, int end_bit, char* temp, void* stream) {
+	return radix_sort_pairs_u32(ki, ko, vi, vo, n, end_bit, temp, (hipStream_t)stream);
+}

@@ -1,0 +1,81 @@
+// Shared host/device helpers for the gfx950 AD-GS hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string>
+
+namespace adgs {
+
+constexpr int TILE_X = 16;     // RAST/cuda_rasterizer/config.h:16-17
+constexpr int TILE_Y = 16;
+constexpr int TILE_PIX = TILE_X * TILE_Y;
+constexpr int MAX_SEMANTIC = 32; // config.h:18
+constexpr int WAVE = 64;
+
+// Per-Gaussian record written by the forward preprocess and gathered by the
+// blend kernels: one aligned 64-byte line per Gaussian.
+struct __attribute__((aligned(64))) Splat {
+	float x, y;              // pixel-space mean (means2D)
+	float ca, cb, cc;        // conic (inverse 2D covariance) xx, xy, yy
+	float opacity;
+	float r, g, b;           // colour (SH-evaluated or colors_precomp)
+	float dval;              // blended depth value: z or 1/(z+1e-7) (forward.cu:374-375)
+	float fx, fy, fz;        // flow point (world position at the other time)
+	float sem0;              // first semantic channel
+	float zview;             // raw view-space depth
+	float pad;
+};
+static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
+
+void set_error(const std::string& msg);
+
+#define ADGS_HIP_CHECK(expr)                                                             \
+	do {                                                                                 \
+		hipError_t _e = (expr);                                                          \
+		if (_e != hipSuccess) {                                                          \
+			adgs::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) +  \
+				" (" + __FILE__ + ":" + std::to_string(__LINE__) + ")");                \
+			return -1;                                                                   \
+		}                                                                                \
+	} while (0)
+
+// After a kernel launch: always check the launch error; with debug also
+// synchronise like the reference's CHECK_CUDA (auxiliary.h:166-173).
+#define ADGS_LAUNCH_CHECK(debug, stream)                                                 \
+	do {                                                                                 \
+		ADGS_HIP_CHECK(hipGetLastError());                                               \
+		if (debug) ADGS_HIP_CHECK(hipStreamSynchronize(stream));                         \
+	} while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Sub-allocator over a caller-provided chunk (the role of `obtain` in
+// RAST/cuda_rasterizer/rasterizer_impl.h:22-28); 256-byte alignment.
+struct Carver {
+	char* base; size_t off;
+	explicit Carver(char* b) : base(b), off(0) {}
+	template <typename T> T* take(size_t count) {
+		off = align_up(off, 256);
+		T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+		off += count * sizeof(T);
+		return p;
+	}
+	size_t size() const { return align_up(off, 256) + 256; }
+};
+
+// ---- device primitives (primitives.hip) ----
+size_t scan_temp_bytes(size_t n);
+// out[i] = sum_{j<i} in[j]  (in == out allowed)
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
+
+size_t sort_temp_bytes(size_t n);
+// Stable LSD radix sort of (key,value) pairs on key bits [0, end_bit).
+// Result is left in keys_out/vals_out; *_in are clobbered.
+int radix_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n, int end_bit, char* temp, hipStream_t stream);
+int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n, int end_bit, char* temp, hipStream_t stream);
+
+} // namespace adgs

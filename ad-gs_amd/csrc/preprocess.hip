@@ -1,0 +1,260 @@
+// Per-Gaussian forward preprocess (projection, EWA covariance, radius / tile
+// rectangle, SH -> RGB) for gfx950.
+//
+// Reference semantics: RAST/cuda_rasterizer/forward.cu:20-256 and
+// auxiliary.h:41-164.  This translation unit is
+// compiled with -ffp-contract=off: the integer outputs of this stage (radii,
+// tile rectangle, clamp flags, depth-key bits) must be bit-identical to a plain
+// one-rounding-per-operation evaluation, and an FMA in `ceil(3*sqrt(lambda))`
+// or in the tile-rectangle arithmetic would move Gaussians across tile borders.
+//
+// Roofline: pure HBM streaming.  Reads P*(12+12+16+4+12*M) B, writes P*4 (radii)
+// + 4 (tiles_touched) and, per visible Gaussian, one 64-B Splat line + 24 B cov3D
+// + 1 B clamp flags.
+#include "common.h"
+#include "kernels.h"
+
+namespace adgs {
+
+namespace {
+
+struct M3 { float v[3][3]; };   // v[col][row]
+
+__device__ __forceinline__ M3 m3mul(const M3& a, const M3& b) {
+	M3 r;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++)
+			r.v[c][rr] = a.v[0][rr] * b.v[c][0] + a.v[1][rr] * b.v[c][1] + a.v[2][rr] * b.v[c][2];
+	return r;
+}
+__device__ __forceinline__ M3 m3t(const M3& a) {
+	M3 r;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++) r.v[c][rr] = a.v[rr][c];
+	return r;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) {
+	// double arithmetic, rounded once (auxiliary.h:41-44 uses 1.0 / 0.5 literals)
+	return (float)((((double)v + 1.0) * S - 1.0) * 0.5);
+}
+
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy,
+	uint32_t& minx, uint32_t& miny, uint32_t& maxx, uint32_t& maxy) {
+	minx = (uint32_t)min(gx, max(0, (int)((px - radius) / TILE_X)));
+	miny = (uint32_t)min(gy, max(0, (int)((py - radius) / TILE_Y)));
+	maxx = (uint32_t)min(gx, max(0, (int)((px + radius + TILE_X - 1) / TILE_X)));
+	maxy = (uint32_t)min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q, float* out) {
+	M3 S = { { { 1.f, 0.f, 0.f }, { 0.f, 1.f, 0.f }, { 0.f, 0.f, 1.f } } };
+	S.v[0][0] = mod * s3[0]; S.v[1][1] = mod * s3[1]; S.v[2][2] = mod * s3[2];
+	const float r = q[0], x = q[1], y = q[2], z = q[3];     // un-normalised on purpose (forward.cu:127)
+	M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
+	           { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
+	           { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } } };
+	M3 Mm = m3mul(S, R);
+	M3 Sig = m3mul(m3t(Mm), Mm);
+	out[0] = Sig.v[0][0]; out[1] = Sig.v[0][1]; out[2] = Sig.v[0][2];
+	out[3] = Sig.v[1][1]; out[4] = Sig.v[1][2]; out[5] = Sig.v[2][2];
+}
+
+// SH basis evaluation, same association order as forward.cu:20-71.
+__device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, float x, float y, float z) {
+	float result = 0.28209479177387814f * sh[0 * 3 + c];
+	if (deg > 0) {
+		const float C1 = 0.4886025119029199f;
+		result = result - C1 * y * sh[1 * 3 + c] + C1 * z * sh[2 * 3 + c] - C1 * x * sh[3 * 3 + c];
+		if (deg > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+			result = result +
+				1.0925484305920792f * xy * sh[4 * 3 + c] +
+				-1.0925484305920792f * yz * sh[5 * 3 + c] +
+				0.31539156525252005f * (2.0f * zz - xx - yy) * sh[6 * 3 + c] +
+				-1.0925484305920792f * xz * sh[7 * 3 + c] +
+				0.5462742152960396f * (xx - yy) * sh[8 * 3 + c];
+			if (deg > 2) {
+				result = result +
+					-0.5900435899266435f * y * (3.0f * xx - yy) * sh[9 * 3 + c] +
+					2.890611442640554f * xy * z * sh[10 * 3 + c] +
+					-0.4570457994644658f * y * (4.0f * zz - xx - yy) * sh[11 * 3 + c] +
+					0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * 3 + c] +
+					-0.4570457994644658f * x * (4.0f * zz - xx - yy) * sh[13 * 3 + c] +
+					1.445305721320277f * z * (xx - yy) * sh[14 * 3 + c] +
+					-0.5900435899266435f * x * (xx - 3.0f * yy) * sh[15 * 3 + c];
+			}
+		}
+	}
+	return result + 0.5f;
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= a.P) return;
+	a.radii[idx] = 0;
+	a.tiles_touched[idx] = 0;
+
+	const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
+	const float* V = a.view; const float* PJ = a.proj;
+	// near cull only (auxiliary.h:154)
+	const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
+	if (vz <= 0.2f) return;
+	const float vx = V[0] * px + V[4] * py + V[8] * pz + V[12];
+	const float vy = V[1] * px + V[5] * py + V[9] * pz + V[13];
+	const float hx = PJ[0] * px + PJ[4] * py + PJ[8] * pz + PJ[12];
+	const float hy = PJ[1] * px + PJ[5] * py + PJ[9] * pz + PJ[13];
+	const float hw = PJ[3] * px + PJ[7] * py + PJ[11] * pz + PJ[15];
+	const float p_w = 1.0f / (hw + 0.0000001f);
+	const float projx = hx * p_w, projy = hy * p_w;
+
+	float c3[6];
+	if (a.cov3D_precomp) {
+#pragma unroll
+		for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+	} else {
+		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
+#pragma unroll
+		for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = c3[k];
+	}
+
+	// EWA 2D covariance (forward.cu:74-113)
+	float tx = vx, ty = vy; const float tz = vz;
+	const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+	const float txtz = tx / tz, tytz = ty / tz;
+	tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+	ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+	M3 J = { { { a.focal_x / tz, 0.0f, -(a.focal_x * tx) / (tz * tz) },
+	           { 0.0f, a.focal_y / tz, -(a.focal_y * ty) / (tz * tz) },
+	           { 0.f, 0.f, 0.f } } };
+	M3 Wm = { { { V[0], V[4], V[8] }, { V[1], V[5], V[9] }, { V[2], V[6], V[10] } } };
+	M3 T = m3mul(Wm, J);
+	M3 Vrk = { { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } } };
+	M3 cov = m3mul(m3mul(m3t(T), m3t(Vrk)), T);
+	const float cxx = cov.v[0][0] + 0.3f, cxy = cov.v[0][1], cyy = cov.v[1][1] + 0.3f;
+
+	const float det = cxx * cyy - cxy * cxy;
+	if (det == 0.0f) return;
+	const float det_inv = 1.f / det;
+	const float conx = cyy * det_inv, cony = -cxy * det_inv, conz = cxx * det_inv;
+	const float mid = 0.5f * (cxx + cyy);
+	const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+	const float pix = ndc2pix(projx, a.W), piy = ndc2pix(projy, a.H);
+	uint32_t minx, miny, maxx, maxy;
+	tile_rect(pix, piy, (int)my_radius, a.gx, a.gy, minx, miny, maxx, maxy);
+	if ((maxx - minx) * (maxy - miny) == 0) return;
+
+	Splat s;
+	s.x = pix; s.y = piy; s.ca = conx; s.cb = cony; s.cc = conz; s.opacity = a.opacities[idx];
+	uint8_t clamp_bits = 0;
+	if (a.colors_precomp) {
+		s.r = a.colors_precomp[3 * (size_t)idx]; s.g = a.colors_precomp[3 * (size_t)idx + 1]; s.b = a.colors_precomp[3 * (size_t)idx + 2];
+	} else if (a.shs) {
+		float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+		dx = dx / len; dy = dy / len; dz = dz / len;
+		const float* sh = a.shs + (size_t)idx * a.M * 3;
+		float rgb[3];
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			const float v = sh_channel(a.D, sh, c, dx, dy, dz);
+			if (v < 0.f) clamp_bits |= (uint8_t)(1u << c);
+			rgb[c] = fmaxf(v, 0.0f);
+		}
+		s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2];
+	} else {
+		s.r = 0.f; s.g = 0.f; s.b = 0.f;
+	}
+	s.dval = a.inv_depth ? (1.0f / (vz + 0.0000001f)) : vz;
+	if (a.flow_points) { s.fx = a.flow_points[3 * (size_t)idx]; s.fy = a.flow_points[3 * (size_t)idx + 1]; s.fz = a.flow_points[3 * (size_t)idx + 2]; }
+	else { s.fx = 0.f; s.fy = 0.f; s.fz = 0.f; }
+	s.sem0 = (a.semantic && a.D_S > 0) ? a.semantic[(size_t)idx * a.D_S] : 0.f;
+	s.zview = vz;
+	s.pad = 0.f;
+	// one 64-byte line, four 16-byte stores
+	float4* dst = reinterpret_cast<float4*>(a.splats + idx);
+	dst[0] = make_float4(s.x, s.y, s.ca, s.cb);
+	dst[1] = make_float4(s.cc, s.opacity, s.r, s.g);
+	dst[2] = make_float4(s.b, s.dval, s.fx, s.fy);
+	dst[3] = make_float4(s.fz, s.sem0, s.zview, s.pad);
+	a.clamped[idx] = clamp_bits;
+	a.radii[idx] = (int)my_radius;
+	a.tiles_touched[idx] = (maxy - miny) * (maxx - minx);
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ V, uint8_t* __restrict__ present) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= P) return;
+	const float vz = V[2] * means[3 * idx] + V[6] * means[3 * idx + 1] + V[10] * means[3 * idx + 2] + V[14];
+	present[idx] = vz <= 0.2f ? 0 : 1;
+}
+
+// rasterizer_impl.cu:70-111: one (tile | depth) key + Gaussian index per covered tile.
+__global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat* __restrict__ splats, const uint32_t* __restrict__ offsets,
+	const int* __restrict__ radii, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, int gy) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= P) return;
+	const int r = radii[idx];
+	if (r > 0) {
+		uint32_t off = offsets[idx];       // exclusive scan: start slot of this Gaussian
+		const float2 xy = *reinterpret_cast<const float2*>(&splats[idx].x);
+		const uint32_t dbits = __float_as_uint(splats[idx].zview);
+		uint32_t minx, miny, maxx, maxy;
+		tile_rect(xy.x, xy.y, r, gx, gy, minx, miny, maxx, maxy);
+		for (uint32_t y = miny; y < maxy; y++)
+			for (uint32_t x = minx; x < maxx; x++) {
+				uint64_t key = (uint64_t)(y * gx + x);
+				key <<= 32; key |= dbits;
+				keys[off] = key; vals[off] = (uint32_t)idx; off++;
+			}
+	}
+}
+
+// rasterizer_impl.cu:116-138
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= L) return;
+	const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+	if (idx == 0) ranges[currtile].x = 0;
+	else {
+		const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+		if (currtile != prevtile) { ranges[prevtile].y = idx; ranges[currtile].x = idx; }
+	}
+	if (idx == L - 1) ranges[currtile].y = L;
+}
+
+} // namespace
+
+int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream) {
+	if (a.P == 0) return 0;
+	hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means, view, present);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, const int* radii, uint64_t* keys, uint32_t* vals,
+	int gx, int gy, hipStream_t stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(duplicate_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, offsets, radii, keys, vals, gx, gy);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t stream) {
+	if (L == 0) return 0;
+	hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys, ranges);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+} // namespace adgs

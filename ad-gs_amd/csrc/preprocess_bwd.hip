@@ -1,0 +1,241 @@
+// Per-Gaussian backward of the preprocess stage, fused into ONE pass over P
+// (the reference runs two kernels: computeCov2DCUDA then preprocessCUDA,
+// RAST/cuda_rasterizer/backward.cu:144-274, 346-414, driver :648-716).
+//
+// conic grads -> cov2D -> cov3D -> (scale, rotation) and -> mean;
+// mean2D grads -> mean through the projection; depth grads -> mean;
+// colour grads -> SH coefficients and (view direction) -> mean.
+// The reference's non-derivative details are kept: 1/(det^2+1e-7), clamp masks on
+// t.x/t.y only, un-normalised quaternion (no normalisation Jacobian).
+//
+// Roofline: HBM streaming; the 12*M-byte dL_dsh row per visible Gaussian
+// dominates the writes.
+#include "common.h"
+#include "kernels.h"
+
+namespace adgs {
+namespace {
+
+struct M3 { float v[3][3]; };
+__device__ __forceinline__ M3 m3mul(const M3& a, const M3& b) {
+	M3 r;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++)
+			r.v[c][rr] = a.v[0][rr] * b.v[c][0] + a.v[1][rr] * b.v[c][1] + a.v[2][rr] * b.v[c][2];
+	return r;
+}
+__device__ __forceinline__ M3 m3t(const M3& a) {
+	M3 r;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++) r.v[c][rr] = a.v[rr][c];
+	return r;
+}
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= a.P || !(a.radii[idx] > 0)) return;
+	const float* V = a.view; const float* PJ = a.proj;
+	const float mx = a.means3D[3 * (size_t)idx], my = a.means3D[3 * (size_t)idx + 1], mz = a.means3D[3 * (size_t)idx + 2];
+
+	// ---------------- cov2D backward (backward.cu:144-274)
+	const float* c3 = a.cov3D + 6 * (size_t)idx;
+	const float dcon_x = a.dL_dconic[4 * (size_t)idx], dcon_y = a.dL_dconic[4 * (size_t)idx + 1], dcon_z = a.dL_dconic[4 * (size_t)idx + 3];
+	float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+	float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+	const float tz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+	const float h_x = a.focal_x, h_y = a.focal_y;
+	const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+	const float txtz = tx / tz, tytz = ty / tz;
+	tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+	ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+	const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+	const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+	M3 J = { { { h_x / tz, 0.0f, -(h_x * tx) / (tz * tz) }, { 0.0f, h_y / tz, -(h_y * ty) / (tz * tz) }, { 0.f, 0.f, 0.f } } };
+	M3 Wm = { { { V[0], V[4], V[8] }, { V[1], V[5], V[9] }, { V[2], V[6], V[10] } } };
+	M3 Vrk = { { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } } };
+	M3 T = m3mul(Wm, J);
+	M3 cov2D = m3mul(m3mul(m3t(T), m3t(Vrk)), T);
+	const float ca = cov2D.v[0][0] + 0.3f, cb = cov2D.v[0][1], cc = cov2D.v[1][1] + 0.3f;
+	const float denom = ca * cc - cb * cb;
+	float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+	const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+	float dcov[6];
+	if (denom2inv != 0) {
+		dL_da = denom2inv * (-cc * cc * dcon_x + 2 * cb * cc * dcon_y + (denom - ca * cc) * dcon_z);
+		dL_dc = denom2inv * (-ca * ca * dcon_z + 2 * ca * cb * dcon_y + (denom - ca * cc) * dcon_x);
+		dL_db = denom2inv * 2 * (cb * cc * dcon_x - (denom + 2 * cb * cb) * dcon_y + ca * cb * dcon_z);
+		dcov[0] = (T.v[0][0] * T.v[0][0] * dL_da + T.v[0][0] * T.v[1][0] * dL_db + T.v[1][0] * T.v[1][0] * dL_dc);
+		dcov[3] = (T.v[0][1] * T.v[0][1] * dL_da + T.v[0][1] * T.v[1][1] * dL_db + T.v[1][1] * T.v[1][1] * dL_dc);
+		dcov[5] = (T.v[0][2] * T.v[0][2] * dL_da + T.v[0][2] * T.v[1][2] * dL_db + T.v[1][2] * T.v[1][2] * dL_dc);
+		dcov[1] = 2 * T.v[0][0] * T.v[0][1] * dL_da + (T.v[0][0] * T.v[1][1] + T.v[0][1] * T.v[1][0]) * dL_db + 2 * T.v[1][0] * T.v[1][1] * dL_dc;
+		dcov[2] = 2 * T.v[0][0] * T.v[0][2] * dL_da + (T.v[0][0] * T.v[1][2] + T.v[0][2] * T.v[1][0]) * dL_db + 2 * T.v[1][0] * T.v[1][2] * dL_dc;
+		dcov[4] = 2 * T.v[0][2] * T.v[0][1] * dL_da + (T.v[0][1] * T.v[1][2] + T.v[0][2] * T.v[1][1]) * dL_db + 2 * T.v[1][1] * T.v[1][2] * dL_dc;
+	} else {
+#pragma unroll
+		for (int i = 0; i < 6; i++) dcov[i] = 0.f;
+	}
+#pragma unroll
+	for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+
+	const float tv0 = T.v[0][0] * Vrk.v[0][0] + T.v[0][1] * Vrk.v[0][1] + T.v[0][2] * Vrk.v[0][2];
+	const float tv1 = T.v[0][0] * Vrk.v[1][0] + T.v[0][1] * Vrk.v[1][1] + T.v[0][2] * Vrk.v[1][2];
+	const float tv2 = T.v[0][0] * Vrk.v[2][0] + T.v[0][1] * Vrk.v[2][1] + T.v[0][2] * Vrk.v[2][2];
+	const float uv0 = T.v[1][0] * Vrk.v[0][0] + T.v[1][1] * Vrk.v[0][1] + T.v[1][2] * Vrk.v[0][2];
+	const float uv1 = T.v[1][0] * Vrk.v[1][0] + T.v[1][1] * Vrk.v[1][1] + T.v[1][2] * Vrk.v[1][2];
+	const float uv2 = T.v[1][0] * Vrk.v[2][0] + T.v[1][1] * Vrk.v[2][1] + T.v[1][2] * Vrk.v[2][2];
+	const float dL_dT00 = 2 * tv0 * dL_da + uv0 * dL_db;
+	const float dL_dT01 = 2 * tv1 * dL_da + uv1 * dL_db;
+	const float dL_dT02 = 2 * tv2 * dL_da + uv2 * dL_db;
+	const float dL_dT10 = 2 * uv0 * dL_dc + tv0 * dL_db;
+	const float dL_dT11 = 2 * uv1 * dL_dc + tv1 * dL_db;
+	const float dL_dT12 = 2 * uv2 * dL_dc + tv2 * dL_db;
+	const float dL_dJ00 = Wm.v[0][0] * dL_dT00 + Wm.v[0][1] * dL_dT01 + Wm.v[0][2] * dL_dT02;
+	const float dL_dJ02 = Wm.v[2][0] * dL_dT00 + Wm.v[2][1] * dL_dT01 + Wm.v[2][2] * dL_dT02;
+	const float dL_dJ11 = Wm.v[1][0] * dL_dT10 + Wm.v[1][1] * dL_dT11 + Wm.v[1][2] * dL_dT12;
+	const float dL_dJ12 = Wm.v[2][0] * dL_dT10 + Wm.v[2][1] * dL_dT11 + Wm.v[2][2] * dL_dT12;
+	const float itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+	const float dL_dtx = x_grad_mul * -h_x * itz2 * dL_dJ02;
+	const float dL_dty = y_grad_mul * -h_y * itz2 * dL_dJ12;
+	const float dL_dtz = -h_x * itz2 * dL_dJ00 - h_y * itz2 * dL_dJ11 + (2 * h_x * tx) * itz3 * dL_dJ02 + (2 * h_y * ty) * itz3 * dL_dJ12;
+	// transformVec4x3Transpose (auxiliary.h:89-97); this ASSIGNS (backward.cu:273)
+	float gmx = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+	float gmy = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+	float gmz = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+
+	// ---------------- projection path (backward.cu:371-390)
+	{
+		const float hw = PJ[3] * mx + PJ[7] * my + PJ[11] * mz + PJ[15];
+		const float m_w = 1.0f / (hw + 0.0000001f);
+		const float mul1 = (PJ[0] * mx + PJ[4] * my + PJ[8] * mz + PJ[12]) * m_w * m_w;
+		const float mul2 = (PJ[1] * mx + PJ[5] * my + PJ[9] * mz + PJ[13]) * m_w * m_w;
+		const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+		gmx += (PJ[0] * m_w - PJ[3] * mul1) * g2x + (PJ[1] * m_w - PJ[3] * mul2) * g2y;
+		gmy += (PJ[4] * m_w - PJ[7] * mul1) * g2x + (PJ[5] * m_w - PJ[7] * mul2) * g2y;
+		gmz += (PJ[8] * m_w - PJ[11] * mul1) * g2x + (PJ[9] * m_w - PJ[11] * mul2) * g2y;
+	}
+	// ---------------- depth path (backward.cu:392-405)
+	{
+		const float mul3 = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+		const float demon = a.inv_depth ? (-1.0f / (mul3 * mul3 + 0.0000001f)) : 1.0f;
+		const float gd = a.dL_ddepth[idx];
+		gmx += (V[2] - V[3] * mul3) * gd * demon;
+		gmy += (V[6] - V[7] * mul3) * gd * demon;
+		gmz += (V[10] - V[11] * mul3) * gd * demon;
+	}
+	// ---------------- SH path (backward.cu:20-139)
+	if (a.shs) {
+		const float ox = mx - a.campos[0], oy = my - a.campos[1], oz = mz - a.campos[2];
+		const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+		const float x = ox / len, y = oy / len, z = oz / len;
+		const float* sh = a.shs + (size_t)idx * a.M * 3;
+		float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+		const uint8_t cl = a.clamped[idx];
+		float g[3];
+#pragma unroll
+		for (int c = 0; c < 3; c++) g[c] = ((cl >> c) & 1) ? 0.f : a.dL_dcolor[3 * (size_t)idx + c];
+		float dx3[3] = { 0.f, 0.f, 0.f }, dy3[3] = { 0.f, 0.f, 0.f }, dz3[3] = { 0.f, 0.f, 0.f };
+		const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+		const float C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
+		const float C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+			-0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+#define SETSH(k, coef) { const float _c = (coef); dsh[(k) * 3 + 0] = _c * g[0]; dsh[(k) * 3 + 1] = _c * g[1]; dsh[(k) * 3 + 2] = _c * g[2]; }
+		SETSH(0, C0);
+		const int deg = a.D;
+		if (deg > 0) {
+			SETSH(1, -C1 * y); SETSH(2, C1 * z); SETSH(3, -C1 * x);
+#pragma unroll
+			for (int c = 0; c < 3; c++) { dx3[c] = -C1 * sh[3 * 3 + c]; dy3[c] = -C1 * sh[1 * 3 + c]; dz3[c] = C1 * sh[2 * 3 + c]; }
+			if (deg > 1) {
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				SETSH(4, C2[0] * xy); SETSH(5, C2[1] * yz); SETSH(6, C2[2] * (2.f * zz - xx - yy));
+				SETSH(7, C2[3] * xz); SETSH(8, C2[4] * (xx - yy));
+#pragma unroll
+				for (int c = 0; c < 3; c++) {
+					dx3[c] += C2[0] * y * sh[4 * 3 + c] + C2[2] * 2.f * -x * sh[6 * 3 + c] + C2[3] * z * sh[7 * 3 + c] + C2[4] * 2.f * x * sh[8 * 3 + c];
+					dy3[c] += C2[0] * x * sh[4 * 3 + c] + C2[1] * z * sh[5 * 3 + c] + C2[2] * 2.f * -y * sh[6 * 3 + c] + C2[4] * 2.f * -y * sh[8 * 3 + c];
+					dz3[c] += C2[1] * y * sh[5 * 3 + c] + C2[2] * 2.f * 2.f * z * sh[6 * 3 + c] + C2[3] * x * sh[7 * 3 + c];
+				}
+				if (deg > 2) {
+					SETSH(9, C3[0] * y * (3.f * xx - yy));
+					SETSH(10, C3[1] * xy * z);
+					SETSH(11, C3[2] * y * (4.f * zz - xx - yy));
+					SETSH(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+					SETSH(13, C3[4] * x * (4.f * zz - xx - yy));
+					SETSH(14, C3[5] * z * (xx - yy));
+					SETSH(15, C3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+					for (int c = 0; c < 3; c++) {
+						dx3[c] += (C3[0] * sh[9 * 3 + c] * 3.f * 2.f * xy + C3[1] * sh[10 * 3 + c] * yz + C3[2] * sh[11 * 3 + c] * -2.f * xy +
+							C3[3] * sh[12 * 3 + c] * -3.f * 2.f * xz + C3[4] * sh[13 * 3 + c] * (-3.f * xx + 4.f * zz - yy) +
+							C3[5] * sh[14 * 3 + c] * 2.f * xz + C3[6] * sh[15 * 3 + c] * 3.f * (xx - yy));
+						dy3[c] += (C3[0] * sh[9 * 3 + c] * 3.f * (xx - yy) + C3[1] * sh[10 * 3 + c] * xz + C3[2] * sh[11 * 3 + c] * (-3.f * yy + 4.f * zz - xx) +
+							C3[3] * sh[12 * 3 + c] * -3.f * 2.f * yz + C3[4] * sh[13 * 3 + c] * -2.f * xy + C3[5] * sh[14 * 3 + c] * -2.f * yz +
+							C3[6] * sh[15 * 3 + c] * -3.f * 2.f * xy);
+						dz3[c] += (C3[1] * sh[10 * 3 + c] * xy + C3[2] * sh[11 * 3 + c] * 4.f * 2.f * yz + C3[3] * sh[12 * 3 + c] * 3.f * (2.f * zz - xx - yy) +
+							C3[4] * sh[13 * 3 + c] * 4.f * 2.f * xz + C3[5] * sh[14 * 3 + c] * (xx - yy));
+					}
+				}
+			}
+		}
+#undef SETSH
+		const float ddx = dx3[0] * g[0] + dx3[1] * g[1] + dx3[2] * g[2];
+		const float ddy = dy3[0] * g[0] + dy3[1] * g[1] + dy3[2] * g[2];
+		const float ddz = dz3[0] * g[0] + dz3[1] * g[1] + dz3[2] * g[2];
+		// dnormvdv (auxiliary.h:107-117)
+		const float sum2 = ox * ox + oy * oy + oz * oz;
+		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+		gmx += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+		gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+		gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+	}
+	a.dL_dmean3D[3 * (size_t)idx] = gmx; a.dL_dmean3D[3 * (size_t)idx + 1] = gmy; a.dL_dmean3D[3 * (size_t)idx + 2] = gmz;
+
+	// ---------------- cov3D -> scale / rotation (backward.cu:278-341)
+	if (a.scales) {
+		const float* q = a.rotations + 4 * (size_t)idx;
+		const float r = q[0], x = q[1], y = q[2], z = q[3];
+		M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
+		           { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
+		           { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } } };
+		const float s0 = a.scale_modifier * a.scales[3 * (size_t)idx], s1 = a.scale_modifier * a.scales[3 * (size_t)idx + 1], s2 = a.scale_modifier * a.scales[3 * (size_t)idx + 2];
+		M3 S = { { { s0, 0.f, 0.f }, { 0.f, s1, 0.f }, { 0.f, 0.f, s2 } } };
+		M3 Mm = m3mul(S, R);
+		M3 dSig = { { { dcov[0], 0.5f * dcov[1], 0.5f * dcov[2] }, { 0.5f * dcov[1], dcov[3], 0.5f * dcov[4] }, { 0.5f * dcov[2], 0.5f * dcov[4], dcov[5] } } };
+		M3 twoM;
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+#pragma unroll
+			for (int rr = 0; rr < 3; rr++) twoM.v[c][rr] = Mm.v[c][rr] * 2.0f;
+		M3 dL_dM = m3mul(twoM, dSig);
+		M3 Rt = m3t(R);
+		M3 dMt = m3t(dL_dM);
+		a.dL_dscale[3 * (size_t)idx + 0] = Rt.v[0][0] * dMt.v[0][0] + Rt.v[0][1] * dMt.v[0][1] + Rt.v[0][2] * dMt.v[0][2];
+		a.dL_dscale[3 * (size_t)idx + 1] = Rt.v[1][0] * dMt.v[1][0] + Rt.v[1][1] * dMt.v[1][1] + Rt.v[1][2] * dMt.v[1][2];
+		a.dL_dscale[3 * (size_t)idx + 2] = Rt.v[2][0] * dMt.v[2][0] + Rt.v[2][1] * dMt.v[2][1] + Rt.v[2][2] * dMt.v[2][2];
+#pragma unroll
+		for (int k = 0; k < 3; k++) { dMt.v[0][k] *= s0; dMt.v[1][k] *= s1; dMt.v[2][k] *= s2; }
+#define MT(i, j) dMt.v[i][j]
+		float4 dq;
+		dq.x = 2 * z * (MT(0, 1) - MT(1, 0)) + 2 * y * (MT(2, 0) - MT(0, 2)) + 2 * x * (MT(1, 2) - MT(2, 1));
+		dq.y = 2 * y * (MT(1, 0) + MT(0, 1)) + 2 * z * (MT(2, 0) + MT(0, 2)) + 2 * r * (MT(1, 2) - MT(2, 1)) - 4 * x * (MT(2, 2) + MT(1, 1));
+		dq.z = 2 * x * (MT(1, 0) + MT(0, 1)) + 2 * r * (MT(2, 0) - MT(0, 2)) + 2 * z * (MT(1, 2) + MT(2, 1)) - 4 * y * (MT(2, 2) + MT(0, 0));
+		dq.w = 2 * r * (MT(0, 1) - MT(1, 0)) + 2 * x * (MT(2, 0) + MT(0, 2)) + 2 * y * (MT(1, 2) + MT(2, 1)) - 4 * z * (MT(1, 1) + MT(0, 0));
+#undef MT
+		*reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;     // no normalisation Jacobian (backward.cu:340)
+	}
+}
+
+} // namespace
+
+int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
+	if (a.P == 0) return 0;
+	hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+} // namespace adgs

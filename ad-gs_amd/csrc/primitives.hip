@@ -1,0 +1,223 @@
+// Device-wide exclusive scan and stable LSD radix sort for gfx950 (wave64).
+//
+// These replace the reference's cub::DeviceScan::InclusiveSum and
+// cub::DeviceRadixSort::SortPairs calls (RAST/cuda_rasterizer/rasterizer_impl.cu:284,310-315;
+// KNN/simple_knn.cu:210-213).  Both are HBM-streaming passes:
+//   scan : reads n*4 B twice, writes n*4 B                       (~12 B/item)
+//   sort : per 8-bit pass reads keys twice + values once, writes both
+//          (u64 key + u32 value: 8 + 12 + 12 = 32 B/item/pass)
+#include "common.h"
+
+namespace adgs {
+
+constexpr int PB = 256;            // threads per block
+constexpr int SCAN_ITEMS = 8;      // items per thread
+constexpr int SCAN_TILE = PB * SCAN_ITEMS;
+constexpr int SORT_ROUNDS = 8;
+constexpr int SORT_TILE = PB * SORT_ROUNDS;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+	for (int off = 1; off < WAVE; off <<= 1) {
+		uint32_t o = __shfl_up(v, off, WAVE);
+		if (lane >= off) v += o;
+	}
+	return v;
+}
+
+// mode 0: write per-block sums only.  mode 1: write exclusive scan (+ block offset).
+template <int MODE>
+__global__ void __launch_bounds__(PB) scan_tile_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+	size_t n, const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ block_sums) {
+	__shared__ uint32_t wave_tot[PB / WAVE];
+	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * SCAN_ITEMS;
+	uint32_t v[SCAN_ITEMS];
+	uint32_t tsum = 0;
+	if (base + SCAN_ITEMS <= n) {
+		const uint4* p = reinterpret_cast<const uint4*>(in + base);
+		uint4 a = p[0], b = p[1];
+		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+	} else {
+#pragma unroll
+		for (int k = 0; k < SCAN_ITEMS; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+	}
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) tsum += v[k];
+	uint32_t incl = wave_incl_scan(tsum, lane);
+	if (lane == WAVE - 1) wave_tot[wid] = incl;
+	__syncthreads();
+	uint32_t wave_prefix = 0, block_total = 0;
+#pragma unroll
+	for (int w = 0; w < PB / WAVE; w++) {
+		uint32_t t = wave_tot[w];
+		if (w < wid) wave_prefix += t;
+		block_total += t;
+	}
+	if (MODE == 0) {
+		if (tid == 0) block_sums[blockIdx.x] = block_total;
+		return;
+	}
+	uint32_t run = (block_offsets ? block_offsets[blockIdx.x] : 0u) + wave_prefix + (incl - tsum);
+	uint32_t o[SCAN_ITEMS];
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) { o[k] = run; run += v[k]; }
+	if (base + SCAN_ITEMS <= n) {
+		uint4* q = reinterpret_cast<uint4*>(out + base);
+		q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+		q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+	} else {
+#pragma unroll
+		for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] = o[k];
+	}
+}
+
+static size_t scan_blocks(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+size_t scan_temp_bytes(size_t n) {
+	size_t total = 0;
+	while (n > (size_t)SCAN_TILE) {
+		n = scan_blocks(n);
+		total += align_up(n * sizeof(uint32_t), 256);
+	}
+	return total + 256;
+}
+
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream) {
+	if (n == 0) return 0;
+	const size_t nb = scan_blocks(n);
+	if (nb == 1) {
+		hipLaunchKernelGGL(scan_tile_kernel<1>, dim3(1), dim3(PB), 0, stream, in, out, n, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+		ADGS_HIP_CHECK(hipGetLastError());
+		return 0;
+	}
+	uint32_t* sums = reinterpret_cast<uint32_t*>(temp);
+	char* next_temp = temp + align_up(nb * sizeof(uint32_t), 256);
+	hipLaunchKernelGGL(scan_tile_kernel<0>, dim3((unsigned)nb), dim3(PB), 0, stream, in, (uint32_t*)nullptr, n, (const uint32_t*)nullptr, sums);
+	ADGS_HIP_CHECK(hipGetLastError());
+	if (exclusive_scan_u32(sums, sums, nb, next_temp, stream) != 0) return -1;
+	hipLaunchKernelGGL(scan_tile_kernel<1>, dim3((unsigned)nb), dim3(PB), 0, stream, in, out, n, (const uint32_t*)sums, (uint32_t*)nullptr);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+// ------------------------------------------------------------------ radix sort
+template <typename KeyT>
+__global__ void __launch_bounds__(PB) sort_hist_kernel(const KeyT* __restrict__ keys, size_t n, int shift, uint32_t mask,
+	uint32_t* __restrict__ block_hist, uint32_t nblocks) {
+	__shared__ uint32_t hist[256];
+	const int tid = threadIdx.x;
+	hist[tid] = 0;
+	__syncthreads();
+	const size_t tile0 = (size_t)blockIdx.x * SORT_TILE;
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		size_t i = tile0 + (size_t)r * PB + tid;
+		if (i < n) {
+			uint32_t d = (uint32_t)(keys[i] >> shift) & mask;
+			atomicAdd(&hist[d], 1u);
+		}
+	}
+	__syncthreads();
+	block_hist[(size_t)tid * nblocks + blockIdx.x] = hist[tid];
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(PB) sort_scatter_kernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_out,
+	const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ vals_out, size_t n, int shift, uint32_t mask,
+	const uint32_t* __restrict__ block_hist_scanned, uint32_t nblocks) {
+	__shared__ uint32_t global_base[256];
+	__shared__ uint32_t running[256];
+	__shared__ uint32_t wave_cnt[PB / WAVE][256];
+	__shared__ uint32_t wave_base[PB / WAVE][256];
+	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	global_base[tid] = block_hist_scanned[(size_t)tid * nblocks + blockIdx.x];
+	running[tid] = 0;
+	const size_t tile0 = (size_t)blockIdx.x * SORT_TILE;
+	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const size_t i = tile0 + (size_t)r * PB + tid;
+		if (tile0 + (size_t)r * PB >= n) break;   // block-uniform
+		const bool valid = i < n;
+		KeyT key = valid ? keys_in[i] : (KeyT)0;
+		uint32_t val = valid ? vals_in[i] : 0u;
+		const uint32_t d = (uint32_t)(key >> shift) & mask;
+		// wave-level match-any on the 8-bit digit
+		uint64_t peers = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < 8; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t m = __ballot(valid && bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t rank_in_wave = __popcll(peers & lt_mask);
+		const uint32_t count = __popcll(peers);
+#pragma unroll
+		for (int k = 0; k < PB / WAVE; k++) wave_cnt[k][tid] = 0;
+		__syncthreads();
+		if (valid && rank_in_wave == 0) wave_cnt[wid][d] = count;
+		__syncthreads();
+		{
+			uint32_t b = running[tid];
+#pragma unroll
+			for (int w = 0; w < PB / WAVE; w++) { wave_base[w][tid] = b; b += wave_cnt[w][tid]; }
+			running[tid] = b;
+		}
+		__syncthreads();
+		if (valid) {
+			const size_t dst = (size_t)global_base[d] + wave_base[wid][d] + rank_in_wave;
+			keys_out[dst] = key;
+			vals_out[dst] = val;
+		}
+	}
+}
+
+static size_t sort_blocks(size_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+
+size_t sort_temp_bytes(size_t n) {
+	const size_t nb = sort_blocks(n);
+	return align_up(256 * nb * sizeof(uint32_t), 256) + scan_temp_bytes(256 * nb) + 256;
+}
+
+template <typename KeyT>
+static int radix_sort_pairs(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n, int end_bit, char* temp, hipStream_t stream) {
+	if (n == 0) return 0;
+	const size_t nb = sort_blocks(n);
+	uint32_t* block_hist = reinterpret_cast<uint32_t*>(temp);
+	char* scan_temp = temp + align_up(256 * nb * sizeof(uint32_t), 256);
+	const int passes = (end_bit + 7) / 8;
+	KeyT* kin = keys_in; KeyT* kout = keys_out; uint32_t* vin = vals_in; uint32_t* vout = vals_out;
+	// make the final pass land in keys_out/vals_out
+	if (passes % 2 == 0) { kin = keys_in; kout = keys_out; }
+	for (int p = 0; p < passes; p++) {
+		const int shift = p * 8;
+		const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+		const uint32_t mask = (1u << bits) - 1u;
+		hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3((unsigned)nb), dim3(PB), 0, stream, (const KeyT*)kin, n, shift, mask, block_hist, (uint32_t)nb);
+		ADGS_HIP_CHECK(hipGetLastError());
+		if (exclusive_scan_u32(block_hist, block_hist, 256 * nb, scan_temp, stream) != 0) return -1;
+		hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3((unsigned)nb), dim3(PB), 0, stream, (const KeyT*)kin, kout,
+			(const uint32_t*)vin, vout, n, shift, mask, (const uint32_t*)block_hist, (uint32_t)nb);
+		ADGS_HIP_CHECK(hipGetLastError());
+		KeyT* tk = kin; kin = kout; kout = tk;
+		uint32_t* tv = vin; vin = vout; vout = tv;
+	}
+	// after the loop `kin` holds the sorted data
+	if (kin != keys_out) {
+		ADGS_HIP_CHECK(hipMemcpyAsync(keys_out, kin, n * sizeof(KeyT), hipMemcpyDeviceToDevice, stream));
+		ADGS_HIP_CHECK(hipMemcpyAsync(vals_out, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+	}
+	return 0;
+}
+
+int radix_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n, int end_bit, char* temp, hipStream_t stream) {
+	return radix_sort_pairs<uint64_t>(keys_in, keys_out, vals_in, vals_out, n, end_bit, temp, stream);
+}
+int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n, int end_bit, char* temp, hipStream_t stream) {
+	return radix_sort_pairs<uint32_t>(keys_in, keys_out, vals_in, vals_out, n, end_bit, temp, stream);
+}
+
+} // namespace adgs

@@ -1,0 +1,147 @@
+"""`diff_gaussian_rasterization._C` drop-in: same three entry points as the reference's
+pybind module (submodules/depth-diff-gaussian-rasterization/ext.cpp:15-19,
+rasterize_points.cu:35-275), implemented over the C ABI of libadgs_hip.so.
+
+Tensors must live on a HIP ("cuda") device; there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from adgs import _lib
+
+NUM_CHANNELS = 3
+FLOW_CHANNELS = 3
+SEMANTIC_CHANNELS = 32
+
+
+def _ptr(t):
+    """Data pointer of a contiguous fp32/int32 tensor; NULL for an empty tensor
+    (the reference passes `torch.Tensor([])` for absent inputs)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _prep(t, device, name, dtype=torch.float32):
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError("%s must be on %s (got %s); there is no CPU rasterizer" % (name, device, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+class _Buffer:
+    """Byte buffer grown through the C allocator callback (the reference's resizeFunctional,
+    rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+
+        def cb(_user, nbytes):
+            self.t.resize_(int(nbytes))
+            return self.t.data_ptr()
+        self.cb = _lib.ALLOC_FN(cb)
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, flow_points, semantic,
+                        degree, campos, prefiltered, inv_depth, debug):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be on a HIP device; there is no CPU rasterizer")
+    lib = _lib.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    D_S = 0
+    if semantic.size(0) != 0:
+        D_S = semantic.size(1)
+        assert D_S <= SEMANTIC_CHANNELS
+    if flow_points.size(0) != 0:
+        assert flow_points.size(1) == FLOW_CHANNELS
+    f32 = dict(dtype=torch.float32, device=dev)
+    out_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
+    out_depth = torch.zeros((1, H, W), **f32)
+    img_opacity = torch.zeros((1, H, W), **f32)
+    img_flow = torch.zeros((FLOW_CHANNELS, H, W), **f32)
+    img_semantic = torch.zeros((D_S, H, W), **f32)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Buffer(dev), _Buffer(dev), _Buffer(dev)
+    rendered = 0
+    if P != 0:
+        M = sh.size(1) if sh.size(0) != 0 else 0
+        keep = [_prep(t, dev, n) for t, n in (
+            (background, "bg"), (means3D, "means3D"), (sh, "sh"), (colors, "colors_precomp"), (flow_points, "flow_points"),
+            (semantic, "semantic"), (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"),
+            (cov3D_precomp, "cov3D_precomp"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"))]
+        bg_, m3_, sh_, col_, fl_, sem_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
+        with torch.cuda.device(dev):
+            rendered = _lib.check(lib.adgs_raster_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, D_S, _ptr(bg_), W, H,
+                _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
+                _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic), int(bool(inv_depth)),
+                _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward")
+    return rendered, out_color, out_depth, img_opacity, radii, geom.t, binning.t, img.t, img_flow, img_semantic
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_flow,
+                                 dL_dout_semantic, semantic, flow_points, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                 imageBuffer, img_opacity, grad_img_opacity, inv_depth, debug):
+    lib = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.size(0) != 0 else 0
+    D_S = 0
+    if semantic.size(0) != 0:
+        D_S = semantic.size(1)
+        assert D_S <= SEMANTIC_CHANNELS
+    if flow_points.size(0) != 0:
+        assert flow_points.size(1) == FLOW_CHANNELS
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 1)
+    dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = z(P, 2, 2), z(P, 1), z(P, 6), z(P, M, 3)
+    dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic = z(P, 3), z(P, 4), z(P, FLOW_CHANNELS), z(P, D_S)
+    if P != 0:
+        keep = [_prep(t, dev, n) for t, n in (
+            (background, "bg"), (means3D, "means3D"), (sh, "sh"), (colors, "colors_precomp"), (flow_points, "flow_points"),
+            (semantic, "semantic"), (scales, "scales"), (rotations, "rotations"), (cov3D_precomp, "cov3D_precomp"),
+            (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"), (dL_dout_color, "dL_dout_color"),
+            (dL_dout_depth, "dL_dout_depth"), (dL_dout_flow, "dL_dout_flow"), (dL_dout_semantic, "dL_dout_semantic"),
+            (grad_img_opacity, "grad_img_opacity"), (img_opacity, "img_opacity"))]
+        bg_, m3_, sh_, col_, fl_, sem_, sc_, rot_, cov_, view_, proj_, cam_, gc_, gd_, gf_, gs_, go_, io_ = keep
+        radii_ = _prep(radii, dev, "radii", torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.adgs_raster_backward(
+                P, int(degree), M, int(R), D_S, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_),
+                _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_),
+                float(tan_fovx), float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(gc_), _ptr(gd_), _ptr(gf_), _ptr(gs_),
+                _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
+                _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dflow_points), _ptr(dL_dsemantic),
+                _ptr(go_), _ptr(io_), int(bool(inv_depth)), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_backward")
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+            dL_dflow_points, dL_dsemantic)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be on a HIP device; there is no CPU rasterizer")
+    lib = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m3, view, proj = (_prep(t, dev, n) for t, n in ((means3D, "means3D"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix")))
+        with torch.cuda.device(dev):
+            _lib.check(lib.adgs_mark_visible(P, _ptr(m3), _ptr(view), _ptr(proj), _ptr(present), _stream_ptr(dev)), "adgs_mark_visible")
+    return present

@@ -1,0 +1,121 @@
+"""Drop-in `diff_gaussian_rasterization` for AD-GS on MI355X (gfx950).
+
+Same public surface and autograd contract as the reference package
+(submodules/depth-diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py:21-251):
+
+    GaussianRasterizationSettings   13-field NamedTuple            (ref :176-189)
+    GaussianRasterizer(nn.Module)   .forward(...) -> 6-tuple, .markVisible(...)   (ref :191-251)
+    rasterize_gaussians(...)        functional form                 (ref :21-46)
+
+so `gaussian_renderer.render()`, `scene/gaussian_model.py` and `train.py` of the
+reference run unchanged.  Underneath, `_C` is a ctypes binding of the hand-written
+HIP library (libadgs_hip.so); nothing here falls back to PyTorch or the CPU.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    inv_depth: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU copies of every tensor argument, for the debug dumps (ref :17-19)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_with_dump(fn, args, debug, dump_name, phase):
+    """With settings.debug the reference snapshots the arguments before the call and
+    writes them with torch.save if the native call raises (ref :92-99, :149-156)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print("\nAn error occured in %s. Writing %s for debugging.\n" % (phase, dump_name))
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """11 inputs -> 6 outputs; backward returns 11 grads in input order (ref :48-174)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                flow_points, semantic, raster_settings):
+        s = raster_settings
+        native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, flow_points,
+                       semantic, s.sh_degree, s.campos, s.prefiltered, s.inv_depth, s.debug)
+        (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow,
+         img_semantic) = _call_with_dump(_C.rasterize_gaussians, native_args, s.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = s
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
+                              img_buf, img_opacity, flow_points, semantic)
+        return color, radii, depth, img_opacity, img_flow, img_semantic
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_img_opacity, grad_img_flow, grad_img_semantic):
+        s = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf,
+         img_opacity, flow_points, semantic) = ctx.saved_tensors
+        native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_depth, grad_img_flow,
+                       grad_img_semantic, semantic, flow_points, sh, s.sh_degree, s.campos, geom_buf, ctx.num_rendered,
+                       binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_flow_points, grad_semantic) = _call_with_dump(
+            _C.rasterize_gaussians_backward, native_args, s.debug, "snapshot_bw.dump", "backward")
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, grad_flow_points, grad_semantic, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
+                        semantic, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     flow_points, semantic, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of points passing the near-plane test for this camera (ref :196-205)."""
+        with torch.no_grad():
+            s = self.raster_settings
+            return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, flow_points=None, semantic=None):
+        # validation identical to ref :214-218 (neither shs nor colours is allowed)
+        if shs is not None and colors_precomp is not None:
+            raise Exception('Cannot provice both shs and colors_precomp')
+        has_sr = scales is not None and rotations is not None
+        any_sr = scales is not None or rotations is not None
+        if (not has_sr and cov3D_precomp is None) or (any_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        # absent optional inputs travel as empty CPU tensors, like the reference (:220-236)
+        empty = lambda t: torch.Tensor([]) if t is None else t
+        return rasterize_gaussians(means3D, means2D, empty(shs), empty(colors_precomp), opacities, empty(scales),
+                                   empty(rotations), empty(cov3D_precomp), empty(flow_points), empty(semantic),
+                                   self.raster_settings)

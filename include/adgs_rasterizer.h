@@ -1,0 +1,144 @@
+/*
+ * adgs_rasterizer.h -- C ABI of the MI355X-native AD-GS hot path (libadgs_hip.so).
+ *
+ * Drop-in boundary for the reference's native extension entry points.  Every
+ * function takes plain device pointers and sizes (no torch types) and enqueues
+ * its work on the HIP stream passed as `stream` (a hipStream_t, 0 = default
+ * stream).  "RAST/" = submodules/depth-diff-gaussian-rasterization, "KNN/" =
+ * submodules/simple-knn of the reference.
+ *
+ * Return value convention: >= 0 success (adgs_raster_forward returns
+ * num_rendered), < 0 failure; adgs_last_error() then returns a thread-local,
+ * NUL-terminated description.  The reference throws std::runtime_error instead
+ * (RAST/cuda_rasterizer/auxiliary.h:166-173, rasterizer_impl.cu:249-252).
+ *
+ * All float data is fp32.  Optional inputs are NULL (the reference passes the
+ * data pointer of an empty tensor, RAST/diff_gaussian_rasterization/__init__.py:220-236).
+ */
+#ifndef ADGS_RASTERIZER_H
+#define ADGS_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Replaces std::function<char*(size_t)> (RAST/cuda_rasterizer/rasterizer.h:26-28,
+ * RAST/rasterize_points.cu:27-33): must return a device buffer of at least
+ * `bytes` bytes that stays valid until the matching backward call. */
+typedef char* (*adgs_alloc_fn)(void* user, size_t bytes);
+
+const char* adgs_last_error(void);
+
+/* Library / device probe; returns 0 when a gfx950 device is usable. */
+int adgs_device_check(void);
+
+/* CudaRasterizer::Rasterizer::forward  (RAST/cuda_rasterizer/rasterizer.h:31-62,
+ * rasterizer_impl.cu:198-352).  Outputs must be zero-initialised by the caller
+ * (RAST/rasterize_points.cu:82-87).  Returns num_rendered. */
+int adgs_raster_forward(
+	adgs_alloc_fn geometryBuffer, void* geometryUser,
+	adgs_alloc_fn binningBuffer, void* binningUser,
+	adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S,
+	const float* background,
+	int width, int height,
+	const float* means3D,
+	const float* shs,
+	const float* colors_precomp,
+	const float* flow_points,
+	const float* semantic,
+	const float* opacities,
+	const float* scales,
+	float scale_modifier,
+	const float* rotations,
+	const float* cov3D_precomp,
+	const float* viewmatrix,
+	const float* projmatrix,
+	const float* cam_pos,
+	float tan_fovx, float tan_fovy,
+	int prefiltered,
+	float* out_color,
+	float* out_depth,
+	float* img_opacity,
+	float* img_flow,
+	float* img_semantic,
+	int inv_depth,
+	int* radii,
+	int debug,
+	void* stream);
+
+/* CudaRasterizer::Rasterizer::backward  (RAST/cuda_rasterizer/rasterizer.h:64-103,
+ * rasterizer_impl.cu:356-476).  All dL_* outputs must be zero-initialised by the
+ * caller (RAST/rasterize_points.cu:195-206).  Returns 0. */
+int adgs_raster_backward(
+	int P, int D, int M, int R, int D_S,
+	const float* background,
+	int width, int height,
+	const float* means3D,
+	const float* shs,
+	const float* colors_precomp,
+	const float* flow_points,
+	const float* semantic,
+	const float* scales,
+	float scale_modifier,
+	const float* rotations,
+	const float* cov3D_precomp,
+	const float* viewmatrix,
+	const float* projmatrix,
+	const float* campos,
+	float tan_fovx, float tan_fovy,
+	const int* radii,
+	char* geom_buffer,
+	char* binning_buffer,
+	char* img_buffer,
+	const float* dL_dpix,
+	const float* dL_dpix_depth,
+	const float* dL_dpix_flow,
+	const float* dL_dpix_semantic,
+	float* dL_dmean2D,
+	float* dL_dconic,
+	float* dL_dopacity,
+	float* dL_dcolor,
+	float* dL_ddepth,
+	float* dL_dmean3D,
+	float* dL_dcov3D,
+	float* dL_dsh,
+	float* dL_dscale,
+	float* dL_drot,
+	float* dL_dflow,
+	float* dL_dsemantic,
+	const float* grad_img_opacity,
+	const float* img_opacity,
+	int inv_depth,
+	int debug,
+	void* stream);
+
+/* CudaRasterizer::Rasterizer::markVisible (RAST/cuda_rasterizer/rasterizer.h:24-29,
+ * rasterizer_impl.cu:141-153).  `present` is a bool (1 byte) array of length P. */
+int adgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+	uint8_t* present, void* stream);
+
+/* SimpleKNN::knn (KNN/simple_knn.h:17-20, simple_knn.cu:185-221): mean squared
+ * distance to the 3 nearest other points.  `workspace` must hold
+ * adgs_knn_workspace_bytes(P) bytes of device memory. */
+size_t adgs_knn_workspace_bytes(int P);
+int adgs_knn_dist2(int P, const float* points, float* meanDists, char* workspace, void* stream);
+
+/* Statistics of the most recent adgs_raster_forward on this thread
+ * (P_visible, num_rendered, max tile-list length); host-side, for bench.py. */
+typedef struct adgs_frame_stats {
+	int64_t num_rendered;
+	int32_t tiles;
+	int32_t sort_bits;
+	int32_t sort_passes;
+	int32_t reserved;
+} adgs_frame_stats;
+void adgs_get_frame_stats(adgs_frame_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADGS_RASTERIZER_H */

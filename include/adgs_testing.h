@@ -1,0 +1,23 @@
+/*
+ * adgs_testing.h -- test-only entry points of libadgs_hip.so (device primitives that
+ * the rasterizer and kNN paths are built from).  Not part of the drop-in boundary;
+ * used by tests/ to check the hand-written scan / radix sort directly.
+ */
+#ifndef ADGS_TESTING_H
+#define ADGS_TESTING_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+size_t adgs_test_scan_temp_bytes(size_t n);
+/* out[i] = sum_{j<i} in[j]; in == out allowed */
+int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream);
+size_t adgs_test_sort_temp_bytes(size_t n);
+/* stable LSD radix sort on key bits [0,end_bit); *_in are clobbered */
+int adgs_test_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit, char* temp, void* stream);
+int adgs_test_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit, char* temp, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif
