@@ -32,6 +32,10 @@ SIGNATURES = {
     "adgs_knn_workspace_bytes": (ctypes.c_size_t, [c_i]),
     "adgs_knn_dist2": (c_i, [c_i, c_p, c_p, c_p, c_p]),
     "adgs_get_frame_stats": (None, [c_p]),
+    "adgs_profile_enable": (None, [c_i]),
+    "adgs_profile_num_stages": (c_i, []),
+    "adgs_profile_stage_name": (ctypes.c_char_p, [c_i]),
+    "adgs_profile_collect": (c_i, [c_p, c_p]),
     # include/adgs_testing.h
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),
@@ -78,3 +82,22 @@ def frame_stats():
     st = FrameStats()
     lib().adgs_get_frame_stats(ctypes.byref(st))
     return dict(num_rendered=int(st.num_rendered), tiles=int(st.tiles), sort_bits=int(st.sort_bits), sort_passes=int(st.sort_passes))
+
+
+class StageProfiler:
+    """Per-stage HIP-event timing of the native pipeline (bench.py)."""
+
+    def __init__(self):
+        self.lib = lib()
+        self.n = self.lib.adgs_profile_num_stages()
+        self.names = [self.lib.adgs_profile_stage_name(i).decode() for i in range(self.n)]
+        self.total = (ctypes.c_double * self.n)()
+        self.count = (ctypes.c_int64 * self.n)()
+
+    def enable(self, on=True):
+        self.lib.adgs_profile_enable(1 if on else 0)
+
+    def collect(self):
+        """Call after torch.cuda.synchronize(); returns {stage: (avg_ms, launches)}."""
+        self.lib.adgs_profile_collect(self.total, self.count)
+        return {self.names[i]: ((self.total[i] / self.count[i]) if self.count[i] else 0.0, int(self.count[i])) for i in range(self.n)}

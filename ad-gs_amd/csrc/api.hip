@@ -8,11 +8,12 @@
 #include "../../include/adgs_rasterizer.h"
 
 #include <mutex>
+#include <vector>
 
 namespace adgs {
 
 static thread_local std::string g_last_error;
-static thread_local adgs_frame_stats g_stats = { 0, 0, 0, 0, 0 };
+static adgs_frame_stats g_stats = { 0, 0, 0, 0, 0 };   // process-wide (autograd runs backward on its own thread)
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 // rasterizer_impl.cu:35-50 (next-highest bit of the MSB)
@@ -66,6 +67,29 @@ struct BinState {
 	}
 };
 
+// ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
+enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+static const char* const kStageNames[ST_COUNT] = { "preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
+	"render_fwd", "render_bwd", "preprocess_bwd" };
+struct ProfRec { int stage; hipEvent_t a, b; };
+// process-wide: torch.autograd calls the backward from its own worker thread
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+	hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+struct StageTimer {
+	bool on; ProfRec r; hipStream_t s;
+	StageTimer(int stage, hipStream_t stream) : on(g_prof_on), s(stream) {
+		if (on) { r.stage = stage; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, s); }
+	}
+	~StageTimer() { if (on) { (void)hipEventRecord(r.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back(r); } }
+};
+
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
 static uint32_t* pinned_word() {
@@ -81,6 +105,22 @@ using namespace adgs;
 extern "C" const char* adgs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_stats; }
+
+extern "C" void adgs_profile_enable(int on) { g_prof_on = on != 0; }
+extern "C" int adgs_profile_num_stages(void) { return ST_COUNT; }
+extern "C" const char* adgs_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+// Resolves all recorded (start, stop) event pairs: the caller must have synchronised the stream.
+// total_ms[i] += elapsed, counts[i] += launches; arrays have adgs_profile_num_stages() entries.
+extern "C" int adgs_profile_collect(double* total_ms, int64_t* counts) {
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	for (auto& r : g_prof_recs) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms[r.stage] += ms; counts[r.stage] += 1; }
+		g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b);
+	}
+	g_prof_recs.clear();
+	return 0;
+}
 
 extern "C" int adgs_device_check(void) {
 	int n = 0;
@@ -136,12 +176,15 @@ extern "C" int adgs_raster_forward(
 	pa.focal_x = width / (2.0f * tan_fovx);
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
-	if (launch_preprocess_fwd(pa, stream) != 0) return -1;
+	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	// tiles_touched[P] = 0 sentinel so that the exclusive scan yields the total at [P]
-	ADGS_HIP_CHECK(hipMemsetAsync(geom.tiles_touched + P, 0, sizeof(uint32_t), stream));
-	if (exclusive_scan_u32(geom.tiles_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
+	{
+		StageTimer t(ST_SCAN, stream);
+		ADGS_HIP_CHECK(hipMemsetAsync(geom.tiles_touched + P, 0, sizeof(uint32_t), stream));
+		if (exclusive_scan_u32(geom.tiles_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
+	}
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	uint32_t* host_word = pinned_word();
@@ -156,13 +199,16 @@ extern "C" int adgs_raster_forward(
 	if (!bchunk) { set_error("binning allocator returned NULL"); return -1; }
 	BinState bin = BinState::carve(bchunk, (size_t)num_rendered, nullptr);
 
-	if (launch_duplicate_keys(P, geom.splats, geom.offsets, radii, bin.keys_unsorted, bin.list_unsorted, gx, gy, stream) != 0) return -1;
+	{ StageTimer t(ST_DUPLICATE, stream);
+	  if (launch_duplicate_keys(P, geom.splats, geom.offsets, radii, bin.keys_unsorted, bin.list_unsorted, gx, gy, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 	const int bit = (int)higher_msb((uint32_t)ntiles);
-	if (radix_sort_pairs_u64(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, (size_t)num_rendered, 32 + bit, bin.sort_temp, stream) != 0) return -1;
+	{ StageTimer t(ST_SORT, stream);
+	  if (radix_sort_pairs_u64(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, (size_t)num_rendered, 32 + bit, bin.sort_temp, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
-	ADGS_HIP_CHECK(hipMemsetAsync(img.ranges, 0, ntiles * sizeof(uint2), stream));
-	if (launch_tile_ranges(num_rendered, bin.keys, img.ranges, stream) != 0) return -1;
+	{ StageTimer t(ST_RANGES, stream);
+	  ADGS_HIP_CHECK(hipMemsetAsync(img.ranges, 0, ntiles * sizeof(uint2), stream));
+	  if (launch_tile_ranges(num_rendered, bin.keys, img.ranges, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	RenderFwdArgs ra;
@@ -173,7 +219,7 @@ extern "C" int adgs_raster_forward(
 	ra.semantic = semantic; ra.bg = background;
 	ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 	ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
-	if (launch_render_fwd(ra, stream) != 0) return -1;
+	{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd(ra, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	g_stats.num_rendered = num_rendered; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
@@ -217,7 +263,7 @@ extern "C" int adgs_raster_backward(
 	ra.dL_dmean2D = dL_dmean2D; ra.dL_dconic = dL_dconic; ra.dL_dopacity = dL_dopacity; ra.dL_dcolor = dL_dcolor;
 	ra.dL_ddepth = dL_ddepth; ra.dL_dflow = dL_dflow; ra.dL_dsem = dL_dsemantic;
 	if (R > 0) {
-		if (launch_render_bwd(ra, stream) != 0) return -1;
+		{ StageTimer t(ST_RENDER_BWD, stream); if (launch_render_bwd(ra, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 	}
 
@@ -231,7 +277,7 @@ extern "C" int adgs_raster_backward(
 	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
 	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
 	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
-	if (launch_preprocess_bwd(pa, stream) != 0) return -1;
+	{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 	return 0;
 }

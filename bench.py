@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fwd+bwd frames/s of the AD-GS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config C3]
+
+One "step" = one frame = per-frame deformation (when the config has dynamic objects)
++ GaussianRasterizer forward + backward with non-zero upstream gradients on colour,
+depth, accumulated opacity, flow and semantic; loss and optimizer are
+excluded, as in BASELINE.md.  Inputs are synthetic (seeded) and resident
+in HBM before the timed region.  With N > 1 every rank (one process per GPU, launched by
+torch.distributed.run) renders its own camera of the same replicated scene and the
+parameter gradients are all-reduced over RCCL inside the step (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra
+objects: "roofline" for the dominant kernel (algorithmic bytes per launch / HIP-event
+time of that kernel) and "cpu_baseline" (the CPU oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
+    """Algorithmic bytes per launch of every stage."""
+    pay = 12 + 4 + 12 * F + 4 * D_S
+    return {
+        "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 4 + V * 68,
+        "scan": P * 8,
+        "duplicate_keys": V * 16 + R * 12,
+        "radix_sort": passes * R * 24 + R * 8,
+        "tile_ranges": R * 8 + T * 8,
+        "render_fwd": R * 28 + R * pay + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4),
+        "render_bwd": R * 28 + R * pay + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4) + V * (12 + 16 + 4 + 12 + 4 + 12 * F + 4 * D_S),
+        "preprocess_bwd": P * (12 + 12 + 16 + 4 + 12 * M) + V * (24 + 3 + 4) + V * (12 + 16 + 12 + 4) + P * (12 + 12 * M + 12 + 16),
+    }
+
+
+class StaticFrame:
+    """Per-frame work on already-deformed parameters: rasterizer forward (+ autograd backward)."""
+
+    deform_bytes = 0
+    deform_desc = "none (static, already activated parameters)"
+
+    def __init__(self, sc, rasterizer, device, use_flow_sem):
+        import torch
+        self.rast = rasterizer
+        self.leaf = {k: sc[k].to(device).clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        self.means2D = torch.zeros(sc["P"], 3, device=device, requires_grad=True)
+        self.flow = sc["flow_points"].to(device) if use_flow_sem else None
+        self.sem = sc["semantic"].to(device) if use_flow_sem else None
+        self.last_radii = None
+
+    def parameters(self):
+        return list(self.leaf.values())
+
+    def zero_grad(self):
+        for p in self.parameters():
+            p.grad = None
+        self.means2D.grad = None
+
+    def forward(self):
+        L = self.leaf
+        color, radii, depth, op, flow, sem = self.rast(
+            means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+            rotations=L["rotations"], flow_points=self.flow, semantic=self.sem)
+        self.last_radii = radii
+        return [color, depth, op] + ([flow, sem] if self.flow is not None else [])
+
+
+def cpu_baseline(sc, cam, cfg, use_fs, up):
+    """The CPU oracle (oracle/, a port of the reference kernels -- the reference has no CPU path)
+    timed on this host's cores for ONE frame of the same workload."""
+    import numpy as np
+    from oracle import oracle
+    H, W = cfg["H"], cfg["W"]
+    o = oracle.RasterOracle("f32")
+    t0 = time.perf_counter()
+    o.forward(sc["bg"], sc["means3D"], None, sc["opacities"], sc["scales"], sc["rotations"], 1.0, None, cam["viewmatrix"],
+              cam["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, sc["shs"], sc["flow_points"] if use_fs else None,
+              sc["semantic"] if use_fs else None, cfg["sh_degree"], cam["campos"], False, True)
+    t1 = time.perf_counter()
+    o.backward(up["color"], up["depth"], up["flow"] if use_fs else np.zeros((3, H, W), np.float32), up["semantic"] if use_fs else None,
+               up["img_opacity"])
+    t2 = time.perf_counter()
+    return {"value": round(1.0 / (t2 - t0), 5), "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "1 full frame (fwd %.2f s + bwd %.2f s) of the same scene and camera, OpenMP over Gaussians/tiles, "
+                      "g++ -O3 -fno-fast-math -ffp-contract=off" % (t1 - t0, t2 - t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flow-sem", action="store_true", help="render without the flow / semantic outputs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from adgs import _lib, synthetic, dp
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+    if _lib.lib().adgs_device_check() != 0:
+        raise SystemExit(_lib.last_error())
+
+    cfg = synthetic.CONFIGS[args.config]
+    sc = synthetic.make_config_scene(args.config)
+    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if world == 1 else rank)
+    H, W, P = cfg["H"], cfg["W"], cfg["P"]
+    use_fs = not args.no_flow_sem
+    d = lambda t: t.to(device)
+    settings = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], d(sc["bg"]), 1.0, d(cam["viewmatrix"]),
+                                             d(cam["projmatrix"]), cfg["sh_degree"], d(cam["campos"]), False, True, False)
+    rasterizer = GaussianRasterizer(settings)
+    frame = StaticFrame(sc, rasterizer, device, use_fs)
+    up = synthetic.make_upstream_grads(sc, 0)
+    up_list = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
+
+    def step():
+        outs = frame.forward()
+        torch.autograd.backward(outs, up_list)
+        if world > 1:
+            dp.allreduce_gradients(frame.parameters())
+        frame.zero_grad()
+
+    for _ in range(args.warmup):
+        step()
+    prof = _lib.StageProfiler()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof.enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof.enable(False)
+    stages = prof.collect()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        stats = _lib.frame_stats()
+        outs = frame.forward()
+        V = int((frame.last_radii > 0).sum().item())
+        R = stats["num_rendered"]
+        X, T = H * W, stats["tiles"]
+        M = sc["shs"].shape[1]
+        F, D_S = (1, 1) if use_fs else (0, 0)
+        ab = alg_bytes(P, V, R, X, T, M, F, D_S, stats["sort_passes"])
+        frame_bytes = sum(ab.values()) + frame.deform_bytes
+        dom = max(stages, key=lambda k: stages[k][0] * max(stages[k][1], 1) / max(args.steps, 1))
+        dom_ms = stages[dom][0]
+        achieved = ab.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        fps = args.steps * world / elapsed
+        result = {
+            "metric": "fwd+bwd frames/s",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, 1 camera/GPU/step" % (
+                args.config, P, W, H, cfg["sh_degree"], cfg["n_objects"], ", flow+semantic outputs" if use_fs else ""),
+                "P": P, "P_visible": V, "num_rendered": R, "R_over_P": round(R / max(P, 1), 2), "tiles": T,
+                "deformation": frame.deform_desc,
+                "parallelism": "dp%d (camera-parallel, RCCL gradient all-reduce)" % world if world > 1 else "single GPU",
+                "alg_bytes_per_frame": int(frame_bytes),
+                "frame_hbm_frac_of_8TBs": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4)},
+            "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sc, cam, cfg, use_fs, up)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,7 +127,7 @@ int adgs_mark_visible(int P, const float* means3D, const float* viewmatrix, cons
 size_t adgs_knn_workspace_bytes(int P);
 int adgs_knn_dist2(int P, const float* points, float* meanDists, char* workspace, void* stream);
 
-/* Statistics of the most recent adgs_raster_forward on this thread
+/* Statistics of the most recent adgs_raster_forward in this process
  * (P_visible, num_rendered, max tile-list length); host-side, for bench.py. */
 typedef struct adgs_frame_stats {
 	int64_t num_rendered;
@@ -137,6 +137,15 @@ typedef struct adgs_frame_stats {
 	int32_t reserved;
 } adgs_frame_stats;
 void adgs_get_frame_stats(adgs_frame_stats* out);
+
+/* Optional per-stage timing with HIP events recorded on the launch stream (used by bench.py
+ * for the roofline figure).  Process-wide.  adgs_profile_collect() must be called after the
+ * stream has been synchronised; it ADDS into total_ms[] / counts[] (adgs_profile_num_stages()
+ * entries each). */
+void adgs_profile_enable(int on);
+int adgs_profile_num_stages(void);
+const char* adgs_profile_stage_name(int stage);
+int adgs_profile_collect(double* total_ms, int64_t* counts);
 
 #ifdef __cplusplus
 }
