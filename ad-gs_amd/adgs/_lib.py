@@ -36,6 +36,11 @@ SIGNATURES = {
     "adgs_profile_num_stages": (c_i, []),
     "adgs_profile_stage_name": (ctypes.c_char_p, [c_i]),
     "adgs_profile_collect": (c_i, [c_p, c_p]),
+    # include/adgs_deform.h
+    "adgs_func_eval_forward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p]),
+    "adgs_func_eval_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_deform_forward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_deform_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     # include/adgs_testing.h
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),

@@ -1,0 +1,274 @@
+"""Per-frame deformation on the HIP path: drop-in `get_func_result` and a fused
+`get_deformed_pkg` for objects that carry the reference GaussianModel's raw parameters.
+
+Mirrors utils/func_utils.py:33-173 and scene/gaussian_model.py:88-231 of the reference.
+The time-dependent basis values are identical for all Gaussians; they are evaluated here on
+the host once per frame with the same float32 torch ops the reference uses, and handed to
+the HIP kernels (adgs_func_eval_* / adgs_deform_* in include/adgs_deform.h) that do the
+per-Gaussian work.  Both directions are hand-written HIP; there is no PyTorch fallback.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_TERMS = 48
+MAX_QUAT = 8
+
+
+class FuncEval(ctypes.Structure):
+    _fields_ = [("n_params", ctypes.c_int32), ("n_terms", ctypes.c_int32 * 3), ("index", ctypes.c_int32 * MAX_TERMS),
+                ("weight", ctypes.c_float * MAX_TERMS), ("quat_start", ctypes.c_int32), ("quat_k", ctypes.c_int32),
+                ("quat_cum", ctypes.c_float * MAX_QUAT)]
+
+
+_PTRS = ["scene_xyz", "obj_xyz", "scene_rotation", "obj_rotation", "scene_shs_dc", "obj_shs_dc", "scene_shs_rest", "obj_shs_rest",
+         "scene_opacity", "obj_opacity", "scene_scaling", "obj_scaling", "xyz_deform_param", "rotation_deform_param",
+         "shs_deform_param_scene", "shs_deform_param_obj", "background_deform_param", "gs_time", "gs_time_sigma"]
+
+
+class DeformParams(ctypes.Structure):
+    _fields_ = [("Ns", ctypes.c_int32), ("No", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32), ("use_time_mask", ctypes.c_int32),
+                ("t", ctypes.c_float)] + [(n, ctypes.c_void_p) for n in _PTRS]
+
+
+class DeformOutputs(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("xyz", "rotation", "shs", "opacity", "scales")]
+
+
+_GRADS = ["scene_xyz", "obj_xyz", "scene_rotation", "obj_rotation", "scene_shs_dc", "obj_shs_dc", "scene_shs_rest", "obj_shs_rest",
+          "scene_opacity", "obj_opacity", "scene_scaling", "obj_scaling", "xyz_deform_param", "rotation_deform_param",
+          "shs_deform_param_scene", "shs_deform_param_obj", "background_deform_param", "gs_time_sigma"]
+
+
+class DeformGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in _GRADS]
+
+
+_M_CACHE = {}
+
+
+def get_deboor_cox_mat(order):
+    """De Boor-Cox basis matrix of order k, (k+1)x(k+1) float32 (reference utils/func_utils.py:33-50)."""
+    if order in _M_CACHE:
+        return _M_CACHE[order]
+    if order == 0:
+        m = np.array([[1.0]], dtype=np.float32)
+    else:
+        prior = get_deboor_cox_mat(order - 1)
+        zrow = np.zeros((1, prior.shape[1]), dtype=np.float32)
+        lo, hi = np.concatenate([prior, zrow], 0), np.concatenate([zrow, prior], 0)
+        i = np.arange(order, dtype=np.int32)
+        a = np.zeros((order, order + 1), dtype=np.float32)
+        a[i, i] = i + 1
+        a[i, i + 1] = order - i - 1
+        b = np.zeros((order, order + 1), dtype=np.float32)
+        b[i, i] = -1
+        b[i, i + 1] = 1
+        m = (lo @ a + hi @ b) / order
+    _M_CACHE[order] = m
+    return m
+
+
+def get_param_num(args):
+    return args[0] + args[2] + 2 * args[3] + args[4]
+
+
+def _bspline_basis(u, order):
+    freq = torch.arange(0.0, order + 1.0, 1.0, dtype=torch.float32)
+    return (u ** freq) @ torch.tensor(get_deboor_cox_mat(order), dtype=torch.float32)
+
+
+def make_func_eval(v, order_args, n_params=None):
+    """Host-side evaluation of every basis value of get_func_result(v, ., order_args)."""
+    oa = list(order_args)
+    f = FuncEval()
+    f.n_params = int(get_param_num(oa) if n_params is None else n_params)
+    f.quat_start, f.quat_k = -1, 0
+    idx, wts, counts, offset = [], [], [0, 0, 0], 0
+    if oa[0] != 0:
+        interval = oa[0] - oa[1]
+        start = min(int(v * interval), interval - 1)
+        u = v * interval - start
+        b = _bspline_basis(u, oa[1])
+        idx += [start + offset + j for j in range(oa[1] + 1)]
+        wts += b.tolist()
+        counts[0] = oa[1] + 1
+        offset += oa[0]
+    if oa[2] != 0:
+        freq = torch.linspace(1.0, oa[2], oa[2], dtype=torch.float32)
+        idx += [offset + j for j in range(oa[2])]
+        wts += (v ** freq).tolist()
+        counts[1] = oa[2]
+        offset += oa[2]
+    if oa[3] != 0:
+        freq = torch.linspace(1.0, oa[3], oa[3], dtype=torch.float32) * np.pi
+        idx += [offset + j for j in range(2 * oa[3])]
+        wts += torch.cat([torch.sin(v * freq), torch.cos(v * freq)]).tolist()
+        counts[2] = 2 * oa[3]
+        offset += 2 * oa[3]
+    if oa[4] != 0:
+        interval = oa[4] - oa[5]
+        start = min(int(v * interval), interval - 1)
+        u = v * interval - start
+        b = _bspline_basis(u, oa[5])
+        cum = torch.flip(torch.cumsum(torch.flip(b, dims=(-1,)), dim=-1), dims=(-1,))[1:]
+        if oa[5] + 1 > MAX_QUAT:
+            raise ValueError("quaternion spline order %d not supported (max %d)" % (oa[5], MAX_QUAT - 1))
+        f.quat_start, f.quat_k = start + offset, oa[5]
+        for j, c in enumerate(cum.tolist()):
+            f.quat_cum[j] = c
+    if len(idx) > MAX_TERMS:
+        raise ValueError("too many basis terms (%d > %d)" % (len(idx), MAX_TERMS))
+    for j, (i, w) in enumerate(zip(idx, wts)):
+        f.index[j] = int(i)
+        f.weight[j] = float(w)
+    for j in range(3):
+        f.n_terms[j] = counts[j]
+    return f
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _dp(t):
+    return None if (t is None or t.numel() == 0) else t.data_ptr()
+
+
+class _FuncEvalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, param, feval):
+        if not param.is_cuda:
+            raise RuntimeError("get_func_result: param must be on a HIP device; there is no CPU path")
+        p = param.contiguous().float()
+        lead, D = p.shape[:-2], p.shape[-2]
+        N = int(np.prod(lead)) if len(lead) else 1
+        out = torch.empty(*lead, D, dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().adgs_func_eval_forward(N, D, p.data_ptr(), ctypes.byref(feval), out.data_ptr(), _stream(p.device)),
+                       "adgs_func_eval_forward")
+        ctx.save_for_backward(p)
+        ctx.feval, ctx.N, ctx.D = feval, N, D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        gp = torch.zeros_like(p)
+        g = g.contiguous().float()
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().adgs_func_eval_backward(ctx.N, ctx.D, p.data_ptr(), ctypes.byref(ctx.feval), g.data_ptr(), gp.data_ptr(),
+                                                          _stream(p.device)), "adgs_func_eval_backward")
+        return gp, None
+
+
+def get_func_result(v, param, order_args):
+    """Drop-in for utils.func_utils.get_func_result (reference :121-173): returns the python float
+    0.0 when every order is zero, else a tensor [..., D] differentiable w.r.t. `param`."""
+    if all(int(a) == 0 for a in order_args):
+        return 0.0
+    return _FuncEvalFn.apply(param, make_func_eval(float(v), order_args, param.shape[-1]))
+
+
+# ------------------------------------------------------------------ fused get_deformed_pkg
+_MODEL_ATTRS = {  # ctypes field -> reference GaussianModel attribute (scene/gaussian_model.py:47-84)
+    "scene_xyz": "_scene_xyz", "obj_xyz": "_obj_xyz", "scene_rotation": "_scene_rotation", "obj_rotation": "_obj_rotation",
+    "scene_shs_dc": "_scene_shs_dc", "obj_shs_dc": "_obj_shs_dc", "scene_shs_rest": "_scene_shs_rest", "obj_shs_rest": "_obj_shs_rest",
+    "scene_opacity": "_scene_opacity", "obj_opacity": "_obj_opacity", "scene_scaling": "_scene_scaling", "obj_scaling": "_obj_scaling",
+    "xyz_deform_param": "xyz_deform_param", "rotation_deform_param": "rotation_deform_param",
+    "shs_deform_param_scene": "shs_deform_param_scene", "shs_deform_param_obj": "shs_deform_param_obj",
+    "background_deform_param": "background_deform_param", "gs_time": "gs_time", "gs_time_sigma": "gs_time_sigma"}
+
+
+class _DeformPkgFn(torch.autograd.Function):
+    """19 raw parameter tensors -> (xyz, rotation, shs, opacity, scales)."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        t, order_args, use_time_mask, want = meta
+        ts = [None if x is None else x.contiguous() for x in tensors]
+        named = dict(zip(_PTRS, ts))
+        dev = named["scene_xyz"].device
+        if dev.type != "cuda":
+            raise RuntimeError("get_deformed_pkg: parameters must be on a HIP device; there is no CPU path")
+        Ns, No = named["scene_xyz"].shape[0], named["obj_xyz"].shape[0]
+        N = Ns + No
+        M = 1 + named["scene_shs_rest"].shape[1]
+        p = DeformParams()
+        p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)), float(t)
+        for n in _PTRS:
+            setattr(p, n, _dp(named[n]))
+        fe = {k: make_func_eval(float(t), order_args[k], named[pn].shape[-1] if named[pn] is not None and named[pn].numel() else 0)
+              for k, pn in (("xyz", "xyz_deform_param"), ("rotation", "rotation_deform_param"), ("shs", "shs_deform_param_scene"),
+                            ("background", "background_deform_param"))}
+        f32 = dict(dtype=torch.float32, device=dev)
+        outs = dict(xyz=torch.empty(N, 3, **f32) if "xyz" in want else None,
+                    rotation=torch.empty(N, 4, **f32) if "rotation" in want else None,
+                    shs=torch.empty(N, M, 3, **f32) if "shs" in want else None,
+                    opacity=torch.empty(N, 1, **f32) if "opacity" in want else None,
+                    scales=torch.empty(N, 3, **f32) if "scales" in want else None)
+        o = DeformOutputs()
+        for k, v in outs.items():
+            setattr(o, k, _dp(v))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().adgs_deform_forward(ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]),
+                                                      ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]), ctypes.byref(o),
+                                                      _stream(dev)), "adgs_deform_forward")
+        ctx.save_for_backward(*[x for x in ts if x is not None])
+        ctx.present = [x is not None for x in ts]
+        ctx.meta, ctx.fe, ctx.dims = meta, fe, (Ns, No, M)
+        order = ("xyz", "rotation", "shs", "opacity", "scales")
+        ctx.want = want
+        return tuple(outs[k] if outs[k] is not None else torch.empty(0, **f32) for k in order)
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_shs, g_op, g_sc):
+        t, order_args, use_time_mask, want = ctx.meta
+        saved = list(ctx.saved_tensors)
+        ts = [saved.pop(0) if pr else None for pr in ctx.present]
+        named = dict(zip(_PTRS, ts))
+        dev = named["scene_xyz"].device
+        Ns, No, M = ctx.dims
+        p = DeformParams()
+        p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)), float(t)
+        for n in _PTRS:
+            setattr(p, n, _dp(named[n]))
+        grads, gs = {}, DeformGrads()
+        for n in _GRADS:
+            src = named[n]
+            need = src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)]
+            grads[n] = torch.zeros_like(src) if need else None
+            setattr(gs, n, _dp(grads[n]))
+        up = {}
+        for k, g in (("xyz", g_xyz), ("rotation", g_rot), ("shs", g_shs), ("opacity", g_op), ("scales", g_sc)):
+            up[k] = g.contiguous().float() if (k in want and g is not None and g.numel() > 0) else None
+        fe = ctx.fe
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().adgs_deform_backward(ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]),
+                                                       ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]),
+                                                       _dp(up["xyz"]), _dp(up["rotation"]), _dp(up["shs"]), _dp(up["opacity"]), _dp(up["scales"]),
+                                                       ctypes.byref(gs), _stream(dev)), "adgs_deform_backward")
+        return (None,) + tuple(grads.get(n) for n in _PTRS)
+
+
+def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales")):
+    """Fused scene/gaussian_model.py:216-231 (+ get_scaling :89-91) on the raw parameters of `model`
+    (any object with the reference GaussianModel's attributes).  Returns the reference's dict
+    {'xyz','rotation','shs','opacity'} plus 'scales'."""
+    tensors = [getattr(model, _MODEL_ATTRS[n], None) for n in _PTRS]
+    meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want))
+    xyz, rot, shs, op, sc = _DeformPkgFn.apply(meta, *tensors)
+    out = {}
+    for k, v in (("xyz", xyz), ("rotation", rot), ("shs", shs), ("opacity", op), ("scales", sc)):
+        if k in want:
+            out[k] = v
+    return out
+
+
+def get_deformed_xyz(model, t):
+    """scene/gaussian_model.py:173-185 (used for the flow points at flow_time)."""
+    return get_deformed_pkg(model, t, want=("xyz",))["xyz"]

@@ -124,3 +124,18 @@ def make_upstream_grads(scene, seed=0, D_S=1):
     return dict(color=torch.randn(3, H, W, generator=g) / n, depth=torch.randn(1, H, W, generator=g) / n,
                 img_opacity=torch.randn(1, H, W, generator=g) / n, flow=torch.randn(3, H, W, generator=g) / n,
                 semantic=torch.randn(D_S, H, W, generator=g) / n)
+
+
+class CameraObject:
+    """The attributes gaussian_renderer.render() reads from the reference Camera (scene/cameras.py:17-100)."""
+
+    def __init__(self, W, H, fovx, fovy, view, full_proj, center, time):
+        self.image_width, self.image_height = W, H
+        self.FoVx, self.FoVy = fovx, fovy
+        self.world_view_transform, self.full_proj_transform, self.camera_center = view, full_proj, center
+        self.time = time
+
+
+def camera_object(cam, time=0.37):
+    """Wrap a make_camera()/make_scene() dict as a Camera-like object."""
+    return CameraObject(cam["W"], cam["H"], cam["fovx"], cam["fovy"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], time)

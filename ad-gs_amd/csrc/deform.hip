@@ -1,0 +1,510 @@
+// Fused per-frame deformation for gfx950: B-spline / polynomial / Fourier trajectories,
+// cumulative quaternion B-spline, scene||object concatenation and the activations
+// (exp, sigmoid x time mask, normalize) in ONE streaming pass, with a hand-written backward.
+//
+// Reference semantics: utils/func_utils.py:121-173 (get_func_result) and
+// scene/gaussian_model.py:88-231 (getters / get_deformed_pkg); the roma quaternion helpers
+// (unitquat_to_rotvec / rotvec_to_unitquat / quat_product, XYZW) are restated from the
+// library's published algorithm (see oracle/deform_oracle.py for the parity status).
+//
+// Roofline: HBM streaming.  Per Gaussian the forward reads the raw parameters once
+// (59 floats + deformation rows) and writes the 59 activated floats the rasterizer reads;
+// the backward reads the 59 upstream gradients and writes every parameter gradient.
+#include "common.h"
+#include "../../include/adgs_deform.h"
+#include <cstring>
+
+namespace adgs {
+namespace {
+
+constexpr int MAXQ = ADGS_FUNC_MAX_QUAT;     // control quaternions per evaluation: quat_k + 1 <= MAXQ
+
+struct Q { float w, x, y, z; };
+__device__ __forceinline__ Q qmul(const Q& a, const Q& b) {
+	Q c;
+	c.x = a.w * b.x + b.w * a.x + (a.y * b.z - a.z * b.y);
+	c.y = a.w * b.y + b.w * a.y + (a.z * b.x - a.x * b.z);
+	c.z = a.w * b.z + b.w * a.z + (a.x * b.y - a.y * b.x);
+	c.w = a.w * b.w - (a.x * b.x + a.y * b.y + a.z * b.z);
+	return c;
+}
+__device__ __forceinline__ Q qconj(const Q& a) { return { a.w, -a.x, -a.y, -a.z }; }
+__device__ __forceinline__ Q qadd(const Q& a, const Q& b) { return { a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ float qdot(const Q& a, const Q& b) { return a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// log map with shortest-arc flip (roma.unitquat_to_rotvec)
+struct LogSave { float f, a, m, wq; bool flip; float vx, vy, vz; };
+__device__ __forceinline__ void qlog(Q d, float* om, LogSave& s) {
+	s.flip = d.w < 0.f;
+	if (s.flip) { d.w = -d.w; d.x = -d.x; d.y = -d.y; d.z = -d.z; }
+	const float m = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+	const float a = 2.f * atan2f(m, d.w);
+	float f;
+	if (a <= 1e-3f) { const float a2 = a * a; f = 2.f + a2 / 12.f + 7.f * a2 * a2 / 2880.f; }
+	else f = a / sinf(a * 0.5f);
+	om[0] = f * d.x; om[1] = f * d.y; om[2] = f * d.z;
+	s.f = f; s.a = a; s.m = m; s.wq = d.w; s.vx = d.x; s.vy = d.y; s.vz = d.z;
+}
+__device__ __forceinline__ Q qlog_bwd(const LogSave& s, const float* g_om) {
+	const float a = s.a;
+	float fp;
+	if (a <= 1e-3f) fp = a / 6.f + 7.f * a * a * a / 720.f;
+	else { const float sh = sinf(a * 0.5f), ch = cosf(a * 0.5f); fp = (sh - 0.5f * a * ch) / (sh * sh); }
+	const float sdot = s.vx * g_om[0] + s.vy * g_om[1] + s.vz * g_om[2];
+	const float denom = s.m * s.m + s.wq * s.wq;
+	const float da_dm = 2.f * s.wq / denom, da_dw = -2.f * s.m / denom;
+	const float kv = (s.m > 0.f) ? fp * sdot * da_dm / s.m : 0.f;
+	Q g;
+	g.x = s.f * g_om[0] + kv * s.vx; g.y = s.f * g_om[1] + kv * s.vy; g.z = s.f * g_om[2] + kv * s.vz;
+	g.w = fp * sdot * da_dw;
+	if (s.flip) { g.w = -g.w; g.x = -g.x; g.y = -g.y; g.z = -g.z; }
+	return g;
+}
+// exp map (roma.rotvec_to_unitquat)
+__device__ __forceinline__ Q qexp(const float* rv, float& n_out, float& sc_out) {
+	const float n = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+	float sc;
+	if (n <= 1e-3f) { const float n2 = n * n; sc = 0.5f - n2 / 48.f + n2 * n2 / 3840.f; }
+	else sc = sinf(n * 0.5f) / n;
+	n_out = n; sc_out = sc;
+	return { cosf(n * 0.5f), sc * rv[0], sc * rv[1], sc * rv[2] };
+}
+__device__ __forceinline__ void qexp_bwd(const float* rv, float n, float sc, const Q& g, float* g_rv) {
+	float dsc_over_n, sinc;
+	if (n <= 1e-3f) { dsc_over_n = -1.f / 24.f + n * n / 960.f; sinc = (n > 0.f) ? sinf(n * 0.5f) / n : 0.5f; }
+	else { const float sh = sinf(n * 0.5f), ch = cosf(n * 0.5f); dsc_over_n = ((0.5f * ch * n - sh) / (n * n)) / n; sinc = sh / n; }
+	const float t = rv[0] * g.x + rv[1] * g.y + rv[2] * g.z;
+	const float k = dsc_over_n * t - 0.5f * sinc * g.w;
+	g_rv[0] = sc * g.x + rv[0] * k; g_rv[1] = sc * g.y + rv[1] * k; g_rv[2] = sc * g.z + rv[2] * k;
+}
+
+// ---- linear families: out = ((0 + bspline) + poly) + fft, each part summed in order ----
+__device__ __forceinline__ float lin_eval(const float* __restrict__ row, const adgs_func_eval& f) {
+	float result = 0.f;
+	int i = 0;
+#pragma unroll
+	for (int part = 0; part < 3; part++) {
+		const int cnt = f.n_terms[part];
+		if (cnt > 0) {
+			float s = 0.f;
+			for (int k = 0; k < cnt; k++, i++) s += row[f.index[i]] * f.weight[i];
+			result = result + s;
+		}
+	}
+	return result;
+}
+__device__ __forceinline__ void lin_bwd(float* __restrict__ grow, const adgs_func_eval& f, float g) {
+	const int total = f.n_terms[0] + f.n_terms[1] + f.n_terms[2];
+	for (int i = 0; i < total; i++) grow[f.index[i]] = f.weight[i] * g;
+}
+__device__ __forceinline__ bool has_lin(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0; }
+
+// ---- cumulative quaternion B-spline (func_utils.py:156-171), wxyz in / wxyz out ----
+// param block of one Gaussian: [4][n_params]
+__device__ __forceinline__ Q quat_spline_fwd(const float* __restrict__ p, const adgs_func_eval& f) {
+	const int kq = f.quat_k, np = f.n_params, c0 = f.quat_start;
+	Q ctrl_prev, acc;
+	{
+		Q c = { p[0 * np + c0] + 1.0f, p[1 * np + c0], p[2 * np + c0], p[3 * np + c0] };
+		const float inv = 1.f / fmaxf(sqrtf(qdot(c, c)), 1e-12f);
+		ctrl_prev = { c.w * inv, c.x * inv, c.y * inv, c.z * inv };
+		acc = ctrl_prev;
+	}
+	for (int j = 1; j <= kq; j++) {
+		Q c = { p[0 * np + c0 + j] + 1.0f, p[1 * np + c0 + j], p[2 * np + c0 + j], p[3 * np + c0 + j] };
+		const float inv = 1.f / fmaxf(sqrtf(qdot(c, c)), 1e-12f);
+		const Q q = { c.w * inv, c.x * inv, c.y * inv, c.z * inv };
+		float om[3]; LogSave ls;
+		qlog(qmul(qconj(ctrl_prev), q), om, ls);
+		const float B = f.quat_cum[j - 1];
+		float rv[3] = { om[0] * B, om[1] * B, om[2] * B };
+		float n, sc;
+		acc = qmul(acc, qexp(rv, n, sc));
+		ctrl_prev = q;
+	}
+	return acc;
+}
+
+// backward: writes d/dparam of (g . out) into gp [4][n_params] (columns c0..c0+kq), ASSIGNING
+__device__ __forceinline__ void quat_spline_bwd(const float* __restrict__ p, const adgs_func_eval& f, const Q& g_out, float* __restrict__ gp) {
+	const int kq = f.quat_k, np = f.n_params, c0 = f.quat_start;
+	Q q[MAXQ]; float nrm[MAXQ];
+	Q r[MAXQ]; float rv[MAXQ][3], rn[MAXQ], rsc[MAXQ]; LogSave ls[MAXQ];
+	Q part[MAXQ];               // part[j] = q0 * r1 * ... * rj
+#pragma unroll
+	for (int j = 0; j < MAXQ; j++) {
+		if (j <= kq) {
+			Q c = { p[0 * np + c0 + j] + 1.0f, p[1 * np + c0 + j], p[2 * np + c0 + j], p[3 * np + c0 + j] };
+			nrm[j] = fmaxf(sqrtf(qdot(c, c)), 1e-12f);
+			const float inv = 1.f / nrm[j];
+			q[j] = { c.w * inv, c.x * inv, c.y * inv, c.z * inv };
+		}
+	}
+	part[0] = q[0];
+#pragma unroll
+	for (int j = 1; j < MAXQ; j++) {
+		if (j <= kq) {
+			float om[3];
+			qlog(qmul(qconj(q[j - 1]), q[j]), om, ls[j]);
+			const float B = f.quat_cum[j - 1];
+			rv[j][0] = om[0] * B; rv[j][1] = om[1] * B; rv[j][2] = om[2] * B;
+			r[j] = qexp(rv[j], rn[j], rsc[j]);
+			part[j] = qmul(part[j - 1], r[j]);
+		}
+	}
+	Q gq[MAXQ];
+#pragma unroll
+	for (int j = 0; j < MAXQ; j++) gq[j] = { 0.f, 0.f, 0.f, 0.f };
+	Q G = g_out;                 // gradient w.r.t. part[kq]
+#pragma unroll
+	for (int j = MAXQ - 1; j >= 1; j--) {
+		if (j <= kq) {
+			const Q g_r = qmul(qconj(part[j - 1]), G);       // d(part[j-1] * r_j)/d r_j
+			G = qmul(G, qconj(r[j]));                        // -> gradient w.r.t. part[j-1]
+			float g_rv[3];
+			qexp_bwd(rv[j], rn[j], rsc[j], g_r, g_rv);
+			const float B = f.quat_cum[j - 1];
+			float g_om[3] = { g_rv[0] * B, g_rv[1] * B, g_rv[2] * B };
+			const Q g_d = qlog_bwd(ls[j], g_om);             // gradient w.r.t. delta_j = conj(q_{j-1}) * q_j
+			gq[j] = qadd(gq[j], qmul(q[j - 1], g_d));        // L(conj(q_{j-1}))^T g = q_{j-1} * g
+			gq[j - 1] = qadd(gq[j - 1], qconj(qmul(g_d, qconj(q[j]))));   // through the conjugation
+		}
+	}
+	gq[0] = qadd(gq[0], G);
+#pragma unroll
+	for (int j = 0; j < MAXQ; j++) {
+		if (j <= kq) {
+			const float d = qdot(q[j], gq[j]);
+			const float inv = 1.f / nrm[j];
+			gp[0 * np + c0 + j] = (gq[j].w - q[j].w * d) * inv;
+			gp[1 * np + c0 + j] = (gq[j].x - q[j].x * d) * inv;
+			gp[2 * np + c0 + j] = (gq[j].y - q[j].y * d) * inv;
+			gp[3 * np + c0 + j] = (gq[j].z - q[j].z * d) * inv;
+		}
+	}
+}
+
+// ------------------------------------------------------------------ generic get_func_result
+template <int D>
+__global__ void __launch_bounds__(256) func_eval_fwd_kernel(int N, const float* __restrict__ param, adgs_func_eval f, float* __restrict__ out) {
+	const int n = blockIdx.x * blockDim.x + threadIdx.x;
+	if (n >= N) return;
+	const float* p = param + (size_t)n * D * f.n_params;
+	float res[D];
+#pragma unroll
+	for (int d = 0; d < D; d++) res[d] = lin_eval(p + d * f.n_params, f);
+	if (D == 4 && f.quat_start >= 0) {
+		const Q qv = quat_spline_fwd(p, f);
+		res[0] = res[0] + qv.w; res[1] = res[1] + qv.x; res[2] = res[2] + qv.y; res[3 % D] = res[3 % D] + qv.z;
+	}
+#pragma unroll
+	for (int d = 0; d < D; d++) out[(size_t)n * D + d] = res[d];
+}
+template <int D>
+__global__ void __launch_bounds__(256) func_eval_bwd_kernel(int N, const float* __restrict__ param, adgs_func_eval f,
+	const float* __restrict__ dL_dout, float* __restrict__ dL_dparam) {
+	const int n = blockIdx.x * blockDim.x + threadIdx.x;
+	if (n >= N) return;
+	const float* p = param + (size_t)n * D * f.n_params;
+	float* gp = dL_dparam + (size_t)n * D * f.n_params;
+	float g[D];
+#pragma unroll
+	for (int d = 0; d < D; d++) { g[d] = dL_dout[(size_t)n * D + d]; lin_bwd(gp + d * f.n_params, f, g[d]); }
+	if (D == 4 && f.quat_start >= 0) quat_spline_bwd(p, f, { g[0], g[1], g[2], g[3 % D] }, gp);
+}
+
+// ------------------------------------------------------------------ fused get_deformed_pkg
+struct DeformArgs {
+	adgs_deform_params p; adgs_func_eval fx, fr, fs, fb; adgs_deform_outputs o;
+};
+
+__global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
+	const int n = blockIdx.x * blockDim.x + threadIdx.x;
+	const int Ns = a.p.Ns, N = a.p.Ns + a.p.No;
+	if (n >= N) return;
+	const bool is_obj = n >= Ns;
+	const int m = is_obj ? n - Ns : n;
+	// ---- xyz (gaussian_model.py:173-185)
+	if (a.o.xyz) {
+		float bg[3] = { 0.f, 0.f, 0.f };
+		if (a.p.background_deform_param && has_lin(a.fb)) {
+#pragma unroll
+			for (int d = 0; d < 3; d++) bg[d] = lin_eval(a.p.background_deform_param + d * a.fb.n_params, a.fb);
+		}
+		const float* base = is_obj ? a.p.obj_xyz + 3 * (size_t)m : a.p.scene_xyz + 3 * (size_t)m;
+#pragma unroll
+		for (int d = 0; d < 3; d++) {
+			float v = base[d];
+			if (is_obj && a.p.xyz_deform_param && has_lin(a.fx))
+				v = v + lin_eval(a.p.xyz_deform_param + ((size_t)m * 3 + d) * a.fx.n_params, a.fx);
+			a.o.xyz[3 * (size_t)n + d] = v + bg[d];
+		}
+	}
+	// ---- rotation (gaussian_model.py:187-196): normalize(cat(scene_rot, obj_rot))
+	if (a.o.rotation) {
+		float u[4];
+		if (!is_obj) {
+#pragma unroll
+			for (int d = 0; d < 4; d++) u[d] = a.p.scene_rotation[4 * (size_t)m + d];
+		} else {
+			const float* rp = a.p.rotation_deform_param ? a.p.rotation_deform_param + (size_t)m * 4 * a.fr.n_params : nullptr;
+			float fv[4] = { 0.f, 0.f, 0.f, 0.f };
+			if (rp) {
+#pragma unroll
+				for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * a.fr.n_params, a.fr);
+				if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
+			}
+			if (a.fr.quat_start >= 0) {
+#pragma unroll
+				for (int d = 0; d < 4; d++) u[d] = fv[d];          // quaternion spline replaces _obj_rotation (:189-190)
+			} else {
+#pragma unroll
+				for (int d = 0; d < 4; d++) u[d] = a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
+			}
+		}
+		const float inv = 1.f / fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]), 1e-12f);
+		*reinterpret_cast<float4*>(a.o.rotation + 4 * (size_t)n) = make_float4(u[0] * inv, u[1] * inv, u[2] * inv, u[3] * inv);
+	}
+	// ---- shs (gaussian_model.py:198-205)
+	if (a.o.shs) {
+		const int M = a.p.sh_coeffs;
+		const float* dc = is_obj ? a.p.obj_shs_dc + 3 * (size_t)m : a.p.scene_shs_dc + 3 * (size_t)m;
+		const float* sp = is_obj ? a.p.shs_deform_param_obj : a.p.shs_deform_param_scene;
+		float* o = a.o.shs + (size_t)n * M * 3;
+#pragma unroll
+		for (int d = 0; d < 3; d++) {
+			float v = dc[d];
+			if (sp && has_lin(a.fs)) v = v + lin_eval(sp + ((size_t)m * 3 + d) * a.fs.n_params, a.fs);
+			o[d] = v;
+		}
+		const float* rest = is_obj ? a.p.obj_shs_rest + (size_t)m * (M - 1) * 3 : a.p.scene_shs_rest + (size_t)m * (M - 1) * 3;
+		for (int k = 0; k < (M - 1) * 3; k++) o[3 + k] = rest[k];
+	}
+	// ---- opacity (gaussian_model.py:207-214)
+	if (a.o.opacity) {
+		const float x = is_obj ? a.p.obj_opacity[m] : a.p.scene_opacity[m];
+		float o = 1.f / (1.f + expf(-x));
+		if (is_obj && a.p.use_time_mask) {
+			const float dt = a.p.t - a.p.gs_time[m];
+			const float sig = expf(dt < 0.f ? a.p.gs_time_sigma[2 * (size_t)m] : a.p.gs_time_sigma[2 * (size_t)m + 1]);
+			const float r = dt / sig;
+			o = o * expf(-0.5f * (r * r));
+		}
+		a.o.opacity[n] = o;
+	}
+	// ---- scales (gaussian_model.py:89-91)
+	if (a.o.scales) {
+		const float* s = is_obj ? a.p.obj_scaling + 3 * (size_t)m : a.p.scene_scaling + 3 * (size_t)m;
+#pragma unroll
+		for (int d = 0; d < 3; d++) a.o.scales[3 * (size_t)n + d] = expf(s[d]);
+	}
+}
+
+struct DeformBwdArgs {
+	adgs_deform_params p; adgs_func_eval fx, fr, fs, fb;
+	const float *g_xyz, *g_rot, *g_shs, *g_op, *g_sc;
+	adgs_deform_grads g;
+};
+
+__global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
+	__shared__ float s_bg[3][256 / WAVE];
+	const int n = blockIdx.x * blockDim.x + threadIdx.x;
+	const int Ns = a.p.Ns, N = a.p.Ns + a.p.No;
+	const bool valid = n < N;
+	const bool is_obj = valid && n >= Ns;
+	const int m = is_obj ? n - Ns : n;
+	// ---- xyz
+	float gx[3] = { 0.f, 0.f, 0.f };
+	if (valid && a.g_xyz) {
+#pragma unroll
+		for (int d = 0; d < 3; d++) gx[d] = a.g_xyz[3 * (size_t)n + d];
+	}
+	if (valid) {
+		float* dst = is_obj ? (a.g.obj_xyz ? a.g.obj_xyz + 3 * (size_t)m : nullptr) : (a.g.scene_xyz ? a.g.scene_xyz + 3 * (size_t)m : nullptr);
+		if (dst) { dst[0] = gx[0]; dst[1] = gx[1]; dst[2] = gx[2]; }
+		if (is_obj && a.g.xyz_deform_param) {
+#pragma unroll
+			for (int d = 0; d < 3; d++) lin_bwd(a.g.xyz_deform_param + ((size_t)m * 3 + d) * a.fx.n_params, a.fx, gx[d]);
+		}
+	}
+	// background: the same [1,3,Cb] row is added to every Gaussian -> reduce g over all n
+	if (a.g.background_deform_param && has_lin(a.fb)) {
+#pragma unroll
+		for (int d = 0; d < 3; d++) {
+			float v = gx[d];
+#pragma unroll
+			for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+			if ((threadIdx.x & (WAVE - 1)) == 0) s_bg[d][threadIdx.x / WAVE] = v;
+		}
+		__syncthreads();
+		if (threadIdx.x < 3) {
+			float v = 0.f;
+			for (int w = 0; w < 256 / WAVE; w++) v += s_bg[threadIdx.x][w];
+			const int total = a.fb.n_terms[0] + a.fb.n_terms[1] + a.fb.n_terms[2];
+			for (int i = 0; i < total; i++)
+				atomicAdd(a.g.background_deform_param + threadIdx.x * a.fb.n_params + a.fb.index[i], a.fb.weight[i] * v);
+		}
+	}
+	if (!valid) return;
+	// ---- rotation: r = u / |u|
+	if (a.g_rot) {
+		float u[4];
+		const float* rp = (is_obj && a.p.rotation_deform_param) ? a.p.rotation_deform_param + (size_t)m * 4 * a.fr.n_params : nullptr;
+		if (!is_obj) {
+#pragma unroll
+			for (int d = 0; d < 4; d++) u[d] = a.p.scene_rotation[4 * (size_t)m + d];
+		} else {
+			float fv[4] = { 0.f, 0.f, 0.f, 0.f };
+			if (rp) {
+#pragma unroll
+				for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * a.fr.n_params, a.fr);
+				if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
+			}
+#pragma unroll
+			for (int d = 0; d < 4; d++) u[d] = (a.fr.quat_start >= 0) ? fv[d] : a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
+		}
+		const float nr = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
+		const float inv = 1.f / fmaxf(nr, 1e-12f);
+		float g[4], r[4], dot = 0.f;
+#pragma unroll
+		for (int d = 0; d < 4; d++) { g[d] = a.g_rot[4 * (size_t)n + d]; r[d] = u[d] * inv; dot += r[d] * g[d]; }
+		float gu[4];
+#pragma unroll
+		for (int d = 0; d < 4; d++) gu[d] = (nr > 1e-12f) ? (g[d] - r[d] * dot) * inv : g[d] * inv;
+		if (!is_obj) {
+			if (a.g.scene_rotation) *reinterpret_cast<float4*>(a.g.scene_rotation + 4 * (size_t)m) = make_float4(gu[0], gu[1], gu[2], gu[3]);
+		} else {
+			if (a.g.obj_rotation) {
+				const float k = (a.fr.quat_start >= 0) ? 0.f : 1.f;
+				*reinterpret_cast<float4*>(a.g.obj_rotation + 4 * (size_t)m) = make_float4(k * gu[0], k * gu[1], k * gu[2], k * gu[3]);
+			}
+			if (a.g.rotation_deform_param && rp) {
+				float* gp = a.g.rotation_deform_param + (size_t)m * 4 * a.fr.n_params;
+#pragma unroll
+				for (int d = 0; d < 4; d++) lin_bwd(gp + d * a.fr.n_params, a.fr, gu[d]);
+				if (a.fr.quat_start >= 0) quat_spline_bwd(rp, a.fr, { gu[0], gu[1], gu[2], gu[3] }, gp);
+			}
+		}
+	}
+	// ---- shs
+	if (a.g_shs) {
+		const int M = a.p.sh_coeffs;
+		const float* gs = a.g_shs + (size_t)n * M * 3;
+		float* gdc = is_obj ? (a.g.obj_shs_dc ? a.g.obj_shs_dc + 3 * (size_t)m : nullptr) : (a.g.scene_shs_dc ? a.g.scene_shs_dc + 3 * (size_t)m : nullptr);
+		float* gsp = is_obj ? a.g.shs_deform_param_obj : a.g.shs_deform_param_scene;
+#pragma unroll
+		for (int d = 0; d < 3; d++) {
+			const float v = gs[d];
+			if (gdc) gdc[d] = v;
+			if (gsp) lin_bwd(gsp + ((size_t)m * 3 + d) * a.fs.n_params, a.fs, v);
+		}
+		float* grest = is_obj ? (a.g.obj_shs_rest ? a.g.obj_shs_rest + (size_t)m * (M - 1) * 3 : nullptr)
+		                      : (a.g.scene_shs_rest ? a.g.scene_shs_rest + (size_t)m * (M - 1) * 3 : nullptr);
+		if (grest) for (int k = 0; k < (M - 1) * 3; k++) grest[k] = gs[3 + k];
+	}
+	// ---- opacity
+	if (a.g_op) {
+		const float g = a.g_op[n];
+		const float x = is_obj ? a.p.obj_opacity[m] : a.p.scene_opacity[m];
+		const float sg = 1.f / (1.f + expf(-x));
+		float mask = 1.f;
+		if (is_obj && a.p.use_time_mask) {
+			const float dt = a.p.t - a.p.gs_time[m];
+			const bool neg = dt < 0.f;
+			const float sig = expf(neg ? a.p.gs_time_sigma[2 * (size_t)m] : a.p.gs_time_sigma[2 * (size_t)m + 1]);
+			const float r = dt / sig;
+			mask = expf(-0.5f * (r * r));
+			if (a.g.gs_time_sigma) {
+				const float gsel = g * sg * mask * (r * r);      // d mask / d log-sigma = mask * (dt/sigma)^2
+				a.g.gs_time_sigma[2 * (size_t)m] = neg ? gsel : 0.f;
+				a.g.gs_time_sigma[2 * (size_t)m + 1] = neg ? 0.f : gsel;
+			}
+		} else if (is_obj && a.g.gs_time_sigma) {
+			a.g.gs_time_sigma[2 * (size_t)m] = 0.f; a.g.gs_time_sigma[2 * (size_t)m + 1] = 0.f;
+		}
+		float* dst = is_obj ? a.g.obj_opacity : a.g.scene_opacity;
+		if (dst) dst[m] = g * mask * sg * (1.f - sg);
+	}
+	// ---- scales
+	if (a.g_sc) {
+		const float* s = is_obj ? a.p.obj_scaling + 3 * (size_t)m : a.p.scene_scaling + 3 * (size_t)m;
+		float* dst = is_obj ? (a.g.obj_scaling ? a.g.obj_scaling + 3 * (size_t)m : nullptr) : (a.g.scene_scaling ? a.g.scene_scaling + 3 * (size_t)m : nullptr);
+		if (dst) {
+#pragma unroll
+			for (int d = 0; d < 3; d++) dst[d] = a.g_sc[3 * (size_t)n + d] * expf(s[d]);
+		}
+	}
+}
+
+static adgs_func_eval empty_func() { adgs_func_eval f; memset(&f, 0, sizeof(f)); f.quat_start = -1; return f; }
+static int check_func(const adgs_func_eval* f, const char* what) {
+	if (!f) return 0;
+	const int total = f->n_terms[0] + f->n_terms[1] + f->n_terms[2];
+	if (total < 0 || total > ADGS_FUNC_MAX_TERMS) { set_error(std::string(what) + ": too many basis terms"); return -1; }
+	for (int i = 0; i < total; i++) if (f->index[i] < 0 || f->index[i] >= f->n_params) { set_error(std::string(what) + ": term index out of range"); return -1; }
+	if (f->quat_start >= 0 && (f->quat_k + 1 > MAXQ || f->quat_k < 0 || f->quat_start + f->quat_k >= f->n_params)) {
+		set_error(std::string(what) + ": quaternion spline window out of range"); return -1;
+	}
+	return 0;
+}
+
+} // namespace
+} // namespace adgs
+
+using namespace adgs;
+
+extern "C" int adgs_func_eval_forward(int N, int D, const float* param, const adgs_func_eval* f, float* out, void* stream_) {
+	if (N <= 0) return 0;
+	if (!param || !f || !out || (D != 3 && D != 4)) { set_error("adgs_func_eval_forward: bad arguments"); return -1; }
+	if (check_func(f, "adgs_func_eval_forward") != 0) return -1;
+	if (D == 3 && f->quat_start >= 0) { set_error("quaternion spline needs D == 4"); return -1; }
+	hipStream_t stream = (hipStream_t)stream_;
+	if (D == 3) hipLaunchKernelGGL(func_eval_fwd_kernel<3>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, out);
+	else hipLaunchKernelGGL(func_eval_fwd_kernel<4>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, out);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int adgs_func_eval_backward(int N, int D, const float* param, const adgs_func_eval* f, const float* dL_dout, float* dL_dparam, void* stream_) {
+	if (N <= 0) return 0;
+	if (!param || !f || !dL_dout || !dL_dparam || (D != 3 && D != 4)) { set_error("adgs_func_eval_backward: bad arguments"); return -1; }
+	if (check_func(f, "adgs_func_eval_backward") != 0) return -1;
+	hipStream_t stream = (hipStream_t)stream_;
+	if (D == 3) hipLaunchKernelGGL(func_eval_bwd_kernel<3>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, dL_dout, dL_dparam);
+	else hipLaunchKernelGGL(func_eval_bwd_kernel<4>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, dL_dout, dL_dparam);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int adgs_deform_forward(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_deform_outputs* out, void* stream_) {
+	if (!p || !out) { set_error("adgs_deform_forward: NULL params/outputs"); return -1; }
+	const int N = p->Ns + p->No;
+	if (N <= 0) return 0;
+	if (check_func(f_xyz, "f_xyz") || check_func(f_rotation, "f_rotation") || check_func(f_shs, "f_shs") || check_func(f_background, "f_background")) return -1;
+	DeformArgs a;
+	a.p = *p; a.o = *out;
+	a.fx = f_xyz ? *f_xyz : empty_func(); a.fr = f_rotation ? *f_rotation : empty_func();
+	a.fs = f_shs ? *f_shs : empty_func(); a.fb = f_background ? *f_background : empty_func();
+	hipLaunchKernelGGL(deform_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int adgs_deform_backward(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background,
+	const float* dL_dxyz, const float* dL_drotation, const float* dL_dshs, const float* dL_dopacity, const float* dL_dscales,
+	const adgs_deform_grads* grads, void* stream_) {
+	if (!p || !grads) { set_error("adgs_deform_backward: NULL params/grads"); return -1; }
+	const int N = p->Ns + p->No;
+	if (N <= 0) return 0;
+	if (check_func(f_xyz, "f_xyz") || check_func(f_rotation, "f_rotation") || check_func(f_shs, "f_shs") || check_func(f_background, "f_background")) return -1;
+	DeformBwdArgs a;
+	a.p = *p; a.g = *grads;
+	a.fx = f_xyz ? *f_xyz : empty_func(); a.fr = f_rotation ? *f_rotation : empty_func();
+	a.fs = f_shs ? *f_shs : empty_func(); a.fb = f_background ? *f_background : empty_func();
+	a.g_xyz = dL_dxyz; a.g_rot = dL_drotation; a.g_shs = dL_dshs; a.g_op = dL_dopacity; a.g_sc = dL_dscales;
+	hipLaunchKernelGGL(deform_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}

@@ -49,7 +49,8 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
     foreground, radii, depth, img_opacity, img_flow, img_semantic = rasterizer(
         means3D=deform_pkg['xyz'], means2D=screenspace_points,
         shs=deform_pkg['shs'] if override_color is None else None, colors_precomp=override_color,
-        opacities=deform_pkg['opacity'], scales=pc.get_scaling, rotations=deform_pkg['rotation'],
+        opacities=deform_pkg['opacity'], scales=deform_pkg['scales'] if 'scales' in deform_pkg else pc.get_scaling,
+        rotations=deform_pkg['rotation'],
         flow_points=flow_points, semantic=semantic)
 
     if env_map is not None:
