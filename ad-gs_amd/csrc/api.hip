@@ -9,6 +9,8 @@
 
 #include <mutex>
 #include <vector>
+#include <cstdlib>
+#include <algorithm>
 
 namespace adgs {
 
@@ -66,6 +68,68 @@ struct BinState {
 		return b;
 	}
 };
+
+// ---- v2 (coarse-binned) state ----
+struct GeomStateV2 {
+	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; uint2* rects;
+	float* gacc; char* scan_temp;
+	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
+		Carver c(chunk); GeomStateV2 g;
+		g.splats = c.take<Splat>(P);
+		g.gacc = c.take<float>(P * GACC_STRIDE);
+		g.cov3D = c.take<float>(P * 6);
+		g.rects = c.take<uint2>(P);
+		g.clamped = c.take<uint8_t>(P);
+		g.cells_touched = c.take<uint32_t>(P + 1);
+		g.offsets = c.take<uint32_t>(P + 1);
+		g.fine_touched = c.take<uint32_t>(P + 1);
+		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
+		if (bytes) *bytes = c.size();
+		return g;
+	}
+};
+struct ImgStateV2 {
+	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed;
+	static ImgStateV2 carve(char* chunk, size_t npix, size_t ntiles, size_t ncells, size_t* bytes) {
+		Carver c(chunk); ImgStateV2 s;
+		s.n_contrib = c.take<uint32_t>(npix);
+		s.cell_ranges = c.take<uint2>(ncells);
+		s.tile_last_chunk = c.take<uint32_t>(ntiles);
+		s.tile_consumed = c.take<uint32_t>(ntiles);
+		if (bytes) *bytes = c.size();
+		return s;
+	}
+};
+struct BinStateV2 {
+	uint32_t* pool_cursor; uint32_t* pool;     // first, so that the backward finds them without knowing the sizes
+	uint64_t* keys_unsorted; uint64_t* keys; uint32_t* list_unsorted; uint32_t* list; char* sort_temp;
+	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + ntiles + 1; }
+	static BinStateV2 carve(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
+		Carver c(chunk); BinStateV2 b;
+		b.pool_cursor = c.take<uint32_t>(64);
+		b.pool = c.take<uint32_t>(pool_chunks(R_fine, ntiles) * CHUNK_WORDS);
+		b.list = c.take<uint32_t>(R_cells);
+		b.list_unsorted = c.take<uint32_t>(R_cells);
+		b.keys = c.take<uint64_t>(R_cells);
+		b.keys_unsorted = c.take<uint64_t>(R_cells);
+		b.sort_temp = c.take<char>(sort_temp_bytes(R_cells));
+		if (bytes) *bytes = c.size();
+		return b;
+	}
+};
+
+static int env_int(const char* name, int dflt) {
+	const char* v = getenv(name);
+	return (v && *v) ? atoi(v) : dflt;
+}
+// "classic" reproduces the reference pipeline stage by stage (full (tile|depth) sort, num_rendered
+// equal to the reference's); "v2" (default) is the coarse-binned lazy pipeline.  Multi-channel
+// semantics (D_S > 1) always take the classic kernels.
+static bool use_v2(int D_S) {
+	const char* m = getenv("ADGS_RASTER_MODE");
+	if (m && std::string(m) == "classic") return false;
+	return D_S <= 1;
+}
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
 enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
@@ -154,6 +218,98 @@ extern "C" int adgs_raster_forward(
 	if (!means3D || !opacities || (!cov3D_precomp && (!scales || !rotations)) || !radii) { set_error("missing required input pointer"); return -1; }
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	if (gx > 65535 || gy > 65535) { set_error("image too large"); return -1; }
+
+	if (use_v2(D_S)) {
+		const int cell_tiles = std::max(1, env_int("ADGS_CELL_TILES", 8));
+		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
+		const size_t ncells = (size_t)cgx * cgy;
+		size_t gb = 0, ib = 0;
+		GeomStateV2::carve(nullptr, P, &gb);
+		char* gch = geometryBuffer(geometryUser, gb);
+		ImgStateV2::carve(nullptr, npix, ntiles, ncells, &ib);
+		char* ich = imageBuffer(imageUser, ib);
+		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
+		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr);
+		ImgStateV2 img = ImgStateV2::carve(ich, npix, ntiles, ncells, nullptr);
+
+		PreprocessArgs pa;
+		pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
+		pa.means3D = means3D; pa.scales = scales; pa.scale_modifier = scale_modifier; pa.rotations = rotations;
+		pa.opacities = opacities; pa.shs = shs; pa.cov3D_precomp = cov3D_precomp; pa.colors_precomp = colors_precomp;
+		pa.flow_points = flow_points; pa.semantic = semantic;
+		pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
+		pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy;
+		pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy;
+		pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
+		pa.inv_depth = inv_depth;
+		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;
+		pa.rects = geom.rects; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
+		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
+		ADGS_LAUNCH_CHECK(debug, stream);
+		{
+			StageTimer t(ST_SCAN, stream);
+			ADGS_HIP_CHECK(hipMemsetAsync(geom.cells_touched + P, 0, sizeof(uint32_t), stream));
+			ADGS_HIP_CHECK(hipMemsetAsync(geom.fine_touched + P, 0, sizeof(uint32_t), stream));
+			if (exclusive_scan_u32(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
+			if (exclusive_scan_u32(geom.fine_touched, geom.fine_touched, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
+		}
+		ADGS_LAUNCH_CHECK(debug, stream);
+		uint32_t* hw = pinned_word();
+		if (!hw) { set_error("hipHostMalloc failed"); return -1; }
+		ADGS_HIP_CHECK(hipMemcpyAsync(hw, geom.offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		ADGS_HIP_CHECK(hipMemcpyAsync(hw + 1, geom.fine_touched + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		ADGS_HIP_CHECK(hipStreamSynchronize(stream));
+		const size_t R_cells = hw[0], R_fine = hw[1];
+		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
+		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu\n", P, ncells, R_cells, R_fine);
+#define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
+		if (dbg_stop == 0) {
+			std::vector<uint32_t> h(P + 1), f(P + 1); std::vector<uint2> rc(P);
+			(void)hipMemcpy(h.data(), geom.cells_touched, (P + 1) * 4, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(f.data(), geom.fine_touched, (P + 1) * 4, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(rc.data(), geom.rects, (size_t)P * 8, hipMemcpyDeviceToHost);
+			size_t bi = 0; unsigned long long sum = 0; int nbig = 0;
+			for (int i = 0; i < P; i++) { sum += h[i]; if (h[i] > h[bi]) bi = i; if (h[i] > 1000) nbig++; }
+			fprintf(stderr, "[adgs v2] cells sum=%llu max=%u at %zu (nbig=%d) rect=%08x %08x sentinel=%u fine_scan[max]=%u\n", sum, h[bi], bi, nbig, rc[bi].x, rc[bi].y, h[P], f[bi]);
+		}
+		ADGS_DBG_STOP(0)
+
+		size_t bb = 0;
+		BinStateV2::carve(nullptr, R_cells, R_fine, ntiles, &bb);
+		char* bch = binningBuffer(binningUser, bb);
+		if (!bch) { set_error("binning allocator returned NULL"); return -1; }
+		BinStateV2 bin = BinStateV2::carve(bch, R_cells, R_fine, ntiles, nullptr);
+		{ StageTimer t(ST_DUPLICATE, stream);
+		  if (launch_duplicate_cells(P, geom.splats, geom.rects, geom.offsets, bin.keys_unsorted, bin.list_unsorted, cell_tiles, cgx, stream) != 0) return -1; }
+		ADGS_LAUNCH_CHECK(debug, stream);
+		ADGS_DBG_STOP(1)
+		const int bit = (int)higher_msb((uint32_t)ncells);
+		{ StageTimer t(ST_SORT, stream);
+		  if (radix_sort_pairs_u64(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, R_cells, 32 + bit, bin.sort_temp, stream) != 0) return -1; }
+		ADGS_LAUNCH_CHECK(debug, stream);
+		ADGS_DBG_STOP(2)
+		{ StageTimer t(ST_RANGES, stream);
+		  ADGS_HIP_CHECK(hipMemsetAsync(img.cell_ranges, 0, ncells * sizeof(uint2), stream));
+		  ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream));
+		  if (launch_tile_ranges((int)R_cells, bin.keys, img.cell_ranges, stream) != 0) return -1; }
+		ADGS_LAUNCH_CHECK(debug, stream);
+		ADGS_DBG_STOP(3)
+		RenderV2FwdArgs ra;
+		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
+		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
+		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr);
+		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
+		ra.bg = background;
+		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
+		ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
+		ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
+		{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
+		ADGS_LAUNCH_CHECK(debug, stream);
+		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
+		g_stats.reserved = (int32_t)std::min<size_t>(R_fine, 0x7fffffff);
+		return (int)R_cells;
+	}
 
 	size_t gbytes = 0, ibytes = 0;
 	GeomState::carve(nullptr, P, &gbytes);
@@ -176,6 +332,7 @@ extern "C" int adgs_raster_forward(
 	pa.focal_x = width / (2.0f * tan_fovx);
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
+	pa.rects = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
@@ -242,6 +399,48 @@ extern "C" int adgs_raster_backward(
 	if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) { set_error("backward called without forward state buffers"); return -1; }
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	if (use_v2(D_S)) {
+		const int cell_tiles = std::max(1, env_int("ADGS_CELL_TILES", 8));
+		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr);
+		ImgStateV2 img = ImgStateV2::carve(img_buffer, npix, ntiles, ncells, nullptr);
+		BinStateV2 bin = BinStateV2::carve(binning_buffer, 0, 0, ntiles, nullptr);     // only pool_cursor / pool are used
+		const bool has_color = (colors_precomp != nullptr) || (shs != nullptr);
+		RenderV2BwdArgs ra;
+		ra.splats = geom.splats; ra.pool = bin.pool; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
+		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy;
+		ra.bg = background; ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
+		ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dpix_flow = dL_dpix_flow; ra.dL_dpix_sem = dL_dpix_semantic;
+		ra.dL_dpix_opacity = grad_img_opacity;
+		ra.do_color = dL_dpix && has_color;
+		ra.do_flow = dL_dpix_flow && flow_points;
+		ra.do_sem = dL_dpix_semantic && semantic && D_S > 0;
+		ra.do_depth = dL_dpix_depth != nullptr;
+		ra.do_opacity = grad_img_opacity != nullptr;
+		ra.gacc = geom.gacc;
+		{
+			StageTimer t(ST_RENDER_BWD, stream);
+			ADGS_HIP_CHECK(hipMemsetAsync(geom.gacc, 0, (size_t)P * GACC_STRIDE * sizeof(float), stream));
+			if (binning_buffer && launch_render_bwd_v2(ra, stream) != 0) return -1;
+		}
+		ADGS_LAUNCH_CHECK(debug, stream);
+		PreprocessBwdArgs pa;
+		pa.P = P; pa.D = D; pa.M = M;
+		pa.means3D = means3D; pa.radii = radii; pa.shs = shs; pa.clamped = geom.clamped;
+		pa.scales = scales; pa.rotations = rotations; pa.scale_modifier = scale_modifier;
+		pa.cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+		pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = campos;
+		pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
+		pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
+		pa.dL_dmean2D = nullptr; pa.dL_dconic = nullptr; pa.dL_dcolor = nullptr; pa.dL_ddepth = nullptr;
+		pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
+		pa.gacc = geom.gacc;
+		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
+		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
+		{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
+		ADGS_LAUNCH_CHECK(debug, stream);
+		return 0;
+	}
 	GeomState geom = GeomState::carve(geom_buffer, P, nullptr);
 	ImgState img = ImgState::carve(img_buffer, npix, ntiles, nullptr);
 	BinState bin = BinState::carve(binning_buffer, (size_t)R, nullptr);
@@ -277,6 +476,8 @@ extern "C" int adgs_raster_backward(
 	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
 	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
 	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
+	pa.gacc = nullptr; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
+	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;
 	{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 	return 0;

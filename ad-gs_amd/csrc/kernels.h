@@ -15,6 +15,10 @@ struct PreprocessArgs {
 	int inv_depth;
 	// outputs
 	int* radii; Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched;
+	// v2 (coarse-binned) extras; rects == nullptr selects the classic behaviour
+	uint2* rects;                    // per-Gaussian fine-tile rectangle (u16 x4), possibly empty
+	uint32_t* fine_touched;          // #fine tiles covered per Gaussian (its sum bounds the chunk pool)
+	int cell_tiles, cgx, cgy;        // coarse cell = cell_tiles x cell_tiles fine tiles
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
@@ -62,8 +66,42 @@ struct PreprocessBwdArgs {
 	int inv_depth;
 	const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor; const float* dL_ddepth;
 	float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+	// v2: per-Gaussian sums arrive packed in gacc ([P][16]); they are unpacked into the ABI outputs
+	// below (which are then written, not read).  gacc == nullptr selects the classic inputs above.
+	const float* gacc;
+	float* out_mean2D; float* out_conic; float* out_opacity; float* out_color; float* out_depth; float* out_flow; float* out_sem;
+	int D_S;
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
+
+// ---- v2 pipeline (render_v2.hip) ----
+constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
+constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumulators per Gaussian
+constexpr int GACC_USED = 14;           // mx my ca cb cc op c0 c1 c2 d f0 f1 f2 s0
+
+int launch_duplicate_cells(int P, const Splat* splats, const uint2* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
+	int cell_tiles, int cgx, hipStream_t stream);
+
+struct RenderV2FwdArgs {
+	const uint2* cell_ranges; const uint32_t* cell_list; const uint2* rects; const Splat* splats;
+	int W, H, gx, gy, cell_tiles, cgx;
+	bool has_color, has_flow, has_sem;
+	const float* bg;
+	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed;
+	float* final_T; uint32_t* n_contrib;
+	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
+};
+int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
+
+struct RenderV2BwdArgs {
+	const Splat* splats; const uint32_t* pool; const uint32_t* tile_last_chunk; const uint32_t* tile_consumed;
+	int W, H, gx, gy;
+	const float* bg; const float* final_T; const uint32_t* n_contrib;
+	const float* dL_dpix; const float* dL_dpix_depth; const float* dL_dpix_flow; const float* dL_dpix_sem; const float* dL_dpix_opacity;
+	bool do_color, do_flow, do_sem, do_depth, do_opacity;
+	float* gacc;                     // [P][GACC_STRIDE], zero-initialised
+};
+int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream);
 
 int knn_run(int P, const float* points, float* meanDists, char* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int P);

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	if (idx >= a.P) return;
 	a.radii[idx] = 0;
 	a.tiles_touched[idx] = 0;
+	if (a.rects) { a.rects[idx] = make_uint2(0u, 0u); a.fine_touched[idx] = 0; }
 
 	const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
 	const float* V = a.view; const float* PJ = a.proj;
@@ -185,7 +186,36 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	dst[3] = make_float4(s.fz, s.sem0, s.zview, s.pad);
 	a.clamped[idx] = clamp_bits;
 	a.radii[idx] = (int)my_radius;
-	a.tiles_touched[idx] = (maxy - miny) * (maxx - minx);
+	if (!a.rects) {
+		a.tiles_touched[idx] = (maxy - miny) * (maxx - minx);
+		return;
+	}
+	// ---- v2: shrink the reference rectangle to the tiles on which alpha can reach 1/255.
+	// alpha = opacity * exp(-0.5 d^T Q d) >= 1/255  <=>  d^T Q d <= tau = 2 ln(255 opacity); the
+	// axis-aligned bound of that ellipse is |dx| <= sqrt(tau * cov_xx), |dy| <= sqrt(tau * cov_yy)
+	// (cov = Q^-1).  A 1% slack on alpha (+0.02 on tau) and 1e-3 relative + 0.01 px on the extents
+	// dominate every fp32 rounding in the per-pixel test, so no contributing pixel is ever lost.
+	uint32_t sminx = 0, sminy = 0, smaxx = 0, smaxy = 0;
+	const float tau = 2.f * logf(255.f * s.opacity) + 0.02f;
+	if (tau > 0.f) {
+		const float ex = sqrtf(tau * cxx) * 1.001f + 0.01f, ey = sqrtf(tau * cyy) * 1.001f + 0.01f;
+		// tile t covers pixel centres [16t, 16t+15]
+		const int tminx = (int)ceilf((pix - ex - (float)(TILE_X - 1)) / TILE_X), tmaxx = (int)fminf(floorf((pix + ex) / TILE_X) + 1.f, 1.0e9f);
+		const int tminy = (int)ceilf((piy - ey - (float)(TILE_Y - 1)) / TILE_Y), tmaxy = (int)fminf(floorf((piy + ey) / TILE_Y) + 1.f, 1.0e9f);
+		// intersect in signed arithmetic (the opacity-aware bound can lie entirely off-screen)
+		const int ix0 = max((int)minx, tminx), ix1 = min((int)maxx, tmaxx);
+		const int iy0 = max((int)miny, tminy), iy1 = min((int)maxy, tmaxy);
+		if (ix1 > ix0 && iy1 > iy0) { sminx = (uint32_t)ix0; smaxx = (uint32_t)ix1; sminy = (uint32_t)iy0; smaxy = (uint32_t)iy1; }
+	}
+	a.rects[idx] = make_uint2(sminx | (sminy << 16), smaxx | (smaxy << 16));
+	uint32_t ncell = 0;
+	const uint32_t nfine = (smaxx - sminx) * (smaxy - sminy);
+	if (nfine) {
+		const uint32_t c0x = sminx / a.cell_tiles, c1x = (smaxx - 1) / a.cell_tiles, c0y = sminy / a.cell_tiles, c1y = (smaxy - 1) / a.cell_tiles;
+		ncell = (c1x - c0x + 1) * (c1y - c0y + 1);
+	}
+	a.tiles_touched[idx] = ncell;
+	a.fine_touched[idx] = nfine;     // scanned on the host side of the pipeline: chunk-pool capacity bound
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ V, uint8_t* __restrict__ present) {
@@ -214,6 +244,25 @@ __global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat*
 				keys[off] = key; vals[off] = (uint32_t)idx; off++;
 			}
 	}
+}
+
+// v2: one (cell | depth) key per covered coarse cell.
+__global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat* __restrict__ splats, const uint2* __restrict__ rects,
+	const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int cell_tiles, int cgx) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= P) return;
+	const uint2 r = rects[idx];
+	const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu, maxy = r.y >> 16;
+	if (maxx <= minx || maxy <= miny) return;
+	uint32_t off = offsets[idx];
+	const uint32_t dbits = __float_as_uint(splats[idx].zview);
+	const uint32_t c0x = minx / cell_tiles, c1x = (maxx - 1) / cell_tiles, c0y = miny / cell_tiles, c1y = (maxy - 1) / cell_tiles;
+	for (uint32_t y = c0y; y <= c1y; y++)
+		for (uint32_t x = c0x; x <= c1x; x++) {
+			uint64_t key = (uint64_t)(y * cgx + x);
+			key <<= 32; key |= dbits;
+			keys[off] = key; vals[off] = (uint32_t)idx; off++;
+		}
 }
 
 // rasterizer_impl.cu:116-138
@@ -247,6 +296,13 @@ int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, c
 	int gx, int gy, hipStream_t stream) {
 	if (P == 0) return 0;
 	hipLaunchKernelGGL(duplicate_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, offsets, radii, keys, vals, gx, gy);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_duplicate_cells(int P, const Splat* splats, const uint2* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
+	int cell_tiles, int cgx, hipStream_t stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, rects, offsets, keys, vals, cell_tiles, cgx);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -41,9 +41,29 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 	const float* V = a.view; const float* PJ = a.proj;
 	const float mx = a.means3D[3 * (size_t)idx], my = a.means3D[3 * (size_t)idx + 1], mz = a.means3D[3 * (size_t)idx + 2];
 
+	// per-Gaussian sums of the blend backward: classic = separate ABI arrays filled by atomics,
+	// v2 = one packed 64-byte line per Gaussian, unpacked here into the ABI outputs
+	float dcon_x, dcon_y, dcon_z, g2x, g2y, gd, gcol[3];
+	if (a.gacc) {
+		const float4* ga = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GACC_STRIDE);
+		const float4 u0 = ga[0], u1 = ga[1], u2 = ga[2], u3 = ga[3];   // mx my ca cb | cc op c0 c1 | c2 d f0 f1 | f2 s0 - -
+		g2x = u0.x; g2y = u0.y; dcon_x = u0.z; dcon_y = u0.w; dcon_z = u1.x;
+		gcol[0] = u1.z; gcol[1] = u1.w; gcol[2] = u2.x; gd = u2.y;
+		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y;
+		*reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
+		a.out_opacity[idx] = u1.y;
+		a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2];
+		a.out_depth[idx] = gd;
+		if (a.out_flow) { a.out_flow[3 * (size_t)idx] = u2.z; a.out_flow[3 * (size_t)idx + 1] = u2.w; a.out_flow[3 * (size_t)idx + 2] = u3.x; }
+		if (a.out_sem && a.D_S == 1) a.out_sem[idx] = u3.y;
+	} else {
+		dcon_x = a.dL_dconic[4 * (size_t)idx]; dcon_y = a.dL_dconic[4 * (size_t)idx + 1]; dcon_z = a.dL_dconic[4 * (size_t)idx + 3];
+		g2x = a.dL_dmean2D[3 * (size_t)idx]; g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+		gd = a.dL_ddepth[idx];
+		gcol[0] = a.dL_dcolor[3 * (size_t)idx]; gcol[1] = a.dL_dcolor[3 * (size_t)idx + 1]; gcol[2] = a.dL_dcolor[3 * (size_t)idx + 2];
+	}
 	// ---------------- cov2D backward (backward.cu:144-274)
 	const float* c3 = a.cov3D + 6 * (size_t)idx;
-	const float dcon_x = a.dL_dconic[4 * (size_t)idx], dcon_y = a.dL_dconic[4 * (size_t)idx + 1], dcon_z = a.dL_dconic[4 * (size_t)idx + 3];
 	float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 	float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
 	const float tz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
@@ -112,7 +132,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 		const float m_w = 1.0f / (hw + 0.0000001f);
 		const float mul1 = (PJ[0] * mx + PJ[4] * my + PJ[8] * mz + PJ[12]) * m_w * m_w;
 		const float mul2 = (PJ[1] * mx + PJ[5] * my + PJ[9] * mz + PJ[13]) * m_w * m_w;
-		const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
 		gmx += (PJ[0] * m_w - PJ[3] * mul1) * g2x + (PJ[1] * m_w - PJ[3] * mul2) * g2y;
 		gmy += (PJ[4] * m_w - PJ[7] * mul1) * g2x + (PJ[5] * m_w - PJ[7] * mul2) * g2y;
 		gmz += (PJ[8] * m_w - PJ[11] * mul1) * g2x + (PJ[9] * m_w - PJ[11] * mul2) * g2y;
@@ -121,7 +140,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 	{
 		const float mul3 = V[2] * mx + V[6] * my + V[10] * mz + V[14];
 		const float demon = a.inv_depth ? (-1.0f / (mul3 * mul3 + 0.0000001f)) : 1.0f;
-		const float gd = a.dL_ddepth[idx];
 		gmx += (V[2] - V[3] * mul3) * gd * demon;
 		gmy += (V[6] - V[7] * mul3) * gd * demon;
 		gmz += (V[10] - V[11] * mul3) * gd * demon;
@@ -136,7 +154,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 		const uint8_t cl = a.clamped[idx];
 		float g[3];
 #pragma unroll
-		for (int c = 0; c < 3; c++) g[c] = ((cl >> c) & 1) ? 0.f : a.dL_dcolor[3 * (size_t)idx + c];
+		for (int c = 0; c < 3; c++) g[c] = ((cl >> c) & 1) ? 0.f : gcol[c];
 		float dx3[3] = { 0.f, 0.f, 0.f }, dy3[3] = { 0.f, 0.f, 0.f }, dz3[3] = { 0.f, 0.f, 0.f };
 		const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
 		const float C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };

@@ -1,0 +1,347 @@
+// v2 blend kernels for gfx950: coarse-binned, lazily filtered, one wave64 per 16x16 tile.
+//
+// Why (measured on MI355X, profiles/r01/v1_baseline_*): with the classic pipeline a 1M-Gaussian
+// 1920x1280 frame has 47M (tile, Gaussian) pairs; sorting them costs 4 ms and the blend kernels
+// only ever consume the front ~5% of every tile list because pixels saturate.  v2 therefore
+//   * bins/sorts Gaussians only into COARSE cells (128x128 px: ~20x fewer pairs), by
+//     (cell | depth) with the same stable radix sort, and
+//   * lets every 16x16 tile walk its cell's depth-sorted list lazily: 64 entries at a time are
+//     tested against the tile (the Gaussian's tile rectangle = the reference rectangle shrunk by
+//     an opacity-aware bound, so only entries that can reach alpha >= 1/255 on the tile survive),
+//     survivors are compacted IN ORDER with a wave ballot (no sort needed) and blended until
+//     all 256 pixels are saturated.  Entries behind the saturation depth are never touched.
+// The per-pixel result is identical to the reference's: it depends only on the ordered sequence
+// of Gaussians that pass the per-pixel tests, and removed entries are exactly those that fail
+// `alpha >= 1/255` on every pixel of the tile (or lie outside the reference's tile rectangle).
+//
+// One workgroup = one wave64 = one tile; each lane owns 4 pixels (column x = lane&15, rows
+// (lane>>4) + 4k).  Per-Gaussian data is broadcast from LDS once per 4 pixels, the backward's
+// cross-lane reductions (DPP row_shr/row_bcast adds, no LDS) are amortised over 256 pixels and
+// the 14 per-Gaussian partial sums go out as ONE atomic instruction onto one 64-byte line.
+// The consumed (tile, Gaussian) sequence is written to a chunk pool (linked 64-entry chunks) so
+// the backward replays exactly what the forward blended, back to front.
+#include "common.h"
+#include "kernels.h"
+
+namespace adgs {
+namespace {
+
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_STOP = 0.0001f;
+constexpr int PPL = 4;                    // pixels per lane
+constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
+
+__device__ __forceinline__ bool tile_in_rect(uint2 rect, uint32_t tx, uint32_t ty) {
+	const uint32_t minx = rect.x & 0xFFFFu, miny = rect.x >> 16, maxx = rect.y & 0xFFFFu, maxy = rect.y >> 16;
+	return tx >= minx && tx < maxx && ty >= miny && ty < maxy;
+}
+
+__global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
+	__shared__ float4 s_splat[WAVE * 4];
+	__shared__ uint32_t s_queue[2 * WAVE];
+	const int lane = threadIdx.x;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
+	const uint32_t cell = (ty / a.cell_tiles) * a.cgx + (tx / a.cell_tiles);
+	const uint2 range = a.cell_ranges[cell];
+	const uint32_t px = tx * TILE_X + (lane & 15);
+	const uint32_t py0 = ty * TILE_Y + (lane >> 4);
+	const float pxf = (float)px;
+	float pyf[PPL]; bool inside[PPL], done[PPL];
+	float T[PPL], C0[PPL], C1[PPL], C2[PPL], Dp[PPL], F0[PPL], F1[PPL], F2[PPL], S0[PPL];
+	uint32_t last_contrib[PPL];
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		const uint32_t py = py0 + 4 * k;
+		pyf[k] = (float)py;
+		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
+		done[k] = !inside[k];
+		T[k] = 1.f; C0[k] = C1[k] = C2[k] = Dp[k] = F0[k] = F1[k] = F2[k] = S0[k] = 0.f;
+		last_contrib[k] = 0;
+	}
+	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
+	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
+
+	while (true) {
+		const bool all_done = __all(done[0] && done[1] && done[2] && done[3]);
+		if (all_done) break;
+		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction)
+		while (qcount < WAVE && pos < range.y) {
+			const uint32_t e = pos + lane;
+			bool pass = false; uint32_t id = 0;
+			if (e < range.y) {
+				id = a.cell_list[e];
+				pass = tile_in_rect(a.rects[id], tx, ty);
+			}
+			const uint64_t m = __ballot(pass);
+			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
+			qcount += __popcll(m);
+			pos += WAVE;
+		}
+		const uint32_t n = min(qcount, (uint32_t)WAVE);
+		if (n == 0) break;
+		__syncthreads();
+		uint32_t myid = 0;
+		if ((uint32_t)lane < n) {
+			myid = s_queue[(qhead + lane) & (2 * WAVE - 1)];
+			const float4* src = reinterpret_cast<const float4*>(a.splats + myid);
+			s_splat[lane * 4 + 0] = src[0];
+			s_splat[lane * 4 + 1] = src[1];
+			s_splat[lane * 4 + 2] = src[2];
+			s_splat[lane * 4 + 3] = src[3];
+		}
+		qhead = (qhead + n) & (2 * WAVE - 1); qcount -= n;
+		// ---- publish the chunk for the backward replay
+		uint32_t chunk = 0;
+		if (lane == 0) chunk = atomicAdd(a.pool_cursor, 1u);
+		chunk = __shfl(chunk, 0, WAVE);
+		{
+			uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
+			if (lane == 0) { c[0] = prev_chunk; c[1] = n; }
+			if ((uint32_t)lane < n) c[2 + lane] = myid;
+		}
+		prev_chunk = chunk;
+		__syncthreads();
+		// ---- blend
+		for (uint32_t j = 0; j < n; j++) {
+			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
+			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
+			const float dx = q0.x - pxf;
+			float alpha[PPL]; bool act[PPL]; bool any_act = false;
+#pragma unroll
+			for (int k = 0; k < PPL; k++) {
+				const float dy = q0.y - pyf[k];
+				const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+				alpha[k] = fminf(ALPHA_MAX, q1.y * expf(power));
+				act[k] = !done[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
+				any_act = any_act || act[k];
+			}
+			if (!__any(any_act)) continue;
+			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
+			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview pad
+#pragma unroll
+			for (int k = 0; k < PPL; k++) {
+				if (act[k]) {
+					const float test_T = T[k] * (1 - alpha[k]);
+					if (test_T < T_STOP) { done[k] = true; }
+					else {
+						const float w = alpha[k] * T[k];
+						C0[k] += q1.z * w; C1[k] += q1.w * w; C2[k] += q2.x * w;
+						F0[k] += q2.z * w; F1[k] += q2.w * w; F2[k] += q3.x * w;
+						Dp[k] += q2.y * w; S0[k] += q3.y * w;
+						T[k] = test_T;
+						last_contrib[k] = consumed + j + 1;
+					}
+				}
+			}
+		}
+		consumed += n;
+	}
+	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; }
+	const size_t HW = (size_t)a.H * a.W;
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		if (inside[k]) {
+			const size_t pix_id = (size_t)a.W * (py0 + 4 * k) + px;
+			a.final_T[pix_id] = (float)(1.0 - (double)T[k]);
+			a.n_contrib[pix_id] = last_contrib[k];
+			if (a.has_color) {
+				a.out_color[0 * HW + pix_id] = C0[k] + T[k] * a.bg[0];
+				a.out_color[1 * HW + pix_id] = C1[k] + T[k] * a.bg[1];
+				a.out_color[2 * HW + pix_id] = C2[k] + T[k] * a.bg[2];
+			}
+			if (a.has_flow) { a.out_flow[0 * HW + pix_id] = F0[k]; a.out_flow[1 * HW + pix_id] = F1[k]; a.out_flow[2 * HW + pix_id] = F2[k]; }
+			if (a.has_sem) a.out_semantic[pix_id] = S0[k];
+			a.out_depth[pix_id] = Dp[k];
+		}
+	}
+}
+
+// wave64 sum with DPP (no LDS): quad xor1, xor2, row_ror 4, row_ror 8, row_bcast15, row_bcast31.
+// The total ends up in lane 63.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+	int x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false)); x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false)); x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false)); x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false)); x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
+	return v;
+}
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
+__global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) {
+	__shared__ float4 s_splat[WAVE * 4];
+	__shared__ uint32_t s_id[WAVE];
+	const int lane = threadIdx.x;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
+	const uint32_t px = tx * TILE_X + (lane & 15);
+	const uint32_t py0 = ty * TILE_Y + (lane >> 4);
+	const float pxf = (float)px;
+	const size_t HW = (size_t)a.H * a.W;
+	float pyf[PPL]; bool inside[PPL];
+	float T[PPL], T_final[PPL];
+	int last_contributor[PPL];
+	float A_c0[PPL], A_c1[PPL], A_c2[PPL], A_f0[PPL], A_f1[PPL], A_f2[PPL], A_d[PPL], A_s[PPL];
+	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gO[PPL], gS[PPL], bgdot[PPL];
+	int max_contrib = 0;
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		const uint32_t py = py0 + 4 * k;
+		pyf[k] = (float)py;
+		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
+		const size_t pix_id = (size_t)a.W * py + px;
+		T_final[k] = inside[k] ? (float)(1.0 - (double)a.final_T[pix_id]) : 0.f;
+		T[k] = T_final[k];
+		last_contributor[k] = inside[k] ? (int)a.n_contrib[pix_id] : 0;
+		max_contrib = max(max_contrib, last_contributor[k]);
+		A_c0[k] = A_c1[k] = A_c2[k] = A_f0[k] = A_f1[k] = A_f2[k] = A_d[k] = A_s[k] = 0.f;
+		gC0[k] = gC1[k] = gC2[k] = gF0[k] = gF1[k] = gF2[k] = gD[k] = gO[k] = gS[k] = 0.f;
+		if (inside[k]) {
+			if (a.do_color) { gC0[k] = a.dL_dpix[0 * HW + pix_id]; gC1[k] = a.dL_dpix[1 * HW + pix_id]; gC2[k] = a.dL_dpix[2 * HW + pix_id]; }
+			if (a.do_flow) { gF0[k] = a.dL_dpix_flow[0 * HW + pix_id]; gF1[k] = a.dL_dpix_flow[1 * HW + pix_id]; gF2[k] = a.dL_dpix_flow[2 * HW + pix_id]; }
+			if (a.do_sem) gS[k] = a.dL_dpix_sem[pix_id];
+			if (a.do_depth) gD[k] = a.dL_dpix_depth[pix_id];
+			if (a.do_opacity) gO[k] = a.dL_dpix_opacity[pix_id];
+		}
+		float b = 0.f;
+		b += a.bg[0] * gC0[k]; b += a.bg[1] * gC1[k]; b += a.bg[2] * gC2[k];
+		bgdot[k] = b;
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
+	const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
+
+	uint32_t chunk = a.tile_last_chunk[tile];
+	int base = (int)a.tile_consumed[tile];        // one past the last position of the current chunk
+	while (chunk != NO_CHUNK) {
+		const uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
+		const uint32_t prev = c[0];
+		const int n = (int)c[1];
+		base -= n;
+		if (base < max_contrib) {
+			__syncthreads();
+			if (lane < n) {
+				const uint32_t id = c[2 + lane];
+				const float4* src = reinterpret_cast<const float4*>(a.splats + id);
+				s_splat[lane * 4 + 0] = src[0];
+				s_splat[lane * 4 + 1] = src[1];
+				s_splat[lane * 4 + 2] = src[2];
+				s_splat[lane * 4 + 3] = src[3];
+				s_id[lane] = id;
+			}
+			__syncthreads();
+			for (int j = n - 1; j >= 0; j--) {
+				const int contributor = base + j;
+				if (contributor >= max_contrib) continue;
+				const float4 q0 = s_splat[j * 4 + 0];
+				const float4 q1 = s_splat[j * 4 + 1];
+				const float dx = q0.x - pxf;
+				float alpha[PPL], G[PPL], dy[PPL]; bool act[PPL]; bool any_act = false;
+#pragma unroll
+				for (int k = 0; k < PPL; k++) {
+					dy[k] = q0.y - pyf[k];
+					const float power = -0.5f * (q0.z * dx * dx + q1.x * dy[k] * dy[k]) - q0.w * dx * dy[k];
+					G[k] = expf(power);
+					alpha[k] = fminf(ALPHA_MAX, q1.y * G[k]);
+					act[k] = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
+					any_act = any_act || act[k];
+				}
+				if (!__any(any_act)) continue;
+				const float4 q2 = s_splat[j * 4 + 2];
+				const float4 q3 = s_splat[j * 4 + 3];
+				float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_s = 0.f, v_d = 0.f;
+				float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
+#pragma unroll
+				for (int k = 0; k < PPL; k++) {
+					if (act[k]) {
+						const float al = alpha[k];
+						T[k] = T[k] / (1.f - al);
+						const float dch = al * T[k];
+						float dL_dalpha = 0.0f;
+						// suffix-blend recurrences of backward.cu:578-607, applied right after use
+						// (A_next = alpha*c + (1-alpha)*A is what the reference forms at the next
+						// contributing entry from last_alpha/last_color: same operations, same values)
+						if (a.do_color) {
+							dL_dalpha += (q1.z - A_c0[k]) * gC0[k]; v_c0 += dch * gC0[k]; A_c0[k] = al * q1.z + (1.f - al) * A_c0[k];
+							dL_dalpha += (q1.w - A_c1[k]) * gC1[k]; v_c1 += dch * gC1[k]; A_c1[k] = al * q1.w + (1.f - al) * A_c1[k];
+							dL_dalpha += (q2.x - A_c2[k]) * gC2[k]; v_c2 += dch * gC2[k]; A_c2[k] = al * q2.x + (1.f - al) * A_c2[k];
+						}
+						if (a.do_flow) {
+							dL_dalpha += (q2.z - A_f0[k]) * gF0[k]; v_f0 += dch * gF0[k]; A_f0[k] = al * q2.z + (1.f - al) * A_f0[k];
+							dL_dalpha += (q2.w - A_f1[k]) * gF1[k]; v_f1 += dch * gF1[k]; A_f1[k] = al * q2.w + (1.f - al) * A_f1[k];
+							dL_dalpha += (q3.x - A_f2[k]) * gF2[k]; v_f2 += dch * gF2[k]; A_f2[k] = al * q3.x + (1.f - al) * A_f2[k];
+						}
+						if (a.do_sem) { dL_dalpha += (q3.y - A_s[k]) * gS[k]; v_s += dch * gS[k]; A_s[k] = al * q3.y + (1.f - al) * A_s[k]; }
+						if (a.do_depth) { dL_dalpha += (q2.y - A_d[k]) * gD[k]; v_d += dch * gD[k]; A_d[k] = al * q2.y + (1.f - al) * A_d[k]; }
+						if (a.do_opacity) dL_dalpha += gO[k] * T_final[k] / (1.f - al);    // before the *= T: reference quirk
+						dL_dalpha *= T[k];
+						dL_dalpha += (-T_final[k] / (1.f - al)) * bgdot[k];
+						const float dL_dG = q1.y * dL_dalpha;
+						const float gdx = G[k] * dx, gdy = G[k] * dy[k];
+						const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+						const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+						v_mx += dL_dG * dG_ddelx * ddelx_dx;
+						v_my += dL_dG * dG_ddely * ddely_dy;
+						v_ca += -0.5f * gdx * dx * dL_dG;
+						v_cb += -0.5f * gdx * dy[k] * dL_dG;
+						v_cc += -0.5f * gdy * dy[k] * dL_dG;
+						v_op += G[k] * dL_dalpha;
+					}
+				}
+				// 14 wave sums (totals in lane 63) -> lanes 0..13 -> one atomic instruction on one 64-B line
+				float out = 0.f;
+				{
+					float s;
+					s = lane63(wave_sum_dpp(v_mx)); if (lane == 0) out = s;
+					s = lane63(wave_sum_dpp(v_my)); if (lane == 1) out = s;
+					s = lane63(wave_sum_dpp(v_ca)); if (lane == 2) out = s;
+					s = lane63(wave_sum_dpp(v_cb)); if (lane == 3) out = s;
+					s = lane63(wave_sum_dpp(v_cc)); if (lane == 4) out = s;
+					s = lane63(wave_sum_dpp(v_op)); if (lane == 5) out = s;
+					if (a.do_color) {
+						s = lane63(wave_sum_dpp(v_c0)); if (lane == 6) out = s;
+						s = lane63(wave_sum_dpp(v_c1)); if (lane == 7) out = s;
+						s = lane63(wave_sum_dpp(v_c2)); if (lane == 8) out = s;
+					}
+					if (a.do_depth) { s = lane63(wave_sum_dpp(v_d)); if (lane == 9) out = s; }
+					if (a.do_flow) {
+						s = lane63(wave_sum_dpp(v_f0)); if (lane == 10) out = s;
+						s = lane63(wave_sum_dpp(v_f1)); if (lane == 11) out = s;
+						s = lane63(wave_sum_dpp(v_f2)); if (lane == 12) out = s;
+					}
+					if (a.do_sem) { s = lane63(wave_sum_dpp(v_s)); if (lane == 13) out = s; }
+				}
+				if (lane < GACC_USED) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + lane, out);
+			}
+		}
+		chunk = prev;
+	}
+}
+
+// per-tile bookkeeping reset + pool cursor
+__global__ void __launch_bounds__(256) reset_tiles_kernel(uint32_t T, uint32_t* last_chunk, uint32_t* consumed, uint32_t* cursor) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < T) { last_chunk[i] = NO_CHUNK; consumed[i] = 0; }
+	if (i == 0) *cursor = 0;
+}
+
+} // namespace
+
+int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
+	const uint32_t T = (uint32_t)a.gx * a.gy;
+	hipLaunchKernelGGL(render_fwd_v2_kernel, dim3(T), dim3(WAVE), 0, stream, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
+	const uint32_t T = (uint32_t)a.gx * a.gy;
+	hipLaunchKernelGGL(render_bwd_v2_kernel, dim3(T), dim3(WAVE), 0, stream, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+} // namespace adgs

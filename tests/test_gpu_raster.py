@@ -120,8 +120,11 @@ def test_forward_backward_small(seed, degree, inv_depth):
     compare(sc, degree=degree, inv_depth=inv_depth, grads=synthetic.make_upstream_grads(sc, seed))
 
 
-def test_num_rendered_matches_oracle():
+def test_num_rendered_matches_oracle(monkeypatch):
+    """In the stage-by-stage "classic" mode even the opaque integer num_rendered equals the reference's;
+    the default coarse-binned pipeline returns its (much smaller) number of (cell, Gaussian) pairs."""
     from diff_gaussian_rasterization import _C
+    monkeypatch.setenv("ADGS_RASTER_MODE", "classic")
     sc = synthetic.make_scene(5000, 320, 200, 200.0, seed=7)
     e = torch.Tensor([])
     r = _C.rasterize_gaussians(dev(sc["bg"]), dev(sc["means3D"]), e, dev(sc["opacities"]), dev(sc["scales"]), dev(sc["rotations"]), 1.0, e,
@@ -131,6 +134,29 @@ def test_num_rendered_matches_oracle():
     assert r[0] == o["num_rendered"] and r[0] > 0
     assert r[5].dtype == torch.uint8 and r[5].numel() > 0 and r[6].numel() > 0 and r[7].numel() > 0
     assert tuple(r[9].shape) == (0, sc["H"], sc["W"])
+    monkeypatch.delenv("ADGS_RASTER_MODE")
+    r2 = _C.rasterize_gaussians(dev(sc["bg"]), dev(sc["means3D"]), e, dev(sc["opacities"]), dev(sc["scales"]), dev(sc["rotations"]), 1.0, e,
+                                dev(sc["viewmatrix"]), dev(sc["projmatrix"]), sc["tanfovx"], sc["tanfovy"], sc["H"], sc["W"], dev(sc["shs"]),
+                                e, e, 3, dev(sc["campos"]), False, True, False)
+    assert 0 < r2[0] < r[0]
+    assert torch.equal(r2[4], r[4])                       # radii do not depend on the pipeline
+    assert_close("color v2 vs classic", r2[1].cpu().numpy(), r[1].cpu().numpy(), tol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["classic", "v2"])
+def test_both_pipelines_match_oracle(monkeypatch, mode):
+    monkeypatch.setenv("ADGS_RASTER_MODE", mode)
+    sc = synthetic.make_scene(8000, 330, 210, 220.0, seed=21, n_objects=2)
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 21))
+
+
+def test_offscreen_and_transparent_gaussians_v2_rect_shrink():
+    """Gaussians whose opacity-aware footprint is off-screen / empty while the reference rectangle is not,
+    and opacities around the 1/255 visibility threshold."""
+    sc = synthetic.make_scene(6000, 200, 120, 90.0, seed=22, scale_mult=0.02)
+    sc["means3D"][:1500, 0] *= 1.6                        # push a quarter far off-axis (left/right of the frustum)
+    sc["opacities"][1500:3000] = torch.linspace(0.0005, 0.02, 1500)[:, None]
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 22))
 
 
 def test_c1_config_full_size():
