@@ -32,6 +32,7 @@ SIGNATURES = {
     "adgs_knn_workspace_bytes": (ctypes.c_size_t, [c_i]),
     "adgs_knn_dist2": (c_i, [c_i, c_p, c_p, c_p, c_p]),
     "adgs_get_frame_stats": (None, [c_p]),
+    "adgs_raster_needs_zero_init": (c_i, [c_i]),
     "adgs_profile_enable": (None, [c_i]),
     "adgs_profile_num_stages": (c_i, []),
     "adgs_profile_stage_name": (ctypes.c_char_p, [c_i]),

@@ -241,7 +241,9 @@ class _DeformPkgFn(torch.autograd.Function):
         for n in _GRADS:
             src = named[n]
             need = src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)]
-            grads[n] = torch.zeros_like(src) if need else None
+            # SH-related gradients are fully written by the flat kernels when an upstream SH gradient exists
+            full = g_shs is not None and g_shs.numel() > 0 and "shs" in want and ("shs_dc" in n or "shs_rest" in n or n.startswith("shs_deform"))
+            grads[n] = (torch.empty_like(src) if full else torch.zeros_like(src)) if need else None
             setattr(gs, n, _dp(grads[n]))
         up = {}
         for k, g in (("xyz", g_xyz), ("rotation", g_rot), ("shs", g_shs), ("opacity", g_op), ("scales", g_sc)):

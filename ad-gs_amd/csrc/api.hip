@@ -71,14 +71,14 @@ struct BinState {
 
 // ---- v2 (coarse-binned) state ----
 struct GeomStateV2 {
-	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; uint2* rects;
+	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects;
 	float* gacc; char* scan_temp;
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
 		Carver c(chunk); GeomStateV2 g;
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
 		g.cov3D = c.take<float>(P * 6);
-		g.rects = c.take<uint2>(P);
+		g.rects = c.take<FilterRec>(P);
 		g.clamped = c.take<uint8_t>(P);
 		g.cells_touched = c.take<uint32_t>(P + 1);
 		g.offsets = c.take<uint32_t>(P + 1);
@@ -169,6 +169,10 @@ using namespace adgs;
 extern "C" const char* adgs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_stats; }
+
+// 1 if the caller must zero-fill the outputs of forward/backward for this D_S (the classic,
+// atomics-into-outputs pipeline; also the reference's contract), 0 if every element is written.
+extern "C" int adgs_raster_needs_zero_init(int D_S) { return use_v2(D_S) ? 0 : 1; }
 
 extern "C" void adgs_profile_enable(int on) { g_prof_on = on != 0; }
 extern "C" int adgs_profile_num_stages(void) { return ST_COUNT; }
@@ -264,15 +268,6 @@ extern "C" int adgs_raster_forward(
 		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
 		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu\n", P, ncells, R_cells, R_fine);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
-		if (dbg_stop == 0) {
-			std::vector<uint32_t> h(P + 1), f(P + 1); std::vector<uint2> rc(P);
-			(void)hipMemcpy(h.data(), geom.cells_touched, (P + 1) * 4, hipMemcpyDeviceToHost);
-			(void)hipMemcpy(f.data(), geom.fine_touched, (P + 1) * 4, hipMemcpyDeviceToHost);
-			(void)hipMemcpy(rc.data(), geom.rects, (size_t)P * 8, hipMemcpyDeviceToHost);
-			size_t bi = 0; unsigned long long sum = 0; int nbig = 0;
-			for (int i = 0; i < P; i++) { sum += h[i]; if (h[i] > h[bi]) bi = i; if (h[i] > 1000) nbig++; }
-			fprintf(stderr, "[adgs v2] cells sum=%llu max=%u at %zu (nbig=%d) rect=%08x %08x sentinel=%u fine_scan[max]=%u\n", sum, h[bi], bi, nbig, rc[bi].x, rc[bi].y, h[P], f[bi]);
-		}
 		ADGS_DBG_STOP(0)
 
 		size_t bb = 0;

@@ -29,6 +29,16 @@ struct __attribute__((aligned(64))) Splat {
 };
 static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 
+// What the v2 tile filter needs to decide "can this Gaussian reach alpha >= 1/255 on that tile":
+// half a cache line per Gaussian.
+struct __attribute__((aligned(32))) FilterRec {
+	float x, y;              // pixel-space mean
+	float ca, cb, cc;        // conic
+	float tau;               // 2 ln(255 opacity) + slack: alpha >= 1/255  <=>  d^T Q d <= tau
+	uint32_t rmin, rmax;     // tile rectangle (reference rect shrunk by the opacity-aware bound): x | y << 16
+};
+static_assert(sizeof(FilterRec) == 32, "FilterRec must be 32 bytes");
+
 void set_error(const std::string& msg);
 
 #define ADGS_HIP_CHECK(expr)                                                             \

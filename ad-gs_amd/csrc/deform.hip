@@ -300,6 +300,83 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
 	}
 }
 
+
+// ---- SH coefficients as flat, fully coalesced streams (the per-Gaussian 192-byte rows are the
+// bulk of the deformation traffic; one thread per Gaussian would touch 64 cache lines per access)
+struct ShsFwdArgs {
+	int Ns, N, M;
+	const float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *sp_scene, *sp_obj;
+	adgs_func_eval fs;
+	float* out;
+};
+__global__ void __launch_bounds__(256) deform_shs_fwd_kernel(ShsFwdArgs a) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of the output
+	const int row = a.M * 3;                                             // floats per Gaussian (multiple of 4 for M = 16; generic path below)
+	const size_t total = (size_t)a.N * row;
+	const size_t e0 = i * 4;
+	if (e0 >= total) return;
+	float v[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const size_t e = e0 + k;
+		if (e >= total) { v[k] = 0.f; continue; }
+		const int n = (int)(e / row), c = (int)(e % row);
+		const bool is_obj = n >= a.Ns;
+		const int m = is_obj ? n - a.Ns : n;
+		if (c < 3) {
+			float x = (is_obj ? a.obj_dc : a.scene_dc)[3 * (size_t)m + c];
+			const float* sp = is_obj ? a.sp_obj : a.sp_scene;
+			if (sp && has_lin(a.fs)) x = x + lin_eval(sp + ((size_t)m * 3 + c) * a.fs.n_params, a.fs);
+			v[k] = x;
+		} else {
+			v[k] = (is_obj ? a.obj_rest : a.scene_rest)[(size_t)m * (row - 3) + (c - 3)];
+		}
+	}
+	if (e0 + 4 <= total && (row & 3) == 0) *reinterpret_cast<float4*>(a.out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+	else { for (int k = 0; k < 4; k++) if (e0 + k < total) a.out[e0 + k] = v[k]; }
+}
+
+struct ShsBwdArgs {
+	int Ns, N, M;
+	const float* g;                                   // [N, M, 3]
+	float *g_scene_dc, *g_obj_dc, *g_scene_rest, *g_obj_rest;
+};
+__global__ void __launch_bounds__(256) deform_shs_bwd_copy_kernel(ShsBwdArgs a) {
+	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int row = a.M * 3;
+	if (e >= (size_t)a.N * row) return;
+	const int n = (int)(e / row), c = (int)(e % row);
+	const bool is_obj = n >= a.Ns;
+	const int m = is_obj ? n - a.Ns : n;
+	const float v = a.g[e];
+	if (c < 3) { float* d = is_obj ? a.g_obj_dc : a.g_scene_dc; if (d) d[3 * (size_t)m + c] = v; }
+	else { float* d = is_obj ? a.g_obj_rest : a.g_scene_rest; if (d) d[(size_t)m * (row - 3) + (c - 3)] = v; }
+}
+// d/d(param[n, c, k]) = w[k] * g[n, 0, c]: every column is written (zeros outside the active terms)
+struct ParamGradArgs {
+	int n0, count, D, gstride;                        // Gaussians [n0, n0+count) of g; D rows per Gaussian
+	const float* g;                                   // g[(n0 + m) * gstride + d]
+	float* out;                                       // [count, D, n_params]
+	adgs_func_eval f;
+};
+__global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
+	extern __shared__ float s_w[];
+	const int np = a.f.n_params;
+	for (int k = threadIdx.x; k < np; k += blockDim.x) s_w[k] = 0.f;
+	__syncthreads();
+	const int total = a.f.n_terms[0] + a.f.n_terms[1] + a.f.n_terms[2];
+	if (threadIdx.x == 0) for (int i = 0; i < total; i++) s_w[a.f.index[i]] = a.f.weight[i];
+	__syncthreads();
+	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t tot = (size_t)a.count * a.D * np;
+	if (e >= tot) return;
+	const int k = (int)(e % np);
+	const size_t md = e / np;
+	const int d = (int)(md % a.D);
+	const size_t m = md / a.D;
+	a.out[e] = s_w[k] * a.g[(a.n0 + m) * (size_t)a.gstride + d];
+}
+
 struct DeformBwdArgs {
 	adgs_deform_params p; adgs_func_eval fx, fr, fs, fb;
 	const float *g_xyz, *g_rot, *g_shs, *g_op, *g_sc;
@@ -486,8 +563,22 @@ extern "C" int adgs_deform_forward(const adgs_deform_params* p, const adgs_func_
 	a.p = *p; a.o = *out;
 	a.fx = f_xyz ? *f_xyz : empty_func(); a.fr = f_rotation ? *f_rotation : empty_func();
 	a.fs = f_shs ? *f_shs : empty_func(); a.fb = f_background ? *f_background : empty_func();
-	hipLaunchKernelGGL(deform_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
-	ADGS_HIP_CHECK(hipGetLastError());
+	hipStream_t stream = (hipStream_t)stream_;
+	float* shs_out = a.o.shs;
+	a.o.shs = nullptr;                       // SH rows go through the flat coalesced kernel below
+	if (a.o.xyz || a.o.rotation || a.o.opacity || a.o.scales) {
+		hipLaunchKernelGGL(deform_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
+		ADGS_HIP_CHECK(hipGetLastError());
+	}
+	if (shs_out) {
+		ShsFwdArgs sa;
+		sa.Ns = p->Ns; sa.N = N; sa.M = p->sh_coeffs;
+		sa.scene_dc = p->scene_shs_dc; sa.obj_dc = p->obj_shs_dc; sa.scene_rest = p->scene_shs_rest; sa.obj_rest = p->obj_shs_rest;
+		sa.sp_scene = p->shs_deform_param_scene; sa.sp_obj = p->shs_deform_param_obj; sa.fs = a.fs; sa.out = shs_out;
+		const size_t quads = ((size_t)N * p->sh_coeffs * 3 + 3) / 4;
+		hipLaunchKernelGGL(deform_shs_fwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, sa);
+		ADGS_HIP_CHECK(hipGetLastError());
+	}
 	return 0;
 }
 
@@ -503,8 +594,30 @@ extern "C" int adgs_deform_backward(const adgs_deform_params* p, const adgs_func
 	a.p = *p; a.g = *grads;
 	a.fx = f_xyz ? *f_xyz : empty_func(); a.fr = f_rotation ? *f_rotation : empty_func();
 	a.fs = f_shs ? *f_shs : empty_func(); a.fb = f_background ? *f_background : empty_func();
-	a.g_xyz = dL_dxyz; a.g_rot = dL_drotation; a.g_shs = dL_dshs; a.g_op = dL_dopacity; a.g_sc = dL_dscales;
-	hipLaunchKernelGGL(deform_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
-	ADGS_HIP_CHECK(hipGetLastError());
+	hipStream_t stream = (hipStream_t)stream_;
+	a.g_xyz = dL_dxyz; a.g_rot = dL_drotation; a.g_shs = nullptr; a.g_op = dL_dopacity; a.g_sc = dL_dscales;
+	if (dL_dxyz || dL_drotation || dL_dopacity || dL_dscales) {
+		hipLaunchKernelGGL(deform_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
+		ADGS_HIP_CHECK(hipGetLastError());
+	}
+	if (dL_dshs) {
+		const int M = p->sh_coeffs;
+		ShsBwdArgs sb;
+		sb.Ns = p->Ns; sb.N = N; sb.M = M; sb.g = dL_dshs;
+		sb.g_scene_dc = grads->scene_shs_dc; sb.g_obj_dc = grads->obj_shs_dc; sb.g_scene_rest = grads->scene_shs_rest; sb.g_obj_rest = grads->obj_shs_rest;
+		const size_t tot = (size_t)N * M * 3;
+		hipLaunchKernelGGL(deform_shs_bwd_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, sb);
+		ADGS_HIP_CHECK(hipGetLastError());
+		for (int part = 0; part < 2; part++) {
+			float* out = part == 0 ? grads->shs_deform_param_scene : grads->shs_deform_param_obj;
+			const int count = part == 0 ? p->Ns : p->No;
+			if (!out || count == 0 || a.fs.n_params == 0) continue;
+			ParamGradArgs pg;
+			pg.n0 = part == 0 ? 0 : p->Ns; pg.count = count; pg.D = 3; pg.gstride = M * 3; pg.g = dL_dshs; pg.out = out; pg.f = a.fs;
+			const size_t t2 = (size_t)count * 3 * a.fs.n_params;
+			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), a.fs.n_params * sizeof(float), stream, pg);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
+	}
 	return 0;
 }

@@ -16,7 +16,7 @@ struct PreprocessArgs {
 	// outputs
 	int* radii; Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched;
 	// v2 (coarse-binned) extras; rects == nullptr selects the classic behaviour
-	uint2* rects;                    // per-Gaussian fine-tile rectangle (u16 x4), possibly empty
+	FilterRec* rects;                // per-Gaussian tile-filter record (rectangle possibly empty)
 	uint32_t* fine_touched;          // #fine tiles covered per Gaussian (its sum bounds the chunk pool)
 	int cell_tiles, cgx, cgy;        // coarse cell = cell_tiles x cell_tiles fine tiles
 };
@@ -79,11 +79,11 @@ constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
 constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumulators per Gaussian
 constexpr int GACC_USED = 14;           // mx my ca cb cc op c0 c1 c2 d f0 f1 f2 s0
 
-int launch_duplicate_cells(int P, const Splat* splats, const uint2* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
+int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	int cell_tiles, int cgx, hipStream_t stream);
 
 struct RenderV2FwdArgs {
-	const uint2* cell_ranges; const uint32_t* cell_list; const uint2* rects; const Splat* splats;
+	const uint2* cell_ranges; const uint32_t* cell_list; const FilterRec* rects; const Splat* splats;
 	int W, H, gx, gy, cell_tiles, cgx;
 	bool has_color, has_flow, has_sem;
 	const float* bg;

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	if (idx >= a.P) return;
 	a.radii[idx] = 0;
 	a.tiles_touched[idx] = 0;
-	if (a.rects) { a.rects[idx] = make_uint2(0u, 0u); a.fine_touched[idx] = 0; }
+	if (a.rects) { a.rects[idx].rmin = 0u; a.rects[idx].rmax = 0u; a.fine_touched[idx] = 0; }
 
 	const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
 	const float* V = a.view; const float* PJ = a.proj;
@@ -207,7 +207,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		const int iy0 = max((int)miny, tminy), iy1 = min((int)maxy, tmaxy);
 		if (ix1 > ix0 && iy1 > iy0) { sminx = (uint32_t)ix0; smaxx = (uint32_t)ix1; sminy = (uint32_t)iy0; smaxy = (uint32_t)iy1; }
 	}
-	a.rects[idx] = make_uint2(sminx | (sminy << 16), smaxx | (smaxy << 16));
+	{
+		FilterRec fr;
+		fr.x = pix; fr.y = piy; fr.ca = conx; fr.cb = cony; fr.cc = conz; fr.tau = tau;
+		fr.rmin = sminx | (sminy << 16); fr.rmax = smaxx | (smaxy << 16);
+		float4* d = reinterpret_cast<float4*>(a.rects + idx);
+		d[0] = make_float4(fr.x, fr.y, fr.ca, fr.cb);
+		d[1] = make_float4(fr.cc, fr.tau, __uint_as_float(fr.rmin), __uint_as_float(fr.rmax));
+	}
 	uint32_t ncell = 0;
 	const uint32_t nfine = (smaxx - sminx) * (smaxy - sminy);
 	if (nfine) {
@@ -247,12 +254,12 @@ __global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat*
 }
 
 // v2: one (cell | depth) key per covered coarse cell.
-__global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat* __restrict__ splats, const uint2* __restrict__ rects,
+__global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat* __restrict__ splats, const FilterRec* __restrict__ rects,
 	const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int cell_tiles, int cgx) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (idx >= P) return;
-	const uint2 r = rects[idx];
-	const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu, maxy = r.y >> 16;
+	const uint32_t rmin = rects[idx].rmin, rmax = rects[idx].rmax;
+	const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, maxx = rmax & 0xFFFFu, maxy = rmax >> 16;
 	if (maxx <= minx || maxy <= miny) return;
 	uint32_t off = offsets[idx];
 	const uint32_t dbits = __float_as_uint(splats[idx].zview);
@@ -299,7 +306,7 @@ int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, c
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
-int launch_duplicate_cells(int P, const Splat* splats, const uint2* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
+int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	int cell_tiles, int cgx, hipStream_t stream) {
 	if (P == 0) return 0;
 	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, rects, offsets, keys, vals, cell_tiles, cgx);

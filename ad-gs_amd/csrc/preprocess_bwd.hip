@@ -37,7 +37,26 @@ __device__ __forceinline__ M3 m3t(const M3& a) {
 
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= a.P || !(a.radii[idx] > 0)) return;
+	if (idx >= a.P) return;
+	if (!(a.radii[idx] > 0)) {
+		// v2: every output row is written here, so the caller does not have to zero-fill them
+		if (a.gacc) {
+			a.out_mean2D[3 * (size_t)idx] = 0.f; a.out_mean2D[3 * (size_t)idx + 1] = 0.f; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
+			*reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+			a.out_opacity[idx] = 0.f; a.out_depth[idx] = 0.f;
+			a.out_color[3 * (size_t)idx] = 0.f; a.out_color[3 * (size_t)idx + 1] = 0.f; a.out_color[3 * (size_t)idx + 2] = 0.f;
+			if (a.out_flow) { a.out_flow[3 * (size_t)idx] = 0.f; a.out_flow[3 * (size_t)idx + 1] = 0.f; a.out_flow[3 * (size_t)idx + 2] = 0.f; }
+			if (a.out_sem && a.D_S == 1) a.out_sem[idx] = 0.f;
+			a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f;
+			for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+			if (a.shs) { float* dsh = a.dL_dsh + (size_t)idx * a.M * 3; for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f; }
+			if (a.scales) {
+				a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f;
+				*reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+		}
+		return;
+	}
 	const float* V = a.view; const float* PJ = a.proj;
 	const float mx = a.means3D[3 * (size_t)idx], my = a.means3D[3 * (size_t)idx + 1], mz = a.means3D[3 * (size_t)idx + 2];
 
@@ -49,7 +68,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 		const float4 u0 = ga[0], u1 = ga[1], u2 = ga[2], u3 = ga[3];   // mx my ca cb | cc op c0 c1 | c2 d f0 f1 | f2 s0 - -
 		g2x = u0.x; g2y = u0.y; dcon_x = u0.z; dcon_y = u0.w; dcon_z = u1.x;
 		gcol[0] = u1.z; gcol[1] = u1.w; gcol[2] = u2.x; gd = u2.y;
-		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y;
+		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
 		*reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
 		a.out_opacity[idx] = u1.y;
 		a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2];
@@ -200,6 +219,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 			}
 		}
 #undef SETSH
+		// coefficients above the active degree receive no gradient
+		for (int k = (deg + 1) * (deg + 1); k < a.M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
 		const float ddx = dx3[0] * g[0] + dx3[1] * g[1] + dx3[2] * g[2];
 		const float ddy = dy3[0] * g[0] + dy3[1] * g[1] + dy3[2] * g[2];
 		const float ddz = dz3[0] * g[0] + dz3[1] * g[1] + dz3[2] * g[2];

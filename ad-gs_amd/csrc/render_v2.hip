@@ -32,9 +32,36 @@ constexpr float T_STOP = 0.0001f;
 constexpr int PPL = 4;                    // pixels per lane
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
 
-__device__ __forceinline__ bool tile_in_rect(uint2 rect, uint32_t tx, uint32_t ty) {
-	const uint32_t minx = rect.x & 0xFFFFu, miny = rect.x >> 16, maxx = rect.y & 0xFFFFu, maxy = rect.y >> 16;
-	return tx >= minx && tx < maxx && ty >= miny && ty < maxy;
+#ifndef ADGS_PRECISE_EXP
+#define ADGS_EXP(x) __expf(x)      // v_exp_f32(x * log2 e): ~3e-7 relative, far inside the 1e-4 budget
+#else
+#define ADGS_EXP(x) expf(x)
+#endif
+
+// Can Gaussian `f` reach alpha >= 1/255 on any pixel centre of tile (tx,ty)?  Exact minimum of the
+// quadratic form d^T Q d over the tile's pixel-centre rectangle [16tx,16tx+15]x[16ty,16ty+15]
+// (a lower bound of the minimum over its integer pixels), compared with tau (which carries the slack).
+__device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float4 f1, uint32_t tx, uint32_t ty) {
+	const uint32_t rmin = __float_as_uint(f1.z), rmax = __float_as_uint(f1.w);
+	const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, maxx = rmax & 0xFFFFu, maxy = rmax >> 16;
+	if (!(tx >= minx && tx < maxx && ty >= miny && ty < maxy)) return false;
+	const float A = f0.z, B = f0.w, C = f1.x, tau = f1.y;
+	// rectangle relative to the mean: d = pixel - mean (the form is symmetric in the sign of d)
+	const float x0 = (float)(tx * TILE_X) - f0.x, x1 = x0 + (float)(TILE_X - 1);
+	const float y0 = (float)(ty * TILE_Y) - f0.y, y1 = y0 + (float)(TILE_Y - 1);
+	if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;      // mean inside the tile
+	// minimum over the four edges: fix one coordinate, clamp the unconstrained minimiser of the other
+	float best = 3.0e38f;
+#pragma unroll
+	for (int e = 0; e < 2; e++) {
+		const float dx = e ? x1 : x0;
+		const float dy = fminf(fmaxf(-B * dx / C, y0), y1);
+		best = fminf(best, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
+		const float ey = e ? y1 : y0;
+		const float ex = fminf(fmaxf(-B * ey / A, x0), x1);
+		best = fminf(best, A * ex * ex + 2.f * B * ex * ey + C * ey * ey);
+	}
+	return best <= tau * 1.0005f + 1e-3f;
 }
 
 __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
@@ -72,7 +99,8 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			bool pass = false; uint32_t id = 0;
 			if (e < range.y) {
 				id = a.cell_list[e];
-				pass = tile_in_rect(a.rects[id], tx, ty);
+				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
+				pass = tile_may_contribute(fr[0], fr[1], tx, ty);
 			}
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
@@ -113,7 +141,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			for (int k = 0; k < PPL; k++) {
 				const float dy = q0.y - pyf[k];
 				const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-				alpha[k] = fminf(ALPHA_MAX, q1.y * expf(power));
+				alpha[k] = fminf(ALPHA_MAX, q1.y * ADGS_EXP(power));
 				act[k] = !done[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
 				any_act = any_act || act[k];
 			}
@@ -245,7 +273,7 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 				for (int k = 0; k < PPL; k++) {
 					dy[k] = q0.y - pyf[k];
 					const float power = -0.5f * (q0.z * dx * dx + q1.x * dy[k] * dy[k]) - q0.w * dx * dy[k];
-					G[k] = expf(power);
+					G[k] = ADGS_EXP(power);
 					alpha[k] = fminf(ALPHA_MAX, q1.y * G[k]);
 					act[k] = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
 					any_act = any_act || act[k];

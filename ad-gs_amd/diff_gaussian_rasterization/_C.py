@@ -67,12 +67,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if flow_points.size(0) != 0:
         assert flow_points.size(1) == FLOW_CHANNELS
     f32 = dict(dtype=torch.float32, device=dev)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
-    out_depth = torch.zeros((1, H, W), **f32)
-    img_opacity = torch.zeros((1, H, W), **f32)
-    img_flow = torch.zeros((FLOW_CHANNELS, H, W), **f32)
-    img_semantic = torch.zeros((D_S, H, W), **f32)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # outputs the kernels fully overwrite need no zero fill (adgs_raster_needs_zero_init)
+    lazy = P != 0 and lib.adgs_raster_needs_zero_init(D_S) == 0
+    alloc = lambda written, *shape: (torch.empty if (lazy and written) else torch.zeros)(shape, **f32)
+    out_color = alloc(sh.size(0) != 0 or colors.size(0) != 0, NUM_CHANNELS, H, W)
+    out_depth = alloc(True, 1, H, W)
+    img_opacity = alloc(True, 1, H, W)
+    img_flow = alloc(flow_points.size(0) != 0, FLOW_CHANNELS, H, W)
+    img_semantic = alloc(D_S > 0, D_S, H, W)
+    radii = (torch.empty if lazy else torch.zeros)((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Buffer(dev), _Buffer(dev), _Buffer(dev)
     rendered = 0
     if P != 0:
@@ -107,10 +110,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         assert D_S <= SEMANTIC_CHANNELS
     if flow_points.size(0) != 0:
         assert flow_points.size(1) == FLOW_CHANNELS
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 1)
-    dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = z(P, 2, 2), z(P, 1), z(P, 6), z(P, M, 3)
-    dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic = z(P, 3), z(P, 4), z(P, FLOW_CHANNELS), z(P, D_S)
+    lazy = P != 0 and lib.adgs_raster_needs_zero_init(D_S) == 0
+    z = lambda written, *shape: (torch.empty if (lazy and written) else torch.zeros)(shape, dtype=torch.float32, device=dev)
+    has_sr = scales.size(0) != 0
+    has_flow = flow_points.size(0) != 0 and dL_dout_flow is not None and dL_dout_flow.numel() != 0
+    has_sem = D_S > 0 and dL_dout_semantic is not None and dL_dout_semantic.numel() != 0
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = z(True, P, 3), z(True, P, 3), z(True, P, NUM_CHANNELS), z(True, P, 1)
+    dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = z(True, P, 2, 2), z(True, P, 1), z(True, P, 6), z(True, P, M, 3)
+    dL_dscales, dL_drotations = z(has_sr, P, 3), z(has_sr, P, 4)
+    dL_dflow_points, dL_dsemantic = z(has_flow, P, FLOW_CHANNELS), z(has_sem, P, D_S)
     if P != 0:
         keep = [_prep(t, dev, n) for t, n in (
             (background, "bg"), (means3D, "means3D"), (sh, "sh"), (colors, "colors_precomp"), (flow_points, "flow_points"),

@@ -116,6 +116,14 @@ int adgs_raster_backward(
 	int debug,
 	void* stream);
 
+/* The reference requires the caller to zero-fill every output of forward and backward
+ * (rasterize_points.cu:82-87,195-206).  Zero-filled outputs are always accepted; this returns 0
+ * when the pipeline selected for D_S semantic channels writes every element itself (the default
+ * coarse-binned pipeline), so a caller may skip the fills, and 1 otherwise.  Exceptions that
+ * must stay zero-filled when the corresponding input is absent: out_color (no shs/colours),
+ * img_flow / dL_dflow (no flow_points), dL_dscale / dL_drot (cov3D_precomp given). */
+int adgs_raster_needs_zero_init(int D_S);
+
 /* CudaRasterizer::Rasterizer::markVisible (RAST/cuda_rasterizer/rasterizer.h:24-29,
  * rasterizer_impl.cu:141-153).  `present` is a bool (1 byte) array of length P. */
 int adgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
