@@ -429,7 +429,7 @@ extern "C" int adgs_raster_backward(
 		pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
 		pa.dL_dmean2D = nullptr; pa.dL_dconic = nullptr; pa.dL_dcolor = nullptr; pa.dL_ddepth = nullptr;
 		pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
-		pa.gacc = geom.gacc;
+		pa.gacc = geom.gacc; pa.splats = geom.splats; pa.W = width; pa.H = height;
 		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
 		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
 		{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
@@ -471,7 +471,7 @@ extern "C" int adgs_raster_backward(
 	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
 	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
 	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
-	pa.gacc = nullptr; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
+	pa.gacc = nullptr; pa.splats = nullptr; pa.W = width; pa.H = height; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
 	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;
 	{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);

@@ -68,7 +68,7 @@ struct PreprocessBwdArgs {
 	float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 	// v2: per-Gaussian sums arrive packed in gacc ([P][16]); they are unpacked into the ABI outputs
 	// below (which are then written, not read).  gacc == nullptr selects the classic inputs above.
-	const float* gacc;
+	const float* gacc; const Splat* splats; int W, H;
 	float* out_mean2D; float* out_conic; float* out_opacity; float* out_color; float* out_depth; float* out_flow; float* out_sem;
 	int D_S;
 };
@@ -77,7 +77,7 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
 // ---- v2 pipeline (render_v2.hip) ----
 constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
 constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumulators per Gaussian
-constexpr int GACC_USED = 14;           // mx my ca cb cc op c0 c1 c2 d f0 f1 f2 s0
+constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
 int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	int cell_tiles, int cgx, hipStream_t stream);

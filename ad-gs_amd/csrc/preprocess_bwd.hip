@@ -65,12 +65,19 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 	float dcon_x, dcon_y, dcon_z, g2x, g2y, gd, gcol[3];
 	if (a.gacc) {
 		const float4* ga = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GACC_STRIDE);
-		const float4 u0 = ga[0], u1 = ga[1], u2 = ga[2], u3 = ga[3];   // mx my ca cb | cc op c0 c1 | c2 d f0 f1 | f2 s0 - -
-		g2x = u0.x; g2y = u0.y; dcon_x = u0.z; dcon_y = u0.w; dcon_z = u1.x;
+		const float4 u0 = ga[0], u1 = ga[1], u2 = ga[2], u3 = ga[3];
+		// u0 = (S0, Sx, Sy, Sxx), u1 = (Sxy, Syy, c0, c1): raw moment sums of L = G*dL/dalpha (render_v2.hip);
+		// the per-Gaussian factors of backward.cu:626-643 are applied here, once per Gaussian
+		const float4* sp = reinterpret_cast<const float4*>(a.splats + idx);
+		const float4 s0 = sp[0], s1 = sp[1];               // x y ca cb | cc op r g
+		const float op = s1.y, qa = s0.z, qb = s0.w, qc = s1.x;
+		g2x = -op * (qa * u0.y + qb * u0.z) * (float)(0.5 * a.W);
+		g2y = -op * (qc * u0.z + qb * u0.y) * (float)(0.5 * a.H);
+		dcon_x = -0.5f * op * u0.w; dcon_y = -0.5f * op * u1.x; dcon_z = -0.5f * op * u1.y;
 		gcol[0] = u1.z; gcol[1] = u1.w; gcol[2] = u2.x; gd = u2.y;
 		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
 		*reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
-		a.out_opacity[idx] = u1.y;
+		a.out_opacity[idx] = u0.x;
 		a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2];
 		a.out_depth[idx] = gd;
 		if (a.out_flow) { a.out_flow[3 * (size_t)idx] = u2.z; a.out_flow[3 * (size_t)idx + 1] = u2.w; a.out_flow[3 * (size_t)idx + 2] = u3.x; }

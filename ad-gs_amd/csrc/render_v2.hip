@@ -22,6 +22,7 @@
 // the backward replays exactly what the forward blended, back to front.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace adgs {
 namespace {
@@ -31,6 +32,9 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
 constexpr int PPL = 4;                    // pixels per lane
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
+#ifndef ADGS_BWD_WAVES
+#define ADGS_BWD_WAVES 3          // waves per SIMD the backward's register allocation is sized for
+#endif
 
 #ifndef ADGS_PRECISE_EXP
 #define ADGS_EXP(x) __expf(x)      // v_exp_f32(x * log2 e): ~3e-7 relative, far inside the 1e-4 budget
@@ -200,7 +204,8 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
-__global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) {
+template <int OCC>
+__global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArgs a) {
 	__shared__ float4 s_splat[WAVE * 4];
 	__shared__ uint32_t s_id[WAVE];
 	const int lane = threadIdx.x;
@@ -241,8 +246,6 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 	}
 #pragma unroll
 	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
-	const float ddelx_dx = (float)(0.5 * a.W), ddely_dy = (float)(0.5 * a.H);
-
 	uint32_t chunk = a.tile_last_chunk[tile];
 	int base = (int)a.tile_consumed[tile];        // one past the last position of the current chunk
 	while (chunk != NO_CHUNK) {
@@ -282,54 +285,55 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 				const float4 q2 = s_splat[j * 4 + 2];
 				const float4 q3 = s_splat[j * 4 + 3];
 				float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_s = 0.f, v_d = 0.f;
+				// geometric part: with L = G * dL/dalpha per pixel, the reference's six sums are linear in
+				//   S0 = sum L, Sx = sum L dx, Sy = sum L dy, Sxx = sum L dx^2, Sxy = sum L dx dy, Syy = sum L dy^2
+				// (dL/dmean2D = -op*(ca Sx + cb Sy)*W/2 ..., dL/dconic = -op/2 * S.., dL/dopacity = S0); the
+				// per-Gaussian factors are applied once per Gaussian in the preprocess backward.
 				float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
 					if (act[k]) {
 						const float al = alpha[k];
-						T[k] = T[k] / (1.f - al);
+						const float rinv = __builtin_amdgcn_rcpf(1.f - al);
+						T[k] = T[k] * rinv;
 						const float dch = al * T[k];
 						float dL_dalpha = 0.0f;
-						// suffix-blend recurrences of backward.cu:578-607, applied right after use
-						// (A_next = alpha*c + (1-alpha)*A is what the reference forms at the next
-						// contributing entry from last_alpha/last_color: same operations, same values)
+						// suffix-blend recurrences of backward.cu:578-607, applied right after use:
+						// A_next = A + alpha*(c - A) is the value the reference forms at the next contributing
+						// entry from last_alpha/last_color.
 						if (a.do_color) {
-							dL_dalpha += (q1.z - A_c0[k]) * gC0[k]; v_c0 += dch * gC0[k]; A_c0[k] = al * q1.z + (1.f - al) * A_c0[k];
-							dL_dalpha += (q1.w - A_c1[k]) * gC1[k]; v_c1 += dch * gC1[k]; A_c1[k] = al * q1.w + (1.f - al) * A_c1[k];
-							dL_dalpha += (q2.x - A_c2[k]) * gC2[k]; v_c2 += dch * gC2[k]; A_c2[k] = al * q2.x + (1.f - al) * A_c2[k];
+							float d;
+							d = q1.z - A_c0[k]; dL_dalpha += d * gC0[k]; v_c0 += dch * gC0[k]; A_c0[k] += al * d;
+							d = q1.w - A_c1[k]; dL_dalpha += d * gC1[k]; v_c1 += dch * gC1[k]; A_c1[k] += al * d;
+							d = q2.x - A_c2[k]; dL_dalpha += d * gC2[k]; v_c2 += dch * gC2[k]; A_c2[k] += al * d;
 						}
 						if (a.do_flow) {
-							dL_dalpha += (q2.z - A_f0[k]) * gF0[k]; v_f0 += dch * gF0[k]; A_f0[k] = al * q2.z + (1.f - al) * A_f0[k];
-							dL_dalpha += (q2.w - A_f1[k]) * gF1[k]; v_f1 += dch * gF1[k]; A_f1[k] = al * q2.w + (1.f - al) * A_f1[k];
-							dL_dalpha += (q3.x - A_f2[k]) * gF2[k]; v_f2 += dch * gF2[k]; A_f2[k] = al * q3.x + (1.f - al) * A_f2[k];
+							float d;
+							d = q2.z - A_f0[k]; dL_dalpha += d * gF0[k]; v_f0 += dch * gF0[k]; A_f0[k] += al * d;
+							d = q2.w - A_f1[k]; dL_dalpha += d * gF1[k]; v_f1 += dch * gF1[k]; A_f1[k] += al * d;
+							d = q3.x - A_f2[k]; dL_dalpha += d * gF2[k]; v_f2 += dch * gF2[k]; A_f2[k] += al * d;
 						}
-						if (a.do_sem) { dL_dalpha += (q3.y - A_s[k]) * gS[k]; v_s += dch * gS[k]; A_s[k] = al * q3.y + (1.f - al) * A_s[k]; }
-						if (a.do_depth) { dL_dalpha += (q2.y - A_d[k]) * gD[k]; v_d += dch * gD[k]; A_d[k] = al * q2.y + (1.f - al) * A_d[k]; }
-						if (a.do_opacity) dL_dalpha += gO[k] * T_final[k] / (1.f - al);    // before the *= T: reference quirk
-						dL_dalpha *= T[k];
-						dL_dalpha += (-T_final[k] / (1.f - al)) * bgdot[k];
-						const float dL_dG = q1.y * dL_dalpha;
-						const float gdx = G[k] * dx, gdy = G[k] * dy[k];
-						const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-						const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-						v_mx += dL_dG * dG_ddelx * ddelx_dx;
-						v_my += dL_dG * dG_ddely * ddely_dy;
-						v_ca += -0.5f * gdx * dx * dL_dG;
-						v_cb += -0.5f * gdx * dy[k] * dL_dG;
-						v_cc += -0.5f * gdy * dy[k] * dL_dG;
-						v_op += G[k] * dL_dalpha;
+						if (a.do_sem) { const float d = q3.y - A_s[k]; dL_dalpha += d * gS[k]; v_s += dch * gS[k]; A_s[k] += al * d; }
+						if (a.do_depth) { const float d = q2.y - A_d[k]; dL_dalpha += d * gD[k]; v_d += dch * gD[k]; A_d[k] += al * d; }
+						const float tfr = T_final[k] * rinv;
+						if (a.do_opacity) dL_dalpha += gO[k] * tfr;    // before the *= T: reference quirk (backward.cu:612-614)
+						dL_dalpha = dL_dalpha * T[k] - tfr * bgdot[k];
+						const float L = G[k] * dL_dalpha;
+						const float Lx = L * dx, Ly = L * dy[k];
+						v_op += L; v_mx += Lx; v_my += Ly;
+						v_ca += Lx * dx; v_cb += Lx * dy[k]; v_cc += Ly * dy[k];
 					}
 				}
 				// 14 wave sums (totals in lane 63) -> lanes 0..13 -> one atomic instruction on one 64-B line
 				float out = 0.f;
 				{
 					float s;
-					s = lane63(wave_sum_dpp(v_mx)); if (lane == 0) out = s;
-					s = lane63(wave_sum_dpp(v_my)); if (lane == 1) out = s;
-					s = lane63(wave_sum_dpp(v_ca)); if (lane == 2) out = s;
-					s = lane63(wave_sum_dpp(v_cb)); if (lane == 3) out = s;
-					s = lane63(wave_sum_dpp(v_cc)); if (lane == 4) out = s;
-					s = lane63(wave_sum_dpp(v_op)); if (lane == 5) out = s;
+					s = lane63(wave_sum_dpp(v_op)); if (lane == 0) out = s;
+					s = lane63(wave_sum_dpp(v_mx)); if (lane == 1) out = s;
+					s = lane63(wave_sum_dpp(v_my)); if (lane == 2) out = s;
+					s = lane63(wave_sum_dpp(v_ca)); if (lane == 3) out = s;
+					s = lane63(wave_sum_dpp(v_cb)); if (lane == 4) out = s;
+					s = lane63(wave_sum_dpp(v_cc)); if (lane == 5) out = s;
 					if (a.do_color) {
 						s = lane63(wave_sum_dpp(v_c0)); if (lane == 6) out = s;
 						s = lane63(wave_sum_dpp(v_c1)); if (lane == 7) out = s;
@@ -367,7 +371,10 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 }
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;
-	hipLaunchKernelGGL(render_bwd_v2_kernel, dim3(T), dim3(WAVE), 0, stream, a);
+	static const int occ = [] { const char* v = getenv("ADGS_BWD_OCC"); return (v && *v) ? atoi(v) : ADGS_BWD_WAVES; }();
+	if (occ >= 4) hipLaunchKernelGGL(render_bwd_v2_kernel<4>, dim3(T), dim3(WAVE), 0, stream, a);
+	else if (occ == 3) hipLaunchKernelGGL(render_bwd_v2_kernel<3>, dim3(T), dim3(WAVE), 0, stream, a);
+	else hipLaunchKernelGGL(render_bwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
