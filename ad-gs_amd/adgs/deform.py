@@ -237,17 +237,29 @@ class _DeformPkgFn(torch.autograd.Function):
         p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)), float(t)
         for n in _PTRS:
             setattr(p, n, _dp(named[n]))
-        grads, gs = {}, DeformGrads()
-        for n in _GRADS:
-            src = named[n]
-            need = src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)]
-            # SH-related gradients are fully written by the flat kernels when an upstream SH gradient exists
-            full = g_shs is not None and g_shs.numel() > 0 and "shs" in want and ("shs_dc" in n or "shs_rest" in n or n.startswith("shs_deform"))
-            grads[n] = (torch.empty_like(src) if full else torch.zeros_like(src)) if need else None
-            setattr(gs, n, _dp(grads[n]))
         up = {}
         for k, g in (("xyz", g_xyz), ("rotation", g_rot), ("shs", g_shs), ("opacity", g_op), ("scales", g_sc)):
             up[k] = g.contiguous().float() if (k in want and g is not None and g.numel() > 0) else None
+        # which output each raw parameter feeds; a parameter whose output has no upstream gradient gets
+        # no gradient tensor at all, the others are fully written by the kernels (no zero fill) except
+        # the atomically accumulated background row
+        dep = {"scene_xyz": "xyz", "obj_xyz": "xyz", "xyz_deform_param": "xyz", "background_deform_param": "xyz",
+               "scene_rotation": "rotation", "obj_rotation": "rotation", "rotation_deform_param": "rotation",
+               "scene_shs_dc": "shs", "obj_shs_dc": "shs", "scene_shs_rest": "shs", "obj_shs_rest": "shs",
+               "shs_deform_param_scene": "shs", "shs_deform_param_obj": "shs",
+               "scene_opacity": "opacity", "obj_opacity": "opacity", "gs_time_sigma": "opacity",
+               "scene_scaling": "scales", "obj_scaling": "scales"}
+        grads, gs = {}, DeformGrads()
+        for n in _GRADS:
+            src = named[n]
+            need = (src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)] and up[dep[n]] is not None)
+            if not need:
+                grads[n] = None
+            elif n == "background_deform_param":          # accumulated with atomics
+                grads[n] = torch.zeros_like(src)
+            else:
+                grads[n] = torch.empty_like(src)
+            setattr(gs, n, _dp(grads[n]))
         fe = ctx.fe
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().adgs_deform_backward(ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]),

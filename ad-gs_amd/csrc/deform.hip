@@ -400,8 +400,10 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 		float* dst = is_obj ? (a.g.obj_xyz ? a.g.obj_xyz + 3 * (size_t)m : nullptr) : (a.g.scene_xyz ? a.g.scene_xyz + 3 * (size_t)m : nullptr);
 		if (dst) { dst[0] = gx[0]; dst[1] = gx[1]; dst[2] = gx[2]; }
 		if (is_obj && a.g.xyz_deform_param) {
+			float* row = a.g.xyz_deform_param + (size_t)m * 3 * a.fx.n_params;
+			for (int k = 0; k < 3 * a.fx.n_params; k++) row[k] = 0.f;       // every column is written: no caller zero-fill
 #pragma unroll
-			for (int d = 0; d < 3; d++) lin_bwd(a.g.xyz_deform_param + ((size_t)m * 3 + d) * a.fx.n_params, a.fx, gx[d]);
+			for (int d = 0; d < 3; d++) lin_bwd(row + d * a.fx.n_params, a.fx, gx[d]);
 		}
 	}
 	// background: the same [1,3,Cb] row is added to every Gaussian -> reduce g over all n
@@ -457,6 +459,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 			}
 			if (a.g.rotation_deform_param && rp) {
 				float* gp = a.g.rotation_deform_param + (size_t)m * 4 * a.fr.n_params;
+				for (int k = 0; k < 4 * a.fr.n_params; k++) gp[k] = 0.f;
 #pragma unroll
 				for (int d = 0; d < 4; d++) lin_bwd(gp + d * a.fr.n_params, a.fr, gu[d]);
 				if (a.fr.quat_start >= 0) quat_spline_bwd(rp, a.fr, { gu[0], gu[1], gu[2], gu[3] }, gp);
