@@ -28,6 +28,12 @@ SIGNATURES = {
     "adgs_raster_backward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
                                    c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "adgs_raster_forward_rawsh": (c_i, [ALLOC_FN, c_p, ALLOC_FN, c_p, ALLOC_FN, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i,
+                                        c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_f, c_f,
+                                        c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "adgs_raster_backward_rawsh": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_p,
+                                         c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                         c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "adgs_mark_visible": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p]),
     "adgs_knn_workspace_bytes": (ctypes.c_size_t, [c_i]),
     "adgs_knn_dist2": (c_i, [c_i, c_p, c_p, c_p, c_p]),

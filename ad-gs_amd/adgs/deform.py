@@ -269,10 +269,18 @@ class _DeformPkgFn(torch.autograd.Function):
         return (None,) + tuple(grads.get(n) for n in _PTRS)
 
 
-def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales")):
+def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales"), raw_sh=False):
     """Fused scene/gaussian_model.py:216-231 (+ get_scaling :89-91) on the raw parameters of `model`
     (any object with the reference GaussianModel's attributes).  Returns the reference's dict
-    {'xyz','rotation','shs','opacity'} plus 'scales'."""
+    {'xyz','rotation','shs','opacity'} plus 'scales'.  With raw_sh=True the [N,M,3] SH tensor is not
+    materialised: 'shs' is a diff_gaussian_rasterization.RawSH for GaussianRasterizer.forward_rawsh."""
+    if raw_sh and "shs" in want:
+        from diff_gaussian_rasterization import RawSH
+        out = get_deformed_pkg(model, t, want=tuple(w for w in want if w != "shs"))
+        sp = model.shs_deform_param_scene
+        out["shs"] = RawSH(model._scene_shs_dc, model._obj_shs_dc, model._scene_shs_rest, model._obj_shs_rest, sp, model.shs_deform_param_obj,
+                           make_func_eval(float(t), model.order_args["shs"], sp.shape[-1]))
+        return out
     tensors = [getattr(model, _MODEL_ATTRS[n], None) for n in _PTRS]
     meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want))
     xyz, rot, shs, op, sc = _DeformPkgFn.apply(meta, *tensors)

@@ -93,10 +93,12 @@ class SyntheticGaussianModel:
     def get_deformed_xyz(self, t):
         return deform.get_deformed_xyz(self, t)
 
+    raw_sh = False     # True: get_deformed_pkg leaves the SH coefficients in raw layout (RawSH) for forward_rawsh
+
     def get_deformed_pkg(self, t):
         """Reference keys 'xyz','rotation','shs','opacity' plus 'scales' (so that render() needs no
         separate get_scaling pass)."""
-        return deform.get_deformed_pkg(self, t)
+        return deform.get_deformed_pkg(self, t, raw_sh=self.raw_sh)
 
     def deform_bytes_per_frame(self):
         """Algorithmic bytes of the deformation stage per frame: deformation

@@ -11,6 +11,7 @@
 #include <vector>
 #include <cstdlib>
 #include <algorithm>
+#include <cstring>
 
 namespace adgs {
 
@@ -72,7 +73,7 @@ struct BinState {
 // ---- v2 (coarse-binned) state ----
 struct GeomStateV2 {
 	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects;
-	float* gacc; char* scan_temp;
+	float* gacc; float* sh0; char* scan_temp;
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
 		Carver c(chunk); GeomStateV2 g;
 		g.splats = c.take<Splat>(P);
@@ -83,6 +84,7 @@ struct GeomStateV2 {
 		g.cells_touched = c.take<uint32_t>(P + 1);
 		g.offsets = c.take<uint32_t>(P + 1);
 		g.fine_touched = c.take<uint32_t>(P + 1);
+		g.sh0 = c.take<float>(P * 3);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
 		if (bytes) *bytes = c.size();
 		return g;
@@ -204,7 +206,7 @@ extern "C" int adgs_device_check(void) {
 	return 0;
 }
 
-extern "C" int adgs_raster_forward(
+static int raster_forward_impl(const ShSource* sh_src,
 	adgs_alloc_fn geometryBuffer, void* geometryUser,
 	adgs_alloc_fn binningBuffer, void* binningUser,
 	adgs_alloc_fn imageBuffer, void* imageUser,
@@ -249,6 +251,9 @@ extern "C" int adgs_raster_forward(
 		pa.inv_depth = inv_depth;
 		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;
 		pa.rects = geom.rects; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
+		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
+		pa.sh0 = geom.sh0;
+		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream) != 0) return -1; }
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		{
@@ -293,7 +298,7 @@ extern "C" int adgs_raster_forward(
 		RenderV2FwdArgs ra;
 		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
-		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr);
+		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
 		ra.bg = background;
 		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
@@ -328,6 +333,8 @@ extern "C" int adgs_raster_forward(
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
 	pa.rects = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
+	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr;
+	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
@@ -378,7 +385,7 @@ extern "C" int adgs_raster_forward(
 	return num_rendered;
 }
 
-extern "C" int adgs_raster_backward(
+static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	int P, int D, int M, int R, int D_S,
 	const float* background, int width, int height,
 	const float* means3D, const float* shs, const float* colors_precomp, const float* flow_points, const float* semantic,
@@ -400,7 +407,7 @@ extern "C" int adgs_raster_backward(
 		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr);
 		ImgStateV2 img = ImgStateV2::carve(img_buffer, npix, ntiles, ncells, nullptr);
 		BinStateV2 bin = BinStateV2::carve(binning_buffer, 0, 0, ntiles, nullptr);     // only pool_cursor / pool are used
-		const bool has_color = (colors_precomp != nullptr) || (shs != nullptr);
+		const bool has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		RenderV2BwdArgs ra;
 		ra.splats = geom.splats; ra.pool = bin.pool; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy;
@@ -430,6 +437,8 @@ extern "C" int adgs_raster_backward(
 		pa.dL_dmean2D = nullptr; pa.dL_dconic = nullptr; pa.dL_dcolor = nullptr; pa.dL_ddepth = nullptr;
 		pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
 		pa.gacc = geom.gacc; pa.splats = geom.splats; pa.W = width; pa.H = height;
+		memset(&pa.sh_src, 0, sizeof(pa.sh_src)); memset(&pa.sh_dst, 0, sizeof(pa.sh_dst));
+		if (sh_src) { pa.sh_src = *sh_src; if (sh_dst) pa.sh_dst = *sh_dst; }
 		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
 		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
 		{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
@@ -471,11 +480,87 @@ extern "C" int adgs_raster_backward(
 	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
 	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
 	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
+	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
+	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); memset(&pa.sh_dst, 0, sizeof(pa.sh_dst));
 	pa.gacc = nullptr; pa.splats = nullptr; pa.W = width; pa.H = height; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
 	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;
 	{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 	return 0;
+}
+
+extern "C" int adgs_raster_forward(
+	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser, adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S, const float* background, int width, int height,
+	const float* means3D, const float* shs, const float* colors_precomp, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream) {
+	return raster_forward_impl(nullptr, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
+		width, height, means3D, shs, colors_precomp, flow_points, semantic, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+		viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, img_opacity, img_flow, img_semantic,
+		inv_depth, radii, debug, stream);
+}
+
+extern "C" int adgs_raster_backward(
+	int P, int D, int M, int R, int D_S, const float* background, int width, int height,
+	const float* means3D, const float* shs, const float* colors_precomp, const float* flow_points, const float* semantic,
+	const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+	const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+	const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+	const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_flow, const float* dL_dpix_semantic,
+	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+	float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dflow, float* dL_dsemantic,
+	const float* grad_img_opacity, const float* img_opacity, int inv_depth, int debug, void* stream) {
+	return raster_backward_impl(nullptr, nullptr, P, D, M, R, D_S, background, width, height, means3D, shs, colors_precomp, flow_points, semantic,
+		scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+		img_buffer, dL_dpix, dL_dpix_depth, dL_dpix_flow, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
+		dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dflow, dL_dsemantic, grad_img_opacity, img_opacity, inv_depth, debug, stream);
+}
+
+static ShSource to_sh_source(const adgs_sh_source* s) {
+	ShSource r;
+	r.Ns = s->Ns; r.scene_dc = s->scene_dc; r.obj_dc = s->obj_dc; r.scene_rest = s->scene_rest; r.obj_rest = s->obj_rest;
+	r.scene_sp = s->scene_deform; r.obj_sp = s->obj_deform; r.f = s->f;
+	return r;
+}
+
+extern "C" int adgs_raster_forward_rawsh(
+	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser, adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S, const float* background, int width, int height,
+	const float* means3D, const adgs_sh_source* sh, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream) {
+	if (!sh || !sh->scene_dc || !sh->obj_dc || (M > 1 && (!sh->scene_rest || !sh->obj_rest))) { set_error("adgs_raster_forward_rawsh: incomplete SH source"); return -1; }
+	const ShSource src = to_sh_source(sh);
+	return raster_forward_impl(&src, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
+		width, height, means3D, nullptr, nullptr, flow_points, semantic, opacities, scales, scale_modifier, rotations, nullptr,
+		viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, img_opacity, img_flow, img_semantic,
+		inv_depth, radii, debug, stream);
+}
+
+extern "C" int adgs_raster_backward_rawsh(
+	int P, int D, int M, int R, int D_S, const float* background, int width, int height,
+	const float* means3D, const adgs_sh_source* sh, const float* flow_points, const float* semantic,
+	const float* scales, float scale_modifier, const float* rotations,
+	const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+	const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+	const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_flow, const float* dL_dpix_semantic,
+	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+	float* dL_dcov3D, const adgs_sh_grads* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dflow, float* dL_dsemantic,
+	const float* grad_img_opacity, const float* img_opacity, int inv_depth, int debug, void* stream) {
+	if (!sh || !dL_dsh) { set_error("adgs_raster_backward_rawsh: NULL SH source / gradients"); return -1; }
+	const ShSource src = to_sh_source(sh);
+	ShGradDst dst;
+	dst.scene_dc = dL_dsh->scene_dc; dst.obj_dc = dL_dsh->obj_dc; dst.scene_rest = dL_dsh->scene_rest; dst.obj_rest = dL_dsh->obj_rest;
+	dst.scene_sp = dL_dsh->scene_deform; dst.obj_sp = dL_dsh->obj_deform;
+	return raster_backward_impl(&src, &dst, P, D, M, R, D_S, background, width, height, means3D, nullptr, nullptr, flow_points, semantic,
+		scales, scale_modifier, rotations, nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+		img_buffer, dL_dpix, dL_dpix_depth, dL_dpix_flow, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
+		dL_dcov3D, nullptr, dL_dscale, dL_drot, dL_dflow, dL_dsemantic, grad_img_opacity, img_opacity, inv_depth, debug, stream);
 }
 
 extern "C" int adgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_) {

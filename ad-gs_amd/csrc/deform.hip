@@ -11,7 +11,7 @@
 // (59 floats + deformation rows) and writes the 59 activated floats the rasterizer reads;
 // the backward reads the 59 upstream gradients and writes every parameter gradient.
 #include "common.h"
-#include "../../include/adgs_deform.h"
+#include "func_eval.h"
 #include <cstring>
 
 namespace adgs {
@@ -77,27 +77,6 @@ __device__ __forceinline__ void qexp_bwd(const float* rv, float n, float sc, con
 	const float k = dsc_over_n * t - 0.5f * sinc * g.w;
 	g_rv[0] = sc * g.x + rv[0] * k; g_rv[1] = sc * g.y + rv[1] * k; g_rv[2] = sc * g.z + rv[2] * k;
 }
-
-// ---- linear families: out = ((0 + bspline) + poly) + fft, each part summed in order ----
-__device__ __forceinline__ float lin_eval(const float* __restrict__ row, const adgs_func_eval& f) {
-	float result = 0.f;
-	int i = 0;
-#pragma unroll
-	for (int part = 0; part < 3; part++) {
-		const int cnt = f.n_terms[part];
-		if (cnt > 0) {
-			float s = 0.f;
-			for (int k = 0; k < cnt; k++, i++) s += row[f.index[i]] * f.weight[i];
-			result = result + s;
-		}
-	}
-	return result;
-}
-__device__ __forceinline__ void lin_bwd(float* __restrict__ grow, const adgs_func_eval& f, float g) {
-	const int total = f.n_terms[0] + f.n_terms[1] + f.n_terms[2];
-	for (int i = 0; i < total; i++) grow[f.index[i]] = f.weight[i] * g;
-}
-__device__ __forceinline__ bool has_lin(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0; }
 
 // ---- cumulative quaternion B-spline (func_utils.py:156-171), wxyz in / wxyz out ----
 // param block of one Gaussian: [4][n_params]
@@ -529,6 +508,40 @@ static int check_func(const adgs_func_eval* f, const char* what) {
 }
 
 } // namespace
+} // namespace adgs
+
+namespace adgs {
+namespace {
+// coefficient 0 of the raw-SH path: sh0[n, c] = dc[n, c] + f_shs(t)(shs_deform_param[n, c, :]); one thread per (n, c),
+// consecutive threads read consecutive parameter rows (fully coalesced overall)
+__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out) {
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= N * 3) return;
+	const int n = e / 3, c = e - n * 3;
+	const bool ob = n >= s.Ns;
+	const size_t m = ob ? n - s.Ns : n;
+	float v = (ob ? s.obj_dc : s.scene_dc)[3 * m + c];
+	const float* sp = ob ? s.obj_sp : s.scene_sp;
+	if (sp && has_lin(s.f)) v = v + lin_eval(sp + (m * 3 + c) * s.f.n_params, s.f);
+	out[e] = v;
+}
+} // namespace
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
+	if (N <= 0) return 0;
+	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N * 3 + 255) / 256)), dim3(256), 0, stream, N, s, out);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream) {
+	if (count <= 0 || f.n_params <= 0) return 0;
+	if (!g || !out) { set_error("launch_lin_param_grad: NULL gradient buffer"); return -1; }
+	ParamGradArgs pg;
+	pg.n0 = 0; pg.count = count; pg.D = D; pg.gstride = gstride; pg.g = g; pg.out = out; pg.f = f;
+	const size_t tot = (size_t)count * D * f.n_params;
+	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), f.n_params * sizeof(float), stream, pg);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
 } // namespace adgs
 
 using namespace adgs;

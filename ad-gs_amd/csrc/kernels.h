@@ -1,6 +1,7 @@
 // Internal launcher interface between api.hip and the kernel translation units.
 #pragma once
 #include "common.h"
+#include "func_eval.h"
 
 namespace adgs {
 
@@ -19,6 +20,8 @@ struct PreprocessArgs {
 	FilterRec* rects;                // per-Gaussian tile-filter record (rectangle possibly empty)
 	uint32_t* fine_touched;          // #fine tiles covered per Gaussian (its sum bounds the chunk pool)
 	int cell_tiles, cgx, cgy;        // coarse cell = cell_tiles x cell_tiles fine tiles
+	ShSource sh_src;                 // raw SH source (sh_src.scene_dc != nullptr) instead of `shs`
+	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
@@ -69,6 +72,7 @@ struct PreprocessBwdArgs {
 	// v2: per-Gaussian sums arrive packed in gacc ([P][16]); they are unpacked into the ABI outputs
 	// below (which are then written, not read).  gacc == nullptr selects the classic inputs above.
 	const float* gacc; const Splat* splats; int W, H;
+	ShSource sh_src; ShGradDst sh_dst;   // raw-SH path: gradients go straight to the raw tensors' layout
 	float* out_mean2D; float* out_conic; float* out_opacity; float* out_color; float* out_depth; float* out_flow; float* out_sem;
 	int D_S;
 };
@@ -102,6 +106,11 @@ struct RenderV2BwdArgs {
 	float* gacc;                     // [P][GACC_STRIDE], zero-initialised
 };
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream);
+
+// flat coalesced d/dparam[m, d, k] = w_k * g[m * gstride + d] for the linear families (deform.hip)
+int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream);   // sh0[N,3] = dc + f_shs(t)
+inline bool has_lin_host(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0 && f.n_params > 0; }
 
 int knn_run(int P, const float* points, float* meanDists, char* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int P);

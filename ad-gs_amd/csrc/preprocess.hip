@@ -13,6 +13,7 @@
 // + 1 B clamp flags.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace adgs {
 
@@ -65,8 +66,9 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod,
 }
 
 // SH basis evaluation, same association order as forward.cu:20-71.
-__device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, float x, float y, float z) {
-	float result = 0.28209479177387814f * sh[0 * 3 + c];
+// `sh0c` is coefficient 0 of channel c; `sh[k*3+c]` must be valid for k >= 1 only
+__device__ __forceinline__ float sh_channel(int deg, float sh0c, const float* sh, int c, float x, float y, float z) {
+	float result = 0.28209479177387814f * sh0c;
 	if (deg > 0) {
 		const float C1 = 0.4886025119029199f;
 		result = result - C1 * y * sh[1 * 3 + c] + C1 * z * sh[2 * 3 + c] - C1 * x * sh[3 * 3 + c];
@@ -93,8 +95,34 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, flo
 	return result + 0.5f;
 }
 
+// STAGED (M == 16, SH input): the block's SH rows are loaded fully coalesced into LDS (odd row
+// stride: conflict-free per-thread reads) instead of 64 scattered 192-byte rows per wave access.
+constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
+
+template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
+	extern __shared__ float s_sh[];
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (STAGED) {
+		const int tid = threadIdx.x, base = blockIdx.x * 256, nvalid = min(256, a.P - base);
+		if (a.sh_src.scene_dc) {
+			for (int e = tid; e < nvalid * SH_ROW_REST; e += 256) {
+				const int g = e / SH_ROW_REST, c = e - g * SH_ROW_REST, gi = base + g;
+				const bool ob = gi >= a.sh_src.Ns;
+				const float* src = ob ? a.sh_src.obj_rest + (size_t)(gi - a.sh_src.Ns) * SH_ROW_REST : a.sh_src.scene_rest + (size_t)gi * SH_ROW_REST;
+				s_sh[e] = src[c];
+			}
+		} else {
+			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
+			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += 256) {
+				const float4 v = src[q];
+				const int g = q / (SH_ROW_FULL / 4), c = (q - g * (SH_ROW_FULL / 4)) * 4;
+				float* d = s_sh + g * SH_ROW_FULL_LDS + c;
+				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+			}
+		}
+		__syncthreads();
+	}
 	if (idx >= a.P) return;
 	a.radii[idx] = 0;
 	a.tiles_touched[idx] = 0;
@@ -156,15 +184,27 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	uint8_t clamp_bits = 0;
 	if (a.colors_precomp) {
 		s.r = a.colors_precomp[3 * (size_t)idx]; s.g = a.colors_precomp[3 * (size_t)idx + 1]; s.b = a.colors_precomp[3 * (size_t)idx + 2];
-	} else if (a.shs) {
+	} else if (a.shs || a.sh_src.scene_dc) {
 		float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
 		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 		dx = dx / len; dy = dy / len; dz = dz / len;
-		const float* sh = a.shs + (size_t)idx * a.M * 3;
+		const float* sh; float sh0[3];
+		if (a.sh_src.scene_dc) {
+			// dc + f_shs(t) || rest, straight from the raw scene/object tensors
+			const bool is_obj = idx >= a.sh_src.Ns;
+			const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
+			sh0[0] = a.sh0[3 * (size_t)idx]; sh0[1] = a.sh0[3 * (size_t)idx + 1]; sh0[2] = a.sh0[3 * (size_t)idx + 2];
+			if (STAGED) sh = s_sh + threadIdx.x * SH_ROW_REST - 3;
+			else sh = (is_obj ? a.sh_src.obj_rest : a.sh_src.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
+		} else {
+			if (STAGED) sh = s_sh + threadIdx.x * SH_ROW_FULL_LDS;
+			else sh = a.shs + (size_t)idx * a.M * 3;
+			sh0[0] = sh[0]; sh0[1] = sh[1]; sh0[2] = sh[2];
+		}
 		float rgb[3];
 #pragma unroll
 		for (int c = 0; c < 3; c++) {
-			const float v = sh_channel(a.D, sh, c, dx, dy, dz);
+			const float v = sh_channel(a.D, sh0[c], sh, c, dx, dy, dz);
 			if (v < 0.f) clamp_bits |= (uint8_t)(1u << c);
 			rgb[c] = fmaxf(v, 0.0f);
 		}
@@ -289,7 +329,14 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream) {
 	if (a.P == 0) return 0;
-	hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+	const bool raw = a.sh_src.scene_dc != nullptr;
+	const bool staged = a.M == 16 && !a.colors_precomp && (raw || a.shs) && getenv("ADGS_NO_SH_STAGING") == nullptr;
+	if (staged) {
+		const size_t lds = (size_t)256 * (raw ? SH_ROW_REST : SH_ROW_FULL_LDS) * sizeof(float);
+		hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, stream, a);
+	} else {
+		hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+	}
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -12,6 +12,8 @@
 // dominates the writes.
 #include "common.h"
 #include "kernels.h"
+#include "func_eval.h"
+#include <cstdlib>
 
 namespace adgs {
 namespace {
@@ -35,10 +37,42 @@ __device__ __forceinline__ M3 m3t(const M3& a) {
 	return r;
 }
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= a.P) return;
-	if (!(a.radii[idx] > 0)) {
+// STAGED (M == 16 only): the block's SH rows go through LDS -- coalesced loads in, per-thread
+// compute on the own row (odd row stride: conflict-free), coalesced stores of the gradient rows out --
+// instead of 64 scattered 192-byte rows per wave access.
+constexpr int BW_THREADS = 256;
+constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
+
+template <bool STAGED>
+__global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+	extern __shared__ float s_sh[];
+	const int tid = threadIdx.x;
+	const int base = blockIdx.x * BW_THREADS;
+	const int idx = base + tid;
+	const bool raw = a.sh_src.scene_dc != nullptr;
+	const int nvalid = min(BW_THREADS, a.P - base);
+	if (STAGED) {
+		if (raw) {
+			for (int e = tid; e < nvalid * SH_ROW_REST; e += BW_THREADS) {
+				const int g = e / SH_ROW_REST, c = e - g * SH_ROW_REST, gi = base + g;
+				const bool ob = gi >= a.sh_src.Ns;
+				const float* src = ob ? a.sh_src.obj_rest + (size_t)(gi - a.sh_src.Ns) * SH_ROW_REST : a.sh_src.scene_rest + (size_t)gi * SH_ROW_REST;
+				s_sh[e] = src[c];
+			}
+		} else {
+			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
+			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
+				const float4 v = src[q];
+				const int g = q / (SH_ROW_FULL / 4), c = (q - g * (SH_ROW_FULL / 4)) * 4;
+				float* d = s_sh + g * SH_ROW_FULL_LDS + c;
+				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+			}
+		}
+		__syncthreads();
+	}
+	const bool valid = idx < a.P;
+	const bool vis = valid && (a.radii[idx] > 0);
+	if (valid && !vis) {
 		// v2: every output row is written here, so the caller does not have to zero-fill them
 		if (a.gacc) {
 			a.out_mean2D[3 * (size_t)idx] = 0.f; a.out_mean2D[3 * (size_t)idx + 1] = 0.f; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
@@ -49,14 +83,25 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 			if (a.out_sem && a.D_S == 1) a.out_sem[idx] = 0.f;
 			a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f;
 			for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
-			if (a.shs) { float* dsh = a.dL_dsh + (size_t)idx * a.M * 3; for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f; }
+			if (raw) {
+				const bool is_obj = idx >= a.sh_src.Ns;
+				const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
+				float* gdc = (is_obj ? a.sh_dst.obj_dc : a.sh_dst.scene_dc);
+				float* gre = (is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest);
+				if (gdc) { gdc[3 * m] = 0.f; gdc[3 * m + 1] = 0.f; gdc[3 * m + 2] = 0.f; }
+				if (STAGED) { for (int i = 0; i < SH_ROW_REST; i++) s_sh[tid * SH_ROW_REST + i] = 0.f; }
+				else if (gre) for (int i = 0; i < (a.M - 1) * 3; i++) gre[m * (size_t)(a.M - 1) * 3 + i] = 0.f;
+			} else if (a.shs) {
+				if (STAGED) { for (int i = 0; i < SH_ROW_FULL; i++) s_sh[tid * SH_ROW_FULL_LDS + i] = 0.f; }
+				else { float* dsh = a.dL_dsh + (size_t)idx * a.M * 3; for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f; }
+			}
 			if (a.scales) {
 				a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f;
 				*reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
 			}
 		}
-		return;
 	}
+	if (vis) {
 	const float* V = a.view; const float* PJ = a.proj;
 	const float mx = a.means3D[3 * (size_t)idx], my = a.means3D[3 * (size_t)idx + 1], mz = a.means3D[3 * (size_t)idx + 2];
 
@@ -171,12 +216,31 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 		gmz += (V[10] - V[11] * mul3) * gd * demon;
 	}
 	// ---------------- SH path (backward.cu:20-139)
-	if (a.shs) {
+	if (a.shs || a.sh_src.scene_dc) {
 		const float ox = mx - a.campos[0], oy = my - a.campos[1], oz = mz - a.campos[2];
 		const float len = sqrtf(ox * ox + oy * oy + oz * oz);
 		const float x = ox / len, y = oy / len, z = oz / len;
-		const float* sh = a.shs + (size_t)idx * a.M * 3;
-		float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+		// `sh[k*3+c]` / `dsh[k*3+c]` are used for k >= 1 only; coefficient 0 goes through dsh0.
+		// STAGED: sh and dsh are the SAME LDS row, so every read of sh happens before any write of dsh.
+		const float* sh; float* dsh; float* dsh0;
+		float dummy0[3];
+		if (raw) {
+			const bool is_obj = idx >= a.sh_src.Ns;
+			const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
+			float* gdc = is_obj ? a.sh_dst.obj_dc : a.sh_dst.scene_dc;
+			dsh0 = gdc ? gdc + 3 * m : dummy0;
+			if (STAGED) { dsh = s_sh + tid * SH_ROW_REST - 3; sh = dsh; }
+			else {
+				sh = (is_obj ? a.sh_src.obj_rest : a.sh_src.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
+				dsh = (is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
+			}
+		} else if (STAGED) {
+			dsh = s_sh + tid * SH_ROW_FULL_LDS; sh = dsh; dsh0 = dsh;
+		} else {
+			sh = a.shs + (size_t)idx * a.M * 3;
+			dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+			dsh0 = dsh;
+		}
 		const uint8_t cl = a.clamped[idx];
 		float g[3];
 #pragma unroll
@@ -186,17 +250,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 		const float C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
 		const float C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
 			-0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
-#define SETSH(k, coef) { const float _c = (coef); dsh[(k) * 3 + 0] = _c * g[0]; dsh[(k) * 3 + 1] = _c * g[1]; dsh[(k) * 3 + 2] = _c * g[2]; }
-		SETSH(0, C0);
 		const int deg = a.D;
+		// ---- pass A: everything that READS the coefficients (d colour / d direction)
+		float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, yz = 0.f, xz = 0.f;
 		if (deg > 0) {
-			SETSH(1, -C1 * y); SETSH(2, C1 * z); SETSH(3, -C1 * x);
 #pragma unroll
 			for (int c = 0; c < 3; c++) { dx3[c] = -C1 * sh[3 * 3 + c]; dy3[c] = -C1 * sh[1 * 3 + c]; dz3[c] = C1 * sh[2 * 3 + c]; }
 			if (deg > 1) {
-				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-				SETSH(4, C2[0] * xy); SETSH(5, C2[1] * yz); SETSH(6, C2[2] * (2.f * zz - xx - yy));
-				SETSH(7, C2[3] * xz); SETSH(8, C2[4] * (xx - yy));
+				xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z;
 #pragma unroll
 				for (int c = 0; c < 3; c++) {
 					dx3[c] += C2[0] * y * sh[4 * 3 + c] + C2[2] * 2.f * -x * sh[6 * 3 + c] + C2[3] * z * sh[7 * 3 + c] + C2[4] * 2.f * x * sh[8 * 3 + c];
@@ -204,13 +265,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 					dz3[c] += C2[1] * y * sh[5 * 3 + c] + C2[2] * 2.f * 2.f * z * sh[6 * 3 + c] + C2[3] * x * sh[7 * 3 + c];
 				}
 				if (deg > 2) {
-					SETSH(9, C3[0] * y * (3.f * xx - yy));
-					SETSH(10, C3[1] * xy * z);
-					SETSH(11, C3[2] * y * (4.f * zz - xx - yy));
-					SETSH(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-					SETSH(13, C3[4] * x * (4.f * zz - xx - yy));
-					SETSH(14, C3[5] * z * (xx - yy));
-					SETSH(15, C3[6] * x * (xx - 3.f * yy));
 #pragma unroll
 					for (int c = 0; c < 3; c++) {
 						dx3[c] += (C3[0] * sh[9 * 3 + c] * 3.f * 2.f * xy + C3[1] * sh[10 * 3 + c] * yz + C3[2] * sh[11 * 3 + c] * -2.f * xy +
@@ -222,6 +276,25 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 						dz3[c] += (C3[1] * sh[10 * 3 + c] * xy + C3[2] * sh[11 * 3 + c] * 4.f * 2.f * yz + C3[3] * sh[12 * 3 + c] * 3.f * (2.f * zz - xx - yy) +
 							C3[4] * sh[13 * 3 + c] * 4.f * 2.f * xz + C3[5] * sh[14 * 3 + c] * (xx - yy));
 					}
+				}
+			}
+		}
+		// ---- pass B: gradients w.r.t. the coefficients (WRITES; may alias the row read above)
+#define SETSH(k, coef) { const float _c = (coef); dsh[(k) * 3 + 0] = _c * g[0]; dsh[(k) * 3 + 1] = _c * g[1]; dsh[(k) * 3 + 2] = _c * g[2]; }
+		dsh0[0] = C0 * g[0]; dsh0[1] = C0 * g[1]; dsh0[2] = C0 * g[2];
+		if (deg > 0) {
+			SETSH(1, -C1 * y); SETSH(2, C1 * z); SETSH(3, -C1 * x);
+			if (deg > 1) {
+				SETSH(4, C2[0] * xy); SETSH(5, C2[1] * yz); SETSH(6, C2[2] * (2.f * zz - xx - yy));
+				SETSH(7, C2[3] * xz); SETSH(8, C2[4] * (xx - yy));
+				if (deg > 2) {
+					SETSH(9, C3[0] * y * (3.f * xx - yy));
+					SETSH(10, C3[1] * xy * z);
+					SETSH(11, C3[2] * y * (4.f * zz - xx - yy));
+					SETSH(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+					SETSH(13, C3[4] * x * (4.f * zz - xx - yy));
+					SETSH(14, C3[5] * z * (xx - yy));
+					SETSH(15, C3[6] * x * (xx - 3.f * yy));
 				}
 			}
 		}
@@ -273,14 +346,49 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 #undef MT
 		*reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;     // no normalisation Jacobian (backward.cu:340)
 	}
+	}   // if (vis)
+	if (STAGED) {
+		// the LDS rows now hold the SH gradients: stream them out fully coalesced
+		__syncthreads();
+		if (raw) {
+			for (int e = tid; e < nvalid * SH_ROW_REST; e += BW_THREADS) {
+				const int g = e / SH_ROW_REST, c = e - g * SH_ROW_REST, gi = base + g;
+				const bool ob = gi >= a.sh_src.Ns;
+				float* dst = ob ? a.sh_dst.obj_rest : a.sh_dst.scene_rest;
+				if (dst) dst[(size_t)(ob ? gi - a.sh_src.Ns : gi) * SH_ROW_REST + c] = s_sh[e];
+			}
+		} else {
+			float4* dst = reinterpret_cast<float4*>(a.dL_dsh + (size_t)base * SH_ROW_FULL);
+			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
+				const int g = q / (SH_ROW_FULL / 4), c = (q - g * (SH_ROW_FULL / 4)) * 4;
+				const float* s = s_sh + g * SH_ROW_FULL_LDS + c;
+				dst[q] = make_float4(s[0], s[1], s[2], s[3]);
+			}
+		}
+	}
 }
 
 } // namespace
 
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
 	if (a.P == 0) return 0;
-	hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+	const bool raw = a.sh_src.scene_dc != nullptr;
+	// the staged kernel needs 16 SH coefficients and, in the v2 (gacc) path, writes every row
+	const bool staged = a.M == 16 && (raw || a.shs) && a.gacc != nullptr && getenv("ADGS_NO_SH_STAGING") == nullptr;
+	const unsigned grid = (unsigned)((a.P + BW_THREADS - 1) / BW_THREADS);
+	if (staged) {
+		const size_t lds = (size_t)BW_THREADS * (raw ? SH_ROW_REST : SH_ROW_FULL_LDS) * sizeof(float);
+		hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(grid), dim3(BW_THREADS), lds, stream, a);
+	} else {
+		hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(grid), dim3(BW_THREADS), 0, stream, a);
+	}
 	ADGS_HIP_CHECK(hipGetLastError());
+	// raw-SH path: d/d(shs_deform_param[m, c, k]) = w_k * dL/d(dc[m, c]) as flat coalesced passes
+	if (raw && has_lin_host(a.sh_src.f)) {
+		const int No = a.P - a.sh_src.Ns;
+		if (a.sh_dst.scene_sp && a.sh_src.Ns > 0 && launch_lin_param_grad(a.sh_src.Ns, 3, a.sh_dst.scene_dc, 3, a.sh_dst.scene_sp, a.sh_src.f, stream) != 0) return -1;
+		if (a.sh_dst.obj_sp && No > 0 && launch_lin_param_grad(No, 3, a.sh_dst.obj_dc, 3, a.sh_dst.obj_sp, a.sh_src.f, stream) != 0) return -1;
+	}
 	return 0;
 }
 

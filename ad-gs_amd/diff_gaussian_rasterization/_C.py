@@ -153,3 +153,106 @@ def mark_visible(means3D, viewmatrix, projmatrix):
         with torch.cuda.device(dev):
             _lib.check(lib.adgs_mark_visible(P, _ptr(m3), _ptr(view), _ptr(proj), _ptr(present), _stream_ptr(dev)), "adgs_mark_visible")
     return present
+
+
+# ------------------------------------------------------------------ raw-SH fast path (no reference counterpart)
+class ShSource(ctypes.Structure):
+    """adgs_sh_source (include/adgs_rasterizer.h)."""
+    from adgs.deform import FuncEval as _FE
+    _fields_ = [("Ns", ctypes.c_int32)] + [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform",
+                                                                              "obj_deform")] + [("f", _FE)]
+
+
+class ShGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform")]
+
+
+def _sh_source(raw, dev):
+    """raw: (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval)."""
+    src = ShSource()
+    ts = [_prep(t, dev, n) for t, n in zip(raw[:6], ("scene_shs_dc", "obj_shs_dc", "scene_shs_rest", "obj_shs_rest",
+                                                      "shs_deform_param_scene", "shs_deform_param_obj"))]
+    src.Ns = raw[0].size(0)
+    for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), ts):
+        setattr(src, name, _ptr(t))
+    src.f = raw[6]
+    return src, ts
+
+
+def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                              image_height, image_width, sh_raw, flow_points, semantic, degree, campos, inv_depth, debug):
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be on a HIP device; there is no CPU rasterizer")
+    lib = _lib.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    D_S = semantic.size(1) if semantic.size(0) != 0 else 0
+    if D_S > 1 or lib.adgs_raster_needs_zero_init(D_S) != 0:
+        raise RuntimeError("the raw-SH path needs the default pipeline and at most one semantic channel")
+    M = 1 + sh_raw[2].size(1)
+    if sh_raw[0].size(0) + sh_raw[1].size(0) != P:
+        raise RuntimeError("raw SH tensors do not match the number of Gaussians")
+    f32 = dict(dtype=torch.float32, device=dev)
+    alloc = lambda written, *shape: (torch.empty if (written and P != 0) else torch.zeros)(shape, **f32)
+    out_color, out_depth, img_opacity = alloc(True, NUM_CHANNELS, H, W), alloc(True, 1, H, W), alloc(True, 1, H, W)
+    img_flow, img_semantic = alloc(flow_points.size(0) != 0, FLOW_CHANNELS, H, W), alloc(D_S > 0, D_S, H, W)
+    radii = (torch.empty if P != 0 else torch.zeros)((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Buffer(dev), _Buffer(dev), _Buffer(dev)
+    rendered = 0
+    if P != 0:
+        src, keep_sh = _sh_source(sh_raw, dev)
+        keep = [_prep(t, dev, n) for t, n in ((background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"),
+                                              (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"), (viewmatrix, "viewmatrix"),
+                                              (projmatrix, "projmatrix"), (campos, "campos"))]
+        bg_, m3_, fl_, sem_, op_, sc_, rot_, view_, proj_, cam_ = keep
+        with torch.cuda.device(dev):
+            rendered = _lib.check(lib.adgs_raster_forward_rawsh(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src),
+                _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_),
+                float(tan_fovx), float(tan_fovy), _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic),
+                int(bool(inv_depth)), _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward_rawsh")
+    return rendered, out_color, out_depth, img_opacity, radii, geom.t, binning.t, img.t, img_flow, img_semantic
+
+
+def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                       dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_semantic, semantic, flow_points, sh_raw,
+                                       sh_needs_grad, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, img_opacity, grad_img_opacity,
+                                       inv_depth, debug):
+    lib = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = 1 + sh_raw[2].size(1)
+    D_S = semantic.size(1) if semantic.size(0) != 0 else 0
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    has_flow = flow_points.size(0) != 0 and dL_dout_flow is not None and dL_dout_flow.numel() != 0
+    has_sem = D_S > 0 and dL_dout_semantic is not None and dL_dout_semantic.numel() != 0
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = e(P, 3), e(P, 3), e(P, NUM_CHANNELS), e(P, 1)
+    dL_dconic, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations = e(P, 2, 2), e(P, 1), e(P, 6), e(P, 3), e(P, 4)
+    dL_dflow_points = e(P, FLOW_CHANNELS) if has_flow else torch.zeros((P, FLOW_CHANNELS), dtype=torch.float32, device=dev)
+    dL_dsemantic = e(P, D_S) if has_sem else torch.zeros((P, D_S), dtype=torch.float32, device=dev)
+    need = list(sh_needs_grad)
+    need[0], need[1] = need[0] or need[4], need[1] or need[5]      # the deform-param gradients are derived from the dc gradients
+    sh_grads = [torch.empty_like(t) if (nd and t is not None and t.numel() != 0) else None for t, nd in zip(sh_raw[:6], need)]
+    if P != 0:
+        src, keep_sh = _sh_source(sh_raw, dev)
+        gs = ShGrads()
+        for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
+            setattr(gs, name, _ptr(t))
+        keep = [_prep(t, dev, n) for t, n in (
+            (background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"), (scales, "scales"),
+            (rotations, "rotations"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"),
+            (dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"), (dL_dout_flow, "dL_dout_flow"),
+            (dL_dout_semantic, "dL_dout_semantic"), (grad_img_opacity, "grad_img_opacity"), (img_opacity, "img_opacity"))]
+        bg_, m3_, fl_, sem_, sc_, rot_, view_, proj_, cam_, gc_, gd_, gf_, gs_, go_, io_ = keep
+        radii_ = _prep(radii, dev, "radii", torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.adgs_raster_backward_rawsh(
+                P, int(degree), M, int(R), D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src), _ptr(fl_), _ptr(sem_), _ptr(sc_),
+                float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), _ptr(radii_),
+                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc_), _ptr(gd_), _ptr(gf_), _ptr(gs_),
+                _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                ctypes.byref(gs), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dflow_points), _ptr(dL_dsemantic), _ptr(go_), _ptr(io_),
+                int(bool(inv_depth)), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_backward_rawsh")
+    sh_grads = [g if nd else None for g, nd in zip(sh_grads, sh_needs_grad)]
+    return dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic

@@ -88,6 +88,47 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_cov3Ds_precomp, grad_flow_points, grad_semantic, None)
 
 
+class RawSH(NamedTuple):
+    """SH coefficients left in the reference GaussianModel's raw layout (scene || object,
+    dc + f_shs(t) || rest) for `GaussianRasterizer.forward_rawsh` (adgs.deform.get_deformed_pkg(raw_sh=True))."""
+    scene_dc: torch.Tensor
+    obj_dc: torch.Tensor
+    scene_rest: torch.Tensor
+    obj_rest: torch.Tensor
+    scene_deform: torch.Tensor
+    obj_deform: torch.Tensor
+    func_eval: object          # adgs.deform.FuncEval of f_shs at the camera time
+
+
+class _RasterizeGaussiansRawSH(torch.autograd.Function):
+    """Same operator as _RasterizeGaussians with the SH input/gradients in the raw tensors' layout."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, scales, rotations, flow_points, semantic, scene_dc, obj_dc, scene_rest, obj_rest,
+                scene_deform, obj_deform, func_eval, raster_settings):
+        s = raster_settings
+        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval)
+        (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow, img_semantic) = _C.rasterize_gaussians_rawsh(
+            s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
+            s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
+        ctx.raster_settings, ctx.num_rendered, ctx.func_eval = s, num_rendered, func_eval
+        ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
+                              scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform)
+        return color, radii, depth, img_opacity, img_flow, img_semantic
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_img_opacity, grad_img_flow, grad_img_semantic):
+        s = ctx.raster_settings
+        (means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
+         scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform) = ctx.saved_tensors
+        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval)
+        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem) = _C.rasterize_gaussians_backward_rawsh(
+            s.bg, means3D, radii, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
+            grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, ctx.needs_input_grad[7:13], s.sh_degree, s.campos,
+            geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug)
+        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
                         semantic, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -104,6 +145,13 @@ class GaussianRasterizer(nn.Module):
         with torch.no_grad():
             s = self.raster_settings
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
+
+    def forward_rawsh(self, means3D, means2D, opacities, sh_raw, scales, rotations, flow_points=None, semantic=None):
+        """Extension (no reference counterpart): like forward(), with the SH coefficients given as a RawSH."""
+        empty = lambda t: torch.Tensor([]) if t is None else t
+        return _RasterizeGaussiansRawSH.apply(means3D, means2D, opacities, scales, rotations, empty(flow_points), empty(semantic),
+                                              sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest, sh_raw.obj_rest, sh_raw.scene_deform,
+                                              sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, flow_points=None, semantic=None):

@@ -46,12 +46,18 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
     deform_pkg = pc.get_deformed_pkg(viewpoint_camera.time)
     semantic = pc.get_obj_mask.float()[..., None] if render_objmask else None
 
-    foreground, radii, depth, img_opacity, img_flow, img_semantic = rasterizer(
-        means3D=deform_pkg['xyz'], means2D=screenspace_points,
-        shs=deform_pkg['shs'] if override_color is None else None, colors_precomp=override_color,
-        opacities=deform_pkg['opacity'], scales=deform_pkg['scales'] if 'scales' in deform_pkg else pc.get_scaling,
-        rotations=deform_pkg['rotation'],
-        flow_points=flow_points, semantic=semantic)
+    shs_in = deform_pkg['shs'] if override_color is None else None
+    if shs_in is not None and not torch.is_tensor(shs_in):
+        # raw-SH fast path (pc.get_deformed_pkg returned a RawSH: the [N,16,3] tensor is never materialised)
+        foreground, radii, depth, img_opacity, img_flow, img_semantic = rasterizer.forward_rawsh(
+            deform_pkg['xyz'], screenspace_points, deform_pkg['opacity'], shs_in,
+            deform_pkg['scales'] if 'scales' in deform_pkg else pc.get_scaling, deform_pkg['rotation'],
+            flow_points=flow_points, semantic=semantic)
+    else:
+        foreground, radii, depth, img_opacity, img_flow, img_semantic = rasterizer(
+            means3D=deform_pkg['xyz'], means2D=screenspace_points, shs=shs_in, colors_precomp=override_color,
+            opacities=deform_pkg['opacity'], scales=deform_pkg['scales'] if 'scales' in deform_pkg else pc.get_scaling,
+            rotations=deform_pkg['rotation'], flow_points=flow_points, semantic=semantic)
 
     if env_map is not None:
         background = env_map.get_image_background(viewpoint_camera)

@@ -85,13 +85,15 @@ class DeformFrame:
         from adgs.model import SyntheticGaussianModel
         self.rast, self.t, self.use_fs = rasterizer, t, use_flow_sem
         self.model = SyntheticGaussianModel.from_scene(sc, device, seed=0)
+        self.model.raw_sh = os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0"     # SH read straight from the raw parameters
         self.means2D = None
         self.sem = self.model.get_obj_mask.float()[:, None].contiguous() if use_flow_sem else None
         self.last_radii = None
         self.deform_bytes = self.model.deform_bytes_per_frame()
         oa = self.model.order_args
-        self.deform_desc = "fused HIP: xyz %s, rotation %s (quaternion spline), shs %s, time-masked opacity; %d object Gaussians" % (
-            oa["xyz"], oa["rotation"], oa["shs"], self.model.get_obj_pts_num)
+        self.deform_desc = "fused HIP: xyz %s, rotation %s (quaternion spline), shs %s%s, time-masked opacity; %d object Gaussians" % (
+            oa["xyz"], oa["rotation"], oa["shs"], " (read in place by the preprocess: raw-SH path)" if self.model.raw_sh else "",
+            self.model.get_obj_pts_num)
 
     def parameters(self):
         return self.model.parameters()
@@ -105,9 +107,13 @@ class DeformFrame:
         pkg = m.get_deformed_pkg(self.t)
         flow = m.get_deformed_xyz(self.t + 0.05) if self.use_fs else None
         means2D = torch.zeros_like(pkg["xyz"], requires_grad=True)
-        color, radii, depth, op, fl, sem = self.rast(
-            means3D=pkg["xyz"], means2D=means2D, opacities=pkg["opacity"], shs=pkg["shs"], scales=pkg["scales"],
-            rotations=pkg["rotation"], flow_points=flow, semantic=self.sem)
+        if torch.is_tensor(pkg["shs"]):
+            color, radii, depth, op, fl, sem = self.rast(
+                means3D=pkg["xyz"], means2D=means2D, opacities=pkg["opacity"], shs=pkg["shs"], scales=pkg["scales"],
+                rotations=pkg["rotation"], flow_points=flow, semantic=self.sem)
+        else:
+            color, radii, depth, op, fl, sem = self.rast.forward_rawsh(pkg["xyz"], means2D, pkg["opacity"], pkg["shs"], pkg["scales"],
+                                                                       pkg["rotation"], flow_points=flow, semantic=self.sem)
         self.last_radii = radii
         return [color, depth, op] + ([fl, sem] if self.use_fs else [])
 
@@ -115,7 +121,8 @@ class DeformFrame:
         """Activated tensors of this frame as CPU float32 (inputs of the CPU baseline)."""
         import torch
         with torch.no_grad():
-            pkg = self.model.get_deformed_pkg(self.t)
+            from adgs import deform
+            pkg = deform.get_deformed_pkg(self.model, self.t)
             flow = self.model.get_deformed_xyz(self.t + 0.05)
         return {k: v.detach().cpu() for k, v in pkg.items()}, flow.cpu()
 

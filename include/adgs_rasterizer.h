@@ -20,6 +20,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include "adgs_deform.h"   /* adgs_func_eval */
 
 #ifdef __cplusplus
 extern "C" {
@@ -115,6 +116,44 @@ int adgs_raster_backward(
 	int inv_depth,
 	int debug,
 	void* stream);
+
+/* ---- "raw SH" fast path (no counterpart in the reference) ----------------
+ * Same operators, but the SH coefficients are read straight from the reference GaussianModel's raw
+ * tensors -- scene || object, coefficient 0 = dc + f_shs(t), coefficients 1.. = rest
+ * (scene/gaussian_model.py:198-205) -- instead of a materialised [P, M, 3] tensor, and the SH
+ * gradients are written straight into the layout of those raw tensors (every element written).
+ * Needs the default pipeline (D_S <= 1, not ADGS_RASTER_MODE=classic); scales/rotations only. */
+typedef struct adgs_sh_source {
+	int32_t Ns;                               /* scene Gaussians come first; No = P - Ns */
+	const float *scene_dc, *obj_dc;           /* [Ns,1,3] [No,1,3] */
+	const float *scene_rest, *obj_rest;       /* [Ns,M-1,3] [No,M-1,3] */
+	const float *scene_deform, *obj_deform;   /* shs_deform_param_{scene,obj} [.,3,C] or NULL */
+	adgs_func_eval f;                         /* f_shs evaluated at the camera time (n_params = C) */
+} adgs_sh_source;
+typedef struct adgs_sh_grads {
+	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_deform, *obj_deform;   /* NULL = not wanted */
+} adgs_sh_grads;
+
+int adgs_raster_forward_rawsh(
+	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser,
+	adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S, const float* background, int width, int height,
+	const float* means3D, const adgs_sh_source* sh, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream);
+
+int adgs_raster_backward_rawsh(
+	int P, int D, int M, int R, int D_S, const float* background, int width, int height,
+	const float* means3D, const adgs_sh_source* sh, const float* flow_points, const float* semantic,
+	const float* scales, float scale_modifier, const float* rotations,
+	const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+	const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+	const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_flow, const float* dL_dpix_semantic,
+	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+	float* dL_dcov3D, const adgs_sh_grads* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dflow, float* dL_dsemantic,
+	const float* grad_img_opacity, const float* img_opacity, int inv_depth, int debug, void* stream);
 
 /* The reference requires the caller to zero-fill every output of forward and backward
  * (rasterize_points.cu:82-87,195-206).  Zero-filled outputs are always accepted; this returns 0

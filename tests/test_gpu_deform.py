@@ -142,3 +142,44 @@ def test_render_entry_runs_on_fused_pkg():
     for p in model.parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all()
     assert float(model.xyz_deform_param.grad.abs().max()) > 0 and float(model.rotation_deform_param.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_raw_sh_path_matches_materialised_sh_path(seed):
+    """GaussianRasterizer.forward_rawsh (SH read from / gradients written to the raw scene||object tensors)
+    == get_deformed_pkg + GaussianRasterizer.forward, forward and backward."""
+    from adgs import synthetic, deform
+    from adgs.model import SyntheticGaussianModel
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = synthetic.make_scene(6000, 208, 130, 150.0, sh_degree=3, seed=seed, n_objects=2)
+    g = synthetic.make_upstream_grads(sc, seed)
+    d = lambda x: x.cuda()
+    s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], d(sc["bg"]), 1.0, d(sc["viewmatrix"]), d(sc["projmatrix"]),
+                                      3 - seed, d(sc["campos"]), False, True, False)
+    rast = GaussianRasterizer(s)
+    res = []
+    for raw in (False, True):
+        model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3)
+        pkg = deform.get_deformed_pkg(model, 0.37, raw_sh=raw)
+        flow = model.get_deformed_xyz(0.42)
+        m2 = torch.zeros_like(pkg["xyz"], requires_grad=True)
+        sem = model.get_obj_mask.float()[:, None].contiguous()
+        if raw:
+            assert not torch.is_tensor(pkg["shs"])
+            out = rast.forward_rawsh(pkg["xyz"], m2, pkg["opacity"], pkg["shs"], pkg["scales"], pkg["rotation"], flow_points=flow, semantic=sem)
+        else:
+            out = rast(means3D=pkg["xyz"], means2D=m2, opacities=pkg["opacity"], shs=pkg["shs"], scales=pkg["scales"], rotations=pkg["rotation"],
+                       flow_points=flow, semantic=sem)
+        color, radii, depth, op, fl, se = out
+        torch.autograd.backward([color, depth, op, fl, se], [d(g["color"]), d(g["depth"]), d(g["img_opacity"]), d(g["flow"]), d(g["semantic"])])
+        res.append((out, model, m2))
+    (o0, m0, a0), (o1, m1, a1) = res
+    assert torch.equal(o0[1], o1[1])
+    for x, y, n in zip(o0, o1, ("color", "radii", "depth", "opacity", "flow", "sem")):
+        if n != "radii":
+            close(n, y.detach().cpu().numpy(), x.detach().cpu().numpy(), tol=2e-5)
+    close("means2D", a1.grad.cpu().numpy(), a0.grad.cpu().numpy(), tol=1e-4)
+    for p0, p1, name in zip(m0.parameters(), m1.parameters(), [n for n in __import__("adgs.model", fromlist=["_RAW"])._RAW]):
+        assert (p0.grad is None) == (p1.grad is None), name
+        if p0.grad is not None:
+            close(name, p1.grad.cpu().numpy(), p0.grad.cpu().numpy(), tol=1e-4)
