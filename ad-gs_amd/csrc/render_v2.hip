@@ -69,7 +69,7 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 }
 
 __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
-	__shared__ float4 s_splat[WAVE * 4];
+	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
 	const int lane = threadIdx.x;
 	const uint32_t tile = blockIdx.x;
@@ -136,9 +136,12 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		prev_chunk = chunk;
 		__syncthreads();
 		// ---- blend
+		float4 nq0 = s_splat[0], nq1 = s_splat[1];
 		for (uint32_t j = 0; j < n; j++) {
-			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
-			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
+			const float4 q0 = nq0;      // x y ca cb
+			const float4 q1 = nq1;      // cc op r g
+			// prefetch the next entry's geometry while this one is evaluated (row n is padding, never used)
+			nq0 = s_splat[(j + 1) * 4 + 0]; nq1 = s_splat[(j + 1) * 4 + 1];
 			const float dx = q0.x - pxf;
 			float alpha[PPL]; bool act[PPL]; bool any_act = false;
 #pragma unroll
@@ -202,11 +205,43 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
 	return v;
 }
+
+// Seven independent wave64 sums at once.  Each step is one v_add_f32 with a DPP source on the value
+// itself (dst tied to the operand, so rows masked off by row_mask simply keep their value); the seven
+// chains are interleaved so that consecutive instructions never depend on each other and no wait
+// state is needed between the VALU write and the DPP read of the same register (a DPP operand needs
+// 2 wait states after a VALU write: 6 independent instructions sit in between).  Totals in lane 63.
+#define ADGS_DPP_STEP(ctrl) \
+	"v_add_f32_dpp %0, %0, %0 " ctrl "\n\t" "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t" "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t" \
+	"v_add_f32_dpp %3, %3, %3 " ctrl "\n\t" "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t" "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t" \
+	"v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"
+__device__ __forceinline__ void wave_sum7(float& a, float& b, float& c, float& d, float& e, float& f, float& g) {
+	asm volatile(
+		"s_nop 1\n\t"
+		ADGS_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+		ADGS_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+		ADGS_DPP_STEP("row_ror:4 row_mask:0xf bank_mask:0xf")
+		ADGS_DPP_STEP("row_ror:8 row_mask:0xf bank_mask:0xf")
+		ADGS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+		ADGS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+		"s_nop 1"
+		: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g));
+}
+template <int LANE_DST>
+__device__ __forceinline__ float put_lane(float out, float v) {
+	// out[LANE_DST] = v[63]
+	const int s = __builtin_amdgcn_readlane(__float_as_int(v), 63);
+	asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(out) : "s"(s), "n"(LANE_DST));
+	return out;
+}
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
-template <int OCC>
+// FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
+// the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
+template <int OCC, bool FULL>
 __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArgs a) {
-	__shared__ float4 s_splat[WAVE * 4];
+	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
+	__shared__ float4 s_splat[(WAVE + 1) * 4];      // entry j lives in row j+1 (row 0: prefetch padding)
 	__shared__ uint32_t s_id[WAVE];
 	const int lane = threadIdx.x;
 	const uint32_t tile = blockIdx.x;
@@ -215,34 +250,35 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 	const uint32_t py0 = ty * TILE_Y + (lane >> 4);
 	const float pxf = (float)px;
 	const size_t HW = (size_t)a.H * a.W;
-	float pyf[PPL]; bool inside[PPL];
-	float T[PPL], T_final[PPL];
+	bool inside[PPL];
+	const float pyf0 = (float)py0;
+	float T[PPL], tfo[PPL], tfb[PPL];      // tfo = dL/dO * T_final, tfb = T_final * (bg . dL/dC)
 	int last_contributor[PPL];
 	float A_c0[PPL], A_c1[PPL], A_c2[PPL], A_f0[PPL], A_f1[PPL], A_f2[PPL], A_d[PPL], A_s[PPL];
-	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gO[PPL], gS[PPL], bgdot[PPL];
+	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gS[PPL];
 	int max_contrib = 0;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		const uint32_t py = py0 + 4 * k;
-		pyf[k] = (float)py;
 		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
 		const size_t pix_id = (size_t)a.W * py + px;
-		T_final[k] = inside[k] ? (float)(1.0 - (double)a.final_T[pix_id]) : 0.f;
-		T[k] = T_final[k];
+		const float T_final = inside[k] ? (float)(1.0 - (double)a.final_T[pix_id]) : 0.f;
+		float gO = 0.f;
+		T[k] = T_final;
 		last_contributor[k] = inside[k] ? (int)a.n_contrib[pix_id] : 0;
 		max_contrib = max(max_contrib, last_contributor[k]);
 		A_c0[k] = A_c1[k] = A_c2[k] = A_f0[k] = A_f1[k] = A_f2[k] = A_d[k] = A_s[k] = 0.f;
-		gC0[k] = gC1[k] = gC2[k] = gF0[k] = gF1[k] = gF2[k] = gD[k] = gO[k] = gS[k] = 0.f;
+		gC0[k] = gC1[k] = gC2[k] = gF0[k] = gF1[k] = gF2[k] = gD[k] = gS[k] = 0.f;
 		if (inside[k]) {
-			if (a.do_color) { gC0[k] = a.dL_dpix[0 * HW + pix_id]; gC1[k] = a.dL_dpix[1 * HW + pix_id]; gC2[k] = a.dL_dpix[2 * HW + pix_id]; }
-			if (a.do_flow) { gF0[k] = a.dL_dpix_flow[0 * HW + pix_id]; gF1[k] = a.dL_dpix_flow[1 * HW + pix_id]; gF2[k] = a.dL_dpix_flow[2 * HW + pix_id]; }
-			if (a.do_sem) gS[k] = a.dL_dpix_sem[pix_id];
-			if (a.do_depth) gD[k] = a.dL_dpix_depth[pix_id];
-			if (a.do_opacity) gO[k] = a.dL_dpix_opacity[pix_id];
+			if (do_color) { gC0[k] = a.dL_dpix[0 * HW + pix_id]; gC1[k] = a.dL_dpix[1 * HW + pix_id]; gC2[k] = a.dL_dpix[2 * HW + pix_id]; }
+			if (do_flow) { gF0[k] = a.dL_dpix_flow[0 * HW + pix_id]; gF1[k] = a.dL_dpix_flow[1 * HW + pix_id]; gF2[k] = a.dL_dpix_flow[2 * HW + pix_id]; }
+			if (do_sem) gS[k] = a.dL_dpix_sem[pix_id];
+			if (do_depth) gD[k] = a.dL_dpix_depth[pix_id];
+			if (do_opacity) gO = a.dL_dpix_opacity[pix_id];
 		}
 		float b = 0.f;
 		b += a.bg[0] * gC0[k]; b += a.bg[1] * gC1[k]; b += a.bg[2] * gC2[k];
-		bgdot[k] = b;
+		tfo[k] = gO * T_final; tfb[k] = T_final * b;
 	}
 #pragma unroll
 	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
@@ -258,23 +294,25 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 			if (lane < n) {
 				const uint32_t id = c[2 + lane];
 				const float4* src = reinterpret_cast<const float4*>(a.splats + id);
-				s_splat[lane * 4 + 0] = src[0];
-				s_splat[lane * 4 + 1] = src[1];
-				s_splat[lane * 4 + 2] = src[2];
-				s_splat[lane * 4 + 3] = src[3];
+				s_splat[(lane + 1) * 4 + 0] = src[0];
+				s_splat[(lane + 1) * 4 + 1] = src[1];
+				s_splat[(lane + 1) * 4 + 2] = src[2];
+				s_splat[(lane + 1) * 4 + 3] = src[3];
 				s_id[lane] = id;
 			}
 			__syncthreads();
+			float4 nq0 = s_splat[n * 4 + 0], nq1 = s_splat[n * 4 + 1];
 			for (int j = n - 1; j >= 0; j--) {
 				const int contributor = base + j;
+				const float4 q0 = nq0, q1 = nq1;
+				// prefetch the next (j-1) entry's geometry; rows are stored at index j+1, row 0 is padding
+				nq0 = s_splat[j * 4 + 0]; nq1 = s_splat[j * 4 + 1];
 				if (contributor >= max_contrib) continue;
-				const float4 q0 = s_splat[j * 4 + 0];
-				const float4 q1 = s_splat[j * 4 + 1];
 				const float dx = q0.x - pxf;
 				float alpha[PPL], G[PPL], dy[PPL]; bool act[PPL]; bool any_act = false;
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
-					dy[k] = q0.y - pyf[k];
+					dy[k] = q0.y - (pyf0 + (float)(4 * k));
 					const float power = -0.5f * (q0.z * dx * dx + q1.x * dy[k] * dy[k]) - q0.w * dx * dy[k];
 					G[k] = ADGS_EXP(power);
 					alpha[k] = fminf(ALPHA_MAX, q1.y * G[k]);
@@ -282,8 +320,8 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 					any_act = any_act || act[k];
 				}
 				if (!__any(any_act)) continue;
-				const float4 q2 = s_splat[j * 4 + 2];
-				const float4 q3 = s_splat[j * 4 + 3];
+				const float4 q2 = s_splat[(j + 1) * 4 + 2];
+				const float4 q3 = s_splat[(j + 1) * 4 + 3];
 				float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_s = 0.f, v_d = 0.f;
 				// geometric part: with L = G * dL/dalpha per pixel, the reference's six sums are linear in
 				//   S0 = sum L, Sx = sum L dx, Sy = sum L dy, Sxx = sum L dx^2, Sxy = sum L dx dy, Syy = sum L dy^2
@@ -301,52 +339,39 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 						// suffix-blend recurrences of backward.cu:578-607, applied right after use:
 						// A_next = A + alpha*(c - A) is the value the reference forms at the next contributing
 						// entry from last_alpha/last_color.
-						if (a.do_color) {
+						if (do_color) {
 							float d;
 							d = q1.z - A_c0[k]; dL_dalpha += d * gC0[k]; v_c0 += dch * gC0[k]; A_c0[k] += al * d;
 							d = q1.w - A_c1[k]; dL_dalpha += d * gC1[k]; v_c1 += dch * gC1[k]; A_c1[k] += al * d;
 							d = q2.x - A_c2[k]; dL_dalpha += d * gC2[k]; v_c2 += dch * gC2[k]; A_c2[k] += al * d;
 						}
-						if (a.do_flow) {
+						if (do_flow) {
 							float d;
 							d = q2.z - A_f0[k]; dL_dalpha += d * gF0[k]; v_f0 += dch * gF0[k]; A_f0[k] += al * d;
 							d = q2.w - A_f1[k]; dL_dalpha += d * gF1[k]; v_f1 += dch * gF1[k]; A_f1[k] += al * d;
 							d = q3.x - A_f2[k]; dL_dalpha += d * gF2[k]; v_f2 += dch * gF2[k]; A_f2[k] += al * d;
 						}
-						if (a.do_sem) { const float d = q3.y - A_s[k]; dL_dalpha += d * gS[k]; v_s += dch * gS[k]; A_s[k] += al * d; }
-						if (a.do_depth) { const float d = q2.y - A_d[k]; dL_dalpha += d * gD[k]; v_d += dch * gD[k]; A_d[k] += al * d; }
-						const float tfr = T_final[k] * rinv;
-						if (a.do_opacity) dL_dalpha += gO[k] * tfr;    // before the *= T: reference quirk (backward.cu:612-614)
-						dL_dalpha = dL_dalpha * T[k] - tfr * bgdot[k];
+						if (do_sem) { const float d = q3.y - A_s[k]; dL_dalpha += d * gS[k]; v_s += dch * gS[k]; A_s[k] += al * d; }
+						if (do_depth) { const float d = q2.y - A_d[k]; dL_dalpha += d * gD[k]; v_d += dch * gD[k]; A_d[k] += al * d; }
+						if (do_opacity) dL_dalpha += tfo[k] * rinv;  // before the *= T: reference quirk (backward.cu:612-614)
+						dL_dalpha = dL_dalpha * T[k] - tfb[k] * rinv;
 						const float L = G[k] * dL_dalpha;
 						const float Lx = L * dx, Ly = L * dy[k];
 						v_op += L; v_mx += Lx; v_my += Ly;
 						v_ca += Lx * dx; v_cb += Lx * dy[k]; v_cc += Ly * dy[k];
 					}
 				}
-				// 14 wave sums (totals in lane 63) -> lanes 0..13 -> one atomic instruction on one 64-B line
+				// 14 wave sums (totals in lane 63) -> lanes 0..13 -> one atomic instruction on one 64-B line.
+				// Channels whose upstream gradient is absent stay exactly 0 and cost nothing extra.
+				wave_sum7(v_op, v_mx, v_my, v_ca, v_cb, v_cc, v_d);
+				wave_sum7(v_c0, v_c1, v_c2, v_f0, v_f1, v_f2, v_s);
 				float out = 0.f;
-				{
-					float s;
-					s = lane63(wave_sum_dpp(v_op)); if (lane == 0) out = s;
-					s = lane63(wave_sum_dpp(v_mx)); if (lane == 1) out = s;
-					s = lane63(wave_sum_dpp(v_my)); if (lane == 2) out = s;
-					s = lane63(wave_sum_dpp(v_ca)); if (lane == 3) out = s;
-					s = lane63(wave_sum_dpp(v_cb)); if (lane == 4) out = s;
-					s = lane63(wave_sum_dpp(v_cc)); if (lane == 5) out = s;
-					if (a.do_color) {
-						s = lane63(wave_sum_dpp(v_c0)); if (lane == 6) out = s;
-						s = lane63(wave_sum_dpp(v_c1)); if (lane == 7) out = s;
-						s = lane63(wave_sum_dpp(v_c2)); if (lane == 8) out = s;
-					}
-					if (a.do_depth) { s = lane63(wave_sum_dpp(v_d)); if (lane == 9) out = s; }
-					if (a.do_flow) {
-						s = lane63(wave_sum_dpp(v_f0)); if (lane == 10) out = s;
-						s = lane63(wave_sum_dpp(v_f1)); if (lane == 11) out = s;
-						s = lane63(wave_sum_dpp(v_f2)); if (lane == 12) out = s;
-					}
-					if (a.do_sem) { s = lane63(wave_sum_dpp(v_s)); if (lane == 13) out = s; }
-				}
+				out = put_lane<0>(out, v_op); out = put_lane<1>(out, v_mx); out = put_lane<2>(out, v_my);
+				out = put_lane<3>(out, v_ca); out = put_lane<4>(out, v_cb); out = put_lane<5>(out, v_cc);
+				out = put_lane<6>(out, v_c0); out = put_lane<7>(out, v_c1); out = put_lane<8>(out, v_c2);
+				out = put_lane<9>(out, v_d);
+				out = put_lane<10>(out, v_f0); out = put_lane<11>(out, v_f1); out = put_lane<12>(out, v_f2);
+				out = put_lane<13>(out, v_s);
 				if (lane < GACC_USED) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + lane, out);
 			}
 		}
@@ -372,9 +397,16 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;
 	static const int occ = [] { const char* v = getenv("ADGS_BWD_OCC"); return (v && *v) ? atoi(v) : ADGS_BWD_WAVES; }();
-	if (occ >= 4) hipLaunchKernelGGL(render_bwd_v2_kernel<4>, dim3(T), dim3(WAVE), 0, stream, a);
-	else if (occ == 3) hipLaunchKernelGGL(render_bwd_v2_kernel<3>, dim3(T), dim3(WAVE), 0, stream, a);
-	else hipLaunchKernelGGL(render_bwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
+	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity;
+	if (full) {
+		if (occ >= 4) hipLaunchKernelGGL((render_bwd_v2_kernel<4, true>), dim3(T), dim3(WAVE), 0, stream, a);
+		else if (occ == 3) hipLaunchKernelGGL((render_bwd_v2_kernel<3, true>), dim3(T), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL((render_bwd_v2_kernel<2, true>), dim3(T), dim3(WAVE), 0, stream, a);
+	} else {
+		if (occ >= 4) hipLaunchKernelGGL((render_bwd_v2_kernel<4, false>), dim3(T), dim3(WAVE), 0, stream, a);
+		else if (occ == 3) hipLaunchKernelGGL((render_bwd_v2_kernel<3, false>), dim3(T), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL((render_bwd_v2_kernel<2, false>), dim3(T), dim3(WAVE), 0, stream, a);
+	}
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
