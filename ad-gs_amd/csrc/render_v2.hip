@@ -236,6 +236,49 @@ __device__ __forceinline__ float put_lane(float out, float v) {
 }
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
+// Fourteen wave64 sums with a transposing butterfly (32 instructions instead of 14 x 6 DPP adds + 14
+// lane moves).  Level 1 pairs registers with v_permlane32_swap (lanes l <-> l+32), level 2 with
+// v_permlane16_swap (row r <-> r^1); a pair (X, Y) becomes ONE register holding X's partial sums in
+// one half of the lanes and Y's in the other.  Levels 3 and 4 do the same across the four quads of a
+// row with bank-masked DPP adds (bank_mask enables quads; row_half_mirror pairs quad 0<->1, 2<->3 and
+// row_ror:8 pairs 0<->2, 1<->3), and two quad_perm steps finish the sum inside each quad.  Value k
+// is complete in every lane with slot_of_lane(lane) == k.
+__device__ __forceinline__ float pair32(float x, float y) {
+	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pair16(float x, float y) {
+	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ int slot_of_lane(int lane) {
+	return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 2) & 1) << 2) | (((lane >> 3) & 1) << 3);
+}
+__device__ __forceinline__ float wave_sum14_transposed(float x0, float x1, float x2, float x3, float x4, float x5, float x6,
+	float x7, float x8, float x9, float x10, float x11, float x12, float x13) {
+	const float y0 = pair32(x0, x1), y1 = pair32(x2, x3), y2 = pair32(x4, x5), y3 = pair32(x6, x7);
+	const float y4 = pair32(x8, x9), y5 = pair32(x10, x11), y6 = pair32(x12, x13);
+	float z0 = pair16(y0, y1), z1 = pair16(y2, y3), z2 = pair16(y4, y5), z3 = pair16(y6, y6);
+	// a DPP source needs 2 wait states after the VALU write of that register: the s_nops / the
+	// interleaving below provide them (the compiler does not look inside the asm block).
+	asm volatile(
+		"s_nop 1\n\t"
+		"v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+		"v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+		"v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+		"v_add_f32_dpp %2, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+		"s_nop 0\n\t"
+		"v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+		"v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+		"s_nop 1\n\t"
+		"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 1\n\t"
+		"v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+		"s_nop 1"
+		: "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
+	return z0;
+}
+
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
 // the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
 template <int OCC, bool FULL>
@@ -257,6 +300,8 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 	float A_c0[PPL], A_c1[PPL], A_c2[PPL], A_f0[PPL], A_f1[PPL], A_f2[PPL], A_d[PPL], A_s[PPL];
 	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gS[PPL];
 	int max_contrib = 0;
+	const int slot = slot_of_lane(lane);
+	const bool writer = (lane & 3) == 0 && slot < GACC_USED;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		const uint32_t py = py0 + 4 * k;
@@ -361,18 +406,11 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 						v_ca += Lx * dx; v_cb += Lx * dy[k]; v_cc += Ly * dy[k];
 					}
 				}
-				// 14 wave sums (totals in lane 63) -> lanes 0..13 -> one atomic instruction on one 64-B line.
-				// Channels whose upstream gradient is absent stay exactly 0 and cost nothing extra.
-				wave_sum7(v_op, v_mx, v_my, v_ca, v_cb, v_cc, v_d);
-				wave_sum7(v_c0, v_c1, v_c2, v_f0, v_f1, v_f2, v_s);
-				float out = 0.f;
-				out = put_lane<0>(out, v_op); out = put_lane<1>(out, v_mx); out = put_lane<2>(out, v_my);
-				out = put_lane<3>(out, v_ca); out = put_lane<4>(out, v_cb); out = put_lane<5>(out, v_cc);
-				out = put_lane<6>(out, v_c0); out = put_lane<7>(out, v_c1); out = put_lane<8>(out, v_c2);
-				out = put_lane<9>(out, v_d);
-				out = put_lane<10>(out, v_f0); out = put_lane<11>(out, v_f1); out = put_lane<12>(out, v_f2);
-				out = put_lane<13>(out, v_s);
-				if (lane < GACC_USED) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + lane, out);
+				// 14 wave sums by a transposing reduction: every level halves the number of live registers
+				// (slot k of the 64-B gradient line ends up in the lanes with slot_of_lane == k) -> one
+				// atomic instruction on one 64-B line.  Absent channels stay exactly 0.
+				const float out = wave_sum14_transposed(v_op, v_mx, v_my, v_ca, v_cb, v_cc, v_c0, v_c1, v_c2, v_d, v_f0, v_f1, v_f2, v_s);
+				if (writer) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
 			}
 		}
 		chunk = prev;
