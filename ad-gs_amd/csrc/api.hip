@@ -7,6 +7,7 @@
 #include "kernels.h"
 #include "../../include/adgs_rasterizer.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <cstdlib>
@@ -158,6 +159,12 @@ struct StageTimer {
 
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
+static std::atomic<size_t> g_hint_cells{0}, g_hint_fine{0};      // speculative binning capacities (v2 forward)
+static hipEvent_t readback_event() {
+	static thread_local hipEvent_t e = nullptr;
+	if (!e) { if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr; }
+	return e;
+}
 static uint32_t* pinned_word() {
 	static thread_local uint32_t* p = nullptr;
 	if (!p) { if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr; }
@@ -252,49 +259,73 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;
 		pa.rects = geom.rects; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
-		pa.sh0 = geom.sh0;
+		pa.sh0 = geom.sh0; pa.gacc = geom.gacc;
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream) != 0) return -1; }
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		{
 			StageTimer t(ST_SCAN, stream);
-			ADGS_HIP_CHECK(hipMemsetAsync(geom.cells_touched + P, 0, sizeof(uint32_t), stream));
-			ADGS_HIP_CHECK(hipMemsetAsync(geom.fine_touched + P, 0, sizeof(uint32_t), stream));
 			if (exclusive_scan_u32(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
 			if (exclusive_scan_u32(geom.fine_touched, geom.fine_touched, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);
+		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning
+		// buffer.  Instead of draining the stream for them (the reference's blocking cudaMemcpy,
+		// rasterizer_impl.cu:288), binning + sort + ranges are enqueued against a speculative capacity
+		// (previous frames' counts + 25%) with the exact count read on the device; the host then waits only
+		// for the scan to finish -- the GPU keeps working on the speculative launches meanwhile -- and
+		// re-runs them with exact sizes in the rare case the capacity was too small.
 		uint32_t* hw = pinned_word();
-		if (!hw) { set_error("hipHostMalloc failed"); return -1; }
+		hipEvent_t ev = readback_event();
+		if (!hw || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return -1; }
 		ADGS_HIP_CHECK(hipMemcpyAsync(hw, geom.offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		ADGS_HIP_CHECK(hipMemcpyAsync(hw + 1, geom.fine_touched + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		ADGS_HIP_CHECK(hipStreamSynchronize(stream));
-		const size_t R_cells = hw[0], R_fine = hw[1];
+		ADGS_HIP_CHECK(hipEventRecord(ev, stream));
 		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
+		const bool speculate = env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99;
+		const int bit = (int)higher_msb((uint32_t)ncells);
+		size_t cap_cells = std::max<size_t>(g_hint_cells.load(), (size_t)P + 4096);
+		size_t cap_fine = std::max<size_t>(g_hint_fine.load(), (size_t)8 * P + 4096);
+		BinStateV2 bin;
+		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
+			size_t bb = 0;
+			BinStateV2::carve(nullptr, cells, fine, ntiles, &bb);
+			char* bch = binningBuffer(binningUser, bb);
+			if (!bch) { set_error("binning allocator returned NULL"); return -1; }
+			bin = BinStateV2::carve(bch, cells, fine, ntiles, nullptr);
+			if (cells == 0) {
+				ADGS_HIP_CHECK(hipMemsetAsync(img.cell_ranges, 0, ncells * sizeof(uint2), stream));
+				ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream));
+				return 0;
+			}
+			{ StageTimer t(ST_DUPLICATE, stream);
+			  if (launch_duplicate_cells(P, geom.splats, geom.rects, geom.offsets, bin.keys_unsorted, bin.list_unsorted, (uint32_t)std::min<size_t>(cells, 0xffffffffu),
+			        cell_tiles, cgx, img.cell_ranges, (int)ncells, bin.pool_cursor, stream) != 0) return -1; }
+			ADGS_LAUNCH_CHECK(debug, stream);
+			{ StageTimer t(ST_SORT, stream);
+			  if (radix_sort_pairs_u64_dn(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, cells, d_count, 32 + bit, bin.sort_temp, stream) != 0) return -1; }
+			ADGS_LAUNCH_CHECK(debug, stream);
+			{ StageTimer t(ST_RANGES, stream);
+			  if (launch_tile_ranges((int)cells, d_count, bin.keys, img.cell_ranges, stream) != 0) return -1; }
+			ADGS_LAUNCH_CHECK(debug, stream);
+			return 0;
+		};
+		if (speculate && enqueue_binning(cap_cells, cap_fine, geom.offsets + P) != 0) return -1;
+		ADGS_HIP_CHECK(hipEventSynchronize(ev));
+		const size_t R_cells = hw[0], R_fine = hw[1];
 		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu\n", P, ncells, R_cells, R_fine);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
 		ADGS_DBG_STOP(0)
-
-		size_t bb = 0;
-		BinStateV2::carve(nullptr, R_cells, R_fine, ntiles, &bb);
-		char* bch = binningBuffer(binningUser, bb);
-		if (!bch) { set_error("binning allocator returned NULL"); return -1; }
-		BinStateV2 bin = BinStateV2::carve(bch, R_cells, R_fine, ntiles, nullptr);
-		{ StageTimer t(ST_DUPLICATE, stream);
-		  if (launch_duplicate_cells(P, geom.splats, geom.rects, geom.offsets, bin.keys_unsorted, bin.list_unsorted, cell_tiles, cgx, stream) != 0) return -1; }
-		ADGS_LAUNCH_CHECK(debug, stream);
-		ADGS_DBG_STOP(1)
-		const int bit = (int)higher_msb((uint32_t)ncells);
-		{ StageTimer t(ST_SORT, stream);
-		  if (radix_sort_pairs_u64(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, R_cells, 32 + bit, bin.sort_temp, stream) != 0) return -1; }
-		ADGS_LAUNCH_CHECK(debug, stream);
-		ADGS_DBG_STOP(2)
-		{ StageTimer t(ST_RANGES, stream);
-		  ADGS_HIP_CHECK(hipMemsetAsync(img.cell_ranges, 0, ncells * sizeof(uint2), stream));
-		  ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream));
-		  if (launch_tile_ranges((int)R_cells, bin.keys, img.cell_ranges, stream) != 0) return -1; }
-		ADGS_LAUNCH_CHECK(debug, stream);
+		if (!speculate || R_cells > cap_cells || R_fine > cap_fine) {
+			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
+		}
 		ADGS_DBG_STOP(3)
+		{	// capacity hints for the next frame: 25% head-room over this frame, slow decay of older peaks
+			const size_t want_c = R_cells + R_cells / 4 + 4096, want_f = R_fine + R_fine / 4 + 4096;
+			const size_t old_c = g_hint_cells.load(), old_f = g_hint_fine.load();
+			g_hint_cells.store(std::max(want_c, old_c - old_c / 16));
+			g_hint_fine.store(std::max(want_f, old_f - old_f / 16));
+		}
 		RenderV2FwdArgs ra;
 		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
@@ -333,7 +364,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
 	pa.rects = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
-	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr;
+	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
@@ -341,7 +372,6 @@ static int raster_forward_impl(const ShSource* sh_src,
 	// tiles_touched[P] = 0 sentinel so that the exclusive scan yields the total at [P]
 	{
 		StageTimer t(ST_SCAN, stream);
-		ADGS_HIP_CHECK(hipMemsetAsync(geom.tiles_touched + P, 0, sizeof(uint32_t), stream));
 		if (exclusive_scan_u32(geom.tiles_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
 	}
 	ADGS_LAUNCH_CHECK(debug, stream);
@@ -367,7 +397,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	ADGS_LAUNCH_CHECK(debug, stream);
 	{ StageTimer t(ST_RANGES, stream);
 	  ADGS_HIP_CHECK(hipMemsetAsync(img.ranges, 0, ntiles * sizeof(uint2), stream));
-	  if (launch_tile_ranges(num_rendered, bin.keys, img.ranges, stream) != 0) return -1; }
+	  if (launch_tile_ranges(num_rendered, nullptr, bin.keys, img.ranges, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	RenderFwdArgs ra;
@@ -422,7 +452,8 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		ra.gacc = geom.gacc;
 		{
 			StageTimer t(ST_RENDER_BWD, stream);
-			ADGS_HIP_CHECK(hipMemsetAsync(geom.gacc, 0, (size_t)P * GACC_STRIDE * sizeof(float), stream));
+			// geom.gacc lines of the visible Gaussians were zeroed by the forward preprocess (and are re-zeroed
+			// by the preprocess backward after it consumed them)
 			if (binning_buffer && launch_render_bwd_v2(ra, stream) != 0) return -1;
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);

@@ -85,6 +85,8 @@ size_t sort_temp_bytes(size_t n);
 // Result is left in keys_out/vals_out; *_in are clobbered.
 int radix_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
 	size_t n, int end_bit, char* temp, hipStream_t stream);
+int radix_sort_pairs_u64_dn(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n_cap, const uint32_t* d_n, int end_bit, char* temp, hipStream_t stream);
 int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
 	size_t n, int end_bit, char* temp, hipStream_t stream);
 

@@ -338,22 +338,27 @@ struct ParamGradArgs {
 	float* out;                                       // [count, D, n_params]
 	adgs_func_eval f;
 };
+constexpr int PG_ITEMS = 8;                          // outputs per thread
 __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
 	extern __shared__ float s_w[];
 	const int np = a.f.n_params;
 	for (int k = threadIdx.x; k < np; k += blockDim.x) s_w[k] = 0.f;
 	__syncthreads();
 	const int total = a.f.n_terms[0] + a.f.n_terms[1] + a.f.n_terms[2];
-	if (threadIdx.x == 0) for (int i = 0; i < total; i++) s_w[a.f.index[i]] = a.f.weight[i];
+	for (int i = threadIdx.x; i < total; i += blockDim.x) s_w[a.f.index[i]] = a.f.weight[i];
 	__syncthreads();
-	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const size_t tot = (size_t)a.count * a.D * np;
-	if (e >= tot) return;
-	const int k = (int)(e % np);
-	const size_t md = e / np;
-	const int d = (int)(md % a.D);
-	const size_t m = md / a.D;
-	a.out[e] = s_w[k] * a.g[(a.n0 + m) * (size_t)a.gstride + d];
+	const size_t e0 = (size_t)blockIdx.x * (256 * PG_ITEMS) + threadIdx.x;
+#pragma unroll
+	for (int it = 0; it < PG_ITEMS; it++) {
+		const size_t e = e0 + (size_t)it * 256;
+		if (e >= tot) break;
+		const int k = (int)(e % np);
+		const size_t md = e / np;
+		const int d = (int)(md % a.D);
+		const size_t m = md / a.D;
+		a.out[e] = s_w[k] * a.g[(a.n0 + m) * (size_t)a.gstride + d];
+	}
 }
 
 struct DeformBwdArgs {
@@ -538,7 +543,7 @@ int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* 
 	ParamGradArgs pg;
 	pg.n0 = 0; pg.count = count; pg.D = D; pg.gstride = gstride; pg.g = g; pg.out = out; pg.f = f;
 	const size_t tot = (size_t)count * D * f.n_params;
-	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), f.n_params * sizeof(float), stream, pg);
+	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((tot + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), f.n_params * sizeof(float), stream, pg);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -631,7 +636,7 @@ extern "C" int adgs_deform_backward(const adgs_deform_params* p, const adgs_func
 			ParamGradArgs pg;
 			pg.n0 = part == 0 ? 0 : p->Ns; pg.count = count; pg.D = 3; pg.gstride = M * 3; pg.g = dL_dshs; pg.out = out; pg.f = a.fs;
 			const size_t t2 = (size_t)count * 3 * a.fs.n_params;
-			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), a.fs.n_params * sizeof(float), stream, pg);
+			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), a.fs.n_params * sizeof(float), stream, pg);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}

@@ -22,13 +22,14 @@ struct PreprocessArgs {
 	int cell_tiles, cgx, cgy;        // coarse cell = cell_tiles x cell_tiles fine tiles
 	ShSource sh_src;                 // raw SH source (sh_src.scene_dc != nullptr) instead of `shs`
 	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
+	float* gacc;                     // v2: [P][GACC_STRIDE] accumulator lines, zeroed here for every visible Gaussian (nullptr: skip)
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
 int launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, const int* radii, uint64_t* keys, uint32_t* vals,
 	int gx, int gy, hipStream_t stream);
-int launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t stream);
+int launch_tile_ranges(int L, const uint32_t* d_L, const uint64_t* keys, uint2* ranges, hipStream_t stream);
 
 struct RenderFwdArgs {
 	const uint2* ranges; const uint32_t* point_list; const Splat* splats;
@@ -71,7 +72,7 @@ struct PreprocessBwdArgs {
 	float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 	// v2: per-Gaussian sums arrive packed in gacc ([P][16]); they are unpacked into the ABI outputs
 	// below (which are then written, not read).  gacc == nullptr selects the classic inputs above.
-	const float* gacc; const Splat* splats; int W, H;
+	float* gacc; const Splat* splats; int W, H;
 	ShSource sh_src; ShGradDst sh_dst;   // raw-SH path: gradients go straight to the raw tensors' layout
 	float* out_mean2D; float* out_conic; float* out_opacity; float* out_color; float* out_depth; float* out_flow; float* out_sem;
 	int D_S;
@@ -84,7 +85,7 @@ constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumula
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
 int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
-	int cell_tiles, int cgx, hipStream_t stream);
+	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, hipStream_t stream);
 
 struct RenderV2FwdArgs {
 	const uint2* cell_ranges; const uint32_t* cell_list; const FilterRec* rects; const Splat* splats;

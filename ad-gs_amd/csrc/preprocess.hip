@@ -124,6 +124,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		__syncthreads();
 	}
 	if (idx >= a.P) return;
+	if (idx == 0) {       // sentinels: the exclusive scans over P + 1 entries leave the totals at [P]
+		a.tiles_touched[a.P] = 0;
+		if (a.rects) a.fine_touched[a.P] = 0;
+	}
 	a.radii[idx] = 0;
 	a.tiles_touched[idx] = 0;
 	if (a.rects) { a.rects[idx].rmin = 0u; a.rects[idx].rmax = 0u; a.fine_touched[idx] = 0; }
@@ -226,6 +230,11 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	dst[3] = make_float4(s.fz, s.sem0, s.zview, s.pad);
 	a.clamped[idx] = clamp_bits;
 	a.radii[idx] = (int)my_radius;
+	if (a.gacc) {     // the blend backward accumulates into this 64-B line (rows of culled Gaussians are never read)
+		float4* g = reinterpret_cast<float4*>(a.gacc + (size_t)idx * GACC_STRIDE);
+		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		g[0] = z; g[1] = z; g[2] = z; g[3] = z;
+	}
 	if (!a.rects) {
 		a.tiles_touched[idx] = (maxy - miny) * (maxx - minx);
 		return;
@@ -295,8 +304,12 @@ __global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat*
 
 // v2: one (cell | depth) key per covered coarse cell.
 __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat* __restrict__ splats, const FilterRec* __restrict__ rects,
-	const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int cell_tiles, int cgx) {
+	const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap, int cell_tiles, int cgx,
+	uint2* __restrict__ cell_ranges, int ncells, uint32_t* __restrict__ pool_cursor) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	// bookkeeping resets for the stages that follow on this stream (tile_ranges, blend forward)
+	for (int c = idx; c < ncells; c += gridDim.x * blockDim.x) cell_ranges[c] = make_uint2(0u, 0u);
+	if (idx == 0) *pool_cursor = 0u;
 	if (idx >= P) return;
 	const uint32_t rmin = rects[idx].rmin, rmax = rects[idx].rmax;
 	const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, maxx = rmax & 0xFFFFu, maxy = rmax >> 16;
@@ -308,13 +321,15 @@ __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat
 		for (uint32_t x = c0x; x <= c1x; x++) {
 			uint64_t key = (uint64_t)(y * cgx + x);
 			key <<= 32; key |= dbits;
-			keys[off] = key; vals[off] = (uint32_t)idx; off++;
+			if (off < cap) { keys[off] = key; vals[off] = (uint32_t)idx; }    // cap: speculative capacity (the host re-runs on overflow)
+			off++;
 		}
 }
 
 // rasterizer_impl.cu:116-138
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* __restrict__ d_L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (d_L) L = (int)min((uint32_t)L, *d_L);      // device-side count, L is the capacity
 	if (idx >= L) return;
 	const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
 	if (idx == 0) ranges[currtile].x = 0;
@@ -354,15 +369,16 @@ int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, c
 	return 0;
 }
 int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
-	int cell_tiles, int cgx, hipStream_t stream) {
+	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, hipStream_t stream) {
 	if (P == 0) return 0;
-	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, rects, offsets, keys, vals, cell_tiles, cgx);
+	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, rects, offsets, keys, vals, cap, cell_tiles, cgx,
+		cell_ranges, ncells, pool_cursor);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
-int launch_tile_ranges(int L, const uint64_t* keys, uint2* ranges, hipStream_t stream) {
+int launch_tile_ranges(int L, const uint32_t* d_L, const uint64_t* keys, uint2* ranges, hipStream_t stream) {
 	if (L == 0) return 0;
-	hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys, ranges);
+	hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, L, d_L, keys, ranges);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -103,10 +103,11 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, 
 
 // ------------------------------------------------------------------ radix sort
 template <typename KeyT>
-__global__ void __launch_bounds__(PB) sort_hist_kernel(const KeyT* __restrict__ keys, size_t n, int shift, uint32_t mask,
+__global__ void __launch_bounds__(PB) sort_hist_kernel(const KeyT* __restrict__ keys, size_t n, const uint32_t* __restrict__ d_n, int shift, uint32_t mask,
 	uint32_t* __restrict__ block_hist, uint32_t nblocks) {
 	__shared__ uint32_t hist[256];
 	const int tid = threadIdx.x;
+	if (d_n) n = min(n, (size_t)*d_n);        // device-side count (speculative capacity launch): n is the capacity
 	hist[tid] = 0;
 	__syncthreads();
 	const size_t tile0 = (size_t)blockIdx.x * SORT_TILE;
@@ -124,9 +125,10 @@ __global__ void __launch_bounds__(PB) sort_hist_kernel(const KeyT* __restrict__ 
 
 template <typename KeyT>
 __global__ void __launch_bounds__(PB) sort_scatter_kernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_out,
-	const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ vals_out, size_t n, int shift, uint32_t mask,
+	const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ vals_out, size_t n, const uint32_t* __restrict__ d_n, int shift, uint32_t mask,
 	const uint32_t* __restrict__ block_hist_scanned, uint32_t nblocks) {
 	__shared__ uint32_t global_base[256];
+	if (d_n) n = min(n, (size_t)*d_n);
 	__shared__ uint32_t running[256];
 	__shared__ uint32_t wave_cnt[PB / WAVE][256];
 	__shared__ uint32_t wave_base[PB / WAVE][256];
@@ -181,7 +183,7 @@ size_t sort_temp_bytes(size_t n) {
 
 template <typename KeyT>
 static int radix_sort_pairs(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, uint32_t* vals_out,
-	size_t n, int end_bit, char* temp, hipStream_t stream) {
+	size_t n, const uint32_t* d_n, int end_bit, char* temp, hipStream_t stream) {
 	if (n == 0) return 0;
 	const size_t nb = sort_blocks(n);
 	uint32_t* block_hist = reinterpret_cast<uint32_t*>(temp);
@@ -194,11 +196,11 @@ static int radix_sort_pairs(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, ui
 		const int shift = p * 8;
 		const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
 		const uint32_t mask = (1u << bits) - 1u;
-		hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3((unsigned)nb), dim3(PB), 0, stream, (const KeyT*)kin, n, shift, mask, block_hist, (uint32_t)nb);
+		hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3((unsigned)nb), dim3(PB), 0, stream, (const KeyT*)kin, n, d_n, shift, mask, block_hist, (uint32_t)nb);
 		ADGS_HIP_CHECK(hipGetLastError());
 		if (exclusive_scan_u32(block_hist, block_hist, 256 * nb, scan_temp, stream) != 0) return -1;
 		hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3((unsigned)nb), dim3(PB), 0, stream, (const KeyT*)kin, kout,
-			(const uint32_t*)vin, vout, n, shift, mask, (const uint32_t*)block_hist, (uint32_t)nb);
+			(const uint32_t*)vin, vout, n, d_n, shift, mask, (const uint32_t*)block_hist, (uint32_t)nb);
 		ADGS_HIP_CHECK(hipGetLastError());
 		KeyT* tk = kin; kin = kout; kout = tk;
 		uint32_t* tv = vin; vin = vout; vout = tv;
@@ -213,11 +215,17 @@ static int radix_sort_pairs(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, ui
 
 int radix_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
 	size_t n, int end_bit, char* temp, hipStream_t stream) {
-	return radix_sort_pairs<uint64_t>(keys_in, keys_out, vals_in, vals_out, n, end_bit, temp, stream);
+	return radix_sort_pairs<uint64_t>(keys_in, keys_out, vals_in, vals_out, n, nullptr, end_bit, temp, stream);
+}
+// n_cap sizes the launch and the temporaries; the number of pairs actually sorted is min(*d_n, n_cap),
+// read on the device (lets the host enqueue the sort before it knows the count).
+int radix_sort_pairs_u64_dn(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
+	size_t n_cap, const uint32_t* d_n, int end_bit, char* temp, hipStream_t stream) {
+	return radix_sort_pairs<uint64_t>(keys_in, keys_out, vals_in, vals_out, n_cap, d_n, end_bit, temp, stream);
 }
 int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
 	size_t n, int end_bit, char* temp, hipStream_t stream) {
-	return radix_sort_pairs<uint32_t>(keys_in, keys_out, vals_in, vals_out, n, end_bit, temp, stream);
+	return radix_sort_pairs<uint32_t>(keys_in, keys_out, vals_in, vals_out, n, nullptr, end_bit, temp, stream);
 }
 
 } // namespace adgs
