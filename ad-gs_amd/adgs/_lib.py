@@ -48,6 +48,8 @@ SIGNATURES = {
     "adgs_func_eval_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "adgs_deform_forward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_deform_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_deform_forward_flow": (c_i, [c_p] * 10),
+    "adgs_deform_backward_flow": (c_i, [c_p] * 15),
     # include/adgs_testing.h
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),

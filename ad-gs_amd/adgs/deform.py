@@ -185,11 +185,11 @@ _MODEL_ATTRS = {  # ctypes field -> reference GaussianModel attribute (scene/gau
 
 
 class _DeformPkgFn(torch.autograd.Function):
-    """19 raw parameter tensors -> (xyz, rotation, shs, opacity, scales)."""
+    """19 raw parameter tensors -> (xyz, rotation, shs, opacity, scales, flow_xyz)."""
 
     @staticmethod
     def forward(ctx, meta, *tensors):
-        t, order_args, use_time_mask, want = meta
+        t, order_args, use_time_mask, want, flow_t = meta
         ts = [None if x is None else x.contiguous() for x in tensors]
         named = dict(zip(_PTRS, ts))
         dev = named["scene_xyz"].device
@@ -205,7 +205,11 @@ class _DeformPkgFn(torch.autograd.Function):
         fe = {k: make_func_eval(float(t), order_args[k], named[pn].shape[-1] if named[pn] is not None and named[pn].numel() else 0)
               for k, pn in (("xyz", "xyz_deform_param"), ("rotation", "rotation_deform_param"), ("shs", "shs_deform_param_scene"),
                             ("background", "background_deform_param"))}
+        if flow_t is not None:
+            for k, pn in (("xyz", "xyz_deform_param"), ("background", "background_deform_param")):
+                fe[k + "_flow"] = make_func_eval(float(flow_t), order_args[k], fe[k].n_params)
         f32 = dict(dtype=torch.float32, device=dev)
+        flow_xyz = torch.empty(N, 3, **f32) if flow_t is not None else None
         outs = dict(xyz=torch.empty(N, 3, **f32) if "xyz" in want else None,
                     rotation=torch.empty(N, 4, **f32) if "rotation" in want else None,
                     shs=torch.empty(N, M, 3, **f32) if "shs" in want else None,
@@ -215,19 +219,21 @@ class _DeformPkgFn(torch.autograd.Function):
         for k, v in outs.items():
             setattr(o, k, _dp(v))
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().adgs_deform_forward(ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]),
-                                                      ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]), ctypes.byref(o),
-                                                      _stream(dev)), "adgs_deform_forward")
+            _lib.check(_lib.lib().adgs_deform_forward_flow(
+                ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]), ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]),
+                ctypes.byref(fe["xyz_flow"]) if flow_t is not None else None, ctypes.byref(fe["background_flow"]) if flow_t is not None else None,
+                ctypes.byref(o), _dp(flow_xyz), _stream(dev)), "adgs_deform_forward_flow")
         ctx.save_for_backward(*[x for x in ts if x is not None])
         ctx.present = [x is not None for x in ts]
         ctx.meta, ctx.fe, ctx.dims = meta, fe, (Ns, No, M)
         order = ("xyz", "rotation", "shs", "opacity", "scales")
         ctx.want = want
-        return tuple(outs[k] if outs[k] is not None else torch.empty(0, **f32) for k in order)
+        return tuple(outs[k] if outs[k] is not None else torch.empty(0, **f32) for k in order) + (
+            flow_xyz if flow_xyz is not None else torch.empty(0, **f32),)
 
     @staticmethod
-    def backward(ctx, g_xyz, g_rot, g_shs, g_op, g_sc):
-        t, order_args, use_time_mask, want = ctx.meta
+    def backward(ctx, g_xyz, g_rot, g_shs, g_op, g_sc, g_flow):
+        t, order_args, use_time_mask, want, flow_t = ctx.meta
         saved = list(ctx.saved_tensors)
         ts = [saved.pop(0) if pr else None for pr in ctx.present]
         named = dict(zip(_PTRS, ts))
@@ -240,6 +246,7 @@ class _DeformPkgFn(torch.autograd.Function):
         up = {}
         for k, g in (("xyz", g_xyz), ("rotation", g_rot), ("shs", g_shs), ("opacity", g_op), ("scales", g_sc)):
             up[k] = g.contiguous().float() if (k in want and g is not None and g.numel() > 0) else None
+        up["flow"] = g_flow.contiguous().float() if (flow_t is not None and g_flow is not None and g_flow.numel() > 0) else None
         # which output each raw parameter feeds; a parameter whose output has no upstream gradient gets
         # no gradient tensor at all, the others are fully written by the kernels (no zero fill) except
         # the atomically accumulated background row
@@ -252,7 +259,8 @@ class _DeformPkgFn(torch.autograd.Function):
         grads, gs = {}, DeformGrads()
         for n in _GRADS:
             src = named[n]
-            need = (src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)] and up[dep[n]] is not None)
+            has_up = up[dep[n]] is not None or (dep[n] == "xyz" and up["flow"] is not None)
+            need = (src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)] and has_up)
             if not need:
                 grads[n] = None
             elif n == "background_deform_param":          # accumulated with atomics
@@ -262,29 +270,35 @@ class _DeformPkgFn(torch.autograd.Function):
             setattr(gs, n, _dp(grads[n]))
         fe = ctx.fe
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().adgs_deform_backward(ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]),
-                                                       ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]),
-                                                       _dp(up["xyz"]), _dp(up["rotation"]), _dp(up["shs"]), _dp(up["opacity"]), _dp(up["scales"]),
-                                                       ctypes.byref(gs), _stream(dev)), "adgs_deform_backward")
+            _lib.check(_lib.lib().adgs_deform_backward_flow(
+                ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]), ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]),
+                ctypes.byref(fe["xyz_flow"]) if flow_t is not None else None, ctypes.byref(fe["background_flow"]) if flow_t is not None else None,
+                _dp(up["xyz"]), _dp(up["rotation"]), _dp(up["shs"]), _dp(up["opacity"]), _dp(up["scales"]), _dp(up["flow"]),
+                ctypes.byref(gs), _stream(dev)), "adgs_deform_backward_flow")
         return (None,) + tuple(grads.get(n) for n in _PTRS)
 
 
-def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales"), raw_sh=False):
+def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales"), raw_sh=False, flow_time=None):
     """Fused scene/gaussian_model.py:216-231 (+ get_scaling :89-91) on the raw parameters of `model`
     (any object with the reference GaussianModel's attributes).  Returns the reference's dict
     {'xyz','rotation','shs','opacity'} plus 'scales'.  With raw_sh=True the [N,M,3] SH tensor is not
-    materialised: 'shs' is a diff_gaussian_rasterization.RawSH for GaussianRasterizer.forward_rawsh."""
+    materialised: 'shs' is a diff_gaussian_rasterization.RawSH for GaussianRasterizer.forward_rawsh.
+    With flow_time the dict also holds 'flow_xyz' = get_deformed_xyz(flow_time) (reference
+    gaussian_renderer/__init__.py:57), evaluated in the same pass over the deformation rows."""
     if raw_sh and "shs" in want:
         from diff_gaussian_rasterization import RawSH
-        out = get_deformed_pkg(model, t, want=tuple(w for w in want if w != "shs"))
+        out = get_deformed_pkg(model, t, want=tuple(w for w in want if w != "shs"), flow_time=flow_time)
         sp = model.shs_deform_param_scene
         out["shs"] = RawSH(model._scene_shs_dc, model._obj_shs_dc, model._scene_shs_rest, model._obj_shs_rest, sp, model.shs_deform_param_obj,
                            make_func_eval(float(t), model.order_args["shs"], sp.shape[-1]))
         return out
     tensors = [getattr(model, _MODEL_ATTRS[n], None) for n in _PTRS]
-    meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want))
-    xyz, rot, shs, op, sc = _DeformPkgFn.apply(meta, *tensors)
+    meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want),
+            None if flow_time is None else float(flow_time))
+    xyz, rot, shs, op, sc, flow = _DeformPkgFn.apply(meta, *tensors)
     out = {}
+    if flow_time is not None:
+        out["flow_xyz"] = flow
     for k, v in (("xyz", xyz), ("rotation", rot), ("shs", shs), ("opacity", op), ("scales", sc)):
         if k in want:
             out[k] = v

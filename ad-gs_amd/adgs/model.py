@@ -95,10 +95,12 @@ class SyntheticGaussianModel:
 
     raw_sh = False     # True: get_deformed_pkg leaves the SH coefficients in raw layout (RawSH) for forward_rawsh
 
-    def get_deformed_pkg(self, t):
+    supports_fused_flow = True     # get_deformed_pkg(t, flow_time=...) also returns 'flow_xyz'
+
+    def get_deformed_pkg(self, t, flow_time=None):
         """Reference keys 'xyz','rotation','shs','opacity' plus 'scales' (so that render() needs no
-        separate get_scaling pass)."""
-        return deform.get_deformed_pkg(self, t, raw_sh=self.raw_sh)
+        separate get_scaling pass) and, with flow_time, 'flow_xyz' = get_deformed_xyz(flow_time)."""
+        return deform.get_deformed_pkg(self, t, raw_sh=self.raw_sh, flow_time=flow_time)
 
     def deform_bytes_per_frame(self):
         """Algorithmic bytes of the deformation stage per frame: deformation

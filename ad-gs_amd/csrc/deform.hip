@@ -13,6 +13,7 @@
 #include "common.h"
 #include "func_eval.h"
 #include <cstring>
+#include <algorithm>
 
 namespace adgs {
 namespace {
@@ -193,72 +194,98 @@ __global__ void __launch_bounds__(256) func_eval_bwd_kernel(int N, const float* 
 }
 
 // ------------------------------------------------------------------ fused get_deformed_pkg
+// One thread per Gaussian of [n_begin, n_end).  The object Gaussians' deformation rows ([3][Cx] for xyz,
+// [4][Cr] for the rotation) are staged through LDS with coalesced loads (func_eval.h: stage_rows), one
+// parameter family after the other in the same buffer; the host launches the scene range without LDS.
+// xyz is evaluated at the camera time and, when flow_xyz is given, at the flow time from the same staged
+// rows (gaussian_renderer/__init__.py:57 calls get_deformed_xyz a second time for it).
 struct DeformArgs {
-	adgs_deform_params p; adgs_func_eval fx, fr, fs, fb; adgs_deform_outputs o;
+	adgs_deform_params p; adgs_func_eval fx, fr, fb, fx2, fb2; adgs_deform_outputs o; float* flow_xyz;
+	int n_begin, n_end, stride_x, stride_r;
 };
 
 __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
-	const int n = blockIdx.x * blockDim.x + threadIdx.x;
-	const int Ns = a.p.Ns, N = a.p.Ns + a.p.No;
-	if (n >= N) return;
-	const bool is_obj = n >= Ns;
+	extern __shared__ float s_rows[];
+	const int tid = threadIdx.x, B = blockDim.x, base = a.n_begin + blockIdx.x * B;
+	const int Ns = a.p.Ns;
+	const int count = min(B, a.n_end - base);
+	const int n = base + tid;
+	const bool valid = tid < count;
+	const bool is_obj = valid && n >= Ns;
 	const int m = is_obj ? n - Ns : n;
-	// ---- xyz (gaussian_model.py:173-185)
-	if (a.o.xyz) {
-		float bg[3] = { 0.f, 0.f, 0.f };
-		if (a.p.background_deform_param && has_lin(a.fb)) {
-#pragma unroll
-			for (int d = 0; d < 3; d++) bg[d] = lin_eval(a.p.background_deform_param + d * a.fb.n_params, a.fb);
+	const bool blk_obj = base + count > Ns;          // block-uniform: some member is an object Gaussian
+	// ---- xyz (gaussian_model.py:173-185), at t and at the flow time
+	if (a.o.xyz || a.flow_xyz) {
+		const int np = a.fx.n_params;
+		const bool lin1 = a.o.xyz && a.p.xyz_deform_param && has_lin(a.fx);
+		const bool lin2 = a.flow_xyz && a.p.xyz_deform_param && has_lin(a.fx2);
+		const bool staged = blk_obj && (lin1 || lin2);
+		if (staged) {
+			stage_rows<true>(s_rows, a.stride_x, 3 * np, base, count, Ns, (const float*)nullptr, a.p.xyz_deform_param, tid, B);
+			__syncthreads();
 		}
-		const float* base = is_obj ? a.p.obj_xyz + 3 * (size_t)m : a.p.scene_xyz + 3 * (size_t)m;
+		if (valid) {
+			float bg[3] = { 0.f, 0.f, 0.f }, bg2[3] = { 0.f, 0.f, 0.f };
+			if (a.p.background_deform_param) {
 #pragma unroll
-		for (int d = 0; d < 3; d++) {
-			float v = base[d];
-			if (is_obj && a.p.xyz_deform_param && has_lin(a.fx))
-				v = v + lin_eval(a.p.xyz_deform_param + ((size_t)m * 3 + d) * a.fx.n_params, a.fx);
-			a.o.xyz[3 * (size_t)n + d] = v + bg[d];
+				for (int d = 0; d < 3; d++) {
+					if (a.o.xyz && has_lin(a.fb)) bg[d] = lin_eval(a.p.background_deform_param + d * a.fb.n_params, a.fb);
+					if (a.flow_xyz && has_lin(a.fb2)) bg2[d] = lin_eval(a.p.background_deform_param + d * a.fb2.n_params, a.fb2);
+				}
+			}
+			const float* bp = is_obj ? a.p.obj_xyz + 3 * (size_t)m : a.p.scene_xyz + 3 * (size_t)m;
+			const float* row = s_rows + tid * a.stride_x;
+#pragma unroll
+			for (int d = 0; d < 3; d++) {
+				const float v = bp[d];
+				if (a.o.xyz) {
+					float v1 = v;
+					if (is_obj && lin1) v1 = v1 + lin_eval(row + d * np, a.fx);
+					a.o.xyz[3 * (size_t)n + d] = v1 + bg[d];
+				}
+				if (a.flow_xyz) {
+					float v2 = v;
+					if (is_obj && lin2) v2 = v2 + lin_eval(row + d * np, a.fx2);
+					a.flow_xyz[3 * (size_t)n + d] = v2 + bg2[d];
+				}
+			}
 		}
+		if (staged) __syncthreads();                  // the buffer is reused below
 	}
 	// ---- rotation (gaussian_model.py:187-196): normalize(cat(scene_rot, obj_rot))
 	if (a.o.rotation) {
-		float u[4];
-		if (!is_obj) {
-#pragma unroll
-			for (int d = 0; d < 4; d++) u[d] = a.p.scene_rotation[4 * (size_t)m + d];
-		} else {
-			const float* rp = a.p.rotation_deform_param ? a.p.rotation_deform_param + (size_t)m * 4 * a.fr.n_params : nullptr;
-			float fv[4] = { 0.f, 0.f, 0.f, 0.f };
-			if (rp) {
-#pragma unroll
-				for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * a.fr.n_params, a.fr);
-				if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
-			}
-			if (a.fr.quat_start >= 0) {
-#pragma unroll
-				for (int d = 0; d < 4; d++) u[d] = fv[d];          // quaternion spline replaces _obj_rotation (:189-190)
+		const int np = a.fr.n_params;
+		const bool staged = blk_obj && a.p.rotation_deform_param != nullptr;
+		if (staged) {
+			stage_rows<true>(s_rows, a.stride_r, 4 * np, base, count, Ns, (const float*)nullptr, a.p.rotation_deform_param, tid, B);
+			__syncthreads();
+		}
+		if (valid) {
+			float u[4];
+			if (!is_obj) {
+				const float4 q = *reinterpret_cast<const float4*>(a.p.scene_rotation + 4 * (size_t)m);
+				u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
 			} else {
+				const float* rp = a.p.rotation_deform_param ? s_rows + tid * a.stride_r : nullptr;
+				float fv[4] = { 0.f, 0.f, 0.f, 0.f };
+				if (rp) {
 #pragma unroll
-				for (int d = 0; d < 4; d++) u[d] = a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
+					for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * np, a.fr);
+					if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
+				}
+				if (a.fr.quat_start >= 0) {
+#pragma unroll
+					for (int d = 0; d < 4; d++) u[d] = fv[d];          // quaternion spline replaces _obj_rotation (:189-190)
+				} else {
+#pragma unroll
+					for (int d = 0; d < 4; d++) u[d] = a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
+				}
 			}
+			const float inv = 1.f / fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]), 1e-12f);
+			*reinterpret_cast<float4*>(a.o.rotation + 4 * (size_t)n) = make_float4(u[0] * inv, u[1] * inv, u[2] * inv, u[3] * inv);
 		}
-		const float inv = 1.f / fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]), 1e-12f);
-		*reinterpret_cast<float4*>(a.o.rotation + 4 * (size_t)n) = make_float4(u[0] * inv, u[1] * inv, u[2] * inv, u[3] * inv);
 	}
-	// ---- shs (gaussian_model.py:198-205)
-	if (a.o.shs) {
-		const int M = a.p.sh_coeffs;
-		const float* dc = is_obj ? a.p.obj_shs_dc + 3 * (size_t)m : a.p.scene_shs_dc + 3 * (size_t)m;
-		const float* sp = is_obj ? a.p.shs_deform_param_obj : a.p.shs_deform_param_scene;
-		float* o = a.o.shs + (size_t)n * M * 3;
-#pragma unroll
-		for (int d = 0; d < 3; d++) {
-			float v = dc[d];
-			if (sp && has_lin(a.fs)) v = v + lin_eval(sp + ((size_t)m * 3 + d) * a.fs.n_params, a.fs);
-			o[d] = v;
-		}
-		const float* rest = is_obj ? a.p.obj_shs_rest + (size_t)m * (M - 1) * 3 : a.p.scene_shs_rest + (size_t)m * (M - 1) * 3;
-		for (int k = 0; k < (M - 1) * 3; k++) o[3 + k] = rest[k];
-	}
+	if (!valid) return;
 	// ---- opacity (gaussian_model.py:207-214)
 	if (a.o.opacity) {
 		const float x = is_obj ? a.p.obj_opacity[m] : a.p.scene_opacity[m];
@@ -338,7 +365,7 @@ struct ParamGradArgs {
 	float* out;                                       // [count, D, n_params]
 	adgs_func_eval f;
 };
-constexpr int PG_ITEMS = 8;                          // outputs per thread
+constexpr int PG_ITEMS = 8;                          // consecutive outputs per thread (two 16-byte stores)
 __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
 	extern __shared__ float s_w[];
 	const int np = a.f.n_params;
@@ -348,124 +375,160 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 	for (int i = threadIdx.x; i < total; i += blockDim.x) s_w[a.f.index[i]] = a.f.weight[i];
 	__syncthreads();
 	const size_t tot = (size_t)a.count * a.D * np;
-	const size_t e0 = (size_t)blockIdx.x * (256 * PG_ITEMS) + threadIdx.x;
+	const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * PG_ITEMS;
+	if (e0 >= tot) return;
+	// (Gaussian m, channel d, column k) of the first output; then advanced incrementally
+	size_t row; int k;
+	if (tot <= 0xffffffffull) { const uint32_t r32 = (uint32_t)e0 / (uint32_t)np; row = r32; k = (int)((uint32_t)e0 - r32 * (uint32_t)np); }
+	else { row = e0 / np; k = (int)(e0 - row * np); }
+	size_t m = row / a.D; int d = (int)(row - m * a.D);
+	float gv = a.g[(a.n0 + m) * (size_t)a.gstride + d];
+	float v[PG_ITEMS];
 #pragma unroll
 	for (int it = 0; it < PG_ITEMS; it++) {
-		const size_t e = e0 + (size_t)it * 256;
-		if (e >= tot) break;
-		const int k = (int)(e % np);
-		const size_t md = e / np;
-		const int d = (int)(md % a.D);
-		const size_t m = md / a.D;
-		a.out[e] = s_w[k] * a.g[(a.n0 + m) * (size_t)a.gstride + d];
+		v[it] = s_w[k] * gv;
+		if (++k == np) {
+			k = 0;
+			if (++d == a.D) { d = 0; m++; }
+			if (e0 + it + 1 < tot) gv = a.g[(a.n0 + m) * (size_t)a.gstride + d];
+		}
+	}
+	if (e0 + PG_ITEMS <= tot) {
+		float4* o = reinterpret_cast<float4*>(a.out + e0);
+		o[0] = make_float4(v[0], v[1], v[2], v[3]); o[1] = make_float4(v[4], v[5], v[6], v[7]);
+	} else {
+		for (int it = 0; it < PG_ITEMS && e0 + it < tot; it++) a.out[e0 + it] = v[it];
 	}
 }
 
 struct DeformBwdArgs {
-	adgs_deform_params p; adgs_func_eval fx, fr, fs, fb;
-	const float *g_xyz, *g_rot, *g_shs, *g_op, *g_sc;
+	adgs_deform_params p; adgs_func_eval fx, fr, fb, fx2, fb2;
+	const float *g_xyz, *g_flow, *g_rot, *g_op, *g_sc;
 	adgs_deform_grads g;
+	int n_begin, n_end, stride_x, stride_r;
 };
 
+// Backward of deform_fwd_kernel.  The object Gaussians' parameter-gradient rows are assembled in LDS (every
+// column written: zeros outside the active terms, so no caller zero-fill) and stored coalesced; the rotation
+// rows need the parameters (staged in) and a second LDS region for the gradients.
 __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
-	__shared__ float s_bg[3][256 / WAVE];
-	const int n = blockIdx.x * blockDim.x + threadIdx.x;
-	const int Ns = a.p.Ns, N = a.p.Ns + a.p.No;
-	const bool valid = n < N;
+	extern __shared__ float s_rows[];
+	__shared__ float s_bg[6][256 / WAVE];
+	const int tid = threadIdx.x, B = blockDim.x, base = a.n_begin + blockIdx.x * B;
+	const int Ns = a.p.Ns;
+	const int count = min(B, a.n_end - base);
+	const int n = base + tid;
+	const bool valid = tid < count;
 	const bool is_obj = valid && n >= Ns;
 	const int m = is_obj ? n - Ns : n;
-	// ---- xyz
-	float gx[3] = { 0.f, 0.f, 0.f };
-	if (valid && a.g_xyz) {
+	const bool blk_obj = base + count > Ns;
+	// ---- xyz: upstream of the camera-time points and of the flow-time points
+	if (a.g_xyz || a.g_flow) {
+		float gx[3] = { 0.f, 0.f, 0.f }, gf[3] = { 0.f, 0.f, 0.f };
+		if (valid) {
 #pragma unroll
-		for (int d = 0; d < 3; d++) gx[d] = a.g_xyz[3 * (size_t)n + d];
-	}
-	if (valid) {
-		float* dst = is_obj ? (a.g.obj_xyz ? a.g.obj_xyz + 3 * (size_t)m : nullptr) : (a.g.scene_xyz ? a.g.scene_xyz + 3 * (size_t)m : nullptr);
-		if (dst) { dst[0] = gx[0]; dst[1] = gx[1]; dst[2] = gx[2]; }
-		if (is_obj && a.g.xyz_deform_param) {
-			float* row = a.g.xyz_deform_param + (size_t)m * 3 * a.fx.n_params;
-			for (int k = 0; k < 3 * a.fx.n_params; k++) row[k] = 0.f;       // every column is written: no caller zero-fill
+			for (int d = 0; d < 3; d++) {
+				if (a.g_xyz) gx[d] = a.g_xyz[3 * (size_t)n + d];
+				if (a.g_flow) gf[d] = a.g_flow[3 * (size_t)n + d];
+			}
+			float* dst = is_obj ? (a.g.obj_xyz ? a.g.obj_xyz + 3 * (size_t)m : nullptr) : (a.g.scene_xyz ? a.g.scene_xyz + 3 * (size_t)m : nullptr);
+			if (dst) { dst[0] = gx[0] + gf[0]; dst[1] = gx[1] + gf[1]; dst[2] = gx[2] + gf[2]; }
+		}
+		const int np = a.fx.n_params;
+		if (blk_obj && a.g.xyz_deform_param) {
+			if (is_obj) {
+				float* row = s_rows + tid * a.stride_x;
+				for (int k = 0; k < 3 * np; k++) row[k] = 0.f;
 #pragma unroll
-			for (int d = 0; d < 3; d++) lin_bwd(row + d * a.fx.n_params, a.fx, gx[d]);
+				for (int d = 0; d < 3; d++) {
+					if (a.g_xyz) lin_bwd_add(row + d * np, a.fx, gx[d]);
+					if (a.g_flow) lin_bwd_add(row + d * np, a.fx2, gf[d]);
+				}
+			}
+			__syncthreads();
+			stage_rows<false>(s_rows, a.stride_x, 3 * np, base, count, Ns, (float*)nullptr, a.g.xyz_deform_param, tid, B);
+			__syncthreads();
+		}
+		// background: the same [1,3,Cb] row is added to every Gaussian -> reduce g over all n
+		if (a.g.background_deform_param && (has_lin(a.fb) || has_lin(a.fb2))) {
+#pragma unroll
+			for (int d = 0; d < 6; d++) {
+				float v = d < 3 ? gx[d % 3] : gf[d % 3];
+#pragma unroll
+				for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+				if ((tid & (WAVE - 1)) == 0) s_bg[d][tid / WAVE] = v;
+			}
+			__syncthreads();
+			if (tid < 6) {
+				float v = 0.f;
+				for (int w = 0; w < (B + WAVE - 1) / WAVE; w++) v += s_bg[tid][w];
+				const adgs_func_eval& f = tid < 3 ? a.fb : a.fb2;
+				const bool on = tid < 3 ? (a.g_xyz != nullptr) : (a.g_flow != nullptr);
+				const int total = f.n_terms[0] + f.n_terms[1] + f.n_terms[2];
+				if (on) for (int i = 0; i < total; i++)
+					atomicAdd(a.g.background_deform_param + (tid % 3) * f.n_params + f.index[i], f.weight[i] * v);
+			}
+			__syncthreads();
 		}
 	}
-	// background: the same [1,3,Cb] row is added to every Gaussian -> reduce g over all n
-	if (a.g.background_deform_param && has_lin(a.fb)) {
-#pragma unroll
-		for (int d = 0; d < 3; d++) {
-			float v = gx[d];
-#pragma unroll
-			for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-			if ((threadIdx.x & (WAVE - 1)) == 0) s_bg[d][threadIdx.x / WAVE] = v;
+	// ---- rotation: r = u / |u|
+	if (a.g_rot) {
+		const int np = a.fr.n_params;
+		const bool haver = a.p.rotation_deform_param != nullptr;
+		const bool staged = blk_obj && haver;
+		float* s_out = s_rows + B * a.stride_r;           // gradient rows
+		if (staged) {
+			stage_rows<true>(s_rows, a.stride_r, 4 * np, base, count, Ns, (const float*)nullptr, a.p.rotation_deform_param, tid, B);
+			__syncthreads();
 		}
-		__syncthreads();
-		if (threadIdx.x < 3) {
-			float v = 0.f;
-			for (int w = 0; w < 256 / WAVE; w++) v += s_bg[threadIdx.x][w];
-			const int total = a.fb.n_terms[0] + a.fb.n_terms[1] + a.fb.n_terms[2];
-			for (int i = 0; i < total; i++)
-				atomicAdd(a.g.background_deform_param + threadIdx.x * a.fb.n_params + a.fb.index[i], a.fb.weight[i] * v);
+		if (valid) {
+			float u[4];
+			const float* rp = (is_obj && haver) ? s_rows + tid * a.stride_r : nullptr;
+			if (!is_obj) {
+				const float4 q = *reinterpret_cast<const float4*>(a.p.scene_rotation + 4 * (size_t)m);
+				u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
+			} else {
+				float fv[4] = { 0.f, 0.f, 0.f, 0.f };
+				if (rp) {
+#pragma unroll
+					for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * np, a.fr);
+					if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
+				}
+#pragma unroll
+				for (int d = 0; d < 4; d++) u[d] = (a.fr.quat_start >= 0) ? fv[d] : a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
+			}
+			const float nr = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
+			const float inv = 1.f / fmaxf(nr, 1e-12f);
+			float g[4], r[4], dot = 0.f;
+			const float4 g4 = *reinterpret_cast<const float4*>(a.g_rot + 4 * (size_t)n);
+			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+#pragma unroll
+			for (int d = 0; d < 4; d++) { r[d] = u[d] * inv; dot += r[d] * g[d]; }
+			float gu[4];
+#pragma unroll
+			for (int d = 0; d < 4; d++) gu[d] = (nr > 1e-12f) ? (g[d] - r[d] * dot) * inv : g[d] * inv;
+			if (!is_obj) {
+				if (a.g.scene_rotation) *reinterpret_cast<float4*>(a.g.scene_rotation + 4 * (size_t)m) = make_float4(gu[0], gu[1], gu[2], gu[3]);
+			} else {
+				if (a.g.obj_rotation) {
+					const float k = (a.fr.quat_start >= 0) ? 0.f : 1.f;
+					*reinterpret_cast<float4*>(a.g.obj_rotation + 4 * (size_t)m) = make_float4(k * gu[0], k * gu[1], k * gu[2], k * gu[3]);
+				}
+				if (a.g.rotation_deform_param && rp) {
+					float* gp = s_out + tid * a.stride_r;
+					for (int k = 0; k < 4 * np; k++) gp[k] = 0.f;
+#pragma unroll
+					for (int d = 0; d < 4; d++) lin_bwd(gp + d * np, a.fr, gu[d]);
+					if (a.fr.quat_start >= 0) quat_spline_bwd(rp, a.fr, { gu[0], gu[1], gu[2], gu[3] }, gp);
+				}
+			}
+		}
+		if (staged && a.g.rotation_deform_param) {
+			__syncthreads();
+			stage_rows<false>(s_out, a.stride_r, 4 * np, base, count, Ns, (float*)nullptr, a.g.rotation_deform_param, tid, B);
 		}
 	}
 	if (!valid) return;
-	// ---- rotation: r = u / |u|
-	if (a.g_rot) {
-		float u[4];
-		const float* rp = (is_obj && a.p.rotation_deform_param) ? a.p.rotation_deform_param + (size_t)m * 4 * a.fr.n_params : nullptr;
-		if (!is_obj) {
-#pragma unroll
-			for (int d = 0; d < 4; d++) u[d] = a.p.scene_rotation[4 * (size_t)m + d];
-		} else {
-			float fv[4] = { 0.f, 0.f, 0.f, 0.f };
-			if (rp) {
-#pragma unroll
-				for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * a.fr.n_params, a.fr);
-				if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
-			}
-#pragma unroll
-			for (int d = 0; d < 4; d++) u[d] = (a.fr.quat_start >= 0) ? fv[d] : a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
-		}
-		const float nr = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
-		const float inv = 1.f / fmaxf(nr, 1e-12f);
-		float g[4], r[4], dot = 0.f;
-#pragma unroll
-		for (int d = 0; d < 4; d++) { g[d] = a.g_rot[4 * (size_t)n + d]; r[d] = u[d] * inv; dot += r[d] * g[d]; }
-		float gu[4];
-#pragma unroll
-		for (int d = 0; d < 4; d++) gu[d] = (nr > 1e-12f) ? (g[d] - r[d] * dot) * inv : g[d] * inv;
-		if (!is_obj) {
-			if (a.g.scene_rotation) *reinterpret_cast<float4*>(a.g.scene_rotation + 4 * (size_t)m) = make_float4(gu[0], gu[1], gu[2], gu[3]);
-		} else {
-			if (a.g.obj_rotation) {
-				const float k = (a.fr.quat_start >= 0) ? 0.f : 1.f;
-				*reinterpret_cast<float4*>(a.g.obj_rotation + 4 * (size_t)m) = make_float4(k * gu[0], k * gu[1], k * gu[2], k * gu[3]);
-			}
-			if (a.g.rotation_deform_param && rp) {
-				float* gp = a.g.rotation_deform_param + (size_t)m * 4 * a.fr.n_params;
-				for (int k = 0; k < 4 * a.fr.n_params; k++) gp[k] = 0.f;
-#pragma unroll
-				for (int d = 0; d < 4; d++) lin_bwd(gp + d * a.fr.n_params, a.fr, gu[d]);
-				if (a.fr.quat_start >= 0) quat_spline_bwd(rp, a.fr, { gu[0], gu[1], gu[2], gu[3] }, gp);
-			}
-		}
-	}
-	// ---- shs
-	if (a.g_shs) {
-		const int M = a.p.sh_coeffs;
-		const float* gs = a.g_shs + (size_t)n * M * 3;
-		float* gdc = is_obj ? (a.g.obj_shs_dc ? a.g.obj_shs_dc + 3 * (size_t)m : nullptr) : (a.g.scene_shs_dc ? a.g.scene_shs_dc + 3 * (size_t)m : nullptr);
-		float* gsp = is_obj ? a.g.shs_deform_param_obj : a.g.shs_deform_param_scene;
-#pragma unroll
-		for (int d = 0; d < 3; d++) {
-			const float v = gs[d];
-			if (gdc) gdc[d] = v;
-			if (gsp) lin_bwd(gsp + ((size_t)m * 3 + d) * a.fs.n_params, a.fs, v);
-		}
-		float* grest = is_obj ? (a.g.obj_shs_rest ? a.g.obj_shs_rest + (size_t)m * (M - 1) * 3 : nullptr)
-		                      : (a.g.scene_shs_rest ? a.g.scene_shs_rest + (size_t)m * (M - 1) * 3 : nullptr);
-		if (grest) for (int k = 0; k < (M - 1) * 3; k++) grest[k] = gs[3 + k];
-	}
 	// ---- opacity
 	if (a.g_op) {
 		const float g = a.g_op[n];
@@ -517,23 +580,37 @@ static int check_func(const adgs_func_eval* f, const char* what) {
 
 namespace adgs {
 namespace {
-// coefficient 0 of the raw-SH path: sh0[n, c] = dc[n, c] + f_shs(t)(shs_deform_param[n, c, :]); one thread per (n, c),
-// consecutive threads read consecutive parameter rows (fully coalesced overall)
+// coefficient 0 of the raw-SH path: sh0[n, c] = dc[n, c] + f_shs(t)(shs_deform_param[n, c, :]).  The block's parameter
+// rows (3 * n_params floats per Gaussian) are staged through LDS with coalesced loads; each thread then evaluates
+// its Gaussian's three channels from its own LDS row.
 __global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out) {
-	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= N * 3) return;
-	const int n = e / 3, c = e - n * 3;
+	extern __shared__ float s_rows[];
+	const int tid = threadIdx.x, base = blockIdx.x * 256, count = min(256, N - base);
+	const int np = s.f.n_params, L = 3 * np, stride = L | 1;
+	const bool lin = (s.scene_sp || s.obj_sp) && has_lin(s.f);
+	if (lin) {
+		stage_rows<true>(s_rows, stride, L, base, count, s.Ns, s.scene_sp, s.obj_sp, tid, 256);
+		__syncthreads();
+	}
+	if (tid >= count) return;
+	const int n = base + tid;
 	const bool ob = n >= s.Ns;
 	const size_t m = ob ? n - s.Ns : n;
-	float v = (ob ? s.obj_dc : s.scene_dc)[3 * m + c];
-	const float* sp = ob ? s.obj_sp : s.scene_sp;
-	if (sp && has_lin(s.f)) v = v + lin_eval(sp + (m * 3 + c) * s.f.n_params, s.f);
-	out[e] = v;
+	const float* dc = (ob ? s.obj_dc : s.scene_dc) + 3 * m;
+	const bool has_row = lin && (ob ? s.obj_sp : s.scene_sp) != nullptr;
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		float v = dc[c];
+		if (has_row) v = v + lin_eval(s_rows + tid * stride + c * np, s.f);
+		out[3 * (size_t)n + c] = v;
+	}
 }
 } // namespace
 int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 	if (N <= 0) return 0;
-	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N * 3 + 255) / 256)), dim3(256), 0, stream, N, s, out);
+	const size_t lds = (size_t)256 * ((3 * s.f.n_params) | 1) * sizeof(float);
+	if (lds > 64 * 1024) { set_error("launch_sh0: more than 5461 SH deformation parameters per channel are not supported"); return -1; }
+	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, stream, N, s, out);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -574,52 +651,102 @@ extern "C" int adgs_func_eval_backward(int N, int D, const float* param, const a
 	return 0;
 }
 
-extern "C" int adgs_deform_forward(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
-	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_deform_outputs* out, void* stream_) {
+// block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB
+static int pick_block(int row_floats, size_t* lds) {
+	for (int B = 256; B >= 64; B >>= 1) {
+		const size_t bytes = (size_t)B * row_floats * sizeof(float);
+		if (bytes <= 48 * 1024 || B == 64) { *lds = bytes; return B; }
+	}
+	return 64;
+}
+
+extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_func_eval* f_xyz_flow, const adgs_func_eval* f_background_flow,
+	const adgs_deform_outputs* out, float* flow_xyz, void* stream_) {
 	if (!p || !out) { set_error("adgs_deform_forward: NULL params/outputs"); return -1; }
 	const int N = p->Ns + p->No;
 	if (N <= 0) return 0;
-	if (check_func(f_xyz, "f_xyz") || check_func(f_rotation, "f_rotation") || check_func(f_shs, "f_shs") || check_func(f_background, "f_background")) return -1;
+	if (check_func(f_xyz, "f_xyz") || check_func(f_rotation, "f_rotation") || check_func(f_shs, "f_shs") || check_func(f_background, "f_background") ||
+	    check_func(f_xyz_flow, "f_xyz_flow") || check_func(f_background_flow, "f_background_flow")) return -1;
 	DeformArgs a;
-	a.p = *p; a.o = *out;
+	a.p = *p; a.o = *out; a.flow_xyz = flow_xyz;
 	a.fx = f_xyz ? *f_xyz : empty_func(); a.fr = f_rotation ? *f_rotation : empty_func();
-	a.fs = f_shs ? *f_shs : empty_func(); a.fb = f_background ? *f_background : empty_func();
+	a.fb = f_background ? *f_background : empty_func();
+	a.fx2 = f_xyz_flow ? *f_xyz_flow : empty_func(); a.fb2 = f_background_flow ? *f_background_flow : empty_func();
+	if (flow_xyz && f_xyz && f_xyz_flow && f_xyz->n_params != f_xyz_flow->n_params) { set_error("f_xyz and f_xyz_flow describe different parameter tensors"); return -1; }
+	if (flow_xyz && !f_xyz_flow) a.fx2.n_params = a.fx.n_params;
+	const adgs_func_eval fs = f_shs ? *f_shs : empty_func();
 	hipStream_t stream = (hipStream_t)stream_;
 	float* shs_out = a.o.shs;
 	a.o.shs = nullptr;                       // SH rows go through the flat coalesced kernel below
-	if (a.o.xyz || a.o.rotation || a.o.opacity || a.o.scales) {
-		hipLaunchKernelGGL(deform_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
-		ADGS_HIP_CHECK(hipGetLastError());
+	if (a.o.xyz || a.flow_xyz || a.o.rotation || a.o.opacity || a.o.scales) {
+		const int np_x = std::max(a.fx.n_params, a.fx2.n_params);
+		a.fx.n_params = a.fx2.n_params = np_x;
+		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
+		if (p->Ns > 0) {                     // scene range: nothing to stage
+			a.n_begin = 0; a.n_end = p->Ns;
+			hipLaunchKernelGGL(deform_fwd_kernel, dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
+		if (p->No > 0) {
+			size_t lds = 0;
+			const int B = pick_block(std::max(a.stride_x, a.stride_r), &lds);
+			if (lds > 64 * 1024) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
+			a.n_begin = p->Ns; a.n_end = N;
+			hipLaunchKernelGGL(deform_fwd_kernel, dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
 	}
 	if (shs_out) {
 		ShsFwdArgs sa;
 		sa.Ns = p->Ns; sa.N = N; sa.M = p->sh_coeffs;
 		sa.scene_dc = p->scene_shs_dc; sa.obj_dc = p->obj_shs_dc; sa.scene_rest = p->scene_shs_rest; sa.obj_rest = p->obj_shs_rest;
-		sa.sp_scene = p->shs_deform_param_scene; sa.sp_obj = p->shs_deform_param_obj; sa.fs = a.fs; sa.out = shs_out;
+		sa.sp_scene = p->shs_deform_param_scene; sa.sp_obj = p->shs_deform_param_obj; sa.fs = fs; sa.out = shs_out;
 		const size_t quads = ((size_t)N * p->sh_coeffs * 3 + 3) / 4;
 		hipLaunchKernelGGL(deform_shs_fwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, sa);
 		ADGS_HIP_CHECK(hipGetLastError());
 	}
 	return 0;
 }
+extern "C" int adgs_deform_forward(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_deform_outputs* out, void* stream_) {
+	return adgs_deform_forward_flow(p, f_xyz, f_rotation, f_shs, f_background, nullptr, nullptr, out, nullptr, stream_);
+}
 
-extern "C" int adgs_deform_backward(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
-	const adgs_func_eval* f_shs, const adgs_func_eval* f_background,
-	const float* dL_dxyz, const float* dL_drotation, const float* dL_dshs, const float* dL_dopacity, const float* dL_dscales,
+extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_func_eval* f_xyz_flow, const adgs_func_eval* f_background_flow,
+	const float* dL_dxyz, const float* dL_drotation, const float* dL_dshs, const float* dL_dopacity, const float* dL_dscales, const float* dL_dflow_xyz,
 	const adgs_deform_grads* grads, void* stream_) {
 	if (!p || !grads) { set_error("adgs_deform_backward: NULL params/grads"); return -1; }
 	const int N = p->Ns + p->No;
 	if (N <= 0) return 0;
-	if (check_func(f_xyz, "f_xyz") || check_func(f_rotation, "f_rotation") || check_func(f_shs, "f_shs") || check_func(f_background, "f_background")) return -1;
+	if (check_func(f_xyz, "f_xyz") || check_func(f_rotation, "f_rotation") || check_func(f_shs, "f_shs") || check_func(f_background, "f_background") ||
+	    check_func(f_xyz_flow, "f_xyz_flow") || check_func(f_background_flow, "f_background_flow")) return -1;
 	DeformBwdArgs a;
 	a.p = *p; a.g = *grads;
 	a.fx = f_xyz ? *f_xyz : empty_func(); a.fr = f_rotation ? *f_rotation : empty_func();
-	a.fs = f_shs ? *f_shs : empty_func(); a.fb = f_background ? *f_background : empty_func();
+	a.fb = f_background ? *f_background : empty_func();
+	a.fx2 = f_xyz_flow ? *f_xyz_flow : empty_func(); a.fb2 = f_background_flow ? *f_background_flow : empty_func();
+	const adgs_func_eval fs = f_shs ? *f_shs : empty_func();
 	hipStream_t stream = (hipStream_t)stream_;
-	a.g_xyz = dL_dxyz; a.g_rot = dL_drotation; a.g_shs = nullptr; a.g_op = dL_dopacity; a.g_sc = dL_dscales;
-	if (dL_dxyz || dL_drotation || dL_dopacity || dL_dscales) {
-		hipLaunchKernelGGL(deform_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, a);
-		ADGS_HIP_CHECK(hipGetLastError());
+	a.g_xyz = dL_dxyz; a.g_flow = dL_dflow_xyz; a.g_rot = dL_drotation; a.g_op = dL_dopacity; a.g_sc = dL_dscales;
+	if (dL_dxyz || dL_dflow_xyz || dL_drotation || dL_dopacity || dL_dscales) {
+		const int np_x = std::max(a.fx.n_params, a.fx2.n_params);
+		a.fx.n_params = a.fx2.n_params = np_x;
+		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
+		if (p->Ns > 0) {
+			a.n_begin = 0; a.n_end = p->Ns;
+			hipLaunchKernelGGL(deform_bwd_kernel, dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
+		if (p->No > 0) {
+			size_t lds = 0;
+			const int B = pick_block(std::max(a.stride_x, 2 * a.stride_r), &lds);
+			if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
+			a.n_begin = p->Ns; a.n_end = N;
+			hipLaunchKernelGGL(deform_bwd_kernel, dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
 	}
 	if (dL_dshs) {
 		const int M = p->sh_coeffs;
@@ -632,13 +759,20 @@ extern "C" int adgs_deform_backward(const adgs_deform_params* p, const adgs_func
 		for (int part = 0; part < 2; part++) {
 			float* out = part == 0 ? grads->shs_deform_param_scene : grads->shs_deform_param_obj;
 			const int count = part == 0 ? p->Ns : p->No;
-			if (!out || count == 0 || a.fs.n_params == 0) continue;
+			if (!out || count == 0 || fs.n_params == 0) continue;
 			ParamGradArgs pg;
-			pg.n0 = part == 0 ? 0 : p->Ns; pg.count = count; pg.D = 3; pg.gstride = M * 3; pg.g = dL_dshs; pg.out = out; pg.f = a.fs;
-			const size_t t2 = (size_t)count * 3 * a.fs.n_params;
-			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), a.fs.n_params * sizeof(float), stream, pg);
+			pg.n0 = part == 0 ? 0 : p->Ns; pg.count = count; pg.D = 3; pg.gstride = M * 3; pg.g = dL_dshs; pg.out = out; pg.f = fs;
+			const size_t t2 = (size_t)count * 3 * fs.n_params;
+			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), fs.n_params * sizeof(float), stream, pg);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}
 	return 0;
+}
+extern "C" int adgs_deform_backward(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background,
+	const float* dL_dxyz, const float* dL_drotation, const float* dL_dshs, const float* dL_dopacity, const float* dL_dscales,
+	const adgs_deform_grads* grads, void* stream_) {
+	return adgs_deform_backward_flow(p, f_xyz, f_rotation, f_shs, f_background, nullptr, nullptr,
+		dL_dxyz, dL_drotation, dL_dshs, dL_dopacity, dL_dscales, nullptr, grads, stream_);
 }

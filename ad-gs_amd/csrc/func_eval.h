@@ -24,7 +24,31 @@ __device__ __forceinline__ void lin_bwd(float* __restrict__ grow, const adgs_fun
 	const int total = f.n_terms[0] + f.n_terms[1] + f.n_terms[2];
 	for (int i = 0; i < total; i++) grow[f.index[i]] = f.weight[i] * g;
 }
+__device__ __forceinline__ void lin_bwd_add(float* __restrict__ grow, const adgs_func_eval& f, float g) {
+	const int total = f.n_terms[0] + f.n_terms[1] + f.n_terms[2];
+	for (int i = 0; i < total; i++) grow[f.index[i]] += f.weight[i] * g;
+}
 __device__ __forceinline__ bool has_lin(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0; }
+
+// Cooperative, fully coalesced transfer of the per-Gaussian parameter rows (L floats each) of the
+// `count` consecutive Gaussians gi0.. between global memory and LDS rows of `stride` floats (odd
+// stride: the later one-row-per-thread accesses are bank-conflict free).  Scene members (gi < Ns)
+// live in `scene`, object members in `obj`; a nullptr side is skipped.  One thread per float,
+// consecutive threads on consecutive addresses; the (row, column) pair advances without divisions.
+template <bool TO_LDS, typename PtrT>
+__device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, int L, int gi0, int count, int Ns, PtrT scene, PtrT obj,
+	int tid, int nthreads) {
+	int g = tid / L, c = tid - g * L;
+	const int dq = nthreads / L, dr = nthreads - dq * L;
+	const int total = count * L;
+	for (int e = tid; e < total; e += nthreads) {
+		const int gi = gi0 + g;
+		PtrT p = (gi >= Ns) ? (obj ? obj + (size_t)(gi - Ns) * L : nullptr) : (scene ? scene + (size_t)gi * L : nullptr);
+		if (p) { if (TO_LDS) s[g * stride + c] = p[c]; else const_cast<float*>(p)[c] = s[g * stride + c]; }
+		c += dr; g += dq;
+		if (c >= L) { c -= L; g++; }
+	}
+}
 
 // SH coefficients assembled on the fly from the reference GaussianModel's raw tensors
 // (scene || object, dc + f_shs(t) || rest; scene/gaussian_model.py:198-205) instead of a

@@ -40,10 +40,14 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
     rasterizer = GaussianRasterizer(raster_settings=settings)
 
     flow_points = None
-    if flow_pkg is not None:
-        flow_points = pc.get_deformed_xyz(flow_pkg[0])          # world positions at the other time stamp
-
-    deform_pkg = pc.get_deformed_pkg(viewpoint_camera.time)
+    if flow_pkg is not None and getattr(pc, "supports_fused_flow", False):
+        # one pass over the deformation rows for both time stamps
+        deform_pkg = pc.get_deformed_pkg(viewpoint_camera.time, flow_time=flow_pkg[0])
+        flow_points = deform_pkg['flow_xyz']
+    else:
+        if flow_pkg is not None:
+            flow_points = pc.get_deformed_xyz(flow_pkg[0])      # world positions at the other time stamp
+        deform_pkg = pc.get_deformed_pkg(viewpoint_camera.time)
     semantic = pc.get_obj_mask.float()[..., None] if render_objmask else None
 
     shs_in = deform_pkg['shs'] if override_color is None else None

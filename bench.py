@@ -86,6 +86,7 @@ class DeformFrame:
         self.rast, self.t, self.use_fs = rasterizer, t, use_flow_sem
         self.model = SyntheticGaussianModel.from_scene(sc, device, seed=0)
         self.model.raw_sh = os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0"     # SH read straight from the raw parameters
+        self.fused_flow = os.environ.get("ADGS_BENCH_FUSED_FLOW", "1") != "0"      # flow-time xyz in the same deformation pass
         self.means2D = None
         self.sem = self.model.get_obj_mask.float()[:, None].contiguous() if use_flow_sem else None
         self.last_radii = None
@@ -104,8 +105,12 @@ class DeformFrame:
     def forward(self):
         import torch
         m = self.model
-        pkg = m.get_deformed_pkg(self.t)
-        flow = m.get_deformed_xyz(self.t + 0.05) if self.use_fs else None
+        if self.use_fs and self.fused_flow:
+            pkg = m.get_deformed_pkg(self.t, flow_time=self.t + 0.05)
+            flow = pkg["flow_xyz"]
+        else:
+            pkg = m.get_deformed_pkg(self.t)
+            flow = m.get_deformed_xyz(self.t + 0.05) if self.use_fs else None
         means2D = torch.zeros_like(pkg["xyz"], requires_grad=True)
         if torch.is_tensor(pkg["shs"]):
             color, radii, depth, op, fl, sem = self.rast(

@@ -86,6 +86,18 @@ int adgs_deform_backward(const adgs_deform_params* p, const adgs_func_eval* f_xy
 	const float* dL_dxyz, const float* dL_drotation, const float* dL_dshs, const float* dL_dopacity, const float* dL_dscales,
 	const adgs_deform_grads* grads, void* stream);
 
+/* The same with the flow points fused in: gaussian_renderer/__init__.py:57 evaluates get_deformed_xyz a second
+ * time at flow_time; here both evaluations share one pass over the xyz deformation rows.  f_xyz_flow /
+ * f_background_flow are the basis values at the flow time, flow_xyz [N,3] the second output (NULL: absent),
+ * dL_dflow_xyz its upstream gradient; the xyz / xyz_deform_param / background gradients are the sums over both. */
+int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_func_eval* f_xyz_flow, const adgs_func_eval* f_background_flow,
+	const adgs_deform_outputs* out, float* flow_xyz, void* stream);
+int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,
+	const adgs_func_eval* f_shs, const adgs_func_eval* f_background, const adgs_func_eval* f_xyz_flow, const adgs_func_eval* f_background_flow,
+	const float* dL_dxyz, const float* dL_drotation, const float* dL_dshs, const float* dL_dopacity, const float* dL_dscales, const float* dL_dflow_xyz,
+	const adgs_deform_grads* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

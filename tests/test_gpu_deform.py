@@ -183,3 +183,58 @@ def test_raw_sh_path_matches_materialised_sh_path(seed):
         assert (p0.grad is None) == (p1.grad is None), name
         if p0.grad is not None:
             close(name, p1.grad.cpu().numpy(), p0.grad.cpu().numpy(), tol=1e-4)
+
+
+@pytest.mark.parametrize("background", [False, True])
+def test_fused_flow_xyz_matches_separate_evaluations(background):
+    """get_deformed_pkg(t, flow_time=t2)['flow_xyz'] == get_deformed_xyz(t2) (reference gaussian_renderer/__init__.py:57),
+    and the parameter gradients of the fused pass equal the sum autograd forms from the two separate passes."""
+    from adgs import synthetic, deform
+    from adgs.model import SyntheticGaussianModel, DEFAULT_ORDER_ARGS
+    sc = synthetic.make_scene(5003, 208, 130, 150.0, sh_degree=3, seed=5, n_objects=3)
+    oa = dict(DEFAULT_ORDER_ARGS)
+    if background:
+        oa["background"] = [5, 3, 2, 0, 0, 0]
+    gen = torch.Generator().manual_seed(11)
+    w = {k: torch.randn(sc["P"], c, generator=gen).cuda() for k, c in (("xyz", 3), ("flow", 3), ("rot", 4), ("op", 1), ("sc", 3))}
+    res = []
+    for fused in (False, True):
+        model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3, order_args=oa)
+        if background:
+            with torch.no_grad():
+                model.background_deform_param.copy_(torch.randn(model.background_deform_param.shape, generator=torch.Generator().manual_seed(2)) * 0.1)
+        if fused:
+            pkg = deform.get_deformed_pkg(model, 0.37, want=("xyz", "rotation", "opacity", "scales"), flow_time=0.42)
+            flow = pkg["flow_xyz"]
+        else:
+            pkg = deform.get_deformed_pkg(model, 0.37, want=("xyz", "rotation", "opacity", "scales"))
+            flow = deform.get_deformed_xyz(model, 0.42)
+        loss = (pkg["xyz"] * w["xyz"]).sum() + (flow * w["flow"]).sum() + (pkg["rotation"] * w["rot"]).sum() + \
+               (pkg["opacity"] * w["op"]).sum() + (pkg["scales"] * w["sc"]).sum()
+        loss.backward()
+        res.append((pkg, flow, model))
+    (p0, f0, m0), (p1, f1, m1) = res
+    assert torch.equal(f0, f1)
+    for k in ("xyz", "rotation", "opacity", "scales"):
+        assert torch.equal(p0[k], p1[k]), k
+    names = __import__("adgs.model", fromlist=["_RAW"])._RAW
+    for a, b, name in zip(m0.parameters(), m1.parameters(), names):
+        assert (a.grad is None) == (b.grad is None), name
+        if a.grad is not None:
+            close(name, b.grad.cpu().numpy(), a.grad.cpu().numpy(), tol=1e-5)
+    assert float(m1.xyz_deform_param.grad.abs().max()) > 0
+
+
+def test_flow_only_gradient_reaches_xyz_parameters():
+    """Only the flow points carry an upstream gradient: xyz / xyz_deform_param still get theirs."""
+    from adgs import synthetic, deform
+    from adgs.model import SyntheticGaussianModel
+    sc = synthetic.make_scene(3001, 208, 130, 150.0, sh_degree=3, seed=6, n_objects=2)
+    model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3)
+    ref = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3)
+    w = torch.randn(sc["P"], 3, generator=torch.Generator().manual_seed(1)).cuda()
+    pkg = deform.get_deformed_pkg(model, 0.2, want=("xyz",), flow_time=0.7)
+    (pkg["flow_xyz"] * w).sum().backward()
+    (deform.get_deformed_xyz(ref, 0.7) * w).sum().backward()
+    for n in ("_scene_xyz", "_obj_xyz", "xyz_deform_param"):
+        close(n, getattr(model, n).grad.cpu().numpy(), getattr(ref, n).grad.cpu().numpy(), tol=1e-6)
