@@ -38,15 +38,33 @@ __device__ __forceinline__ bool has_lin(const adgs_func_eval& f) { return (f.n_t
 template <bool TO_LDS, typename PtrT>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, int L, int gi0, int count, int Ns, PtrT scene, PtrT obj,
 	int tid, int nthreads) {
+	constexpr int U = 8;                      // transfers in flight per thread: all loads of a batch are issued before the first store
 	int g = tid / L, c = tid - g * L;
 	const int dq = nthreads / L, dr = nthreads - dq * L;
 	const int total = count * L;
-	for (int e = tid; e < total; e += nthreads) {
-		const int gi = gi0 + g;
-		PtrT p = (gi >= Ns) ? (obj ? obj + (size_t)(gi - Ns) * L : nullptr) : (scene ? scene + (size_t)gi * L : nullptr);
-		if (p) { if (TO_LDS) s[g * stride + c] = p[c]; else const_cast<float*>(p)[c] = s[g * stride + c]; }
-		c += dr; g += dq;
-		if (c >= L) { c -= L; g++; }
+	for (int e = tid; e < total; e += nthreads * U) {
+		PtrT p[U]; int so[U]; float v[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int gi = gi0 + g;
+			const bool in = e + u * nthreads < total;
+			PtrT q = (gi >= Ns) ? (obj ? obj + (size_t)(gi - Ns) * L : nullptr) : (scene ? scene + (size_t)gi * L : nullptr);
+			p[u] = (in && q) ? q + c : nullptr;
+			so[u] = g * stride + c;
+			c += dr; g += dq;
+			if (c >= L) { c -= L; g++; }
+		}
+		if (TO_LDS) {
+#pragma unroll
+			for (int u = 0; u < U; u++) v[u] = p[u] ? *p[u] : 0.f;
+#pragma unroll
+			for (int u = 0; u < U; u++) if (p[u]) s[so[u]] = v[u];
+		} else {
+#pragma unroll
+			for (int u = 0; u < U; u++) v[u] = p[u] ? s[so[u]] : 0.f;
+#pragma unroll
+			for (int u = 0; u < U; u++) if (p[u]) *const_cast<float*>(p[u]) = v[u];
+		}
 	}
 }
 

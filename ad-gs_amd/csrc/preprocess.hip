@@ -106,12 +106,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	if (STAGED) {
 		const int tid = threadIdx.x, base = blockIdx.x * 256, nvalid = min(256, a.P - base);
 		if (a.sh_src.scene_dc) {
-			for (int e = tid; e < nvalid * SH_ROW_REST; e += 256) {
-				const int g = e / SH_ROW_REST, c = e - g * SH_ROW_REST, gi = base + g;
-				const bool ob = gi >= a.sh_src.Ns;
-				const float* src = ob ? a.sh_src.obj_rest + (size_t)(gi - a.sh_src.Ns) * SH_ROW_REST : a.sh_src.scene_rest + (size_t)gi * SH_ROW_REST;
-				s_sh[e] = src[c];
-			}
+			stage_rows<true>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, 256);
 		} else {
 			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
 			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += 256) {

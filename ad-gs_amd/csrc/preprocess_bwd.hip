@@ -53,12 +53,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	const int nvalid = min(BW_THREADS, a.P - base);
 	if (STAGED) {
 		if (raw) {
-			for (int e = tid; e < nvalid * SH_ROW_REST; e += BW_THREADS) {
-				const int g = e / SH_ROW_REST, c = e - g * SH_ROW_REST, gi = base + g;
-				const bool ob = gi >= a.sh_src.Ns;
-				const float* src = ob ? a.sh_src.obj_rest + (size_t)(gi - a.sh_src.Ns) * SH_ROW_REST : a.sh_src.scene_rest + (size_t)gi * SH_ROW_REST;
-				s_sh[e] = src[c];
-			}
+			stage_rows<true>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, BW_THREADS);
 		} else {
 			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
 			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
@@ -355,12 +350,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		// the LDS rows now hold the SH gradients: stream them out fully coalesced
 		__syncthreads();
 		if (raw) {
-			for (int e = tid; e < nvalid * SH_ROW_REST; e += BW_THREADS) {
-				const int g = e / SH_ROW_REST, c = e - g * SH_ROW_REST, gi = base + g;
-				const bool ob = gi >= a.sh_src.Ns;
-				float* dst = ob ? a.sh_dst.obj_rest : a.sh_dst.scene_rest;
-				if (dst) dst[(size_t)(ob ? gi - a.sh_src.Ns : gi) * SH_ROW_REST + c] = s_sh[e];
-			}
+			stage_rows<false>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_dst.scene_rest, a.sh_dst.obj_rest, tid, BW_THREADS);
 		} else {
 			float4* dst = reinterpret_cast<float4*>(a.dL_dsh + (size_t)base * SH_ROW_FULL);
 			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
