@@ -204,6 +204,7 @@ struct DeformArgs {
 	int n_begin, n_end, stride_x, stride_r;
 };
 
+template <bool OBJ>
 __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
 	extern __shared__ float s_rows[];
 	const int tid = threadIdx.x, B = blockDim.x, base = a.n_begin + blockIdx.x * B;
@@ -211,9 +212,9 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
 	const int count = min(B, a.n_end - base);
 	const int n = base + tid;
 	const bool valid = tid < count;
-	const bool is_obj = valid && n >= Ns;
+	const bool is_obj = OBJ && valid && n >= Ns;
 	const int m = is_obj ? n - Ns : n;
-	const bool blk_obj = base + count > Ns;          // block-uniform: some member is an object Gaussian
+	const bool blk_obj = OBJ && base + count > Ns;   // block-uniform: some member is an object Gaussian
 	// ---- xyz (gaussian_model.py:173-185), at t and at the flow time
 	if (a.o.xyz || a.flow_xyz) {
 		const int np = a.fx.n_params;
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
 		}
 		if (valid) {
 			float u[4];
-			if (!is_obj) {
+			if (!OBJ || !is_obj) {
 				const float4 q = *reinterpret_cast<const float4*>(a.p.scene_rotation + 4 * (size_t)m);
 				u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
 			} else {
@@ -411,6 +412,10 @@ struct DeformBwdArgs {
 // Backward of deform_fwd_kernel.  The object Gaussians' parameter-gradient rows are assembled in LDS (every
 // column written: zeros outside the active terms, so no caller zero-fill) and stored coalesced; the rotation
 // rows need the parameters (staged in) and a second LDS region for the gradients.
+// PARTS: bit 0 = xyz / background, bit 1 = rotation, bit 2 = opacity + scales.  OBJ = false is the scene
+// range (no object member: none of the staging / spline code is instantiated, so the kernel stays light).
+constexpr int DP_XYZ = 1, DP_ROT = 2, DP_REST = 4;
+template <int PARTS, bool OBJ>
 __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 	extern __shared__ float s_rows[];
 	__shared__ float s_bg[6][256 / WAVE];
@@ -419,11 +424,11 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 	const int count = min(B, a.n_end - base);
 	const int n = base + tid;
 	const bool valid = tid < count;
-	const bool is_obj = valid && n >= Ns;
+	const bool is_obj = OBJ && valid && n >= Ns;
 	const int m = is_obj ? n - Ns : n;
-	const bool blk_obj = base + count > Ns;
+	const bool blk_obj = OBJ && base + count > Ns;
 	// ---- xyz: upstream of the camera-time points and of the flow-time points
-	if (a.g_xyz || a.g_flow) {
+	if ((PARTS & DP_XYZ) && (a.g_xyz || a.g_flow)) {
 		float gx[3] = { 0.f, 0.f, 0.f }, gf[3] = { 0.f, 0.f, 0.f };
 		if (valid) {
 #pragma unroll
@@ -436,13 +441,23 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 		}
 		const int np = a.fx.n_params;
 		if (blk_obj && a.g.xyz_deform_param) {
+			// dense basis rows of the two time stamps behind the staging rows: d/dparam[n,d,k] = w1[k] g1[d] + w2[k] g2[d]
+			float* s_w = s_rows + B * a.stride_x;
+			for (int k = tid; k < 2 * np; k += B) s_w[k] = 0.f;
+			__syncthreads();
+			{
+				const int t1 = a.g_xyz ? a.fx.n_terms[0] + a.fx.n_terms[1] + a.fx.n_terms[2] : 0;
+				const int t2 = a.g_flow ? a.fx2.n_terms[0] + a.fx2.n_terms[1] + a.fx2.n_terms[2] : 0;
+				for (int i = tid; i < t1; i += B) s_w[a.fx.index[i]] = a.fx.weight[i];
+				for (int i = tid; i < t2; i += B) s_w[np + a.fx2.index[i]] = a.fx2.weight[i];
+			}
+			__syncthreads();
 			if (is_obj) {
 				float* row = s_rows + tid * a.stride_x;
-				for (int k = 0; k < 3 * np; k++) row[k] = 0.f;
+				for (int k = 0; k < np; k++) {
+					const float w1 = s_w[k], w2 = s_w[np + k];
 #pragma unroll
-				for (int d = 0; d < 3; d++) {
-					if (a.g_xyz) lin_bwd_add(row + d * np, a.fx, gx[d]);
-					if (a.g_flow) lin_bwd_add(row + d * np, a.fx2, gf[d]);
+					for (int d = 0; d < 3; d++) row[d * np + k] = w1 * gx[d] + w2 * gf[d];
 				}
 			}
 			__syncthreads();
@@ -472,7 +487,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 		}
 	}
 	// ---- rotation: r = u / |u|
-	if (a.g_rot) {
+	if ((PARTS & DP_ROT) && a.g_rot) {
 		const int np = a.fr.n_params;
 		const bool haver = a.p.rotation_deform_param != nullptr;
 		const bool staged = blk_obj && haver;
@@ -484,7 +499,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 		if (valid) {
 			float u[4];
 			const float* rp = (is_obj && haver) ? s_rows + tid * a.stride_r : nullptr;
-			if (!is_obj) {
+			if (!OBJ || !is_obj) {
 				const float4 q = *reinterpret_cast<const float4*>(a.p.scene_rotation + 4 * (size_t)m);
 				u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
 			} else {
@@ -507,7 +522,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 			float gu[4];
 #pragma unroll
 			for (int d = 0; d < 4; d++) gu[d] = (nr > 1e-12f) ? (g[d] - r[d] * dot) * inv : g[d] * inv;
-			if (!is_obj) {
+			if (!OBJ || !is_obj) {
 				if (a.g.scene_rotation) *reinterpret_cast<float4*>(a.g.scene_rotation + 4 * (size_t)m) = make_float4(gu[0], gu[1], gu[2], gu[3]);
 			} else {
 				if (a.g.obj_rotation) {
@@ -528,7 +543,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 			stage_rows<false>(s_out, a.stride_r, 4 * np, base, count, Ns, (float*)nullptr, a.g.rotation_deform_param, tid, B);
 		}
 	}
-	if (!valid) return;
+	if (!valid || !(PARTS & DP_REST)) return;
 	// ---- opacity
 	if (a.g_op) {
 		const float g = a.g_op[n];
@@ -685,7 +700,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
 		if (p->Ns > 0) {                     // scene range: nothing to stage
 			a.n_begin = 0; a.n_end = p->Ns;
-			hipLaunchKernelGGL(deform_fwd_kernel, dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
+			hipLaunchKernelGGL(deform_fwd_kernel<false>, dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 		if (p->No > 0) {
@@ -693,7 +708,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 			const int B = pick_block(std::max(a.stride_x, a.stride_r), &lds);
 			if (lds > 64 * 1024) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
 			a.n_begin = p->Ns; a.n_end = N;
-			hipLaunchKernelGGL(deform_fwd_kernel, dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+			hipLaunchKernelGGL(deform_fwd_kernel<true>, dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}
@@ -736,16 +751,27 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
 		if (p->Ns > 0) {
 			a.n_begin = 0; a.n_end = p->Ns;
-			hipLaunchKernelGGL(deform_bwd_kernel, dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
+			hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_ROT | DP_REST, false>), dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 		if (p->No > 0) {
-			size_t lds = 0;
-			const int B = pick_block(std::max(a.stride_x, 2 * a.stride_r), &lds);
-			if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
+			// two launches: the spline backward needs a whole SIMD's registers per wave, the rest does not
 			a.n_begin = p->Ns; a.n_end = N;
-			hipLaunchKernelGGL(deform_bwd_kernel, dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
-			ADGS_HIP_CHECK(hipGetLastError());
+			if (dL_dxyz || dL_dflow_xyz || dL_dopacity || dL_dscales) {
+				size_t lds = 0;
+				const int B = pick_block(a.stride_x, &lds);
+				lds += 2 * (size_t)np_x * sizeof(float);            // dense basis rows of the two time stamps
+				if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
+				hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_REST, true>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+				ADGS_HIP_CHECK(hipGetLastError());
+			}
+			if (dL_drotation) {
+				size_t lds = 0;
+				const int B = pick_block(2 * a.stride_r, &lds);
+				if (lds > 64 * 1024) { set_error("adgs_deform_backward: rotation rows too large for the LDS staging buffer"); return -1; }
+				hipLaunchKernelGGL((deform_bwd_kernel<DP_ROT, true>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+				ADGS_HIP_CHECK(hipGetLastError());
+			}
 		}
 	}
 	if (dL_dshs) {

@@ -55,17 +55,57 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 	const float y0 = (float)(ty * TILE_Y) - f0.y, y1 = y0 + (float)(TILE_Y - 1);
 	if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;      // mean inside the tile
 	// minimum over the four edges: fix one coordinate, clamp the unconstrained minimiser of the other
+	// (any point of an edge bounds its minimum from above and the form is flat at the minimiser, so the
+	// 1-ulp reciprocals only perturb `best` in second order -- far inside the slack carried by tau)
 	float best = 3.0e38f;
+	const float nBrC = -B * __builtin_amdgcn_rcpf(C), nBrA = -B * __builtin_amdgcn_rcpf(A);
 #pragma unroll
 	for (int e = 0; e < 2; e++) {
 		const float dx = e ? x1 : x0;
-		const float dy = fminf(fmaxf(-B * dx / C, y0), y1);
+		const float dy = fminf(fmaxf(nBrC * dx, y0), y1);
 		best = fminf(best, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
 		const float ey = e ? y1 : y0;
-		const float ex = fminf(fmaxf(-B * ey / A, x0), x1);
+		const float ex = fminf(fmaxf(nBrA * ey, x0), x1);
 		best = fminf(best, A * ex * ex + 2.f * B * ex * ey + C * ey * ey);
 	}
 	return best <= tau * 1.0005f + 1e-3f;
+}
+
+// Pixel pairs.  Measured on gfx950: v_pk_fma_f32 / v_pk_mul_f32 issue at half the rate of their scalar
+// counterparts (a SIMD already retires a wave64 v_fma_f32 in 2 cycles), so packed fp32 buys nothing here
+// and costs operand shuffles -- v2f is therefore a plain pair of floats and every op stays scalar
+// (this file is also built with -fno-slp-vectorize so the compiler does not re-pack them).
+struct v2f {
+	float x, y;
+	__device__ __forceinline__ v2f() {}
+	__device__ __forceinline__ explicit v2f(float s) : x(s), y(s) {}
+	__device__ __forceinline__ v2f(float a, float b) : x(a), y(b) {}
+};
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f(a.x * b.x, a.y * b.y); }
+__device__ __forceinline__ v2f& operator+=(v2f& a, v2f b) { a.x += b.x; a.y += b.y; return a; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return v2f(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
+
+// Per-entry, per-lane part of the Gaussian evaluation (the lane's 4 pixels share the column x):
+//   power = -0.5 (A dx^2 + C dy^2) - B dx dy = a0 + dy (b0 + c0 dy)
+// Forward and backward evaluate alpha through this one function, so both take identical
+// per-pixel decisions (power > 0, alpha < 1/255) on identical bits.
+struct EntryGeom { float y, a0, b0, c0, op; };
+__device__ __forceinline__ EntryGeom entry_geom(const float4 q0, const float4 q1, float dx) {
+	EntryGeom g;
+	g.y = q0.y; g.a0 = (-0.5f * q0.z * dx) * dx; g.b0 = -q0.w * dx; g.c0 = -0.5f * q1.x; g.op = q1.y;
+	return g;
+}
+__device__ __forceinline__ void eval_pixel(const EntryGeom& g, float py, float& dy, float& pw, float& G, float& al) {
+	dy = g.y - py;
+	pw = fmaf(dy, fmaf(g.c0, dy, g.b0), g.a0);
+	G = ADGS_EXP(pw);
+	al = fminf(ALPHA_MAX, g.op * G);
+}
+__device__ __forceinline__ void eval_pair(const EntryGeom& g, v2f pyv, v2f& dy, v2f& pw, v2f& G, v2f& al) {
+	eval_pixel(g, pyv.x, dy.x, pw.x, G.x, al.x);
+	eval_pixel(g, pyv.y, dy.y, pw.y, G.y, al.y);
 }
 
 __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
@@ -79,17 +119,22 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	const uint32_t px = tx * TILE_X + (lane & 15);
 	const uint32_t py0 = ty * TILE_Y + (lane >> 4);
 	const float pxf = (float)px;
-	float pyf[PPL]; bool inside[PPL], done[PPL];
-	float T[PPL], C0[PPL], C1[PPL], C2[PPL], Dp[PPL], F0[PPL], F1[PPL], F2[PPL], S0[PPL];
+	bool inside[PPL], done[PPL];
+	constexpr int PAIRS = PPL / 2;            // pixel pair h = rows (lane>>4) + 8h, + 8h + 4
+	v2f pyv[PAIRS], T[PAIRS], C0[PAIRS], C1[PAIRS], C2[PAIRS], Dp[PAIRS], F0[PAIRS], F1[PAIRS], F2[PAIRS], S0[PAIRS];
 	uint32_t last_contrib[PPL];
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		const uint32_t py = py0 + 4 * k;
-		pyf[k] = (float)py;
 		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
 		done[k] = !inside[k];
-		T[k] = 1.f; C0[k] = C1[k] = C2[k] = Dp[k] = F0[k] = F1[k] = F2[k] = S0[k] = 0.f;
 		last_contrib[k] = 0;
+	}
+#pragma unroll
+	for (int h = 0; h < PAIRS; h++) {
+		pyv[h].x = (float)(py0 + 8 * h); pyv[h].y = (float)(py0 + 8 * h + 4);
+		T[h] = v2f(1.f);
+		C0[h] = C1[h] = C2[h] = Dp[h] = F0[h] = F1[h] = F2[h] = S0[h] = v2f(0.f);
 	}
 	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
@@ -104,7 +149,11 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			if (e < range.y) {
 				id = a.cell_list[e];
 				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
-				pass = tile_may_contribute(fr[0], fr[1], tx, ty);
+				float4 f0 = fr[0], f1 = fr[1];
+				// both halves of the record are requested together (otherwise the compiler sinks the first
+				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
+				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
+				pass = tile_may_contribute(f0, f1, tx, ty);
 			}
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
@@ -142,33 +191,33 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			const float4 q1 = nq1;      // cc op r g
 			// prefetch the next entry's geometry while this one is evaluated (row n is padding, never used)
 			nq0 = s_splat[(j + 1) * 4 + 0]; nq1 = s_splat[(j + 1) * 4 + 1];
-			const float dx = q0.x - pxf;
-			float alpha[PPL]; bool act[PPL]; bool any_act = false;
+			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
+			v2f alpha[PAIRS]; bool act[PPL]; bool any_act = false;
 #pragma unroll
-			for (int k = 0; k < PPL; k++) {
-				const float dy = q0.y - pyf[k];
-				const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-				alpha[k] = fminf(ALPHA_MAX, q1.y * ADGS_EXP(power));
-				act[k] = !done[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
-				any_act = any_act || act[k];
+			for (int h = 0; h < PAIRS; h++) {
+				v2f dy, pw, G;
+				eval_pair(eg, pyv[h], dy, pw, G, alpha[h]);
+				act[2 * h] = !done[2 * h] && !(pw.x > 0.0f) && !(alpha[h].x < ALPHA_MIN);
+				act[2 * h + 1] = !done[2 * h + 1] && !(pw.y > 0.0f) && !(alpha[h].y < ALPHA_MIN);
+				any_act = any_act || act[2 * h] || act[2 * h + 1];
 			}
 			if (!__any(any_act)) continue;
 			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
 			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview pad
 #pragma unroll
-			for (int k = 0; k < PPL; k++) {
-				if (act[k]) {
-					const float test_T = T[k] * (1 - alpha[k]);
-					if (test_T < T_STOP) { done[k] = true; }
-					else {
-						const float w = alpha[k] * T[k];
-						C0[k] += q1.z * w; C1[k] += q1.w * w; C2[k] += q2.x * w;
-						F0[k] += q2.z * w; F1[k] += q2.w * w; F2[k] += q3.x * w;
-						Dp[k] += q2.y * w; S0[k] += q3.y * w;
-						T[k] = test_T;
-						last_contrib[k] = consumed + j + 1;
-					}
-				}
+			for (int h = 0; h < PAIRS; h++) {
+				const v2f test_T = T[h] * (v2f(1.f) - alpha[h]);
+				const bool stop_x = act[2 * h] && test_T.x < T_STOP, stop_y = act[2 * h + 1] && test_T.y < T_STOP;
+				const bool up_x = act[2 * h] && !stop_x, up_y = act[2 * h + 1] && !stop_y;
+				done[2 * h] = done[2 * h] || stop_x; done[2 * h + 1] = done[2 * h + 1] || stop_y;
+				v2f w = alpha[h] * T[h];
+				w.x = up_x ? w.x : 0.f; w.y = up_y ? w.y : 0.f;       // pixels that do not blend this entry add exactly 0
+				C0[h] = fma2(v2f(q1.z), w, C0[h]); C1[h] = fma2(v2f(q1.w), w, C1[h]); C2[h] = fma2(v2f(q2.x), w, C2[h]);
+				F0[h] = fma2(v2f(q2.z), w, F0[h]); F1[h] = fma2(v2f(q2.w), w, F1[h]); F2[h] = fma2(v2f(q3.x), w, F2[h]);
+				Dp[h] = fma2(v2f(q2.y), w, Dp[h]); S0[h] = fma2(v2f(q3.y), w, S0[h]);
+				T[h].x = up_x ? test_T.x : T[h].x; T[h].y = up_y ? test_T.y : T[h].y;
+				last_contrib[2 * h] = up_x ? consumed + j + 1 : last_contrib[2 * h];
+				last_contrib[2 * h + 1] = up_y ? consumed + j + 1 : last_contrib[2 * h + 1];
 			}
 		}
 		consumed += n;
@@ -178,17 +227,23 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		if (inside[k]) {
+			const int h = k >> 1;
+			const bool hi = k & 1;
 			const size_t pix_id = (size_t)a.W * (py0 + 4 * k) + px;
-			a.final_T[pix_id] = (float)(1.0 - (double)T[k]);
+			const float Tk = hi ? T[h].y : T[h].x;
+			a.final_T[pix_id] = (float)(1.0 - (double)Tk);
 			a.n_contrib[pix_id] = last_contrib[k];
 			if (a.has_color) {
-				a.out_color[0 * HW + pix_id] = C0[k] + T[k] * a.bg[0];
-				a.out_color[1 * HW + pix_id] = C1[k] + T[k] * a.bg[1];
-				a.out_color[2 * HW + pix_id] = C2[k] + T[k] * a.bg[2];
+				a.out_color[0 * HW + pix_id] = (hi ? C0[h].y : C0[h].x) + Tk * a.bg[0];
+				a.out_color[1 * HW + pix_id] = (hi ? C1[h].y : C1[h].x) + Tk * a.bg[1];
+				a.out_color[2 * HW + pix_id] = (hi ? C2[h].y : C2[h].x) + Tk * a.bg[2];
 			}
-			if (a.has_flow) { a.out_flow[0 * HW + pix_id] = F0[k]; a.out_flow[1 * HW + pix_id] = F1[k]; a.out_flow[2 * HW + pix_id] = F2[k]; }
-			if (a.has_sem) a.out_semantic[pix_id] = S0[k];
-			a.out_depth[pix_id] = Dp[k];
+			if (a.has_flow) {
+				a.out_flow[0 * HW + pix_id] = hi ? F0[h].y : F0[h].x; a.out_flow[1 * HW + pix_id] = hi ? F1[h].y : F1[h].x;
+				a.out_flow[2 * HW + pix_id] = hi ? F2[h].y : F2[h].x;
+			}
+			if (a.has_sem) a.out_semantic[pix_id] = hi ? S0[h].y : S0[h].x;
+			a.out_depth[pix_id] = hi ? Dp[h].y : Dp[h].x;
 		}
 	}
 }
@@ -354,13 +409,12 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 				nq0 = s_splat[j * 4 + 0]; nq1 = s_splat[j * 4 + 1];
 				if (contributor >= max_contrib) continue;
 				const float dx = q0.x - pxf;
+				const EntryGeom eg = entry_geom(q0, q1, dx);
 				float alpha[PPL], G[PPL], dy[PPL]; bool act[PPL]; bool any_act = false;
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
-					dy[k] = q0.y - (pyf0 + (float)(4 * k));
-					const float power = -0.5f * (q0.z * dx * dx + q1.x * dy[k] * dy[k]) - q0.w * dx * dy[k];
-					G[k] = ADGS_EXP(power);
-					alpha[k] = fminf(ALPHA_MAX, q1.y * G[k]);
+					float power;
+					eval_pixel(eg, pyf0 + (float)(4 * k), dy[k], power, G[k], alpha[k]);
 					act[k] = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
 					any_act = any_act || act[k];
 				}
