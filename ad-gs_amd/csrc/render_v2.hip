@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 	const float pyf0 = (float)py0;
 	float T[PPL], tfo[PPL], tfb[PPL];      // tfo = dL/dO * T_final, tfb = T_final * (bg . dL/dC)
 	int last_contributor[PPL];
-	float A_c0[PPL], A_c1[PPL], A_c2[PPL], A_f0[PPL], A_f1[PPL], A_f2[PPL], A_d[PPL], A_s[PPL];
+	float Bsum[PPL];          // sum_ch A_ch * dL/dC_ch of the suffix blend A behind the current entry (see below)
 	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gS[PPL];
 	int max_contrib = 0;
 	const int slot = slot_of_lane(lane);
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 		T[k] = T_final;
 		last_contributor[k] = inside[k] ? (int)a.n_contrib[pix_id] : 0;
 		max_contrib = max(max_contrib, last_contributor[k]);
-		A_c0[k] = A_c1[k] = A_c2[k] = A_f0[k] = A_f1[k] = A_f2[k] = A_d[k] = A_s[k] = 0.f;
+		Bsum[k] = 0.f;
 		gC0[k] = gC1[k] = gC2[k] = gF0[k] = gF1[k] = gF2[k] = gD[k] = gS[k] = 0.f;
 		if (inside[k]) {
 			if (do_color) { gC0[k] = a.dL_dpix[0 * HW + pix_id]; gC1[k] = a.dL_dpix[1 * HW + pix_id]; gC2[k] = a.dL_dpix[2 * HW + pix_id]; }
@@ -434,24 +434,24 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 						const float rinv = __builtin_amdgcn_rcpf(1.f - al);
 						T[k] = T[k] * rinv;
 						const float dch = al * T[k];
-						float dL_dalpha = 0.0f;
-						// suffix-blend recurrences of backward.cu:578-607, applied right after use:
-						// A_next = A + alpha*(c - A) is the value the reference forms at the next contributing
-						// entry from last_alpha/last_color.
+						// backward.cu:578-607 keeps, per channel, the blend A_ch of everything behind this entry
+						// (A' = A + alpha (c - A)) and forms dL/dalpha = sum_ch (c_ch - A_ch) g_ch.  Only the scalar
+						// B = sum_ch A_ch g_ch is ever used, and it obeys the same recurrence
+						//   B' = B + alpha (cg - B),  cg = sum_ch c_ch g_ch,
+						// so one accumulator per pixel replaces the eight per-channel ones.
+						float cg = 0.f;
 						if (do_color) {
-							float d;
-							d = q1.z - A_c0[k]; dL_dalpha += d * gC0[k]; v_c0 += dch * gC0[k]; A_c0[k] += al * d;
-							d = q1.w - A_c1[k]; dL_dalpha += d * gC1[k]; v_c1 += dch * gC1[k]; A_c1[k] += al * d;
-							d = q2.x - A_c2[k]; dL_dalpha += d * gC2[k]; v_c2 += dch * gC2[k]; A_c2[k] += al * d;
+							cg += q1.z * gC0[k]; cg += q1.w * gC1[k]; cg += q2.x * gC2[k];
+							v_c0 += dch * gC0[k]; v_c1 += dch * gC1[k]; v_c2 += dch * gC2[k];
 						}
 						if (do_flow) {
-							float d;
-							d = q2.z - A_f0[k]; dL_dalpha += d * gF0[k]; v_f0 += dch * gF0[k]; A_f0[k] += al * d;
-							d = q2.w - A_f1[k]; dL_dalpha += d * gF1[k]; v_f1 += dch * gF1[k]; A_f1[k] += al * d;
-							d = q3.x - A_f2[k]; dL_dalpha += d * gF2[k]; v_f2 += dch * gF2[k]; A_f2[k] += al * d;
+							cg += q2.z * gF0[k]; cg += q2.w * gF1[k]; cg += q3.x * gF2[k];
+							v_f0 += dch * gF0[k]; v_f1 += dch * gF1[k]; v_f2 += dch * gF2[k];
 						}
-						if (do_sem) { const float d = q3.y - A_s[k]; dL_dalpha += d * gS[k]; v_s += dch * gS[k]; A_s[k] += al * d; }
-						if (do_depth) { const float d = q2.y - A_d[k]; dL_dalpha += d * gD[k]; v_d += dch * gD[k]; A_d[k] += al * d; }
+						if (do_sem) { cg += q3.y * gS[k]; v_s += dch * gS[k]; }
+						if (do_depth) { cg += q2.y * gD[k]; v_d += dch * gD[k]; }
+						float dL_dalpha = cg - Bsum[k];
+						Bsum[k] += al * dL_dalpha;
 						if (do_opacity) dL_dalpha += tfo[k] * rinv;  // before the *= T: reference quirk (backward.cu:612-614)
 						dL_dalpha = dL_dalpha * T[k] - tfb[k] * rinv;
 						const float L = G[k] * dL_dalpha;
