@@ -33,139 +33,130 @@ __device__ __forceinline__ Q qconj(const Q& a) { return { a.w, -a.x, -a.y, -a.z 
 __device__ __forceinline__ Q qadd(const Q& a, const Q& b) { return { a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z }; }
 __device__ __forceinline__ float qdot(const Q& a, const Q& b) { return a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// log map with shortest-arc flip (roma.unitquat_to_rotvec)
-struct LogSave { float f, a, m, wq; bool flip; float vx, vy, vz; };
-__device__ __forceinline__ void qlog(Q d, float* om, LogSave& s) {
-	s.flip = d.w < 0.f;
-	if (s.flip) { d.w = -d.w; d.x = -d.x; d.y = -d.y; d.z = -d.z; }
-	const float m = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-	const float a = 2.f * atan2f(m, d.w);
-	float f;
-	if (a <= 1e-3f) { const float a2 = a * a; f = 2.f + a2 / 12.f + 7.f * a2 * a2 / 2880.f; }
-	else f = a / sinf(a * 0.5f);
-	om[0] = f * d.x; om[1] = f * d.y; om[2] = f * d.z;
-	s.f = f; s.a = a; s.m = m; s.wq = d.w; s.vx = d.x; s.vy = d.y; s.vz = d.z;
-}
-__device__ __forceinline__ Q qlog_bwd(const LogSave& s, const float* g_om) {
-	const float a = s.a;
-	float fp;
-	if (a <= 1e-3f) fp = a / 6.f + 7.f * a * a * a / 720.f;
-	else { const float sh = sinf(a * 0.5f), ch = cosf(a * 0.5f); fp = (sh - 0.5f * a * ch) / (sh * sh); }
-	const float sdot = s.vx * g_om[0] + s.vy * g_om[1] + s.vz * g_om[2];
-	const float denom = s.m * s.m + s.wq * s.wq;
-	const float da_dm = 2.f * s.wq / denom, da_dw = -2.f * s.m / denom;
-	const float kv = (s.m > 0.f) ? fp * sdot * da_dm / s.m : 0.f;
-	Q g;
-	g.x = s.f * g_om[0] + kv * s.vx; g.y = s.f * g_om[1] + kv * s.vy; g.z = s.f * g_om[2] + kv * s.vz;
-	g.w = fp * sdot * da_dw;
-	if (s.flip) { g.w = -g.w; g.x = -g.x; g.y = -g.y; g.z = -g.z; }
-	return g;
-}
-// exp map (roma.rotvec_to_unitquat)
-__device__ __forceinline__ Q qexp(const float* rv, float& n_out, float& sc_out) {
-	const float n = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-	float sc;
-	if (n <= 1e-3f) { const float n2 = n * n; sc = 0.5f - n2 / 48.f + n2 * n2 / 3840.f; }
-	else sc = sinf(n * 0.5f) / n;
-	n_out = n; sc_out = sc;
-	return { cosf(n * 0.5f), sc * rv[0], sc * rv[1], sc * rv[2] };
-}
-__device__ __forceinline__ void qexp_bwd(const float* rv, float n, float sc, const Q& g, float* g_rv) {
-	float dsc_over_n, sinc;
-	if (n <= 1e-3f) { dsc_over_n = -1.f / 24.f + n * n / 960.f; sinc = (n > 0.f) ? sinf(n * 0.5f) / n : 0.5f; }
-	else { const float sh = sinf(n * 0.5f), ch = cosf(n * 0.5f); dsc_over_n = ((0.5f * ch * n - sh) / (n * n)) / n; sinc = sh / n; }
-	const float t = rv[0] * g.x + rv[1] * g.y + rv[2] * g.z;
-	const float k = dsc_over_n * t - 0.5f * sinc * g.w;
-	g_rv[0] = sc * g.x + rv[0] * k; g_rv[1] = sc * g.y + rv[1] * k; g_rv[2] = sc * g.z + rv[2] * k;
-}
-
 // ---- cumulative quaternion B-spline (func_utils.py:156-171), wxyz in / wxyz out ----
-// param block of one Gaussian: [4][n_params]
-__device__ __forceinline__ Q quat_spline_fwd(const float* __restrict__ p, const adgs_func_eval& f) {
-	const int kq = f.quat_k, np = f.n_params, c0 = f.quat_start;
-	Q ctrl_prev, acc;
-	{
-		Q c = { p[0 * np + c0] + 1.0f, p[1 * np + c0], p[2 * np + c0], p[3 * np + c0] };
-		const float inv = 1.f / fmaxf(sqrtf(qdot(c, c)), 1e-12f);
-		ctrl_prev = { c.w * inv, c.x * inv, c.y * inv, c.z * inv };
-		acc = ctrl_prev;
-	}
-	for (int j = 1; j <= kq; j++) {
-		Q c = { p[0 * np + c0 + j] + 1.0f, p[1 * np + c0 + j], p[2 * np + c0 + j], p[3 * np + c0 + j] };
+// param block of one Gaussian: [4][n_params]; control quaternion j = normalize(param[:, c0 + j] + (1,0,0,0)).
+//   out = q_0 * prod_{j>=1} exp(B~_j * log(conj(q_{j-1}) q_j))
+// log = roma.unitquat_to_rotvec (shortest arc: flip when w < 0; angle a = 2 atan2(|v|, w); factor a / sin(a/2),
+// Taylor 2 + a^2/12 + 7a^4/2880 for a <= 1e-3), exp = roma.rotvec_to_unitquat (scale sin(n/2)/n, Taylor
+// 0.5 - n^2/48 + n^4/3840 for n <= 1e-3).  Per segment this costs ONE atan2f and ONE sincosf: sin(a/2) and
+// cos(a/2) of the log map are |v|/r and w/r with r = sqrt(|v|^2 + w^2) (the sine / cosine of atan2(|v|, w)), and
+// the backward reuses the saved forward values instead of re-evaluating any transcendental.
+// NQ = number of control quaternions used (quat_k + 1), a template parameter so that the per-segment state
+// lives in registers sized for the actual spline order.
+template <int NQ> struct QuatSave {
+	Q q[NQ]; float inv_nrm[NQ];                 // normalised control quaternions, 1 / |ctrl|
+	Q r[NQ];                                    // r[j] = exp(B~_j log(conj(q[j-1]) q[j])), j >= 1
+	float vx[NQ], vy[NQ], vz[NQ], wq[NQ];       // delta_j = conj(q[j-1]) q[j] after the shortest-arc flip
+	float a[NQ], n[NQ], she[NQ];                // log angle; |rotvec| of the exp and sin(n/2)
+	bool flip[NQ];
+};
+__device__ __forceinline__ float log_factor(float a, float m, float rr) {
+	if (a <= 1e-3f) { const float a2 = a * a; return 2.f + a2 / 12.f + 7.f * a2 * a2 / 2880.f; }
+	return a * rr / m;                          // a / sin(a/2)
+}
+__device__ __forceinline__ float exp_scale(float n, float she) {
+	if (n <= 1e-3f) { const float n2 = n * n; return 0.5f - n2 / 48.f + n2 * n2 / 3840.f; }
+	return she / n;
+}
+template <int NQ, bool SAVE>
+__device__ __forceinline__ Q quat_spline_eval(const float* __restrict__ p, const adgs_func_eval& f, QuatSave<NQ>* s) {
+	const int np = f.n_params, c0 = f.quat_start;
+	Q prev = { 1.f, 0.f, 0.f, 0.f }, acc = prev;
+#pragma unroll
+	for (int j = 0; j < NQ; j++) {
+		const Q c = { p[0 * np + c0 + j] + 1.0f, p[1 * np + c0 + j], p[2 * np + c0 + j], p[3 * np + c0 + j] };
 		const float inv = 1.f / fmaxf(sqrtf(qdot(c, c)), 1e-12f);
 		const Q q = { c.w * inv, c.x * inv, c.y * inv, c.z * inv };
-		float om[3]; LogSave ls;
-		qlog(qmul(qconj(ctrl_prev), q), om, ls);
-		const float B = f.quat_cum[j - 1];
-		float rv[3] = { om[0] * B, om[1] * B, om[2] * B };
-		float n, sc;
-		acc = qmul(acc, qexp(rv, n, sc));
-		ctrl_prev = q;
+		if (SAVE) { s->q[j] = q; s->inv_nrm[j] = inv; }
+		if (j == 0) acc = q;
+		else {
+			Q dq = qmul(qconj(prev), q);
+			const bool flip = dq.w < 0.f;
+			if (flip) { dq.w = -dq.w; dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; }
+			const float m2 = dq.x * dq.x + dq.y * dq.y + dq.z * dq.z;
+			const float m = sqrtf(m2);
+			const float a = 2.f * atan2f(m, dq.w);
+			const float fl = log_factor(a, m, sqrtf(m2 + dq.w * dq.w));
+			const float B = f.quat_cum[j - 1];
+			const float rv0 = fl * dq.x * B, rv1 = fl * dq.y * B, rv2 = fl * dq.z * B;
+			const float n = sqrtf(rv0 * rv0 + rv1 * rv1 + rv2 * rv2);
+			float she, che;
+			sincosf(n * 0.5f, &she, &che);
+			const float sc = exp_scale(n, she);
+			const Q r = { che, sc * rv0, sc * rv1, sc * rv2 };
+			acc = qmul(acc, r);
+			if (SAVE) {
+				s->r[j] = r; s->vx[j] = dq.x; s->vy[j] = dq.y; s->vz[j] = dq.z; s->wq[j] = dq.w;
+				s->a[j] = a; s->n[j] = n; s->she[j] = she; s->flip[j] = flip;
+			}
+		}
+		prev = q;
 	}
 	return acc;
 }
 
-// backward: writes d/dparam of (g . out) into gp [4][n_params] (columns c0..c0+kq), ASSIGNING
-__device__ __forceinline__ void quat_spline_bwd(const float* __restrict__ p, const adgs_func_eval& f, const Q& g_out, float* __restrict__ gp) {
-	const int kq = f.quat_k, np = f.n_params, c0 = f.quat_start;
-	Q q[MAXQ]; float nrm[MAXQ];
-	Q r[MAXQ]; float rv[MAXQ][3], rn[MAXQ], rsc[MAXQ]; LogSave ls[MAXQ];
-	Q part[MAXQ];               // part[j] = q0 * r1 * ... * rj
+// backward: writes d/dparam of (g_out . out) into gp [4][n_params] (columns c0..c0+NQ-1), ASSIGNING
+template <int NQ>
+__device__ __forceinline__ void quat_spline_bwd(const QuatSave<NQ>& s, const Q& out, const adgs_func_eval& f, const Q& g_out, float* __restrict__ gp) {
+	const int np = f.n_params, c0 = f.quat_start;
+	Q gq[NQ];
 #pragma unroll
-	for (int j = 0; j < MAXQ; j++) {
-		if (j <= kq) {
-			Q c = { p[0 * np + c0 + j] + 1.0f, p[1 * np + c0 + j], p[2 * np + c0 + j], p[3 * np + c0 + j] };
-			nrm[j] = fmaxf(sqrtf(qdot(c, c)), 1e-12f);
-			const float inv = 1.f / nrm[j];
-			q[j] = { c.w * inv, c.x * inv, c.y * inv, c.z * inv };
-		}
-	}
-	part[0] = q[0];
+	for (int j = 0; j < NQ; j++) gq[j] = { 0.f, 0.f, 0.f, 0.f };
+	Q G = g_out;                 // gradient w.r.t. part[j] = q0 r1 ... rj, starting at j = NQ-1
+	Q P = out;                   // part[j], walked back with part[j-1] = part[j] conj(r_j)
 #pragma unroll
-	for (int j = 1; j < MAXQ; j++) {
-		if (j <= kq) {
-			float om[3];
-			qlog(qmul(qconj(q[j - 1]), q[j]), om, ls[j]);
-			const float B = f.quat_cum[j - 1];
-			rv[j][0] = om[0] * B; rv[j][1] = om[1] * B; rv[j][2] = om[2] * B;
-			r[j] = qexp(rv[j], rn[j], rsc[j]);
-			part[j] = qmul(part[j - 1], r[j]);
-		}
-	}
-	Q gq[MAXQ];
-#pragma unroll
-	for (int j = 0; j < MAXQ; j++) gq[j] = { 0.f, 0.f, 0.f, 0.f };
-	Q G = g_out;                 // gradient w.r.t. part[kq]
-#pragma unroll
-	for (int j = MAXQ - 1; j >= 1; j--) {
-		if (j <= kq) {
-			const Q g_r = qmul(qconj(part[j - 1]), G);       // d(part[j-1] * r_j)/d r_j
-			G = qmul(G, qconj(r[j]));                        // -> gradient w.r.t. part[j-1]
-			float g_rv[3];
-			qexp_bwd(rv[j], rn[j], rsc[j], g_r, g_rv);
-			const float B = f.quat_cum[j - 1];
-			float g_om[3] = { g_rv[0] * B, g_rv[1] * B, g_rv[2] * B };
-			const Q g_d = qlog_bwd(ls[j], g_om);             // gradient w.r.t. delta_j = conj(q_{j-1}) * q_j
-			gq[j] = qadd(gq[j], qmul(q[j - 1], g_d));        // L(conj(q_{j-1}))^T g = q_{j-1} * g
-			gq[j - 1] = qadd(gq[j - 1], qconj(qmul(g_d, qconj(q[j]))));   // through the conjugation
-		}
+	for (int j = NQ - 1; j >= 1; j--) {
+		const Q rc = qconj(s.r[j]);
+		const Q Pm = qmul(P, rc);
+		const Q g_r = qmul(qconj(Pm), G);              // d(part[j-1] * r_j) / d r_j
+		G = qmul(G, rc);                               // -> gradient w.r.t. part[j-1]
+		P = Pm;
+		// exp map backward
+		const float vx = s.vx[j], vy = s.vy[j], vz = s.vz[j], w = s.wq[j], a = s.a[j];
+		const float m2 = vx * vx + vy * vy + vz * vz, m = sqrtf(m2), rr2 = m2 + w * w, rr = sqrtf(rr2);
+		const float fl = log_factor(a, m, rr);
+		const float B = f.quat_cum[j - 1];
+		const float rv0 = fl * vx * B, rv1 = fl * vy * B, rv2 = fl * vz * B;
+		const float n = s.n[j], she = s.she[j], che = s.r[j].w;
+		const float sc = exp_scale(n, she);
+		float dsc_over_n, sinc;
+		if (n <= 1e-3f) { dsc_over_n = -1.f / 24.f + n * n / 960.f; sinc = (n > 0.f) ? she / n : 0.5f; }
+		else { dsc_over_n = ((0.5f * che * n - she) / (n * n)) / n; sinc = she / n; }
+		const float t = rv0 * g_r.x + rv1 * g_r.y + rv2 * g_r.z;
+		const float k = dsc_over_n * t - 0.5f * sinc * g_r.w;
+		const float go0 = (sc * g_r.x + rv0 * k) * B, go1 = (sc * g_r.y + rv1 * k) * B, go2 = (sc * g_r.z + rv2 * k) * B;
+		// log map backward: sin(a/2) = m / rr, cos(a/2) = w / rr
+		float fp;
+		if (a <= 1e-3f) fp = a / 6.f + 7.f * a * a * a / 720.f;
+		else { const float sh = m / rr, ch = w / rr; fp = (sh - 0.5f * a * ch) / (sh * sh); }
+		const float sdot = vx * go0 + vy * go1 + vz * go2;
+		const float da_dm = 2.f * w / rr2, da_dw = -2.f * m / rr2;
+		const float kv = (m > 0.f) ? fp * sdot * da_dm / m : 0.f;
+		Q g_d = { fp * sdot * da_dw, fl * go0 + kv * vx, fl * go1 + kv * vy, fl * go2 + kv * vz };
+		if (s.flip[j]) { g_d.w = -g_d.w; g_d.x = -g_d.x; g_d.y = -g_d.y; g_d.z = -g_d.z; }
+		gq[j] = qadd(gq[j], qmul(s.q[j - 1], g_d));                       // L(conj(q_{j-1}))^T g = q_{j-1} * g
+		gq[j - 1] = qadd(gq[j - 1], qconj(qmul(g_d, qconj(s.q[j]))));     // through the conjugation
 	}
 	gq[0] = qadd(gq[0], G);
 #pragma unroll
-	for (int j = 0; j < MAXQ; j++) {
-		if (j <= kq) {
-			const float d = qdot(q[j], gq[j]);
-			const float inv = 1.f / nrm[j];
-			gp[0 * np + c0 + j] = (gq[j].w - q[j].w * d) * inv;
-			gp[1 * np + c0 + j] = (gq[j].x - q[j].x * d) * inv;
-			gp[2 * np + c0 + j] = (gq[j].y - q[j].y * d) * inv;
-			gp[3 * np + c0 + j] = (gq[j].z - q[j].z * d) * inv;
-		}
+	for (int j = 0; j < NQ; j++) {
+		const float dd = qdot(s.q[j], gq[j]);
+		const float inv = s.inv_nrm[j];
+		gp[0 * np + c0 + j] = (gq[j].w - s.q[j].w * dd) * inv;
+		gp[1 * np + c0 + j] = (gq[j].x - s.q[j].x * dd) * inv;
+		gp[2 * np + c0 + j] = (gq[j].y - s.q[j].y * dd) * inv;
+		gp[3 * np + c0 + j] = (gq[j].z - s.q[j].z * dd) * inv;
 	}
 }
 
+// run CALL(NQ) with the compile-time number of control quaternions of `f` (0: no quaternion spline)
+#define ADGS_NQ_SWITCH(f, CALL) \
+	switch ((f).quat_start >= 0 ? (f).quat_k + 1 : 0) { \
+		case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+		case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); break; }
+
 // ------------------------------------------------------------------ generic get_func_result
-template <int D>
+template <int D, int NQ>
 __global__ void __launch_bounds__(256) func_eval_fwd_kernel(int N, const float* __restrict__ param, adgs_func_eval f, float* __restrict__ out) {
 	const int n = blockIdx.x * blockDim.x + threadIdx.x;
 	if (n >= N) return;
@@ -173,14 +164,14 @@ __global__ void __launch_bounds__(256) func_eval_fwd_kernel(int N, const float* 
 	float res[D];
 #pragma unroll
 	for (int d = 0; d < D; d++) res[d] = lin_eval(p + d * f.n_params, f);
-	if (D == 4 && f.quat_start >= 0) {
-		const Q qv = quat_spline_fwd(p, f);
+	if (D == 4 && NQ > 0) {
+		const Q qv = quat_spline_eval<(NQ > 0 ? NQ : 1), false>(p, f, nullptr);
 		res[0] = res[0] + qv.w; res[1] = res[1] + qv.x; res[2] = res[2] + qv.y; res[3 % D] = res[3 % D] + qv.z;
 	}
 #pragma unroll
 	for (int d = 0; d < D; d++) out[(size_t)n * D + d] = res[d];
 }
-template <int D>
+template <int D, int NQ>
 __global__ void __launch_bounds__(256) func_eval_bwd_kernel(int N, const float* __restrict__ param, adgs_func_eval f,
 	const float* __restrict__ dL_dout, float* __restrict__ dL_dparam) {
 	const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,7 +181,11 @@ __global__ void __launch_bounds__(256) func_eval_bwd_kernel(int N, const float* 
 	float g[D];
 #pragma unroll
 	for (int d = 0; d < D; d++) { g[d] = dL_dout[(size_t)n * D + d]; lin_bwd(gp + d * f.n_params, f, g[d]); }
-	if (D == 4 && f.quat_start >= 0) quat_spline_bwd(p, f, { g[0], g[1], g[2], g[3 % D] }, gp);
+	if (D == 4 && NQ > 0) {
+		QuatSave<(NQ > 0 ? NQ : 1)> st;
+		const Q out = quat_spline_eval<(NQ > 0 ? NQ : 1), true>(p, f, &st);
+		quat_spline_bwd<(NQ > 0 ? NQ : 1)>(st, out, f, { g[0], g[1], g[2], g[3 % D] }, gp);
+	}
 }
 
 // ------------------------------------------------------------------ fused get_deformed_pkg
@@ -204,7 +199,7 @@ struct DeformArgs {
 	int n_begin, n_end, stride_x, stride_r;
 };
 
-template <bool OBJ>
+template <bool OBJ, int NQ>
 __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
 	extern __shared__ float s_rows[];
 	const int tid = threadIdx.x, B = blockDim.x, base = a.n_begin + blockIdx.x * B;
@@ -272,7 +267,7 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
 				if (rp) {
 #pragma unroll
 					for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * np, a.fr);
-					if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
+					if (NQ > 0) { const Q qv = quat_spline_eval<(NQ > 0 ? NQ : 1), false>(rp, a.fr, nullptr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
 				}
 				if (a.fr.quat_start >= 0) {
 #pragma unroll
@@ -415,7 +410,7 @@ struct DeformBwdArgs {
 // PARTS: bit 0 = xyz / background, bit 1 = rotation, bit 2 = opacity + scales.  OBJ = false is the scene
 // range (no object member: none of the staging / spline code is instantiated, so the kernel stays light).
 constexpr int DP_XYZ = 1, DP_ROT = 2, DP_REST = 4;
-template <int PARTS, bool OBJ>
+template <int PARTS, bool OBJ, int NQ>
 __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 	extern __shared__ float s_rows[];
 	__shared__ float s_bg[6][256 / WAVE];
@@ -499,6 +494,8 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 		if (valid) {
 			float u[4];
 			const float* rp = (is_obj && haver) ? s_rows + tid * a.stride_r : nullptr;
+			QuatSave<(NQ > 0 ? NQ : 1)> qs;
+			Q qout = { 0.f, 0.f, 0.f, 0.f };
 			if (!OBJ || !is_obj) {
 				const float4 q = *reinterpret_cast<const float4*>(a.p.scene_rotation + 4 * (size_t)m);
 				u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
@@ -507,7 +504,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 				if (rp) {
 #pragma unroll
 					for (int d = 0; d < 4; d++) fv[d] = lin_eval(rp + d * np, a.fr);
-					if (a.fr.quat_start >= 0) { const Q qv = quat_spline_fwd(rp, a.fr); fv[0] += qv.w; fv[1] += qv.x; fv[2] += qv.y; fv[3] += qv.z; }
+					if (NQ > 0) { qout = quat_spline_eval<(NQ > 0 ? NQ : 1), true>(rp, a.fr, &qs); fv[0] += qout.w; fv[1] += qout.x; fv[2] += qout.y; fv[3] += qout.z; }
 				}
 #pragma unroll
 				for (int d = 0; d < 4; d++) u[d] = (a.fr.quat_start >= 0) ? fv[d] : a.p.obj_rotation[4 * (size_t)m + d] + fv[d];
@@ -534,7 +531,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 					for (int k = 0; k < 4 * np; k++) gp[k] = 0.f;
 #pragma unroll
 					for (int d = 0; d < 4; d++) lin_bwd(gp + d * np, a.fr, gu[d]);
-					if (a.fr.quat_start >= 0) quat_spline_bwd(rp, a.fr, { gu[0], gu[1], gu[2], gu[3] }, gp);
+					if (NQ > 0) quat_spline_bwd<(NQ > 0 ? NQ : 1)>(qs, qout, a.fr, { gu[0], gu[1], gu[2], gu[3] }, gp);
 				}
 			}
 		}
@@ -649,8 +646,12 @@ extern "C" int adgs_func_eval_forward(int N, int D, const float* param, const ad
 	if (check_func(f, "adgs_func_eval_forward") != 0) return -1;
 	if (D == 3 && f->quat_start >= 0) { set_error("quaternion spline needs D == 4"); return -1; }
 	hipStream_t stream = (hipStream_t)stream_;
-	if (D == 3) hipLaunchKernelGGL(func_eval_fwd_kernel<3>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, out);
-	else hipLaunchKernelGGL(func_eval_fwd_kernel<4>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, out);
+	if (D == 3) hipLaunchKernelGGL((func_eval_fwd_kernel<3, 0>), dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, out);
+	else {
+#define ADGS_CALL(NQ) hipLaunchKernelGGL((func_eval_fwd_kernel<4, NQ>), dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, out)
+		ADGS_NQ_SWITCH(*f, ADGS_CALL)
+#undef ADGS_CALL
+	}
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -660,8 +661,12 @@ extern "C" int adgs_func_eval_backward(int N, int D, const float* param, const a
 	if (!param || !f || !dL_dout || !dL_dparam || (D != 3 && D != 4)) { set_error("adgs_func_eval_backward: bad arguments"); return -1; }
 	if (check_func(f, "adgs_func_eval_backward") != 0) return -1;
 	hipStream_t stream = (hipStream_t)stream_;
-	if (D == 3) hipLaunchKernelGGL(func_eval_bwd_kernel<3>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, dL_dout, dL_dparam);
-	else hipLaunchKernelGGL(func_eval_bwd_kernel<4>, dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, dL_dout, dL_dparam);
+	if (D == 3) hipLaunchKernelGGL((func_eval_bwd_kernel<3, 0>), dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, dL_dout, dL_dparam);
+	else {
+#define ADGS_CALL(NQ) hipLaunchKernelGGL((func_eval_bwd_kernel<4, NQ>), dim3((N + 255) / 256), dim3(256), 0, stream, N, param, *f, dL_dout, dL_dparam)
+		ADGS_NQ_SWITCH(*f, ADGS_CALL)
+#undef ADGS_CALL
+	}
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -700,7 +705,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
 		if (p->Ns > 0) {                     // scene range: nothing to stage
 			a.n_begin = 0; a.n_end = p->Ns;
-			hipLaunchKernelGGL(deform_fwd_kernel<false>, dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
+			hipLaunchKernelGGL((deform_fwd_kernel<false, 0>), dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 		if (p->No > 0) {
@@ -708,7 +713,9 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 			const int B = pick_block(std::max(a.stride_x, a.stride_r), &lds);
 			if (lds > 64 * 1024) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
 			a.n_begin = p->Ns; a.n_end = N;
-			hipLaunchKernelGGL(deform_fwd_kernel<true>, dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_fwd_kernel<true, NQ>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a)
+			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
+#undef ADGS_CALL
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}
@@ -751,7 +758,7 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
 		if (p->Ns > 0) {
 			a.n_begin = 0; a.n_end = p->Ns;
-			hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_ROT | DP_REST, false>), dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
+			hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_ROT | DP_REST, false, 0>), dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 		if (p->No > 0) {
@@ -762,14 +769,16 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 				const int B = pick_block(a.stride_x, &lds);
 				lds += 2 * (size_t)np_x * sizeof(float);            // dense basis rows of the two time stamps
 				if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
-				hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_REST, true>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+				hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_REST, true, 0>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
 				ADGS_HIP_CHECK(hipGetLastError());
 			}
 			if (dL_drotation) {
 				size_t lds = 0;
 				const int B = pick_block(2 * a.stride_r, &lds);
 				if (lds > 64 * 1024) { set_error("adgs_deform_backward: rotation rows too large for the LDS staging buffer"); return -1; }
-				hipLaunchKernelGGL((deform_bwd_kernel<DP_ROT, true>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
+#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_bwd_kernel<DP_ROT, true, NQ>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a)
+				ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
+#undef ADGS_CALL
 				ADGS_HIP_CHECK(hipGetLastError());
 			}
 		}
