@@ -39,10 +39,46 @@ template <bool TO_LDS, typename PtrT>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, int L, int gi0, int count, int Ns, PtrT scene, PtrT obj,
 	int tid, int nthreads) {
 	constexpr int U = 8;                      // transfers in flight per thread: all loads of a batch are issued before the first store
-	int g = tid / L, c = tid - g * L;
-	const int dq = nthreads / L, dr = nthreads - dq * L;
 	const int total = count * L;
-	for (int e = tid; e < total; e += nthreads * U) {
+	int e_begin = 0;
+	// fast path, block entirely on one side of the scene|object boundary: its rows are one contiguous slab,
+	// moved with 16-byte global accesses (four LDS words each; a quad may straddle two rows)
+	const bool all_scene = gi0 + count <= Ns, all_obj = gi0 >= Ns;
+	if (all_scene || all_obj) {
+		PtrT slab = all_scene ? (scene ? scene + (size_t)gi0 * L : nullptr) : (obj ? obj + (size_t)(gi0 - Ns) * L : nullptr);
+		if (!slab) return;
+		if ((reinterpret_cast<uintptr_t>(slab) & 15) == 0 && L >= 4) {
+			constexpr int U4 = 4;
+			const int total4 = total >> 2;
+			int e = 4 * tid;
+			int g = e / L, c = e - g * L;
+			const int step = 4 * nthreads, dq = step / L, dr = step - dq * L;
+			for (int q = tid; q < total4; q += nthreads * U4) {
+				float4 v[U4]; int so[U4], cc[U4]; bool in[U4];
+#pragma unroll
+				for (int u = 0; u < U4; u++) {
+					in[u] = q + u * nthreads < total4;
+					so[u] = g * stride + c; cc[u] = c;
+					if (TO_LDS) v[u] = in[u] ? reinterpret_cast<const float4*>(slab)[q + u * nthreads] : make_float4(0.f, 0.f, 0.f, 0.f);
+					c += dr; g += dq;
+					if (c >= L) { c -= L; g++; }
+				}
+#pragma unroll
+				for (int u = 0; u < U4; u++) {
+					if (!in[u]) continue;
+					// element i of the quad sits at column cc + i, wrapping into the next row (one pad word further)
+					const int pad = stride - L;
+					const int o0 = so[u], o1 = so[u] + 1 + (cc[u] + 1 >= L ? pad : 0), o2 = so[u] + 2 + (cc[u] + 2 >= L ? pad : 0), o3 = so[u] + 3 + (cc[u] + 3 >= L ? pad : 0);
+					if (TO_LDS) { s[o0] = v[u].x; s[o1] = v[u].y; s[o2] = v[u].z; s[o3] = v[u].w; }
+					else reinterpret_cast<float4*>(const_cast<float*>(slab))[q + u * nthreads] = make_float4(s[o0], s[o1], s[o2], s[o3]);
+				}
+			}
+			e_begin = total4 << 2;            // at most three tail elements go through the generic loop
+		}
+	}
+	int g = (e_begin + tid) / L, c = (e_begin + tid) - g * L;
+	const int dq = nthreads / L, dr = nthreads - dq * L;
+	for (int e = e_begin + tid; e < total; e += nthreads * U) {
 		PtrT p[U]; int so[U]; float v[U];
 #pragma unroll
 		for (int u = 0; u < U; u++) {
