@@ -74,7 +74,7 @@ struct BinState {
 // ---- v2 (coarse-binned) state ----
 struct GeomStateV2 {
 	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects;
-	float* gacc; float* sh0; char* scan_temp;
+	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
 		Carver c(chunk); GeomStateV2 g;
 		g.splats = c.take<Splat>(P);
@@ -86,6 +86,7 @@ struct GeomStateV2 {
 		g.offsets = c.take<uint32_t>(P + 1);
 		g.fine_touched = c.take<uint32_t>(P + 1);
 		g.sh0 = c.take<float>(P * 3);
+		g.fine_total = c.take<unsigned long long>(SCAN_AUX_SLOTS);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
 		if (bytes) *bytes = c.size();
 		return g;
@@ -167,7 +168,7 @@ static hipEvent_t readback_event() {
 }
 static uint32_t* pinned_word() {
 	static thread_local uint32_t* p = nullptr;
-	if (!p) { if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr; }
+	if (!p) { if (hipHostMalloc((void**)&p, 1024, hipHostMallocDefault) != hipSuccess) p = nullptr; }
 	return p;
 }
 
@@ -259,14 +260,14 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;
 		pa.rects = geom.rects; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
-		pa.sh0 = geom.sh0; pa.gacc = geom.gacc;
+		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream) != 0) return -1; }
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		{
 			StageTimer t(ST_SCAN, stream);
-			if (exclusive_scan_u32(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
-			if (exclusive_scan_u32(geom.fine_touched, geom.fine_touched, (size_t)P + 1, geom.scan_temp, stream) != 0) return -1;
+			// offsets of the (cell, Gaussian) pairs; the fine-tile bound of the chunk pool only needs its total
+			if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);
 		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning
@@ -279,7 +280,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		hipEvent_t ev = readback_event();
 		if (!hw || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return -1; }
 		ADGS_HIP_CHECK(hipMemcpyAsync(hw, geom.offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		ADGS_HIP_CHECK(hipMemcpyAsync(hw + 1, geom.fine_touched + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		ADGS_HIP_CHECK(hipMemcpyAsync(hw + 2, geom.fine_total, SCAN_AUX_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		ADGS_HIP_CHECK(hipEventRecord(ev, stream));
 		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
 		const bool speculate = env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99;
@@ -312,7 +313,9 @@ static int raster_forward_impl(const ShSource* sh_src,
 		};
 		if (speculate && enqueue_binning(cap_cells, cap_fine, geom.offsets + P) != 0) return -1;
 		ADGS_HIP_CHECK(hipEventSynchronize(ev));
-		const size_t R_cells = hw[0], R_fine = hw[1];
+		size_t R_fine = 0;
+		for (int i = 0; i < SCAN_AUX_SLOTS; i++) R_fine += (size_t)reinterpret_cast<unsigned long long*>(hw + 2)[i];
+		const size_t R_cells = hw[0];
 		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu\n", P, ncells, R_cells, R_fine);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
 		ADGS_DBG_STOP(0)
@@ -364,7 +367,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
 	pa.rects = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
-	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr;
+	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);

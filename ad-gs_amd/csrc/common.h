@@ -79,6 +79,8 @@ struct Carver {
 size_t scan_temp_bytes(size_t n);
 // out[i] = sum_{j<i} in[j]  (in == out allowed)
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
+constexpr int SCAN_AUX_SLOTS = 32;
+int exclusive_scan_u32_sum(const uint32_t* in, uint32_t* out, size_t n, char* temp, const uint32_t* aux_in, unsigned long long* aux_total, hipStream_t stream);
 
 size_t sort_temp_bytes(size_t n);
 // Stable LSD radix sort of (key,value) pairs on key bits [0, end_bit).

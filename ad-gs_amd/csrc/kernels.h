@@ -23,6 +23,7 @@ struct PreprocessArgs {
 	ShSource sh_src;                 // raw SH source (sh_src.scene_dc != nullptr) instead of `shs`
 	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
 	float* gacc;                     // v2: [P][GACC_STRIDE] accumulator lines, zeroed here for every visible Gaussian (nullptr: skip)
+	unsigned long long* fine_total;  // v2: reset here; the scan pass adds up fine_touched into it
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);

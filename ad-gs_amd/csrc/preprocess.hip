@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		}
 		__syncthreads();
 	}
+	if (a.rects && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
 	if (idx >= a.P) return;
 	if (idx == 0) {       // sentinels: the exclusive scans over P + 1 entries leave the totals at [P]
 		a.tiles_touched[a.P] = 0;

@@ -28,10 +28,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 // mode 0: write per-block sums only.  mode 1: write exclusive scan (+ block offset).
 template <int MODE>
 __global__ void __launch_bounds__(PB) scan_tile_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-	size_t n, const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ block_sums) {
+	size_t n, const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ block_sums,
+	const uint32_t* __restrict__ aux_in, unsigned long long* __restrict__ aux_total) {
 	__shared__ uint32_t wave_tot[PB / WAVE];
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * SCAN_ITEMS;
+	if (MODE == 0 && aux_in) {
+		// side job of the block-sum pass: the plain total of a second array of the same length, one atomic per
+		// block, spread over SCAN_AUX_SLOTS counters (same-address atomics serialise in the L2)
+		__shared__ unsigned long long aux_w[PB / WAVE];
+		unsigned long long s = 0;
+#pragma unroll
+		for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) s += aux_in[base + k];
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+		if (lane == 0) aux_w[wid] = s;
+		__syncthreads();
+		if (tid == 0) {
+			unsigned long long t = 0;
+			for (int w = 0; w < PB / WAVE; w++) t += aux_w[w];
+			if (t) atomicAdd(aux_total + (blockIdx.x % SCAN_AUX_SLOTS), t);
+		}
+	}
 	uint32_t v[SCAN_ITEMS];
 	uint32_t tsum = 0;
 	if (base + SCAN_ITEMS <= n) {
@@ -84,19 +102,29 @@ size_t scan_temp_bytes(size_t n) {
 }
 
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream) {
+	return exclusive_scan_u32_sum(in, out, n, temp, nullptr, nullptr, stream);
+}
+// exclusive scan of `in` plus, when aux_in is given, sum(aux_in[0..n)) added into the SCAN_AUX_SLOTS counters
+// aux_total[] (pre-zeroed by the caller, who adds them up)
+int exclusive_scan_u32_sum(const uint32_t* in, uint32_t* out, size_t n, char* temp, const uint32_t* aux_in, unsigned long long* aux_total, hipStream_t stream) {
 	if (n == 0) return 0;
 	const size_t nb = scan_blocks(n);
+	const uint32_t* no_aux = nullptr; unsigned long long* no_tot = nullptr;
 	if (nb == 1) {
-		hipLaunchKernelGGL(scan_tile_kernel<1>, dim3(1), dim3(PB), 0, stream, in, out, n, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+		if (aux_in) {
+			hipLaunchKernelGGL(scan_tile_kernel<0>, dim3(1), dim3(PB), 0, stream, in, (uint32_t*)nullptr, n, (const uint32_t*)nullptr, reinterpret_cast<uint32_t*>(temp), aux_in, aux_total);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
+		hipLaunchKernelGGL(scan_tile_kernel<1>, dim3(1), dim3(PB), 0, stream, in, out, n, (const uint32_t*)nullptr, (uint32_t*)nullptr, no_aux, no_tot);
 		ADGS_HIP_CHECK(hipGetLastError());
 		return 0;
 	}
 	uint32_t* sums = reinterpret_cast<uint32_t*>(temp);
 	char* next_temp = temp + align_up(nb * sizeof(uint32_t), 256);
-	hipLaunchKernelGGL(scan_tile_kernel<0>, dim3((unsigned)nb), dim3(PB), 0, stream, in, (uint32_t*)nullptr, n, (const uint32_t*)nullptr, sums);
+	hipLaunchKernelGGL(scan_tile_kernel<0>, dim3((unsigned)nb), dim3(PB), 0, stream, in, (uint32_t*)nullptr, n, (const uint32_t*)nullptr, sums, aux_in, aux_total);
 	ADGS_HIP_CHECK(hipGetLastError());
 	if (exclusive_scan_u32(sums, sums, nb, next_temp, stream) != 0) return -1;
-	hipLaunchKernelGGL(scan_tile_kernel<1>, dim3((unsigned)nb), dim3(PB), 0, stream, in, out, n, (const uint32_t*)sums, (uint32_t*)nullptr);
+	hipLaunchKernelGGL(scan_tile_kernel<1>, dim3((unsigned)nb), dim3(PB), 0, stream, in, out, n, (const uint32_t*)sums, (uint32_t*)nullptr, no_aux, no_tot);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -111,13 +139,16 @@ __global__ void __launch_bounds__(PB) sort_hist_kernel(const KeyT* __restrict__ 
 	hist[tid] = 0;
 	__syncthreads();
 	const size_t tile0 = (size_t)blockIdx.x * SORT_TILE;
+	KeyT kk[SORT_ROUNDS];
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
-		size_t i = tile0 + (size_t)r * PB + tid;
-		if (i < n) {
-			uint32_t d = (uint32_t)(keys[i] >> shift) & mask;
-			atomicAdd(&hist[d], 1u);
-		}
+		const size_t i = tile0 + (size_t)r * PB + tid;
+		kk[r] = i < n ? keys[i] : (KeyT)0;
+	}
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const size_t i = tile0 + (size_t)r * PB + tid;
+		if (i < n) atomicAdd(&hist[(uint32_t)(kk[r] >> shift) & mask], 1u);
 	}
 	__syncthreads();
 	block_hist[(size_t)tid * nblocks + blockIdx.x] = hist[tid];
@@ -137,12 +168,22 @@ __global__ void __launch_bounds__(PB) sort_scatter_kernel(const KeyT* __restrict
 	running[tid] = 0;
 	const size_t tile0 = (size_t)blockIdx.x * SORT_TILE;
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
+	// all rounds' pairs are requested up front: one memory round trip per block instead of one per round
+	KeyT keys[SORT_ROUNDS]; uint32_t vals[SORT_ROUNDS];
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const size_t i = tile0 + (size_t)r * PB + tid;
+		const bool valid = i < n;
+		keys[r] = valid ? keys_in[i] : (KeyT)0;
+		vals[r] = valid ? vals_in[i] : 0u;
+	}
+#pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const size_t i = tile0 + (size_t)r * PB + tid;
 		if (tile0 + (size_t)r * PB >= n) break;   // block-uniform
 		const bool valid = i < n;
-		KeyT key = valid ? keys_in[i] : (KeyT)0;
-		uint32_t val = valid ? vals_in[i] : 0u;
+		const KeyT key = keys[r];
+		const uint32_t val = vals[r];
 		const uint32_t d = (uint32_t)(key >> shift) & mask;
 		// wave-level match-any on the 8-bit digit
 		uint64_t peers = __ballot(valid);
