@@ -108,8 +108,13 @@ class StageProfiler:
         self.total = (ctypes.c_double * self.n)()
         self.count = (ctypes.c_int64 * self.n)()
 
-    def enable(self, on=True):
-        self.lib.adgs_profile_enable(1 if on else 0)
+    def enable(self, on=True, stages=None):
+        """stages: iterable of stage names to time (default: all).  Every timed stage costs two event records per launch
+        group, i.e. a ~10 us bubble in the queue: time only what you report inside a throughput measurement."""
+        mask = 0
+        if on:
+            mask = -1 if stages is None else sum(1 << self.names.index(s) for s in stages)
+        self.lib.adgs_profile_enable(mask)
 
     def collect(self):
         """Call after torch.cuda.synchronize(); returns {stage: (avg_ms, launches)}."""

@@ -141,7 +141,7 @@ static const char* const kStageNames[ST_COUNT] = { "preprocess_fwd", "scan", "du
 	"render_fwd", "render_bwd", "preprocess_bwd" };
 struct ProfRec { int stage; hipEvent_t a, b; };
 // process-wide: torch.autograd calls the backward from its own worker thread
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;          // bit i: stage i is timed
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -152,7 +152,7 @@ static hipEvent_t prof_event() {
 }
 struct StageTimer {
 	bool on; ProfRec r; hipStream_t s;
-	StageTimer(int stage, hipStream_t stream) : on(g_prof_on), s(stream) {
+	StageTimer(int stage, hipStream_t stream) : on((g_prof_mask >> stage) & 1u), s(stream) {
 		if (on) { r.stage = stage; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, s); }
 	}
 	~StageTimer() { if (on) { (void)hipEventRecord(r.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back(r); } }
@@ -184,7 +184,7 @@ extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_
 // atomics-into-outputs pipeline; also the reference's contract), 0 if every element is written.
 extern "C" int adgs_raster_needs_zero_init(int D_S) { return use_v2(D_S) ? 0 : 1; }
 
-extern "C" void adgs_profile_enable(int on) { g_prof_on = on != 0; }
+extern "C" void adgs_profile_enable(int stage_mask) { g_prof_mask = (unsigned)stage_mask; }
 extern "C" int adgs_profile_num_stages(void) { return ST_COUNT; }
 extern "C" const char* adgs_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 // Resolves all recorded (start, stop) event pairs: the caller must have synchronised the stream.

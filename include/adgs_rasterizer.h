@@ -189,7 +189,8 @@ void adgs_get_frame_stats(adgs_frame_stats* out);
  * for the roofline figure).  Process-wide.  adgs_profile_collect() must be called after the
  * stream has been synchronised; it ADDS into total_ms[] / counts[] (adgs_profile_num_stages()
  * entries each). */
-void adgs_profile_enable(int on);
+void adgs_profile_enable(int stage_mask);   /* bit i set: time stage i (two HIP events per launch group, ~10 us of
+                                               queue bubble each); 0 = off, -1 = every stage */
 int adgs_profile_num_stages(void);
 const char* adgs_profile_stage_name(int stage);
 int adgs_profile_collect(double* total_ms, int64_t* counts);
