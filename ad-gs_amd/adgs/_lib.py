@@ -61,7 +61,7 @@ SIGNATURES = {
 
 class FrameStats(ctypes.Structure):
     _fields_ = [("num_rendered", ctypes.c_int64), ("tiles", ctypes.c_int32), ("sort_bits", ctypes.c_int32),
-                ("sort_passes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("sort_passes", ctypes.c_int32), ("reserved", ctypes.c_int32), ("fine_pairs", ctypes.c_int64)]
 
 
 def lib():
@@ -95,7 +95,8 @@ def check(code, what):
 def frame_stats():
     st = FrameStats()
     lib().adgs_get_frame_stats(ctypes.byref(st))
-    return dict(num_rendered=int(st.num_rendered), tiles=int(st.tiles), sort_bits=int(st.sort_bits), sort_passes=int(st.sort_passes))
+    return dict(num_rendered=int(st.num_rendered), tiles=int(st.tiles), sort_bits=int(st.sort_bits), sort_passes=int(st.sort_passes),
+                fine_pairs=int(st.fine_pairs))
 
 
 class StageProfiler:

@@ -17,7 +17,7 @@
 namespace adgs {
 
 static thread_local std::string g_last_error;
-static adgs_frame_stats g_stats = { 0, 0, 0, 0, 0 };   // process-wide (autograd runs backward on its own thread)
+static adgs_frame_stats g_stats = { 0, 0, 0, 0, 0, 0 };   // process-wide (autograd runs backward on its own thread)
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 // rasterizer_impl.cu:35-50 (next-highest bit of the MSB)
@@ -341,7 +341,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
-		g_stats.reserved = (int32_t)std::min<size_t>(R_fine, 0x7fffffff);
+		g_stats.reserved = 0; g_stats.fine_pairs = (int64_t)R_fine;
 		return (int)R_cells;
 	}
 
@@ -415,6 +415,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	g_stats.num_rendered = num_rendered; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
+	g_stats.fine_pairs = num_rendered;
 	return num_rendered;
 }
 

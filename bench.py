@@ -44,6 +44,84 @@ def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     }
 
 
+def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, n_obj_rows):
+    """Algorithmic bytes per launch of the default (v2, coarse-binned) pipeline -- DESIGN.md section 5.
+    Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries actually blended."""
+    pay = 12 + 4 + 12 * F + 4 * D_S
+    out = X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4)
+    return {
+        "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 32 + 24 + 1 + 64),
+        "scan": P * 12,
+        "duplicate_keys": V * (8 + 4) + Rc * 12,
+        "radix_sort": passes * Rc * 24 + Rc * 8,
+        "tile_ranges": Rc * 8,
+        "render_fwd": E * (4 + 64 + 4) + out,
+        "render_bwd": E * (4 + 64) + E * 56 + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),
+        "preprocess_bwd": P * (12 + 12 + 16 + 4 + 12 * M) + V * (64 + 32 + 24 + 1) + V * 64 + P * (12 + 12 * M + 12 + 16 + 12 + 16 + 4 + 12 + 4 + 24),
+    }
+
+
+def blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device):
+    """(E, R): E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published; the last
+    chunk of a tile is partly empty, so this is an upper bound within #tiles x 63), R = the reference's num_rendered for the
+    same frame (one extra forward in classic mode)."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    from adgs import deform
+    with torch.no_grad():
+        if isinstance(frame, DeformFrame):
+            pkg = deform.get_deformed_pkg(frame.model, frame.t)
+            flow = frame.model.get_deformed_xyz(frame.t + 0.05) if use_fs else torch.empty(0, device=device)
+            t = dict(means3D=pkg["xyz"], opacities=pkg["opacity"], scales=pkg["scales"], rotations=pkg["rotation"], shs=pkg["shs"])
+            sem = frame.sem if use_fs else torch.empty(0, device=device)
+        else:
+            t = {k: v.detach() for k, v in frame.leaf.items()}
+            flow = frame.flow if use_fs else torch.empty(0, device=device)
+            sem = frame.sem if use_fs else torch.empty(0, device=device)
+        e = torch.empty(0, device=device)
+        s = settings
+        call = lambda: _C.rasterize_gaussians(s.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], s.scale_modifier, e, s.viewmatrix,
+                                              s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, t["shs"], flow, sem, s.sh_degree,
+                                              s.campos, s.prefiltered, s.inv_depth, False)
+        out = call()
+        chunks = int(out[6][:4].view(torch.int32)[0].item())      # BinStateV2 starts with the chunk-pool cursor
+        old = os.environ.get("ADGS_RASTER_MODE")
+        os.environ["ADGS_RASTER_MODE"] = "classic"
+        try:
+            r_ref = int(call()[0])
+        finally:
+            if old is None:
+                del os.environ["ADGS_RASTER_MODE"]
+            else:
+                os.environ["ADGS_RASTER_MODE"] = old
+    return chunks * 64, r_ref
+
+
+def pmc_annotations(stage, config, measured_case):
+    """HBM traffic / VALU occupancy of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01/, collected
+    with this same command line; counters cannot be read from inside the process).  Only attached for the case they were
+    measured on (C3, flow+semantic, default pipeline)."""
+    if config != "C3" or not measured_case:
+        return {}
+    kname = {"render_bwd": "render_bwd_v2_kernel", "render_fwd": "render_fwd_v2_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
+             "preprocess_fwd": "preprocess_fwd_kernel"}.get(stage)
+    out = {}
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_per_kernel.json")))
+        for k, v in tr.items():
+            if kname and kname in k:
+                out["traffic"] = v["hbm_bytes_per_launch"]
+                out["traffic_source"] = "profiles/r01/hbm_traffic_per_kernel.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+                break
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_blend_kernels.json")))["kernels"].get(kname)
+        if pm:
+            out["valu_busy_frac"] = pm["valu_busy_frac"]
+            out["valu_note"] = "fp32-VALU-bound kernel (SURVEY.md 8(d)): SQ_ACTIVE_INST_VALU / (SIMDs x kernel cycles), profiles/r01/pmc_blend_kernels.json"
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 class StaticFrame:
     """Per-frame work on already-deformed parameters: rasterizer forward (+ autograd backward)."""
 
@@ -239,14 +317,25 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        stats = _lib.frame_stats()
         outs = frame.forward()
+        stats = _lib.frame_stats()
         V = int((frame.last_radii > 0).sum().item())
-        R = stats["num_rendered"]
+        Rc = stats["num_rendered"]                # pairs that were sorted: (cell, Gaussian) in v2, (tile, Gaussian) in classic mode
         X, T = H * W, stats["tiles"]
         M = sc["shs"].shape[1]
         F, D_S = (1, 1) if use_fs else (0, 0)
-        ab = alg_bytes(P, V, R, X, T, M, F, D_S, stats["sort_passes"])
+        v2 = _lib.lib().adgs_raster_needs_zero_init(D_S) == 0
+        extra = {}
+        if v2:
+            # scene-level work figures: the reference's pair count R and what v2 actually blends
+            E, R_ref = blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device)
+            ab = alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], 0)
+            extra = {"pipeline": "v2 (coarse cells + lazy per-tile filtering)", "reference_pairs_R": R_ref, "R_over_P": round(R_ref / max(P, 1), 2),
+                     "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E,
+                     "mean_entries_per_tile": round(E / max(T, 1), 1)}
+        else:
+            ab = alg_bytes(P, V, Rc, X, T, M, F, D_S, stats["sort_passes"])
+            extra = {"pipeline": "classic (reference stage order)", "reference_pairs_R": Rc, "R_over_P": round(Rc / max(P, 1), 2)}
         frame_bytes = sum(ab.values()) + frame.deform_bytes
         if stages_all is None:
             stages_all = stages
@@ -254,22 +343,25 @@ def main():
         dom_ms = stages[dom][0]                   # HIP events on the launch stream, over the timed region
         achieved = ab.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         fps = args.steps * world / elapsed
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4)}
+        roof.update(pmc_annotations(dom, args.config, use_fs and v2))
+        if v2 and dom in ("render_fwd", "render_bwd"):
+            roof["pixel_entry_evals_per_s"] = round(extra["blended_entries"] * 256 / (dom_ms * 1e-3), 1)
         result = {
             "metric": "fwd+bwd frames/s",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, 1 camera/GPU/step" % (
+            "config": dict({"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, 1 camera/GPU/step" % (
                 args.config, P, W, H, cfg["sh_degree"], cfg["n_objects"], ", flow+semantic outputs" if use_fs else ""),
-                "P": P, "P_visible": V, "num_rendered": R, "R_over_P": round(R / max(P, 1), 2), "tiles": T,
-                "deformation": frame.deform_desc,
+                "P": P, "P_visible": V, "tiles": T, "deformation": frame.deform_desc,
                 "parallelism": "dp%d (camera-parallel, RCCL gradient all-reduce)" % world if world > 1 else "single GPU",
                 "alg_bytes_per_frame": int(frame_bytes),
-                "frame_hbm_frac_of_8TBs": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4)},
-            "stages_ms": {k: round(v[0], 4) for k, v in stages_all.items()},    # from the warm-up steps (all stages timed)
+                "frame_hbm_frac_of_8TBs": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4)}, **extra),
+            "roofline": roof,
+            "stages_ms": {k: round(v[0], 4) for k, v in stages_all.items()},    # all stages timed: from the last warm-up steps
         }
         if world == 1 and not args.no_cpu_baseline:
             if isinstance(frame, DeformFrame):

@@ -182,6 +182,7 @@ typedef struct adgs_frame_stats {
 	int32_t sort_bits;
 	int32_t sort_passes;
 	int32_t reserved;
+	int64_t fine_pairs;       /* v2: sum over Gaussians of the fine tiles of their shrunk rectangle (bound of the blended pairs) */
 } adgs_frame_stats;
 void adgs_get_frame_stats(adgs_frame_stats* out);
 
