@@ -71,13 +71,14 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		// v2: every output row is written here, so the caller does not have to zero-fill them
 		if (a.gacc) {
 			a.out_mean2D[3 * (size_t)idx] = 0.f; a.out_mean2D[3 * (size_t)idx + 1] = 0.f; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
-			*reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
-			a.out_opacity[idx] = 0.f; a.out_depth[idx] = 0.f;
-			a.out_color[3 * (size_t)idx] = 0.f; a.out_color[3 * (size_t)idx + 1] = 0.f; a.out_color[3 * (size_t)idx + 2] = 0.f;
+			// out_conic / out_color / out_depth / dL_dcov3D are intermediates of the reference's ABI: NULL = not wanted
+			if (a.out_conic) *reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+			a.out_opacity[idx] = 0.f; if (a.out_depth) a.out_depth[idx] = 0.f;
+			if (a.out_color) { a.out_color[3 * (size_t)idx] = 0.f; a.out_color[3 * (size_t)idx + 1] = 0.f; a.out_color[3 * (size_t)idx + 2] = 0.f; }
 			if (a.out_flow) { a.out_flow[3 * (size_t)idx] = 0.f; a.out_flow[3 * (size_t)idx + 1] = 0.f; a.out_flow[3 * (size_t)idx + 2] = 0.f; }
 			if (a.out_sem && a.D_S == 1) a.out_sem[idx] = 0.f;
 			a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f;
-			for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+			if (a.dL_dcov3D) for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
 			if (raw) {
 				const bool is_obj = idx >= a.sh_src.Ns;
 				const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
@@ -120,10 +121,10 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		dcon_x = -0.5f * op * u0.w; dcon_y = -0.5f * op * u1.x; dcon_z = -0.5f * op * u1.y;
 		gcol[0] = u1.z; gcol[1] = u1.w; gcol[2] = u2.x; gd = u2.y;
 		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
-		*reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
+		if (a.out_conic) *reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
 		a.out_opacity[idx] = u0.x;
-		a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2];
-		a.out_depth[idx] = gd;
+		if (a.out_color) { a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2]; }
+		if (a.out_depth) a.out_depth[idx] = gd;
 		if (a.out_flow) { a.out_flow[3 * (size_t)idx] = u2.z; a.out_flow[3 * (size_t)idx + 1] = u2.w; a.out_flow[3 * (size_t)idx + 2] = u3.x; }
 		if (a.out_sem && a.D_S == 1) a.out_sem[idx] = u3.y;
 	} else {
@@ -168,8 +169,10 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 #pragma unroll
 		for (int i = 0; i < 6; i++) dcov[i] = 0.f;
 	}
+	if (a.dL_dcov3D) {
 #pragma unroll
-	for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+		for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+	}
 
 	const float tv0 = T.v[0][0] * Vrk.v[0][0] + T.v[0][1] * Vrk.v[0][1] + T.v[0][2] * Vrk.v[0][2];
 	const float tv1 = T.v[0][0] * Vrk.v[1][0] + T.v[0][1] * Vrk.v[1][1] + T.v[0][2] * Vrk.v[1][2];

@@ -227,8 +227,10 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     has_flow = flow_points.size(0) != 0 and dL_dout_flow is not None and dL_dout_flow.numel() != 0
     has_sem = D_S > 0 and dL_dout_semantic is not None and dL_dout_semantic.numel() != 0
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = e(P, 3), e(P, 3), e(P, NUM_CHANNELS), e(P, 1)
-    dL_dconic, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations = e(P, 2, 2), e(P, 1), e(P, 6), e(P, 3), e(P, 4)
+    dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales, dL_drotations = e(P, 3), e(P, 3), e(P, 1), e(P, 3), e(P, 4)
+    # dL_dconic / dL_dcolors / dL_ddepths / dL_dcov3D are intermediates of the reference's backward (consumed inside the fused
+    # preprocess backward here): not materialised on this path (NULL = not wanted, include/adgs_rasterizer.h)
+    dL_dcolors = dL_ddepths = dL_dconic = dL_dcov3D = None
     dL_dflow_points = e(P, FLOW_CHANNELS) if has_flow else torch.zeros((P, FLOW_CHANNELS), dtype=torch.float32, device=dev)
     dL_dsemantic = e(P, D_S) if has_sem else torch.zeros((P, D_S), dtype=torch.float32, device=dev)
     need = list(sh_needs_grad)

@@ -73,7 +73,10 @@ int adgs_raster_forward(
 
 /* CudaRasterizer::Rasterizer::backward  (RAST/cuda_rasterizer/rasterizer.h:64-103,
  * rasterizer_impl.cu:356-476).  All dL_* outputs must be zero-initialised by the
- * caller (RAST/rasterize_points.cu:195-206).  Returns 0. */
+ * caller (RAST/rasterize_points.cu:195-206) unless adgs_raster_needs_zero_init() says
+ * otherwise.  In that (default, v2) pipeline dL_dconic, dL_dcolor, dL_ddepth and dL_dcov3D
+ * -- intermediates of the reference that never leave its C++ layer except as the
+ * gradients of colors_precomp / cov3D_precomp -- may be NULL (not written).  Returns 0. */
 int adgs_raster_backward(
 	int P, int D, int M, int R, int D_S,
 	const float* background,
