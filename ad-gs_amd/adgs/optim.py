@@ -1,0 +1,82 @@
+"""Fused Adam step on the HIP path.
+
+Drop-in for the `torch.optim.Adam(l, lr=0.0, eps=1e-15)` the reference builds in
+GaussianModel.training_setup (scene/gaussian_model.py:346-372) and steps at train.py:163-167:
+same constructor arguments for what the reference uses, same `param_groups` (so the learning-rate
+schedulers that write `group['lr']` keep working) and the same per-parameter state keys
+(`step`, `exp_avg`, `exp_avg_sq`), which the densification code reads and rewrites
+(scene/gaussian_model.py:413-459, 545-600: cat / prune of the optimizer state).
+
+All groups are updated by ONE kernel launch (adgs_adam_step, include/adgs_optim.h); parameters
+without a gradient are skipped exactly like torch does.  There is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MAX_GROUPS = 32
+
+
+class AdamGroup(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_int32)]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise ValueError("FusedAdam implements the configuration the reference uses: no weight decay, no amsgrad")
+        if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad=False):
+        """One Adam step over every parameter that has a gradient.  zero_grad=True also zeroes the gradients in the same
+        pass (the reference calls optimizer.zero_grad(set_to_none=True) right after, train.py:165)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        batches = {}       # (device, betas, eps) -> list of AdamGroup
+        keep = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32:
+                    raise RuntimeError("FusedAdam: parameters must be fp32 tensors on a HIP device; there is no CPU path")
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)          # same state layout as torch.optim.Adam
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                if p.numel() == 0:
+                    continue
+                if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+                ag = AdamGroup(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
+                               int(st["step"]))
+                keep.append(g)
+                batches.setdefault((p.device, float(b1), float(b2), float(group["eps"])), []).append((ag, p, g))
+        lib = _lib.lib()
+        for (dev, b1, b2, eps), items in batches.items():
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for i in range(0, len(items), MAX_GROUPS):
+                    chunk = items[i:i + MAX_GROUPS]
+                    arr = (AdamGroup * len(chunk))(*[c[0] for c in chunk])
+                    _lib.check(lib.adgs_adam_step(arr, len(chunk), b1, b2, eps, int(bool(zero_grad)), stream), "adgs_adam_step")
+            for _, p, g in items:
+                if zero_grad and g is not p.grad:
+                    p.grad.zero_()          # the kernel zeroed the contiguous copy
+        return loss

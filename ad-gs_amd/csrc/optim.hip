@@ -1,0 +1,99 @@
+// Fused multi-tensor Adam for gfx950: every parameter group of the model in one launch, one pass
+// over (p, g, m, v) -- 16 B read + 12 B written per parameter (+4 B when the gradient is zeroed),
+// the HBM-streaming floor of the update.  Reference: torch.optim.Adam as configured at
+// scene/gaussian_model.py:370 (eps = 1e-15, no weight decay), stepped at train.py:163-167.
+#include "common.h"
+#include "../../include/adgs_optim.h"
+#include <cmath>
+
+namespace adgs {
+namespace {
+
+constexpr int AB = 256;                 // threads per block
+constexpr int AV = 4;                   // elements per thread per iteration (one 16-byte access per array)
+constexpr int AI = 4;                   // iterations per thread
+constexpr int ATILE = AB * AV * AI;     // elements per block
+
+struct AdamTable {
+	adgs_adam_group g[ADGS_ADAM_MAX_GROUPS];
+	uint32_t first_block[ADGS_ADAM_MAX_GROUPS + 1];     // group i owns blocks [first_block[i], first_block[i+1])
+	float step_size[ADGS_ADAM_MAX_GROUPS];               // lr / (1 - beta1^t)
+	float inv_bc2_sqrt[ADGS_ADAM_MAX_GROUPS];            // 1 / sqrt(1 - beta2^t)
+	int n;
+	float beta1, beta2, eps;
+	int zero_grad;
+};
+
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
+	m = m + (1.f - beta1) * (g - m);                     // exp_avg.lerp_(grad, 1 - beta1)
+	v = beta2 * v + (1.f - beta2) * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+	const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+	p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
+	// which group does this block belong to (block-uniform binary search over <= 32 entries)
+	int lo = 0, hi = t.n;
+	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (blockIdx.x >= t.first_block[mid]) lo = mid; else hi = mid; }
+	const adgs_adam_group& G = t.g[lo];
+	const float step_size = t.step_size[lo], ibc2 = t.inv_bc2_sqrt[lo];
+	const int64_t base = (int64_t)(blockIdx.x - t.first_block[lo]) * ATILE;
+	const bool vec = ((reinterpret_cast<uintptr_t>(G.param) | reinterpret_cast<uintptr_t>(G.grad) | reinterpret_cast<uintptr_t>(G.exp_avg) |
+	                   reinterpret_cast<uintptr_t>(G.exp_avg_sq)) & 15) == 0;
+#pragma unroll
+	for (int it = 0; it < AI; it++) {
+		const int64_t i = base + ((int64_t)it * AB + threadIdx.x) * AV;
+		if (i >= G.numel) break;
+		if (vec && i + AV <= G.numel) {
+			float4 p = *reinterpret_cast<float4*>(G.param + i), g = *reinterpret_cast<const float4*>(G.grad + i);
+			float4 m = *reinterpret_cast<float4*>(G.exp_avg + i), v = *reinterpret_cast<float4*>(G.exp_avg_sq + i);
+			adam_update(p.x, m.x, v.x, g.x, t.beta1, t.beta2, t.eps, step_size, ibc2);
+			adam_update(p.y, m.y, v.y, g.y, t.beta1, t.beta2, t.eps, step_size, ibc2);
+			adam_update(p.z, m.z, v.z, g.z, t.beta1, t.beta2, t.eps, step_size, ibc2);
+			adam_update(p.w, m.w, v.w, g.w, t.beta1, t.beta2, t.eps, step_size, ibc2);
+			*reinterpret_cast<float4*>(G.param + i) = p;
+			*reinterpret_cast<float4*>(G.exp_avg + i) = m;
+			*reinterpret_cast<float4*>(G.exp_avg_sq + i) = v;
+			if (t.zero_grad) *reinterpret_cast<float4*>(G.grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+		} else {
+			for (int k = 0; k < AV && i + k < G.numel; k++) {
+				float p = G.param[i + k], m = G.exp_avg[i + k], v = G.exp_avg_sq[i + k];
+				adam_update(p, m, v, G.grad[i + k], t.beta1, t.beta2, t.eps, step_size, ibc2);
+				G.param[i + k] = p; G.exp_avg[i + k] = m; G.exp_avg_sq[i + k] = v;
+				if (t.zero_grad) G.grad[i + k] = 0.f;
+			}
+		}
+	}
+}
+
+} // namespace
+} // namespace adgs
+
+using namespace adgs;
+
+extern "C" int adgs_adam_step(const adgs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int zero_grad, void* stream_) {
+	if (n_groups <= 0) return 0;
+	if (!groups || n_groups > ADGS_ADAM_MAX_GROUPS) { set_error("adgs_adam_step: between 1 and 32 groups per call"); return -1; }
+	AdamTable t;
+	t.n = 0; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.zero_grad = zero_grad;
+	uint64_t blocks = 0;
+	for (int i = 0; i < n_groups; i++) {
+		const adgs_adam_group& g = groups[i];
+		if (g.numel <= 0) continue;
+		if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || g.step < 1) { set_error("adgs_adam_step: NULL pointer or step < 1 in a group"); return -1; }
+		t.g[t.n] = g;
+		t.first_block[t.n] = (uint32_t)blocks;
+		// the host forms the bias corrections in double like torch does (python floats), then rounds once
+		const double bc1 = 1.0 - std::pow((double)beta1, (double)g.step), bc2 = 1.0 - std::pow((double)beta2, (double)g.step);
+		t.step_size[t.n] = (float)((double)g.lr / bc1);
+		t.inv_bc2_sqrt[t.n] = (float)(1.0 / std::sqrt(bc2));
+		blocks += (uint64_t)((g.numel + ATILE - 1) / ATILE);
+		t.n++;
+	}
+	if (t.n == 0) return 0;
+	if (blocks > 0x7fffffffull) { set_error("adgs_adam_step: too many elements for one launch"); return -1; }
+	t.first_block[t.n] = (uint32_t)blocks;
+	hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(AB), 0, (hipStream_t)stream_, t);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}

@@ -1,0 +1,41 @@
+/*
+ * adgs_optim.h -- C ABI of the fused optimizer step (libadgs_hip.so).  SURVEY.md section 8(f) row 1.
+ *
+ * Replaces the torch.optim.Adam(l, lr=0.0, eps=1e-15) step over the 18 parameter groups of
+ * GaussianModel.training_setup (scene/gaussian_model.py:346-372, stepped at train.py:163-167):
+ * ONE launch updates every group (the reference's multi-kernel foreach implementation makes
+ * several passes over p, g, m, v), optionally zeroing the gradients in the same pass.
+ *
+ * Per element, identical to torch.optim.Adam without weight decay / amsgrad / maximize:
+ *   m = m + (1 - beta1) (g - m);   v = beta2 v + (1 - beta2) g g
+ *   p = p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * All pointers are device pointers to fp32; `step` is t (1-based) and may differ per group.
+ */
+#ifndef ADGS_OPTIM_H
+#define ADGS_OPTIM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADGS_ADAM_MAX_GROUPS 32
+
+typedef struct adgs_adam_group {
+	float* param;
+	float* grad;            /* read; zeroed when zero_grad != 0 */
+	float* exp_avg;
+	float* exp_avg_sq;
+	int64_t numel;
+	float lr;
+	int32_t step;           /* t of this parameter after the increment (>= 1) */
+} adgs_adam_group;
+
+/* n_groups <= ADGS_ADAM_MAX_GROUPS per call (call again for more).  Returns 0, or a negative
+ * code with adgs_last_error() set. */
+int adgs_adam_step(const adgs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("adgs_rasterizer.h", "adgs_testing.h", "adgs_deform.h"):
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
         p = os.path.join(ROOT, "include", h)
         if not os.path.exists(p):
             continue

@@ -1,0 +1,74 @@
+"""Fused Adam against the optimizer the reference actually uses: torch.optim.Adam(l, lr=0.0, eps=1e-15)
+(scene/gaussian_model.py:370), run on the CPU in float64 (tight bound) and float32 (same-precision sanity)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _groups(seed, dtype, device):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [((1000, 3), 0.0), ((1000, 1, 3), 2.5e-3), ((1000, 15, 3), 2.5e-3 / 20), ((1000, 1), 0.05), ((1000, 3), 5e-3), ((1000, 4), 1e-3),
+              ((257, 3, 18), 1.6e-4), ((257, 4, 6), 1e-3), ((7,), 1e-2), ((0, 3), 1e-2)]
+    ps = [torch.randn(*s, generator=g).to(dtype).to(device).requires_grad_(True) for s, _ in shapes]
+    return [{"params": [p], "lr": lr, "name": "g%d" % i} for i, (p, (_, lr)) in enumerate(zip(ps, shapes))]
+
+
+def _run(opt_cls, groups, dtype, device, steps, **kw):
+    opt = opt_cls(groups, lr=0.0, eps=1e-15, **kw)
+    g = torch.Generator().manual_seed(99)
+    for it in range(steps):
+        for gi, group in enumerate(opt.param_groups):
+            p = group["params"][0]
+            if gi == 3 and it % 2 == 1:
+                p.grad = None                      # a parameter without gradient is skipped (no state update)
+            else:
+                p.grad = (torch.randn(*p.shape, generator=g) * (10.0 ** (gi % 4 - 2))).to(dtype).to(device)
+            if gi == 4:
+                group["lr"] = 5e-3 * (0.9 ** it)   # schedulers write group['lr'] (train.py / update_learning_rate)
+        opt.step()
+    return opt
+
+
+@pytest.mark.parametrize("steps", [1, 7])
+def test_fused_adam_matches_torch_adam(steps):
+    from adgs.optim import FusedAdam
+    dev = torch.device("cuda")
+    fused = _run(FusedAdam, _groups(0, torch.float32, dev), torch.float32, dev, steps)
+    ref64 = _run(torch.optim.Adam, _groups(0, torch.float64, "cpu"), torch.float64, "cpu", steps)
+    ref32 = _run(torch.optim.Adam, _groups(0, torch.float32, "cpu"), torch.float32, "cpu", steps)
+    for gf, g64, g32 in zip(fused.param_groups, ref64.param_groups, ref32.param_groups):
+        pf, p64, p32 = gf["params"][0], g64["params"][0], g32["params"][0]
+        if pf.numel() == 0:
+            continue
+        a = pf.detach().cpu().double().numpy(); b = p64.detach().numpy(); c = p32.detach().double().numpy()
+        scale = max(np.abs(b).max(), 1e-30)
+        err, err32 = np.abs(a - b).max() / scale, np.abs(c - b).max() / scale
+        assert err <= max(3e-6, 4 * err32), (gf["name"], err, err32)
+        sf, s64 = fused.state[pf], ref64.state[p64]
+        assert float(sf["step"]) == float(s64["step"])
+        for k in ("exp_avg", "exp_avg_sq"):
+            x, y = sf[k].cpu().double().numpy(), s64[k].numpy()
+            np.testing.assert_allclose(x, y, rtol=2e-5, atol=2e-6 * max(np.abs(y).max(), 1e-30), err_msg=gf["name"] + k)
+
+
+def test_fused_adam_zero_grad_and_state_keys():
+    from adgs.optim import FusedAdam
+    dev = torch.device("cuda")
+    p = torch.randn(1001, 5, device=dev, requires_grad=True)
+    q = torch.randn(33, device=dev, requires_grad=True)
+    opt = FusedAdam([{"params": [p], "lr": 1e-2, "name": "p"}, {"params": [q], "lr": 0.0, "name": "q"}], lr=0.0, eps=1e-15)
+    p.grad, q.grad = torch.randn_like(p), torch.randn_like(q)
+    q0 = q.detach().clone()
+    opt.step(zero_grad=True)
+    assert float(p.grad.abs().max()) == 0.0 and float(q.grad.abs().max()) == 0.0
+    assert torch.equal(q.detach(), q0)                               # lr = 0 leaves the parameter untouched, but the moments move
+    st = opt.state[q]
+    assert set(st.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st["exp_avg"].abs().max()) > 0
+    sd = opt.state_dict()                                            # torch.optim.Optimizer plumbing (checkpointing) works
+    opt.load_state_dict(sd)
+    cpu_p = torch.zeros(3, requires_grad=True)
+    cpu_p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError):                                # no CPU fallback
+        FusedAdam([cpu_p], lr=1e-3).step()
