@@ -1,0 +1,155 @@
+// Fused L1 + SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward and backward for gfx950.
+// Reference: utils/loss_utils.py:20-68 (called at train.py:79-80).  One 16x16 output tile per workgroup:
+// the 26x26 input halo of both images is staged in LDS, the separable window runs as a horizontal pass
+// (into LDS) and a vertical pass (registers).  HBM-streaming: forward reads 8 B and writes 12 B per pixel,
+// backward reads 20 B and writes 4 B.
+#include "common.h"
+#include "../../include/adgs_loss.h"
+
+namespace adgs {
+namespace {
+
+constexpr int TS = 16;                    // output tile edge
+constexpr int WR = 5;                     // window radius (11 taps)
+constexpr int HS = TS + 2 * WR;           // halo edge (26)
+constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+
+// gaussian(11, 1.5) of utils/loss_utils.py:26-28: exp(-(x-5)^2 / (2 sigma^2)) normalised by the sum (float32)
+struct Window { float g[2 * WR + 1]; };
+static Window make_window() {
+	Window w; float s = 0.f;
+	for (int x = 0; x < 2 * WR + 1; x++) { w.g[x] = (float)std::exp(-(double)((x - WR) * (x - WR)) / (2.0 * 1.5 * 1.5)); s += w.g[x]; }
+	for (int x = 0; x < 2 * WR + 1; x++) w.g[x] = w.g[x] / s;
+	return w;
+}
+
+__global__ void __launch_bounds__(TS * TS) l1_ssim_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Window win,
+	double* __restrict__ sums, float* __restrict__ d_mu1, float* __restrict__ d_e11, float* __restrict__ d_e12) {
+	__shared__ float s1[HS][HS + 1], s2[HS][HS + 1];
+	__shared__ float h[5][HS][TS + 1];              // horizontally filtered x1, x2, x1^2, x2^2, x1 x2
+	__shared__ double red[2][TS * TS / WAVE];
+	const int tx = threadIdx.x % TS, ty = threadIdx.x / TS, tid = threadIdx.x;
+	const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+	const size_t plane = (size_t)blockIdx.z * H * W;
+	for (int i = tid; i < HS * HS; i += TS * TS) {
+		const int ly = i / HS, lx = i - ly * HS, gy = y0 + ly - WR, gx = x0 + lx - WR;
+		const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+		s1[ly][lx] = in ? img[plane + (size_t)gy * W + gx] : 0.f;      // zero padding (F.conv2d padding=5)
+		s2[ly][lx] = in ? gt[plane + (size_t)gy * W + gx] : 0.f;
+	}
+	__syncthreads();
+	for (int i = tid; i < HS * TS; i += TS * TS) {
+		const int ly = i / TS, lx = i - ly * TS;
+		float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+		for (int k = 0; k < 2 * WR + 1; k++) {
+			const float w = win.g[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
+			a += w * u; b += w * v; aa += w * (u * u); bb += w * (v * v); ab += w * (u * v);
+		}
+		h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+	}
+	__syncthreads();
+	float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+	for (int k = 0; k < 2 * WR + 1; k++) {
+		const float w = win.g[k];
+		mu1 += w * h[0][ty + k][tx]; mu2 += w * h[1][ty + k][tx]; e11 += w * h[2][ty + k][tx]; e22 += w * h[3][ty + k][tx]; e12 += w * h[4][ty + k][tx];
+	}
+	const int gx = x0 + tx, gy = y0 + ty;
+	const bool in = gx < W && gy < H;
+	double l1 = 0.0, sm = 0.0;
+	if (in) {
+		const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+		const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
+		const float A1 = 2.f * mu12 + C1, A2 = 2.f * sg12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = sg1 + sg2 + C2;
+		const float D = B1 * B2, inv = 1.f / D;
+		sm = (double)((A1 * A2) * inv);
+		l1 = (double)fabsf(s1[ty + WR][tx + WR] - s2[ty + WR][tx + WR]);
+		if (d_mu1) {
+			const size_t o = plane + (size_t)gy * W + gx;
+			// partial derivatives of the map w.r.t. the window means mu1, E[x1^2], E[x1 x2] (mu2, E[x2^2] belong to gt)
+			const float num = A1 * A2;
+			const float dnum = 2.f * mu2 * A2 - 2.f * mu2 * A1;           // dA1 = 2 mu2, dA2 = -2 mu2
+			const float dden = 2.f * mu1 * B2 - 2.f * mu1 * B1;           // dB1 = 2 mu1, dB2 = -2 mu1
+			d_mu1[o] = (dnum * D - num * dden) * (inv * inv);
+			d_e11[o] = -num * inv / B2;                                   // dB2 = 1
+			d_e12[o] = 2.f * A1 * inv;                                    // dA2 = 2
+		}
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) { l1 += __shfl_xor(l1, off, WAVE); sm += __shfl_xor(sm, off, WAVE); }
+	if ((tid & (WAVE - 1)) == 0) { red[0][tid / WAVE] = l1; red[1][tid / WAVE] = sm; }
+	__syncthreads();
+	if (tid < 2) {
+		double t = 0.0;
+		for (int w = 0; w < TS * TS / WAVE; w++) t += red[tid][w];
+		atomicAdd(sums + tid, t);
+	}
+}
+
+__global__ void __launch_bounds__(TS * TS) l1_ssim_bwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Window win,
+	const float* __restrict__ d_mu1, const float* __restrict__ d_e11, const float* __restrict__ d_e12,
+	const float* __restrict__ g_l1, const float* __restrict__ g_ssim, float inv_n, float* __restrict__ out) {
+	__shared__ float s[3][HS][HS + 1];
+	__shared__ float h[3][HS][TS + 1];
+	const int tx = threadIdx.x % TS, ty = threadIdx.x / TS, tid = threadIdx.x;
+	const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+	const size_t plane = (size_t)blockIdx.z * H * W;
+	for (int i = tid; i < HS * HS; i += TS * TS) {
+		const int ly = i / HS, lx = i - ly * HS, gy = y0 + ly - WR, gx = x0 + lx - WR;
+		const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;        // map pixels outside the image do not exist: contribute 0
+		const size_t o = plane + (size_t)gy * W + gx;
+		s[0][ly][lx] = in ? d_mu1[o] : 0.f; s[1][ly][lx] = in ? d_e11[o] : 0.f; s[2][ly][lx] = in ? d_e12[o] : 0.f;
+	}
+	__syncthreads();
+	for (int i = tid; i < HS * TS; i += TS * TS) {
+		const int ly = i / TS, lx = i - ly * TS;
+		float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+		for (int k = 0; k < 2 * WR + 1; k++) { const float w = win.g[k]; a += w * s[0][ly][lx + k]; b += w * s[1][ly][lx + k]; c += w * s[2][ly][lx + k]; }
+		h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
+	}
+	__syncthreads();
+	float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+	for (int k = 0; k < 2 * WR + 1; k++) { const float w = win.g[k]; a += w * h[0][ty + k][tx]; b += w * h[1][ty + k][tx]; c += w * h[2][ty + k][tx]; }
+	const int gx = x0 + tx, gy = y0 + ty;
+	if (gx >= W || gy >= H) return;
+	const size_t o = plane + (size_t)gy * W + gx;
+	const float x1 = img[o], x2 = gt[o];
+	const float gs = g_ssim ? g_ssim[0] : 0.f, gl = g_l1 ? g_l1[0] : 0.f;
+	const float dx = x1 - x2;
+	const float sgn = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f);             // torch.abs backward: sign(), 0 at 0
+	out[o] = gl * sgn * inv_n + gs * inv_n * (a + 2.f * x1 * b + x2 * c);
+}
+
+} // namespace
+} // namespace adgs
+
+using namespace adgs;
+
+extern "C" int adgs_l1_ssim_forward(int planes, int H, int W, const float* image, const float* gt, double* sums,
+	float* d_mu1, float* d_e11, float* d_e12, void* stream) {
+	if (planes <= 0 || H <= 0 || W <= 0) return 0;
+	if (!image || !gt || !sums) { set_error("adgs_l1_ssim_forward: NULL image / gt / sums"); return -1; }
+	if ((d_mu1 != nullptr) != (d_e11 != nullptr) || (d_mu1 != nullptr) != (d_e12 != nullptr)) { set_error("adgs_l1_ssim_forward: pass all three derivative maps or none"); return -1; }
+	if (planes > 65535) { set_error("adgs_l1_ssim_forward: more than 65535 planes"); return -1; }
+	static const Window win = make_window();
+	const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+	hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(TS * TS), 0, (hipStream_t)stream, H, W, image, gt, win, sums, d_mu1, d_e11, d_e12);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int adgs_l1_ssim_backward(int planes, int H, int W, const float* image, const float* gt,
+	const float* d_mu1, const float* d_e11, const float* d_e12, const float* g_l1, const float* g_ssim, float* dL_dimage, void* stream) {
+	if (planes <= 0 || H <= 0 || W <= 0) return 0;
+	if (!image || !gt || !d_mu1 || !d_e11 || !d_e12 || !dL_dimage) { set_error("adgs_l1_ssim_backward: NULL pointer"); return -1; }
+	if (planes > 65535) { set_error("adgs_l1_ssim_backward: more than 65535 planes"); return -1; }
+	static const Window win = make_window();
+	const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+	const float inv_n = (float)(1.0 / ((double)planes * H * W));
+	hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(TS * TS), 0, (hipStream_t)stream, H, W, image, gt, win, d_mu1, d_e11, d_e12, g_l1, g_ssim, inv_n, dL_dimage);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}

@@ -1,0 +1,50 @@
+"""CPU restatement (NumPy, float64 or float32) of utils/loss_utils.py:20-68: l1_loss and ssim
+(11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2), plus the hand-derived
+gradient of both means w.r.t. the first image.
+
+TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench cpu baseline).  Pinned against the reference's own
+Python (imported in this container, tests/golden/make_loss_golden.py -> tests/golden/loss_golden.npz:
+values and reference-autograd gradients).
+"""
+import numpy as np
+
+
+def gaussian_window(window_size=11, sigma=1.5, dtype=np.float32):
+    """loss_utils.py:26-28: python-float exp, float32 tensor, divided by its float32 sum."""
+    g = np.array([np.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)], dtype=np.float32)
+    return (g / g.sum(dtype=np.float32)).astype(dtype)
+
+
+def _conv(x, w2):
+    """Depthwise 'same' correlation with zero padding (F.conv2d(x, window, padding=5, groups=C)); x [..., H, W]."""
+    k = w2.shape[0]; r = k // 2
+    H, W = x.shape[-2:]
+    xp = np.zeros(x.shape[:-2] + (H + 2 * r, W + 2 * r), dtype=x.dtype)
+    xp[..., r:r + H, r:r + W] = x
+    out = np.zeros_like(x)
+    for i in range(k):
+        for j in range(k):
+            out += w2[i, j] * xp[..., i:i + H, j:j + W]
+    return out
+
+
+def l1_ssim(img1, img2, dtype=np.float64):
+    """Returns (l1, ssim, d l1 / d img1, d ssim / d img1)."""
+    x1, x2 = np.asarray(img1, dtype), np.asarray(img2, dtype)
+    g = gaussian_window(dtype=np.float32)
+    w2 = np.outer(g, g).astype(np.float32).astype(dtype)          # _1D_window.mm(_1D_window.t()).float()
+    C1, C2 = dtype(0.01 ** 2), dtype(0.03 ** 2)
+    mu1, mu2 = _conv(x1, w2), _conv(x2, w2)
+    e11, e22, e12 = _conv(x1 * x1, w2), _conv(x2 * x2, w2), _conv(x1 * x2, w2)
+    s1, s2, s12 = e11 - mu1 * mu1, e22 - mu2 * mu2, e12 - mu1 * mu2
+    A1, A2, B1, B2 = 2 * mu1 * mu2 + C1, 2 * s12 + C2, mu1 * mu1 + mu2 * mu2 + C1, s1 + s2 + C2
+    m = (A1 * A2) / (B1 * B2)
+    n = x1.size
+    # partials of the map w.r.t. mu1, E[x1^2], E[x1 x2] (the other two window means belong to the constant image)
+    num, den = A1 * A2, B1 * B2
+    d_mu1 = ((2 * mu2 * A2 - 2 * mu2 * A1) * den - num * (2 * mu1 * B2 - 2 * mu1 * B1)) / (den * den)
+    d_e11 = -num / (B1 * B2 * B2)
+    d_e12 = 2 * A1 / den
+    g_ssim = (_conv(d_mu1, w2) + 2 * x1 * _conv(d_e11, w2) + x2 * _conv(d_e12, w2)) / n       # window is symmetric
+    g_l1 = np.sign(x1 - x2) / n
+    return np.abs(x1 - x2).mean(), m.mean(), g_l1, g_ssim
