@@ -12,6 +12,8 @@ import torch
 
 from . import _lib
 
+SLOTS = 256        # ADGS_LOSS_SLOTS
+
 
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -29,14 +31,14 @@ class _L1SSIM(torch.autograd.Function):
         planes = img.numel() // (H * W) if H * W else 0
         n = img.numel()
         need = ctx.needs_input_grad[0]
-        sums = torch.zeros(2, dtype=torch.float64, device=img.device)
+        sums = torch.zeros(SLOTS, 2, dtype=torch.float64, device=img.device)      # spread atomics (include/adgs_loss.h)
         maps = [torch.empty_like(img) for _ in range(3)] if need else [None] * 3
         if n:
             with torch.cuda.device(img.device):
                 _lib.check(_lib.lib().adgs_l1_ssim_forward(planes, H, W, img.data_ptr(), ref.data_ptr(), sums.data_ptr(),
                                                            *[m.data_ptr() if m is not None else None for m in maps], _stream(img.device)),
                            "adgs_l1_ssim_forward")
-        means = (sums / max(n, 1)).float()
+        means = (sums.sum(0) / max(n, 1)).float()
         if need:
             ctx.save_for_backward(img, ref, *maps)
         ctx.dims = (planes, H, W)

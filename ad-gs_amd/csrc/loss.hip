@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(TS * TS) l1_ssim_fwd_kernel(int H, int W, cons
 	if (tid < 2) {
 		double t = 0.0;
 		for (int w = 0; w < TS * TS / WAVE; w++) t += red[tid][w];
-		atomicAdd(sums + tid, t);
+		const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+		atomicAdd(sums + 2 * (b % ADGS_LOSS_SLOTS) + tid, t);
 	}
 }
 

@@ -18,8 +18,11 @@
 extern "C" {
 #endif
 
-/* sums[0] += sum |image - gt|, sums[1] += sum ssim_map  (device doubles, zero-initialised by the caller; divide by
- * planes*H*W for the means).  d_mu1 / d_e11 / d_e12: planes*H*W floats each, or all NULL for a forward without backward. */
+/* sums: ADGS_LOSS_SLOTS x 2 device doubles, zero-initialised by the caller.  Workgroup b adds its partial sums
+ * (sum |image - gt|, sum ssim_map) into row b % ADGS_LOSS_SLOTS -- atomics on ONE address would serialise in the L2;
+ * the caller adds the rows up and divides by planes*H*W for the two means.
+ * d_mu1 / d_e11 / d_e12: planes*H*W floats each, or all NULL for a forward without backward. */
+#define ADGS_LOSS_SLOTS 256
 int adgs_l1_ssim_forward(int planes, int H, int W, const float* image, const float* gt, double* sums,
 	float* d_mu1, float* d_e11, float* d_e12, void* stream);
 
