@@ -48,6 +48,9 @@ SIGNATURES = {
     "adgs_func_eval_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     "adgs_deform_forward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_deform_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    # include/adgs_envmap.h
+    "adgs_envmap_forward": (c_i, [c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "adgs_envmap_backward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     # include/adgs_loss.h
     "adgs_l1_ssim_forward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_l1_ssim_backward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -1,0 +1,108 @@
+// Environment-map background for gfx950: scene/env.py:11-76 in one kernel per direction.
+// One thread per pixel; the ray / angle arithmetic is fp32 in the reference's order (the sample position is
+// sensitive: 1 ulp of the ray is ~5e-4 texel on an 8192^2 map), bilinear weights as ATen's grid_sampler forms them.
+// Forward: 4*C gathered texels in, C floats out per pixel.  Backward: 4*C fp32 atomics per pixel into the map gradient.
+#include "common.h"
+#include "../../include/adgs_envmap.h"
+#include <cmath>
+
+namespace adgs {
+namespace {
+
+constexpr int MAXC = 8;
+struct EnvCam { float inv_f, half_w, half_h; float R[9]; int H, W, Hm, Wm, C; };
+
+struct Taps { int x0, y0; float w[4]; bool ok[4]; };      // nw, ne, sw, se
+
+__device__ __forceinline__ Taps env_taps(const EnvCam& a, int px, int py) {
+	// K^-1 [x, y, 1] with K = [[f,0,W/2],[0,f,H/2],[0,0,1]]  (env.py:11-27), then F.normalize (eps 1e-12)
+	// evaluated as (x - W/2) / f: exactly 0 at the principal point, where the azimuth is singular when the camera looks
+	// along the map's pole (a fused k*x + c would leave a rounding residue there and an arbitrary azimuth)
+	float vx = ((float)px - a.half_w) * a.inv_f, vy = ((float)py - a.half_h) * a.inv_f, vz = 1.0f;
+	float inv = 1.f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+	vx *= inv; vy *= inv; vz *= inv;
+	// world_view_transform[:3,:3] @ ray (env.py:61), normalised again in get_env_color (env.py:70)
+	float rx = a.R[0] * vx + a.R[1] * vy + a.R[2] * vz, ry = a.R[3] * vx + a.R[4] * vy + a.R[5] * vz, rz = a.R[6] * vx + a.R[7] * vy + a.R[8] * vz;
+	inv = 1.f / fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+	rx *= inv; ry *= inv; rz *= inv;
+	const float az = atan2f(ry, rx), el = atan2f(rz, hypotf(rx, ry));          // graphics_utils.py:95-100
+	const float gx = az * 0.31830988618379067f, gy = el * 0.6366197723675814f; // * (1/pi, 2/pi)
+	// grid_sample, align_corners=True: ((g + 1) / 2) * (size - 1); bilinear with zero padding
+	const float ix = ((gx + 1.f) / 2.f) * (float)(a.Wm - 1), iy = ((gy + 1.f) / 2.f) * (float)(a.Hm - 1);
+	const float fx0 = floorf(ix), fy0 = floorf(iy);
+	Taps t;
+	t.x0 = (int)fx0; t.y0 = (int)fy0;
+	const float x1 = fx0 + 1.f, y1 = fy0 + 1.f;
+	t.w[0] = (x1 - ix) * (y1 - iy); t.w[1] = (ix - fx0) * (y1 - iy); t.w[2] = (x1 - ix) * (iy - fy0); t.w[3] = (ix - fx0) * (iy - fy0);
+	const bool xa = t.x0 >= 0 && t.x0 < a.Wm, xb = t.x0 + 1 >= 0 && t.x0 + 1 < a.Wm, ya = t.y0 >= 0 && t.y0 < a.Hm, yb = t.y0 + 1 >= 0 && t.y0 + 1 < a.Hm;
+	t.ok[0] = xa && ya; t.ok[1] = xb && ya; t.ok[2] = xa && yb; t.ok[3] = xb && yb;
+	return t;
+}
+
+__global__ void __launch_bounds__(256) envmap_fwd_kernel(EnvCam a, const float* __restrict__ grid, float* __restrict__ bg) {
+	const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (px >= a.W || py >= a.H) return;
+	const Taps t = env_taps(a, px, py);
+	const size_t plane = (size_t)a.Hm * a.Wm, o = (size_t)py * a.W + px;
+	const size_t base = (size_t)t.y0 * a.Wm + t.x0;
+	for (int c = 0; c < a.C; c++) {
+		const float* g = grid + c * plane;
+		float v = 0.f;
+		if (t.ok[0]) v += g[base] * t.w[0];
+		if (t.ok[1]) v += g[base + 1] * t.w[1];
+		if (t.ok[2]) v += g[base + a.Wm] * t.w[2];
+		if (t.ok[3]) v += g[base + a.Wm + 1] * t.w[3];
+		bg[(size_t)c * a.H * a.W + o] = 1.f / (1.f + expf(-v));
+	}
+}
+
+__global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* __restrict__ bg, const float* __restrict__ g_bg, float* __restrict__ g_grid) {
+	const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (px >= a.W || py >= a.H) return;
+	const Taps t = env_taps(a, px, py);
+	const size_t plane = (size_t)a.Hm * a.Wm, o = (size_t)py * a.W + px;
+	const size_t base = (size_t)t.y0 * a.Wm + t.x0;
+	for (int c = 0; c < a.C; c++) {
+		const float b = bg[(size_t)c * a.H * a.W + o];
+		const float gr = g_bg[(size_t)c * a.H * a.W + o] * (b * (1.f - b));
+		float* g = g_grid + c * plane;
+		if (t.ok[0]) atomicAdd(g + base, gr * t.w[0]);
+		if (t.ok[1]) atomicAdd(g + base + 1, gr * t.w[1]);
+		if (t.ok[2]) atomicAdd(g + base + a.Wm, gr * t.w[2]);
+		if (t.ok[3]) atomicAdd(g + base + a.Wm + 1, gr * t.w[3]);
+	}
+}
+
+static int make_cam(EnvCam& a, int C, int Hm, int Wm, int H, int W, float focal, const float* R9, const char* who) {
+	if (C <= 0 || C > MAXC || Hm < 2 || Wm < 2 || !(focal > 0.f) || !R9) { set_error(std::string(who) + ": bad arguments (1..8 channels, map >= 2x2, focal > 0, R9 != NULL)"); return -1; }
+	a.inv_f = (float)(1.0 / (double)focal); a.half_w = (float)W * 0.5f; a.half_h = (float)H * 0.5f;
+	for (int i = 0; i < 9; i++) a.R[i] = R9[i];
+	a.H = H; a.W = W; a.Hm = Hm; a.Wm = Wm; a.C = C;
+	return 0;
+}
+
+} // namespace
+} // namespace adgs
+
+using namespace adgs;
+
+extern "C" int adgs_envmap_forward(int C, int Hm, int Wm, const float* grid_map, int H, int W, float focal, const float* R9, float* background, void* stream) {
+	if (H <= 0 || W <= 0) return 0;
+	EnvCam a;
+	if (make_cam(a, C, Hm, Wm, H, W, focal, R9, "adgs_envmap_forward") != 0) return -1;
+	if (!grid_map || !background) { set_error("adgs_envmap_forward: NULL grid_map / background"); return -1; }
+	hipLaunchKernelGGL(envmap_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, grid_map, background);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int adgs_envmap_backward(int C, int Hm, int Wm, int H, int W, float focal, const float* R9,
+	const float* background, const float* dL_dbackground, float* dL_dgrid_map, void* stream) {
+	if (H <= 0 || W <= 0) return 0;
+	EnvCam a;
+	if (make_cam(a, C, Hm, Wm, H, W, focal, R9, "adgs_envmap_backward") != 0) return -1;
+	if (!background || !dL_dbackground || !dL_dgrid_map) { set_error("adgs_envmap_backward: NULL pointer"); return -1; }
+	hipLaunchKernelGGL(envmap_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, background, dL_dbackground, dL_dgrid_map);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
