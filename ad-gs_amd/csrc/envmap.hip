@@ -56,11 +56,61 @@ __global__ void __launch_bounds__(256) envmap_fwd_kernel(EnvCam a, const float* 
 	}
 }
 
+// Backward: neighbouring pixels hit the same texels (an 8192^2 map under a 1920-pixel, 50-degree view has ~1.7 pixels
+// per texel and every pixel touches a 2x2 footprint), so the 64x4-pixel workgroup first accumulates its contributions
+// in an LDS image of its texel bounding box (ds_add_f32) and flushes each touched texel with ONE global atomic --
+// about an order of magnitude fewer L2 atomics than one per (pixel, corner, channel).  Workgroups whose footprint
+// does not fit (the azimuth seam, the poles) fall back to direct atomics.
+constexpr int TEXCAP = 2048;            // texels of the LDS footprint image (x MAXC channels would be 64 KiB: sized per launch)
+
 __global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* __restrict__ bg, const float* __restrict__ g_bg, float* __restrict__ g_grid) {
-	const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
-	if (px >= a.W || py >= a.H) return;
-	const Taps t = env_taps(a, px, py);
+	extern __shared__ float s_acc[];                     // [C][TEXCAP]
+	__shared__ int s_box[4];                             // minx, miny, maxx, maxy over the valid corners of the block
+	const int tid = threadIdx.x;
+	const int px = blockIdx.x * 64 + (tid & 63), py = blockIdx.y * 4 + (tid >> 6);
+	const bool valid = px < a.W && py < a.H;
+	if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff; }
+	__syncthreads();
+	Taps t;
+	if (valid) {
+		t = env_taps(a, px, py);
+		const int lox = max(t.x0, 0), hix = min(t.x0 + 1, a.Wm - 1), loy = max(t.y0, 0), hiy = min(t.y0 + 1, a.Hm - 1);
+		if (lox <= hix && loy <= hiy) { atomicMin(&s_box[0], lox); atomicMin(&s_box[1], loy); atomicMax(&s_box[2], hix); atomicMax(&s_box[3], hiy); }
+	}
+	__syncthreads();
+	const int minx = s_box[0], miny = s_box[1];
+	const int fw = s_box[2] - minx + 1, fh = s_box[3] - miny + 1;
+	if (fw <= 0 || fh <= 0) return;                      // nothing inside the map
+	const bool in_lds = (long long)fw * fh <= TEXCAP;    // block-uniform
 	const size_t plane = (size_t)a.Hm * a.Wm, o = (size_t)py * a.W + px;
+	if (in_lds) {
+		const int ntex = fw * fh;
+		for (int i = tid; i < a.C * TEXCAP; i += 256) if (i % TEXCAP < ntex) s_acc[i] = 0.f;
+		__syncthreads();
+		if (valid) {
+			const int lx = t.x0 - minx, ly = t.y0 - miny;
+			for (int c = 0; c < a.C; c++) {
+				const float b = bg[(size_t)c * a.H * a.W + o];
+				const float gr = g_bg[(size_t)c * a.H * a.W + o] * (b * (1.f - b));
+				float* acc = s_acc + c * TEXCAP;
+				if (t.ok[0]) atomicAdd(acc + ly * fw + lx, gr * t.w[0]);
+				if (t.ok[1]) atomicAdd(acc + ly * fw + lx + 1, gr * t.w[1]);
+				if (t.ok[2]) atomicAdd(acc + (ly + 1) * fw + lx, gr * t.w[2]);
+				if (t.ok[3]) atomicAdd(acc + (ly + 1) * fw + lx + 1, gr * t.w[3]);
+			}
+		}
+		__syncthreads();
+		for (int i = tid; i < ntex; i += 256) {
+			const int ly = i / fw, lx = i - ly * fw;
+			const size_t dst = (size_t)(miny + ly) * a.Wm + (minx + lx);
+			for (int c = 0; c < a.C; c++) {
+				const float v = s_acc[c * TEXCAP + i];
+				if (v != 0.f) atomicAdd(g_grid + c * plane + dst, v);
+			}
+		}
+		return;
+	}
+	if (!valid) return;
 	const size_t base = (size_t)t.y0 * a.Wm + t.x0;
 	for (int c = 0; c < a.C; c++) {
 		const float b = bg[(size_t)c * a.H * a.W + o];
@@ -102,7 +152,7 @@ extern "C" int adgs_envmap_backward(int C, int Hm, int Wm, int H, int W, float f
 	EnvCam a;
 	if (make_cam(a, C, Hm, Wm, H, W, focal, R9, "adgs_envmap_backward") != 0) return -1;
 	if (!background || !dL_dbackground || !dL_dgrid_map) { set_error("adgs_envmap_backward: NULL pointer"); return -1; }
-	hipLaunchKernelGGL(envmap_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, background, dL_dbackground, dL_dgrid_map);
+	hipLaunchKernelGGL(envmap_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), (size_t)C * TEXCAP * sizeof(float), (hipStream_t)stream, a, background, dL_dbackground, dL_dgrid_map);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
