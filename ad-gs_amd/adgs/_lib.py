@@ -55,6 +55,7 @@ SIGNATURES = {
     "adgs_l1_ssim_forward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_l1_ssim_backward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     # include/adgs_optim.h
+    "adgs_densification_stats": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_adam_step": (c_i, [c_p, c_i, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_p]),
     "adgs_deform_forward_flow": (c_i, [c_p] * 10),
     "adgs_deform_backward_flow": (c_i, [c_p] * 15),

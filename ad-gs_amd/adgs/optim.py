@@ -80,3 +80,21 @@ class FusedAdam(torch.optim.Optimizer):
                 if zero_grad and g is not p.grad:
                     p.grad.zero_()          # the kernel zeroed the contiguous copy
         return loss
+
+
+def add_densification_stats(xyz_gradient_accum, denom, max_radii2D, viewspace_grad, radii):
+    """train.py:148-150 + GaussianModel.add_densification_stats (scene/gaussian_model.py:863-867) in one kernel, in place:
+    for every Gaussian with radii > 0: max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += ||viewspace_grad[:, :2]||;
+    denom += 1.  No boolean-mask indexing, no host synchronisation.  `max_radii2D` may be None."""
+    for t in (xyz_gradient_accum, denom, viewspace_grad, radii):
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("add_densification_stats: contiguous tensors on a HIP device are required; there is no CPU path")
+    if radii.dtype != torch.int32 or viewspace_grad.dtype != torch.float32 or viewspace_grad.shape[-1] != 3:
+        raise ValueError("add_densification_stats: radii must be int32 [N], viewspace_grad fp32 [N,3]")
+    N = radii.numel()
+    if xyz_gradient_accum.numel() != N or denom.numel() != N or (max_radii2D is not None and max_radii2D.numel() != N):
+        raise ValueError("add_densification_stats: accumulator sizes do not match the number of Gaussians")
+    with torch.cuda.device(radii.device):
+        _lib.check(_lib.lib().adgs_densification_stats(N, radii.data_ptr(), viewspace_grad.data_ptr(), xyz_gradient_accum.data_ptr(), denom.data_ptr(),
+                                                       max_radii2D.data_ptr() if max_radii2D is not None else None,
+                                                       ctypes.c_void_p(torch.cuda.current_stream(radii.device).cuda_stream)), "adgs_densification_stats")

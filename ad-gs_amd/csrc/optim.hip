@@ -66,10 +66,31 @@ __global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
 	}
 }
 
+__global__ void __launch_bounds__(256) densification_stats_kernel(int N, const int32_t* __restrict__ radii, const float* __restrict__ g,
+	float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ max_r) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= N) return;
+	const int r = radii[i];
+	if (r <= 0) return;                                   // visibility_filter = radii > 0 (gaussian_renderer/__init__.py:101)
+	const float gx = g[3 * (size_t)i], gy = g[3 * (size_t)i + 1];
+	accum[i] += sqrtf(gx * gx + gy * gy);                 // torch.norm(grad[:, :2], dim=-1)
+	denom[i] += 1.f;
+	if (max_r) max_r[i] = fmaxf(max_r[i], (float)r);
+}
+
 } // namespace
 } // namespace adgs
 
 using namespace adgs;
+
+extern "C" int adgs_densification_stats(int N, const int32_t* radii, const float* viewspace_grad, float* xyz_gradient_accum, float* denom,
+	float* max_radii2D, void* stream) {
+	if (N <= 0) return 0;
+	if (!radii || !viewspace_grad || !xyz_gradient_accum || !denom) { set_error("adgs_densification_stats: NULL pointer"); return -1; }
+	hipLaunchKernelGGL(densification_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, radii, viewspace_grad, xyz_gradient_accum, denom, max_radii2D);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
 
 extern "C" int adgs_adam_step(const adgs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int zero_grad, void* stream_) {
 	if (n_groups <= 0) return 0;

@@ -35,6 +35,16 @@ typedef struct adgs_adam_group {
  * code with adgs_last_error() set. */
 int adgs_adam_step(const adgs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int zero_grad, void* stream);
 
+/* Per-iteration densification statistics (train.py:148-150):
+ *   gaussians.max_radii2D[vis] = max(gaussians.max_radii2D[vis], radii[vis])
+ *   GaussianModel.add_densification_stats (scene/gaussian_model.py:863-867):
+ *     xyz_gradient_accum[vis] += ||viewspace_points.grad[vis, :2]||,  denom[vis] += 1
+ * with vis = radii > 0, as ONE elementwise kernel (the reference's boolean-mask indexing costs a nonzero() with a host
+ * synchronisation plus ~10 kernels).  viewspace_grad is [N,3] (the rasterizer's dL/dmeans2D), the three accumulators
+ * are fp32 [N] / [N,1]. */
+int adgs_densification_stats(int N, const int32_t* radii, const float* viewspace_grad, float* xyz_gradient_accum, float* denom,
+	float* max_radii2D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

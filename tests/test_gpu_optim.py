@@ -72,3 +72,22 @@ def test_fused_adam_zero_grad_and_state_keys():
     cpu_p.grad = torch.ones(3)
     with pytest.raises(RuntimeError):                                # no CPU fallback
         FusedAdam([cpu_p], lr=1e-3).step()
+
+
+def test_densification_stats_match_the_reference_lines():
+    """train.py:148-150 and scene/gaussian_model.py:863-867 restated with the reference's own torch expressions on the CPU."""
+    from adgs.optim import add_densification_stats
+    g = torch.Generator().manual_seed(5)
+    N = 100003
+    radii = torch.randint(-1, 40, (N,), generator=g, dtype=torch.int32).clamp_min(0)
+    grad = torch.randn(N, 3, generator=g)
+    accum, denom, maxr = torch.rand(N, 1, generator=g), torch.randint(0, 5, (N, 1), generator=g).float(), torch.randint(0, 30, (N,), generator=g).float()
+    d_acc, d_den, d_max = accum.cuda(), denom.cuda(), maxr.cuda()
+    for _ in range(2):
+        add_densification_stats(d_acc, d_den, d_max, grad.cuda(), radii.cuda())
+        vis = radii > 0
+        maxr[vis] = torch.max(maxr[vis], radii[vis])
+        accum[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)
+        denom[vis] += 1
+    assert torch.equal(d_den.cpu(), denom) and torch.equal(d_max.cpu(), maxr)
+    assert torch.allclose(d_acc.cpu(), accum, rtol=1e-6, atol=1e-7)
