@@ -17,5 +17,13 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + w
     rd = 2.0 * fetch.get(k, 0.0) * 1024; wr = write.get(k, 0.0) * 1024
     out[k] = {"launches_sampled": int(cf.get(k, cw.get(k, 0))), "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
+if len(sys.argv) > 4:
+    # per-frame total: all launches of the run (bench.py with ADGS_BENCH_SKIP_STATS=1) divided by the number of frames
+    # = launches of the blend backward (exactly one per frame)
+    frames = max(cf.get(next(k for k in cf if "render_bwd_v2_kernel" in k), 1), 1)
+    tot = sum((2.0 * fetch.get(k, 0.0) * cf.get(k, 0) + write.get(k, 0.0) * cw.get(k, 0)) * 1024 for k in set(fetch) | set(write))
+    json.dump({"frames": int(frames), "hbm_bytes_per_frame": int(tot / frames),
+               "note": "sum over ALL kernels of the run of 2*FETCH_SIZE + WRITE_SIZE (KiB), divided by the number of frames"}, open(sys.argv[4], "w"), indent=1)
+    print("frames", frames, "HBM bytes per frame %.1f MB" % (tot / frames / 1e6))
 for k, v in list(out.items())[:24]:
     print(f"{k[:70]:70s} rd {v['read_bytes_per_launch']/1e6:9.1f} MB  wr {v['write_bytes_per_launch']/1e6:9.1f} MB")
