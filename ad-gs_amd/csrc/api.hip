@@ -135,6 +135,15 @@ static bool use_v2(int D_S) {
 	return D_S <= 1;
 }
 
+// Pixels per lane of the v2 blend kernels: one wave per 16x16 tile (4 px/lane) when that already gives the chip enough
+// waves; 16x8 half tiles (2 px/lane) for small images (KITTI-sized frames have < 2 waves per SIMD otherwise).
+// ADGS_V2_PPL=2|4 overrides; forward and backward of a frame must see the same value.
+static int v2_pixels_per_lane(size_t ntiles16) {
+	const int e = env_int("ADGS_V2_PPL", 0);
+	if (e == 2 || e == 4) return e;
+	return ntiles16 < 4096 ? 2 : 4;
+}
+
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
 enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = { "preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
@@ -241,11 +250,14 @@ static int raster_forward_impl(const ShSource* sh_src,
 		size_t gb = 0, ib = 0;
 		GeomStateV2::carve(nullptr, P, &gb);
 		char* gch = geometryBuffer(geometryUser, gb);
-		ImgStateV2::carve(nullptr, npix, ntiles, ncells, &ib);
+		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
+		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);                    // rows of wave tiles
+		const size_t wtiles = (size_t)gx * wgy;
+		ImgStateV2::carve(nullptr, npix, wtiles, ncells, &ib);
 		char* ich = imageBuffer(imageUser, ib);
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
 		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr);
-		ImgStateV2 img = ImgStateV2::carve(ich, npix, ntiles, ncells, nullptr);
+		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
 
 		PreprocessArgs pa;
 		pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -290,10 +302,10 @@ static int raster_forward_impl(const ShSource* sh_src,
 		BinStateV2 bin;
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
-			BinStateV2::carve(nullptr, cells, fine, ntiles, &bb);
+			BinStateV2::carve(nullptr, cells, fine * sub, wtiles, &bb);        // a Gaussian can enter both halves of a tile
 			char* bch = binningBuffer(binningUser, bb);
 			if (!bch) { set_error("binning allocator returned NULL"); return -1; }
-			bin = BinStateV2::carve(bch, cells, fine, ntiles, nullptr);
+			bin = BinStateV2::carve(bch, cells, fine * sub, wtiles, nullptr);
 			if (cells == 0) {
 				ADGS_HIP_CHECK(hipMemsetAsync(img.cell_ranges, 0, ncells * sizeof(uint2), stream));
 				ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream));
@@ -331,7 +343,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		}
 		RenderV2FwdArgs ra;
 		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
-		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
+		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
 		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
 		ra.bg = background;
@@ -439,12 +451,15 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		const int cell_tiles = std::max(1, env_int("ADGS_CELL_TILES", 8));
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr);
-		ImgStateV2 img = ImgStateV2::carve(img_buffer, npix, ntiles, ncells, nullptr);
-		BinStateV2 bin = BinStateV2::carve(binning_buffer, 0, 0, ntiles, nullptr);     // only pool_cursor / pool are used
+		const int ppl = v2_pixels_per_lane(ntiles);
+		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);
+		const size_t wtiles = (size_t)gx * wgy;
+		ImgStateV2 img = ImgStateV2::carve(img_buffer, npix, wtiles, ncells, nullptr);
+		BinStateV2 bin = BinStateV2::carve(binning_buffer, 0, 0, wtiles, nullptr);     // only pool_cursor / pool are used
 		const bool has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		RenderV2BwdArgs ra;
 		ra.splats = geom.splats; ra.pool = bin.pool; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
-		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = gy;
+		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl;
 		ra.bg = background; ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 		ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dpix_flow = dL_dpix_flow; ra.dL_dpix_sem = dL_dpix_semantic;
 		ra.dL_dpix_opacity = grad_img_opacity;

@@ -90,7 +90,8 @@ int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, c
 
 struct RenderV2FwdArgs {
 	const uint2* cell_ranges; const uint32_t* cell_list; const FilterRec* rects; const Splat* splats;
-	int W, H, gx, gy, cell_tiles, cgx;
+	int W, H, gx, gy, cell_tiles, cgx;      // gy: rows of WAVE tiles (16 x 4*ppl pixels), not of 16x16 tiles
+	int ppl;                                // pixels per lane: 4 or 2 (v2_pixels_per_lane)
 	bool has_color, has_flow, has_sem;
 	const float* bg;
 	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed;
@@ -101,7 +102,7 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
 
 struct RenderV2BwdArgs {
 	const Splat* splats; const uint32_t* pool; const uint32_t* tile_last_chunk; const uint32_t* tile_consumed;
-	int W, H, gx, gy;
+	int W, H, gx, gy, ppl;                  // gy: rows of WAVE tiles, as in the forward
 	const float* bg; const float* final_T; const uint32_t* n_contrib;
 	const float* dL_dpix; const float* dL_dpix_depth; const float* dL_dpix_flow; const float* dL_dpix_sem; const float* dL_dpix_opacity;
 	bool do_color, do_flow, do_sem, do_depth, do_opacity;

@@ -30,11 +30,9 @@ namespace {
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
-constexpr int PPL = 4;                    // pixels per lane
+// pixels per lane: 4 (one wave = one 16x16 tile) or, for small images that would leave the chip idle, 2 (one wave = a 16x8
+// half tile: twice the waves, a shorter dependent chain per wave); PPL is a template parameter of both blend kernels
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
-#ifndef ADGS_BWD_WAVES
-#define ADGS_BWD_WAVES 3          // waves per SIMD the backward's register allocation is sized for
-#endif
 
 #ifndef ADGS_PRECISE_EXP
 #define ADGS_EXP(x) __expf(x)      // v_exp_f32(x * log2 e): ~3e-7 relative, far inside the 1e-4 budget
@@ -45,14 +43,14 @@ constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
 // Can Gaussian `f` reach alpha >= 1/255 on any pixel centre of tile (tx,ty)?  Exact minimum of the
 // quadratic form d^T Q d over the tile's pixel-centre rectangle [16tx,16tx+15]x[16ty,16ty+15]
 // (a lower bound of the minimum over its integer pixels), compared with tau (which carries the slack).
-__device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float4 f1, uint32_t tx, uint32_t ty) {
+__device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float4 f1, uint32_t tx, uint32_t ty16, uint32_t row0, int rows) {
 	const uint32_t rmin = __float_as_uint(f1.z), rmax = __float_as_uint(f1.w);
 	const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, maxx = rmax & 0xFFFFu, maxy = rmax >> 16;
-	if (!(tx >= minx && tx < maxx && ty >= miny && ty < maxy)) return false;
+	if (!(tx >= minx && tx < maxx && ty16 >= miny && ty16 < maxy)) return false;
 	const float A = f0.z, B = f0.w, C = f1.x, tau = f1.y;
 	// rectangle relative to the mean: d = pixel - mean (the form is symmetric in the sign of d)
 	const float x0 = (float)(tx * TILE_X) - f0.x, x1 = x0 + (float)(TILE_X - 1);
-	const float y0 = (float)(ty * TILE_Y) - f0.y, y1 = y0 + (float)(TILE_Y - 1);
+	const float y0 = (float)row0 - f0.y, y1 = y0 + (float)(rows - 1);      // the wave's own rows (a 16x16 tile or a half of one)
 	if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;      // mean inside the tile
 	// minimum over the four edges: fix one coordinate, clamp the unconstrained minimiser of the other
 	// (any point of an edge bounds its minimum from above and the form is flat at the minimiser, so the
@@ -108,16 +106,19 @@ __device__ __forceinline__ void eval_pair(const EntryGeom& g, v2f pyv, v2f& dy, 
 	eval_pixel(g, pyv.y, dy.y, pw.y, G.y, al.y);
 }
 
+template <int PPL>
 __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
+	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
 	const int lane = threadIdx.x;
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
-	const uint32_t cell = (ty / a.cell_tiles) * a.cgx + (tx / a.cell_tiles);
+	const uint32_t ty16 = ty / SUB;                           // row of the 16x16 tile grid the binning works on
+	const uint32_t cell = (ty16 / a.cell_tiles) * a.cgx + (tx / a.cell_tiles);
 	const uint2 range = a.cell_ranges[cell];
 	const uint32_t px = tx * TILE_X + (lane & 15);
-	const uint32_t py0 = ty * TILE_Y + (lane >> 4);
+	const uint32_t py0 = ty * ROWS + (lane >> 4);
 	const float pxf = (float)px;
 	bool inside[PPL], done[PPL];
 	constexpr int PAIRS = PPL / 2;            // pixel pair h = rows (lane>>4) + 8h, + 8h + 4
@@ -140,7 +141,10 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 
 	while (true) {
-		const bool all_done = __all(done[0] && done[1] && done[2] && done[3]);
+		bool mine_done = true;
+#pragma unroll
+		for (int k = 0; k < PPL; k++) mine_done = mine_done && done[k];
+		const bool all_done = __all(mine_done);
 		if (all_done) break;
 		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction)
 		while (qcount < WAVE && pos < range.y) {
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 				// both halves of the record are requested together (otherwise the compiler sinks the first
 				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
 				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
-				pass = tile_may_contribute(f0, f1, tx, ty);
+				pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
 			}
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
@@ -336,8 +340,9 @@ __device__ __forceinline__ float wave_sum14_transposed(float x0, float x1, float
 
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
 // the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
-template <int OCC, bool FULL>
-__global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArgs a) {
+template <int PPL, bool FULL>
+__global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) {
+	constexpr int ROWS = 4 * PPL;
 	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
 	__shared__ float4 s_splat[(WAVE + 1) * 4];      // entry j lives in row j+1 (row 0: prefetch padding)
 	__shared__ uint32_t s_id[WAVE];
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(WAVE, OCC) render_bwd_v2_kernel(RenderV2BwdArg
 	const uint32_t tile = blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	const uint32_t px = tx * TILE_X + (lane & 15);
-	const uint32_t py0 = ty * TILE_Y + (lane >> 4);
+	const uint32_t py0 = ty * ROWS + (lane >> 4);
 	const float pxf = (float)px;
 	const size_t HW = (size_t)a.H * a.W;
 	bool inside[PPL];
@@ -481,23 +486,21 @@ __global__ void __launch_bounds__(256) reset_tiles_kernel(uint32_t T, uint32_t* 
 } // namespace
 
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
-	const uint32_t T = (uint32_t)a.gx * a.gy;
-	hipLaunchKernelGGL(render_fwd_v2_kernel, dim3(T), dim3(WAVE), 0, stream, a);
+	const uint32_t T = (uint32_t)a.gx * a.gy;           // a.gy counts WAVE tiles (16 x 4*ppl pixels)
+	if (a.ppl == 2) hipLaunchKernelGGL(render_fwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
+	else hipLaunchKernelGGL(render_fwd_v2_kernel<4>, dim3(T), dim3(WAVE), 0, stream, a);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;
-	static const int occ = [] { const char* v = getenv("ADGS_BWD_OCC"); return (v && *v) ? atoi(v) : ADGS_BWD_WAVES; }();
 	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity;
-	if (full) {
-		if (occ >= 4) hipLaunchKernelGGL((render_bwd_v2_kernel<4, true>), dim3(T), dim3(WAVE), 0, stream, a);
-		else if (occ == 3) hipLaunchKernelGGL((render_bwd_v2_kernel<3, true>), dim3(T), dim3(WAVE), 0, stream, a);
-		else hipLaunchKernelGGL((render_bwd_v2_kernel<2, true>), dim3(T), dim3(WAVE), 0, stream, a);
-	} else {
-		if (occ >= 4) hipLaunchKernelGGL((render_bwd_v2_kernel<4, false>), dim3(T), dim3(WAVE), 0, stream, a);
-		else if (occ == 3) hipLaunchKernelGGL((render_bwd_v2_kernel<3, false>), dim3(T), dim3(WAVE), 0, stream, a);
+	if (a.ppl == 2) {
+		if (full) hipLaunchKernelGGL((render_bwd_v2_kernel<2, true>), dim3(T), dim3(WAVE), 0, stream, a);
 		else hipLaunchKernelGGL((render_bwd_v2_kernel<2, false>), dim3(T), dim3(WAVE), 0, stream, a);
+	} else {
+		if (full) hipLaunchKernelGGL((render_bwd_v2_kernel<4, true>), dim3(T), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL((render_bwd_v2_kernel<4, false>), dim3(T), dim3(WAVE), 0, stream, a);
 	}
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
