@@ -8,6 +8,7 @@ the HIP kernels (adgs_func_eval_* / adgs_deform_* in include/adgs_deform.h) that
 per-Gaussian work.  Both directions are hand-written HIP; there is no PyTorch fallback.
 """
 import ctypes
+import functools
 import math
 
 import numpy as np
@@ -83,7 +84,14 @@ def _bspline_basis(u, order):
 
 
 def make_func_eval(v, order_args, n_params=None):
-    """Host-side evaluation of every basis value of get_func_result(v, ., order_args)."""
+    """Host-side evaluation of every basis value of get_func_result(v, ., order_args).  Memoised: a training run revisits
+    the same camera time stamps, and the evaluation is a handful of tiny CPU torch ops that have no place in the per-frame
+    launch path (the returned struct is shared and must not be modified)."""
+    return _make_func_eval_cached(float(v), tuple(int(a) for a in order_args), None if n_params is None else int(n_params))
+
+
+@functools.lru_cache(maxsize=8192)
+def _make_func_eval_cached(v, order_args, n_params):
     oa = list(order_args)
     f = FuncEval()
     f.n_params = int(get_param_num(oa) if n_params is None else n_params)
