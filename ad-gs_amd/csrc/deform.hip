@@ -200,11 +200,10 @@ struct DeformArgs {
 };
 
 template <bool OBJ, int NQ>
-__global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a) {
-	extern __shared__ float s_rows[];
-	const int tid = threadIdx.x, B = blockDim.x, base = a.n_begin + blockIdx.x * B;
+__device__ __forceinline__ void deform_fwd_body(const DeformArgs& a, int blk, int n_begin, int n_end, float* __restrict__ s_rows) {
+	const int tid = threadIdx.x, B = blockDim.x, base = n_begin + blk * B;
 	const int Ns = a.p.Ns;
-	const int count = min(B, a.n_end - base);
+	const int count = min(B, n_end - base);
 	const int n = base + tid;
 	const bool valid = tid < count;
 	const bool is_obj = OBJ && valid && n >= Ns;
@@ -411,12 +410,10 @@ struct DeformBwdArgs {
 // range (no object member: none of the staging / spline code is instantiated, so the kernel stays light).
 constexpr int DP_XYZ = 1, DP_ROT = 2, DP_REST = 4;
 template <int PARTS, bool OBJ, int NQ>
-__global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
-	extern __shared__ float s_rows[];
-	__shared__ float s_bg[6][256 / WAVE];
-	const int tid = threadIdx.x, B = blockDim.x, base = a.n_begin + blockIdx.x * B;
+__device__ __forceinline__ void deform_bwd_body(const DeformBwdArgs& a, int blk, int n_begin, int n_end, float* __restrict__ s_rows, float (*s_bg)[256 / WAVE]) {
+	const int tid = threadIdx.x, B = blockDim.x, base = n_begin + blk * B;
 	const int Ns = a.p.Ns;
-	const int count = min(B, a.n_end - base);
+	const int count = min(B, n_end - base);
 	const int n = base + tid;
 	const bool valid = tid < count;
 	const bool is_obj = OBJ && valid && n >= Ns;
@@ -575,6 +572,25 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a) {
 	}
 }
 
+// One launch per direction: the object Gaussians' blocks (splines: long dependent chains, few waves) come FIRST in the
+// grid and the streaming scene blocks fill the rest of the chip around them -- separate launches would run the
+// latency-bound object kernels on a mostly idle GPU.
+template <int NQ>
+__global__ void __launch_bounds__(256) deform_fwd_kernel(DeformArgs a, int nb_obj) {
+	extern __shared__ float s_rows[];
+	if ((int)blockIdx.x < nb_obj) deform_fwd_body<true, NQ>(a, blockIdx.x, a.p.Ns, a.p.Ns + a.p.No, s_rows);
+	else deform_fwd_body<false, 0>(a, blockIdx.x - nb_obj, 0, a.p.Ns, s_rows);
+}
+template <int NQ>
+__global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a, int nb_rot, int nb_xyz) {
+	extern __shared__ float s_rows[];
+	__shared__ float s_bg[6][256 / WAVE];
+	const int b = blockIdx.x;
+	if (b < nb_rot) deform_bwd_body<DP_ROT, true, NQ>(a, b, a.p.Ns, a.p.Ns + a.p.No, s_rows, s_bg);
+	else if (b < nb_rot + nb_xyz) deform_bwd_body<DP_XYZ | DP_REST, true, 0>(a, b - nb_rot, a.p.Ns, a.p.Ns + a.p.No, s_rows, s_bg);
+	else deform_bwd_body<DP_XYZ | DP_ROT | DP_REST, false, 0>(a, b - nb_rot - nb_xyz, 0, a.p.Ns, s_rows, s_bg);
+}
+
 static adgs_func_eval empty_func() { adgs_func_eval f; memset(&f, 0, sizeof(f)); f.quat_start = -1; return f; }
 static int check_func(const adgs_func_eval* f, const char* what) {
 	if (!f) return 0;
@@ -703,17 +719,13 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 		const int np_x = std::max(a.fx.n_params, a.fx2.n_params);
 		a.fx.n_params = a.fx2.n_params = np_x;
 		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
-		if (p->Ns > 0) {                     // scene range: nothing to stage
-			a.n_begin = 0; a.n_end = p->Ns;
-			hipLaunchKernelGGL((deform_fwd_kernel<false, 0>), dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
-			ADGS_HIP_CHECK(hipGetLastError());
-		}
-		if (p->No > 0) {
+		{
 			size_t lds = 0;
-			const int B = pick_block(std::max(a.stride_x, a.stride_r), &lds);
+			const int B = p->No > 0 ? pick_block(std::max(a.stride_x, a.stride_r), &lds) : 256;
 			if (lds > 64 * 1024) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
-			a.n_begin = p->Ns; a.n_end = N;
-#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_fwd_kernel<true, NQ>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a)
+			const int nb_obj = (p->No + B - 1) / B, nb_scene = (p->Ns + B - 1) / B;
+			a.n_begin = 0; a.n_end = N;
+#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_fwd_kernel<NQ>), dim3(nb_obj + nb_scene), dim3(B), lds, stream, a, nb_obj)
 			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
 #undef ADGS_CALL
 			ADGS_HIP_CHECK(hipGetLastError());
@@ -756,31 +768,22 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 		const int np_x = std::max(a.fx.n_params, a.fx2.n_params);
 		a.fx.n_params = a.fx2.n_params = np_x;
 		a.stride_x = (3 * np_x) | 1; a.stride_r = (4 * a.fr.n_params) | 1;
-		if (p->Ns > 0) {
-			a.n_begin = 0; a.n_end = p->Ns;
-			hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_ROT | DP_REST, false, 0>), dim3((p->Ns + 255) / 256), dim3(256), 0, stream, a);
-			ADGS_HIP_CHECK(hipGetLastError());
-		}
-		if (p->No > 0) {
-			// two launches: the spline backward needs a whole SIMD's registers per wave, the rest does not
-			a.n_begin = p->Ns; a.n_end = N;
-			if (dL_dxyz || dL_dflow_xyz || dL_dopacity || dL_dscales) {
-				size_t lds = 0;
-				const int B = pick_block(a.stride_x, &lds);
-				lds += 2 * (size_t)np_x * sizeof(float);            // dense basis rows of the two time stamps
-				if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
-				hipLaunchKernelGGL((deform_bwd_kernel<DP_XYZ | DP_REST, true, 0>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a);
-				ADGS_HIP_CHECK(hipGetLastError());
+		{
+			const bool want_rest = dL_dxyz || dL_dflow_xyz || dL_dopacity || dL_dscales;
+			size_t lds = 0;
+			int B = 256;
+			if (p->No > 0) {
+				B = pick_block(std::max(a.stride_x, 2 * a.stride_r), &lds);
+				lds = std::max(lds, (size_t)B * a.stride_x * sizeof(float) + 2 * (size_t)np_x * sizeof(float));     // + dense basis rows of the two time stamps
 			}
-			if (dL_drotation) {
-				size_t lds = 0;
-				const int B = pick_block(2 * a.stride_r, &lds);
-				if (lds > 64 * 1024) { set_error("adgs_deform_backward: rotation rows too large for the LDS staging buffer"); return -1; }
-#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_bwd_kernel<DP_ROT, true, NQ>), dim3((p->No + B - 1) / B), dim3(B), lds, stream, a)
-				ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
+			if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
+			const int nb_o = (p->No + B - 1) / B;
+			const int nb_rot = dL_drotation ? nb_o : 0, nb_xyz = want_rest ? nb_o : 0, nb_scene = (p->Ns + B - 1) / B;
+			a.n_begin = 0; a.n_end = N;
+#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_bwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz)
+			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
 #undef ADGS_CALL
-				ADGS_HIP_CHECK(hipGetLastError());
-			}
+			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}
 	if (dL_dshs) {
