@@ -305,6 +305,20 @@ def main():
             dp.allreduce_gradients(frame.parameters())
         frame.zero_grad()
 
+    # Settle phase (setup, not a measurement): a fresh process on a fresh box shows one-off stalls of 0.1-0.6 s in its first
+    # second (driver / allocator / clock ramp -- seen as a single 200+ ms step right after another GPU process exited).
+    # Windows of 20 untimed steps run until two consecutive windows agree within 10 % (at most ~3 s), then the contract's
+    # W warm-up steps and K timed steps follow unchanged.
+    if os.environ.get("ADGS_BENCH_SETTLE", "1") != "0":
+        t_end, prev_w, agree = time.perf_counter() + 3.0, None, 0
+        while time.perf_counter() < t_end and agree < 2:
+            t_w = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            w = time.perf_counter() - t_w
+            agree = agree + 1 if (prev_w is not None and abs(w - prev_w) <= 0.1 * min(w, prev_w)) else 0
+            prev_w = w
     # Stage breakdown (all stages timed with HIP events) on the last warm-up steps; the timed region below only keeps
     # the events around the dominant kernel, because every timed stage leaves a ~10 us bubble in the queue.
     stages_all, dom = None, None
