@@ -16,6 +16,7 @@ objects: "roofline" for the dominant kernel (algorithmic bytes per launch / HIP-
 time of that kernel) and "cpu_baseline" (the CPU oracle timed on the host cores).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -341,6 +342,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     prof.enable(True, stages=[dom] if dom else None)       # --warmup 0: no breakdown yet, time every stage
+    gc.collect(); gc.disable()                              # no collector pauses inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -349,6 +351,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     prof.enable(False)
     stages = prof.collect()
     if world > 1:
