@@ -210,7 +210,8 @@ class _DeformPkgFn(torch.autograd.Function):
         p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)), float(t)
         for n in _PTRS:
             setattr(p, n, _dp(named[n]))
-        fe = {k: make_func_eval(float(t), order_args[k], named[pn].shape[-1] if named[pn] is not None and named[pn].numel() else 0)
+        # n_params is the parameter tensor's last dimension even when it has no rows (a model without object Gaussians)
+        fe = {k: make_func_eval(float(t), order_args[k], named[pn].shape[-1] if named[pn] is not None and named[pn].dim() >= 1 else 0)
               for k, pn in (("xyz", "xyz_deform_param"), ("rotation", "rotation_deform_param"), ("shs", "shs_deform_param_scene"),
                             ("background", "background_deform_param"))}
         if flow_t is not None:

@@ -92,10 +92,11 @@ def test_fused_deformed_pkg_vs_reference_golden_and_autograd(tag):
                 close("%s grad %s t=%g" % (tag, name, t), got.cpu().numpy(), want.numpy(), tol=2e-4)
 
 
-def test_large_random_model_matches_numpy_oracle():
+@pytest.mark.parametrize("Ns,No", [(30000, 7000), (777, 0), (0, 333), (129, 127)])
+def test_large_random_model_matches_numpy_oracle(Ns, No):
+    """Also the degenerate splits: no object Gaussians, no scene Gaussians, a block straddling nothing (ranges are separate)."""
     from adgs.deform import get_deformed_pkg, get_deformed_xyz, get_param_num
     g = torch.Generator().manual_seed(0)
-    Ns, No = 30000, 7000
     oa = dict(xyz=[16, 5, 0, 6, 0, 0], rotation=[0, 0, 0, 0, 16, 5], shs=[0, 0, 0, 6, 0, 0], background=[16, 2, 0, 6, 0, 0])
     r = lambda *s: torch.randn(*s, generator=g)
     raw = dict(scene_xyz=r(Ns, 3) * 10, obj_xyz=r(No, 3) * 10, scene_shs_dc=r(Ns, 1, 3), obj_shs_dc=r(No, 1, 3),
@@ -118,6 +119,13 @@ def test_large_random_model_matches_numpy_oracle():
         for key in ("xyz", "rotation", "shs", "opacity", "scales"):
             close("%s t=%g" % (key, t), pkg[key].cpu().numpy(), ref[key])
         np.testing.assert_array_equal(get_deformed_xyz(m, t).cpu().numpy(), pkg["xyz"].cpu().numpy())
+    # and the backward runs on every split (gradients of the existing parameters are finite)
+    leaves = [getattr(m, a) for a in dir(m) if torch.is_tensor(getattr(m, a, None)) and getattr(m, a).numel() > 0 and a not in ("gs_time",)]
+    for p in leaves:
+        p.requires_grad_(True)
+    pkg = get_deformed_pkg(m, 0.4, flow_time=0.45)
+    sum((v * v).sum() for v in pkg.values() if torch.is_tensor(v) and v.numel()).backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in leaves)
 
 
 def test_render_entry_runs_on_fused_pkg():
