@@ -69,21 +69,10 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 	return best <= tau * 1.0005f + 1e-3f;
 }
 
-// Pixel pairs.  Measured on gfx950: v_pk_fma_f32 / v_pk_mul_f32 issue at half the rate of their scalar
-// counterparts (a SIMD already retires a wave64 v_fma_f32 in 2 cycles), so packed fp32 buys nothing here
-// and costs operand shuffles -- v2f is therefore a plain pair of floats and every op stays scalar
-// (this file is also built with -fno-slp-vectorize so the compiler does not re-pack them).
-struct v2f {
-	float x, y;
-	__device__ __forceinline__ v2f() {}
-	__device__ __forceinline__ explicit v2f(float s) : x(s), y(s) {}
-	__device__ __forceinline__ v2f(float a, float b) : x(a), y(b) {}
-};
-__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f(a.x * b.x, a.y * b.y); }
-__device__ __forceinline__ v2f& operator+=(v2f& a, v2f b) { a.x += b.x; a.y += b.y; return a; }
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return v2f(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
+// Measured on gfx950 and NOT used: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 issue at half the rate of their scalar
+// counterparts -- a SIMD already retires a wave64 v_fma_f32 in 2 cycles -- and cost operand shuffles; this file is built
+// with -fno-slp-vectorize so the compiler does not pack either), and branch-free predicated per-pixel code (the
+// wave-uniform per-strip branches below skip ~22 % of the strip work).
 
 // Per-entry, per-lane part of the Gaussian evaluation (the lane's 4 pixels share the column x):
 //   power = -0.5 (A dx^2 + C dy^2) - B dx dy = a0 + dy (b0 + c0 dy)
@@ -101,10 +90,6 @@ __device__ __forceinline__ void eval_pixel(const EntryGeom& g, float py, float& 
 	G = ADGS_EXP(pw);
 	al = fminf(ALPHA_MAX, g.op * G);
 }
-__device__ __forceinline__ void eval_pair(const EntryGeom& g, v2f pyv, v2f& dy, v2f& pw, v2f& G, v2f& al) {
-	eval_pixel(g, pyv.x, dy.x, pw.x, G.x, al.x);
-	eval_pixel(g, pyv.y, dy.y, pw.y, G.y, al.y);
-}
 
 template <int PPL>
 __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
@@ -121,21 +106,17 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	const uint32_t py0 = ty * ROWS + (lane >> 4);
 	const float pxf = (float)px;
 	bool inside[PPL], done[PPL];
-	constexpr int PAIRS = PPL / 2;            // pixel pair h = rows (lane>>4) + 8h, + 8h + 4
-	v2f pyv[PAIRS], T[PAIRS], C0[PAIRS], C1[PAIRS], C2[PAIRS], Dp[PAIRS], F0[PAIRS], F1[PAIRS], F2[PAIRS], S0[PAIRS];
+	float pyf[PPL], T[PPL], C0[PPL], C1[PPL], C2[PPL], Dp[PPL], F0[PPL], F1[PPL], F2[PPL], S0[PPL];
 	uint32_t last_contrib[PPL];
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		const uint32_t py = py0 + 4 * k;
+		pyf[k] = (float)py;
 		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
 		done[k] = !inside[k];
 		last_contrib[k] = 0;
-	}
-#pragma unroll
-	for (int h = 0; h < PAIRS; h++) {
-		pyv[h].x = (float)(py0 + 8 * h); pyv[h].y = (float)(py0 + 8 * h + 4);
-		T[h] = v2f(1.f);
-		C0[h] = C1[h] = C2[h] = Dp[h] = F0[h] = F1[h] = F2[h] = S0[h] = v2f(0.f);
+		T[k] = 1.f;
+		C0[k] = C1[k] = C2[k] = Dp[k] = F0[k] = F1[k] = F2[k] = S0[k] = 0.f;
 	}
 	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
@@ -196,32 +177,30 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			// prefetch the next entry's geometry while this one is evaluated (row n is padding, never used)
 			nq0 = s_splat[(j + 1) * 4 + 0]; nq1 = s_splat[(j + 1) * 4 + 1];
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
-			v2f alpha[PAIRS]; bool act[PPL]; bool any_act = false;
+			float alpha[PPL]; bool act[PPL]; bool any_act = false;
 #pragma unroll
-			for (int h = 0; h < PAIRS; h++) {
-				v2f dy, pw, G;
-				eval_pair(eg, pyv[h], dy, pw, G, alpha[h]);
-				act[2 * h] = !done[2 * h] && !(pw.x > 0.0f) && !(alpha[h].x < ALPHA_MIN);
-				act[2 * h + 1] = !done[2 * h + 1] && !(pw.y > 0.0f) && !(alpha[h].y < ALPHA_MIN);
-				any_act = any_act || act[2 * h] || act[2 * h + 1];
+			for (int k = 0; k < PPL; k++) {
+				float dy, pw, G;
+				eval_pixel(eg, pyf[k], dy, pw, G, alpha[k]);
+				act[k] = !done[k] && !(pw > 0.0f) && !(alpha[k] < ALPHA_MIN);
+				any_act = any_act || act[k];
 			}
 			if (!__any(any_act)) continue;
 			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
 			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview pad
 #pragma unroll
-			for (int h = 0; h < PAIRS; h++) {
-				const v2f test_T = T[h] * (v2f(1.f) - alpha[h]);
-				const bool stop_x = act[2 * h] && test_T.x < T_STOP, stop_y = act[2 * h + 1] && test_T.y < T_STOP;
-				const bool up_x = act[2 * h] && !stop_x, up_y = act[2 * h + 1] && !stop_y;
-				done[2 * h] = done[2 * h] || stop_x; done[2 * h + 1] = done[2 * h + 1] || stop_y;
-				v2f w = alpha[h] * T[h];
-				w.x = up_x ? w.x : 0.f; w.y = up_y ? w.y : 0.f;       // pixels that do not blend this entry add exactly 0
-				C0[h] = fma2(v2f(q1.z), w, C0[h]); C1[h] = fma2(v2f(q1.w), w, C1[h]); C2[h] = fma2(v2f(q2.x), w, C2[h]);
-				F0[h] = fma2(v2f(q2.z), w, F0[h]); F1[h] = fma2(v2f(q2.w), w, F1[h]); F2[h] = fma2(v2f(q3.x), w, F2[h]);
-				Dp[h] = fma2(v2f(q2.y), w, Dp[h]); S0[h] = fma2(v2f(q3.y), w, S0[h]);
-				T[h].x = up_x ? test_T.x : T[h].x; T[h].y = up_y ? test_T.y : T[h].y;
-				last_contrib[2 * h] = up_x ? consumed + j + 1 : last_contrib[2 * h];
-				last_contrib[2 * h + 1] = up_y ? consumed + j + 1 : last_contrib[2 * h + 1];
+			for (int k = 0; k < PPL; k++) {
+				if (!__any(act[k])) continue;           // wave-uniform: a 16x4 pixel strip the entry does not reach costs nothing
+				const float test_T = T[k] * (1.f - alpha[k]);
+				const bool stop = act[k] && test_T < T_STOP;
+				const bool up = act[k] && !stop;
+				done[k] = done[k] || stop;
+				const float w = up ? alpha[k] * T[k] : 0.f;   // pixels that do not blend this entry add exactly 0
+				C0[k] = fmaf(q1.z, w, C0[k]); C1[k] = fmaf(q1.w, w, C1[k]); C2[k] = fmaf(q2.x, w, C2[k]);
+				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
+				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
+				T[k] = up ? test_T : T[k];
+				last_contrib[k] = up ? consumed + j + 1 : last_contrib[k];
 			}
 		}
 		consumed += n;
@@ -231,23 +210,17 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		if (inside[k]) {
-			const int h = k >> 1;
-			const bool hi = k & 1;
 			const size_t pix_id = (size_t)a.W * (py0 + 4 * k) + px;
-			const float Tk = hi ? T[h].y : T[h].x;
-			a.final_T[pix_id] = (float)(1.0 - (double)Tk);
+			a.final_T[pix_id] = (float)(1.0 - (double)T[k]);
 			a.n_contrib[pix_id] = last_contrib[k];
 			if (a.has_color) {
-				a.out_color[0 * HW + pix_id] = (hi ? C0[h].y : C0[h].x) + Tk * a.bg[0];
-				a.out_color[1 * HW + pix_id] = (hi ? C1[h].y : C1[h].x) + Tk * a.bg[1];
-				a.out_color[2 * HW + pix_id] = (hi ? C2[h].y : C2[h].x) + Tk * a.bg[2];
+				a.out_color[0 * HW + pix_id] = C0[k] + T[k] * a.bg[0];
+				a.out_color[1 * HW + pix_id] = C1[k] + T[k] * a.bg[1];
+				a.out_color[2 * HW + pix_id] = C2[k] + T[k] * a.bg[2];
 			}
-			if (a.has_flow) {
-				a.out_flow[0 * HW + pix_id] = hi ? F0[h].y : F0[h].x; a.out_flow[1 * HW + pix_id] = hi ? F1[h].y : F1[h].x;
-				a.out_flow[2 * HW + pix_id] = hi ? F2[h].y : F2[h].x;
-			}
-			if (a.has_sem) a.out_semantic[pix_id] = hi ? S0[h].y : S0[h].x;
-			a.out_depth[pix_id] = hi ? Dp[h].y : Dp[h].x;
+			if (a.has_flow) { a.out_flow[0 * HW + pix_id] = F0[k]; a.out_flow[1 * HW + pix_id] = F1[k]; a.out_flow[2 * HW + pix_id] = F2[k]; }
+			if (a.has_sem) a.out_semantic[pix_id] = S0[k];
+			a.out_depth[pix_id] = Dp[k];
 		}
 	}
 }
