@@ -30,6 +30,7 @@ namespace {
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
+constexpr float PIXEL_DONE = 3.0e38f;      // row coordinate of a pixel that takes no further entries (forward): exp -> 0
 // pixels per lane: 4 (one wave = one 16x16 tile) or, for small images that would leave the chip idle, 2 (one wave = a 16x8
 // half tile: twice the waves, a shorter dependent chain per wave); PPL is a template parameter of both blend kernels
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
@@ -105,15 +106,14 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	const uint32_t px = tx * TILE_X + (lane & 15);
 	const uint32_t py0 = ty * ROWS + (lane >> 4);
 	const float pxf = (float)px;
-	bool inside[PPL], done[PPL];
+	bool inside[PPL];
 	float pyf[PPL], T[PPL], C0[PPL], C1[PPL], C2[PPL], Dp[PPL], F0[PPL], F1[PPL], F2[PPL], S0[PPL];
 	uint32_t last_contrib[PPL];
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
 		const uint32_t py = py0 + 4 * k;
-		pyf[k] = (float)py;
 		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
-		done[k] = !inside[k];
+		pyf[k] = inside[k] ? (float)py : PIXEL_DONE;
 		last_contrib[k] = 0;
 		T[k] = 1.f;
 		C0[k] = C1[k] = C2[k] = Dp[k] = F0[k] = F1[k] = F2[k] = S0[k] = 0.f;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	while (true) {
 		bool mine_done = true;
 #pragma unroll
-		for (int k = 0; k < PPL; k++) mine_done = mine_done && done[k];
+		for (int k = 0; k < PPL; k++) mine_done = mine_done && (pyf[k] == PIXEL_DONE);
 		const bool all_done = __all(mine_done);
 		if (all_done) break;
 		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction)
@@ -181,8 +181,9 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 #pragma unroll
 			for (int k = 0; k < PPL; k++) {
 				float dy, pw, G;
+				// a finished (or out-of-image) pixel sits at row 3e38: its exponent is -inf, alpha 0, so it needs no flag here
 				eval_pixel(eg, pyf[k], dy, pw, G, alpha[k]);
-				act[k] = !done[k] && !(pw > 0.0f) && !(alpha[k] < ALPHA_MIN);
+				act[k] = !(pw > 0.0f) && !(alpha[k] < ALPHA_MIN);
 				any_act = any_act || act[k];
 			}
 			if (!__any(any_act)) continue;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 				const float test_T = T[k] * (1.f - alpha[k]);
 				const bool stop = act[k] && test_T < T_STOP;
 				const bool up = act[k] && !stop;
-				done[k] = done[k] || stop;
+				pyf[k] = stop ? PIXEL_DONE : pyf[k];
 				const float w = up ? alpha[k] * T[k] : 0.f;   // pixels that do not blend this entry add exactly 0
 				C0[k] = fmaf(q1.z, w, C0[k]); C1[k] = fmaf(q1.w, w, C1[k]); C2[k] = fmaf(q2.x, w, C2[k]);
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
