@@ -170,12 +170,9 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		prev_chunk = chunk;
 		__syncthreads();
 		// ---- blend
-		float4 nq0 = s_splat[0], nq1 = s_splat[1];
 		for (uint32_t j = 0; j < n; j++) {
-			const float4 q0 = nq0;      // x y ca cb
-			const float4 q1 = nq1;      // cc op r g
-			// prefetch the next entry's geometry while this one is evaluated (row n is padding, never used)
-			nq0 = s_splat[(j + 1) * 4 + 0]; nq1 = s_splat[(j + 1) * 4 + 1];
+			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
+			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
 			float alpha[PPL]; bool act[PPL]; bool any_act = false;
 #pragma unroll
@@ -380,13 +377,10 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 				s_id[lane] = id;
 			}
 			__syncthreads();
-			float4 nq0 = s_splat[n * 4 + 0], nq1 = s_splat[n * 4 + 1];
 			for (int j = n - 1; j >= 0; j--) {
 				const int contributor = base + j;
-				const float4 q0 = nq0, q1 = nq1;
-				// prefetch the next (j-1) entry's geometry; rows are stored at index j+1, row 0 is padding
-				nq0 = s_splat[j * 4 + 0]; nq1 = s_splat[j * 4 + 1];
 				if (contributor >= max_contrib) continue;
+				const float4 q0 = s_splat[(j + 1) * 4 + 0], q1 = s_splat[(j + 1) * 4 + 1];
 				const float dx = q0.x - pxf;
 				const EntryGeom eg = entry_geom(q0, q1, dx);
 				float alpha[PPL], G[PPL], dy[PPL]; bool act[PPL]; bool any_act = false;
