@@ -40,6 +40,7 @@ SIGNATURES = {
     "adgs_get_frame_stats": (None, [c_p]),
     "adgs_raster_needs_zero_init": (c_i, [c_i]),
     "adgs_profile_enable": (None, [c_i]),
+    "adgs_profile_reserve": (c_i, [c_i]),
     "adgs_profile_num_stages": (c_i, []),
     "adgs_profile_stage_name": (ctypes.c_char_p, [c_i]),
     "adgs_profile_collect": (c_i, [c_p, c_p]),
@@ -117,6 +118,10 @@ class StageProfiler:
         self.names = [self.lib.adgs_profile_stage_name(i).decode() for i in range(self.n)]
         self.total = (ctypes.c_double * self.n)()
         self.count = (ctypes.c_int64 * self.n)()
+
+    def reserve(self, n_events):
+        """Pre-create HIP events (two per timed launch group and step)."""
+        return self.lib.adgs_profile_reserve(int(n_events))
 
     def enable(self, on=True, stages=None):
         """stages: iterable of stage names to time (default: all).  Every timed stage costs two event records per launch

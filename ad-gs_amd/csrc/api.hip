@@ -194,6 +194,14 @@ extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_
 extern "C" int adgs_raster_needs_zero_init(int D_S) { return use_v2(D_S) ? 0 : 1; }
 
 extern "C" void adgs_profile_enable(int stage_mask) { g_prof_mask = (unsigned)stage_mask; }
+// Pre-creates event objects so that a measurement loop never calls hipEventCreate (a driver call that can block).
+extern "C" int adgs_profile_reserve(int n_events) {
+	std::vector<hipEvent_t> fresh;
+	for (int i = 0; i < n_events; i++) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; fresh.push_back(e); }
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	g_prof_pool.insert(g_prof_pool.end(), fresh.begin(), fresh.end());
+	return (int)fresh.size();
+}
 extern "C" int adgs_profile_num_stages(void) { return ST_COUNT; }
 extern "C" const char* adgs_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 // Resolves all recorded (start, stop) event pairs: the caller must have synchronised the stream.

@@ -337,6 +337,7 @@ def main():
         stages_all = wprof.collect()
         dom = max(stages_all, key=lambda k: stages_all[k][0] * max(stages_all[k][1], 1))
     prof = _lib.StageProfiler()
+    prof.reserve(2 * args.steps * (1 if dom else 8) + 64)      # no event creation inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

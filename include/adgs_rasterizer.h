@@ -195,6 +195,7 @@ void adgs_get_frame_stats(adgs_frame_stats* out);
  * entries each). */
 void adgs_profile_enable(int stage_mask);   /* bit i set: time stage i (two HIP events per launch group, ~10 us of
                                                queue bubble each); 0 = off, -1 = every stage */
+int adgs_profile_reserve(int n_events);     /* pre-create event objects (returns how many); a timed loop then never calls hipEventCreate */
 int adgs_profile_num_stages(void);
 const char* adgs_profile_stage_name(int stage);
 int adgs_profile_collect(double* total_ms, int64_t* counts);
