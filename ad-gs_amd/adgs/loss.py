@@ -82,3 +82,42 @@ def photometric_loss(image, gt, lambda_dssim, lambda_l1=1.0):
     l1, s = l1_ssim(image, gt)
     dssim = 1.0 - s
     return (1.0 - lambda_dssim) * lambda_l1 * l1 + lambda_dssim * dssim, l1, dssim
+
+
+DEPTH_WORK_DOUBLES = 256 * 8 + 16        # ADGS_DEPTH_WORK_DOUBLES
+
+
+class _DepthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, mask):
+        if not pred.is_cuda:
+            raise RuntimeError("get_depth_loss: tensors must be on a HIP device; there is no CPU path")
+        p, g = pred.contiguous().float(), gt.contiguous().float()
+        m = None if mask is None else mask.contiguous().float()
+        if p.shape != g.shape or (m is not None and m.shape != p.shape):
+            raise ValueError("get_depth_loss: prediction, target and mask must have the same shape")
+        work = torch.zeros(DEPTH_WORK_DOUBLES, dtype=torch.float64, device=p.device)
+        out = torch.zeros(1, dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().adgs_depth_loss_forward(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else None,
+                                                          work.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_depth_loss_forward")
+        ctx.save_for_backward(p, g, work, *([m] if m is not None else []))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        p, g, work, *rest = ctx.saved_tensors
+        m = rest[0] if rest else None
+        out = torch.empty_like(p)
+        gl = g_loss.reshape(1).float().contiguous()
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().adgs_depth_loss_backward(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else None,
+                                                           work.data_ptr(), gl.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_depth_loss_backward")
+        return out, None, None
+
+
+def get_depth_loss(pred, gt, mask=None):
+    """utils/loss_utils.py:70-75: L1 between the scale/shift-aligned prediction (utils/depth_utils.py:3-45, closed-form least
+    squares) and the target, averaged over the mask; differentiable w.r.t. `pred` through the scale and the shift.  No host
+    synchronisation (the reference's `if det == 0` is one)."""
+    return _DepthLoss.apply(pred, gt.detach(), None if mask is None else mask.detach())

@@ -5,6 +5,7 @@
 // backward reads 20 B and writes 4 B.
 #include "common.h"
 #include "../../include/adgs_loss.h"
+#include <algorithm>
 
 namespace adgs {
 namespace {
@@ -124,10 +125,130 @@ __global__ void __launch_bounds__(TS * TS) l1_ssim_bwd_kernel(int H, int W, cons
 	out[o] = gl * sgn * inv_n + gs * inv_n * (a + 2.f * x1 * b + x2 * c);
 }
 
+// ---------------------------------------------------------------- scale/shift-invariant depth loss
+// work layout (doubles): [slot][8] partial sums (a00, a01, a11, b0, b1 of pass 1; L1, A = sum m sgn p, B = sum m sgn of pass 2),
+// then 16 scalars: [0..4] the five totals, [5] s, [6] t, [7] det, [8] L1 total, [9] A, [10] B.
+constexpr int DSLOTS = 256;
+struct DepthScalars { double a00, a01, a11, b0, b1, s, t, det; };
+
+__global__ void __launch_bounds__(256) depth_sums_kernel(int n, const float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ m, double* __restrict__ work) {
+	double a00 = 0, a01 = 0, a11 = 0, b0 = 0, b1 = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const double w = m ? (double)m[i] : 1.0, x = p[i], y = g[i];
+		a00 += w * x * x; a01 += w * x; a11 += w; b0 += w * x * y; b1 += w * y;
+	}
+	double v[5] = { a00, a01, a11, b0, b1 };
+#pragma unroll
+	for (int q = 0; q < 5; q++) {
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, WAVE);
+		if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(work + (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % DSLOTS) * 8 + q, v[q]);
+	}
+}
+// one block: totals of the slots -> scale, shift (depth_utils.py:30-45)
+__global__ void __launch_bounds__(256) depth_solve_kernel(double* __restrict__ work) {
+	__shared__ double s[5][256 / WAVE];
+	double* out = work + (size_t)DSLOTS * 8;
+	double v[5];
+#pragma unroll
+	for (int q = 0; q < 5; q++) {
+		v[q] = work[(size_t)threadIdx.x * 8 + q];
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, WAVE);
+		if ((threadIdx.x & (WAVE - 1)) == 0) s[q][threadIdx.x / WAVE] = v[q];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t[5];
+		for (int q = 0; q < 5; q++) { t[q] = 0; for (int w = 0; w < 256 / WAVE; w++) t[q] += s[q][w]; out[q] = t[q]; }
+		// the reference forms the sums and the determinant in fp32 (torch.sum of fp32 tensors): round the totals first
+		const float a00 = (float)t[0], a01 = (float)t[1], a11 = (float)t[2], b0 = (float)t[3], b1 = (float)t[4];
+		const float det = a00 * a11 - a01 * a01;
+		float sc = 0.f, sh = 0.f;
+		if (det != 0.f) { sc = (a11 * b0 - a01 * b1) / det; sh = (-a01 * b0 + a00 * b1) / det; }
+		out[5] = sc; out[6] = sh; out[7] = det;
+	}
+}
+__global__ void __launch_bounds__(256) depth_l1_kernel(int n, const float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ m, double* __restrict__ work) {
+	const double* sc = work + (size_t)DSLOTS * 8;
+	const float s = (float)sc[5], t = (float)sc[6];
+	double L = 0, A = 0, B = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const float w = m ? m[i] : 1.f, x = p[i];
+		const float d = (s * x + t) - g[i];
+		const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+		L += (double)(fabsf(d) * w); A += (double)(w * sg * x); B += (double)(w * sg);
+	}
+	double v[3] = { L, A, B };
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, WAVE);
+		if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(work + (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % DSLOTS) * 8 + 5 + q, v[q]);
+	}
+}
+__global__ void __launch_bounds__(256) depth_finish_kernel(double* __restrict__ work, float* __restrict__ loss) {
+	__shared__ double s[3][256 / WAVE];
+	double* out = work + (size_t)DSLOTS * 8;
+	double v[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		v[q] = work[(size_t)threadIdx.x * 8 + 5 + q];
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, WAVE);
+		if ((threadIdx.x & (WAVE - 1)) == 0) s[q][threadIdx.x / WAVE] = v[q];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int q = 0; q < 3; q++) { double t = 0; for (int w = 0; w < 256 / WAVE; w++) t += s[q][w]; out[8 + q] = t; }
+		loss[0] = (float)(out[8] / out[2]);                       // sum(|.| m) / sum(m)
+	}
+}
+__global__ void __launch_bounds__(256) depth_bwd_kernel(int n, const float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ m,
+	const double* __restrict__ work, const float* __restrict__ g_loss, float* __restrict__ out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const double* sc = work + (size_t)DSLOTS * 8;
+	const double a00 = sc[0], a01 = sc[1], a11 = sc[2], b0 = sc[3], b1 = sc[4], s = sc[5], t = sc[6], det = sc[7], A = sc[9], B = sc[10];
+	const float w = m ? m[i] : 1.f, x = p[i], y = g[i];
+	const float d = ((float)s * x + (float)t) - y;
+	const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+	double grad = (double)sg * s;
+	if (det != 0.0) {
+		// through the least-squares solution: s, t depend on a00 = sum m p^2, a01 = sum m p, b0 = sum m p g
+		const double s_a00 = -s * a11 / det, s_a01 = (-b1 + 2.0 * a01 * s) / det, s_b0 = a11 / det;
+		const double t_a00 = (b1 - t * a11) / det, t_a01 = (-b0 + 2.0 * a01 * t) / det, t_b0 = -a01 / det;
+		grad += (A * s_a00 + B * t_a00) * 2.0 * x + (A * s_a01 + B * t_a01) + (A * s_b0 + B * t_b0) * y;
+	} else grad = 0.0;                                             // the reference returns python floats (0.0, 0.0): no graph
+	out[i] = (float)((double)g_loss[0] * (double)w * grad / a11);
+	(void)a00;
+}
+
 } // namespace
 } // namespace adgs
 
 using namespace adgs;
+
+extern "C" int adgs_depth_loss_forward(int n, const float* prediction, const float* target, const float* mask, double* work, float* loss, void* stream_) {
+	if (n <= 0) return 0;
+	if (!prediction || !target || !work || !loss) { set_error("adgs_depth_loss_forward: NULL pointer"); return -1; }
+	hipStream_t stream = (hipStream_t)stream_;
+	const int blocks = std::min((n + 255) / 256, 2048);
+	hipLaunchKernelGGL(depth_sums_kernel, dim3(blocks), dim3(256), 0, stream, n, prediction, target, mask, work);
+	hipLaunchKernelGGL(depth_solve_kernel, dim3(1), dim3(256), 0, stream, work);
+	hipLaunchKernelGGL(depth_l1_kernel, dim3(blocks), dim3(256), 0, stream, n, prediction, target, mask, work);
+	hipLaunchKernelGGL(depth_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_depth_loss_backward(int n, const float* prediction, const float* target, const float* mask, const double* work, const float* g_loss,
+	float* dL_dprediction, void* stream_) {
+	if (n <= 0) return 0;
+	if (!prediction || !target || !work || !g_loss || !dL_dprediction) { set_error("adgs_depth_loss_backward: NULL pointer"); return -1; }
+	hipLaunchKernelGGL(depth_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, n, prediction, target, mask, work, g_loss, dL_dprediction);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
 
 extern "C" int adgs_l1_ssim_forward(int planes, int H, int W, const float* image, const float* gt, double* sums,
 	float* d_mu1, float* d_e11, float* d_e12, void* stream) {

@@ -31,6 +31,20 @@ int adgs_l1_ssim_forward(int planes, int H, int W, const float* image, const flo
 int adgs_l1_ssim_backward(int planes, int H, int W, const float* image, const float* gt,
 	const float* d_mu1, const float* d_e11, const float* d_e12, const float* g_l1, const float* g_ssim, float* dL_dimage, void* stream);
 
+/*
+ * Scale-and-shift-invariant depth loss: utils/loss_utils.py:70-75 get_depth_loss over
+ * utils/depth_utils.py:3-45 (closed-form least squares for scale s and shift t of the prediction, then
+ * sum(|s p + t - g| m) / sum(m)), differentiable through s and t like the reference's autograd, with the
+ * reference's `det == 0 -> (0, 0)` case decided on the device (the reference synchronises for it).
+ * work: ADGS_DEPTH_WORK_DOUBLES device doubles, zero-initialised by the caller, kept for the backward.
+ * mask may be NULL (all ones).  loss: one device float.
+ */
+#define ADGS_DEPTH_WORK_DOUBLES (256 * 8 + 16)
+int adgs_depth_loss_forward(int n, const float* prediction, const float* target, const float* mask, double* work, float* loss, void* stream);
+/* dL_dprediction[i] for the upstream gradient g_loss (DEVICE scalar) */
+int adgs_depth_loss_backward(int n, const float* prediction, const float* target, const float* mask, const double* work, const float* g_loss,
+	float* dL_dprediction, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,3 +48,27 @@ def l1_ssim(img1, img2, dtype=np.float64):
     g_ssim = (_conv(d_mu1, w2) + 2 * x1 * _conv(d_e11, w2) + x2 * _conv(d_e12, w2)) / n       # window is symmetric
     g_l1 = np.sign(x1 - x2) / n
     return np.abs(x1 - x2).mean(), m.mean(), g_l1, g_ssim
+
+
+def depth_loss(pred, gt, mask=None, dtype=np.float64):
+    """utils/loss_utils.py:70-75 over utils/depth_utils.py:3-45.  Returns (loss, d loss / d pred) -- the gradient includes the
+    dependence of the least-squares scale and shift on the prediction, as the reference's autograd does."""
+    p, g = np.asarray(pred, dtype), np.asarray(gt, dtype)
+    m = np.ones_like(p) if mask is None or np.size(mask) == 0 else np.asarray(mask, dtype)
+    a00, a01, a11 = (m * p * p).sum(), (m * p).sum(), m.sum()
+    b0, b1 = (m * p * g).sum(), (m * g).sum()
+    # the reference evaluates the determinant on fp32 sums: an exactly rank-deficient system is detected there
+    f = np.float32
+    det32 = f(a00) * f(a11) - f(a01) * f(a01)
+    det = a00 * a11 - a01 * a01
+    if det32 == 0:
+        return np.abs(0 * p - g)[m > 0].sum() / a11 if mask is not None and np.size(mask) else np.abs(g).mean(), np.zeros_like(p)
+    s, t = (a11 * b0 - a01 * b1) / det, (-a01 * b0 + a00 * b1) / det
+    d = s * p + t - g
+    sg = np.sign(d)
+    loss = (np.abs(d) * m).sum() / a11
+    A, B = (m * sg * p).sum(), (m * sg).sum()
+    s_a00, s_a01, s_b0 = -s * a11 / det, (-b1 + 2 * a01 * s) / det, a11 / det
+    t_a00, t_a01, t_b0 = (b1 - t * a11) / det, (-b0 + 2 * a01 * t) / det, -a01 / det
+    grad = m * (sg * s + (A * s_a00 + B * t_a00) * 2 * p + (A * s_a01 + B * t_a01) + (A * s_b0 + B * t_b0) * g) / a11
+    return loss, grad

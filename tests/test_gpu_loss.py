@@ -9,7 +9,8 @@ from oracle import loss_oracle
 
 pytestmark = pytest.mark.gpu
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_golden.npz"))
-CASES = sorted({k.split("/")[0] for k in GOLD.files})
+CASES = sorted({k.split("/")[0] for k in GOLD.files if not k.startswith("depth")})
+DEPTH_CASES = sorted({k.split("/")[0] for k in GOLD.files if k.startswith("depth")})
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -62,3 +63,31 @@ def test_full_resolution_properties():
     (2.0 * l1b + 3.0 * sb).backward()
     ga = torch.autograd.grad(loss.l1_ssim(img, gt)[0], img)[0]
     assert torch.allclose(img2.grad, 3.0 * img.grad - ga, rtol=1e-4, atol=1e-10)
+
+
+@pytest.mark.parametrize("case", DEPTH_CASES)
+def test_depth_loss_matches_reference_golden(case):
+    from adgs import loss
+    pred = torch.tensor(GOLD[case + "/pred"]).cuda().requires_grad_(True)
+    gt = torch.tensor(GOLD[case + "/gt"]).cuda()
+    mask = torch.tensor(GOLD[case + "/mask"]).cuda() if GOLD[case + "/mask"].size else None
+    val = loss.get_depth_loss(pred, gt, mask)
+    ref = float(GOLD[case + "/loss"])
+    assert abs(float(val) - ref) <= 2e-5 * max(1.0, abs(ref))
+    (gp,) = torch.autograd.grad(val, pred)
+    gref = GOLD[case + "/g_pred"]
+    np.testing.assert_allclose(gp.cpu().numpy(), gref, rtol=0, atol=2e-4 * max(np.abs(gref).max(), 1e-12))
+
+
+def test_depth_loss_full_resolution_against_oracle():
+    from adgs import loss
+    rng = np.random.default_rng(5)
+    gt = (rng.random((1280, 1920)) * 60 + 1).astype(np.float32)
+    pred = (0.02 * gt + 0.3 + 0.1 * rng.standard_normal(gt.shape)).astype(np.float32)
+    mask = (rng.random(gt.shape) > 0.25).astype(np.float32)
+    p = torch.tensor(pred).cuda().requires_grad_(True)
+    val = loss.get_depth_loss(p, torch.tensor(gt).cuda(), torch.tensor(mask).cuda())
+    val.backward()
+    o_loss, o_grad = loss_oracle.depth_loss(pred, gt, mask)
+    assert abs(float(val) - o_loss) <= 1e-4 * o_loss
+    np.testing.assert_allclose(p.grad.cpu().numpy(), o_grad, rtol=0, atol=1e-3 * np.abs(o_grad).max())

@@ -8,7 +8,8 @@ import pytest
 from oracle import loss_oracle
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_golden.npz"))
-CASES = sorted({k.split("/")[0] for k in GOLD.files})
+CASES = sorted({k.split("/")[0] for k in GOLD.files if not k.startswith("depth")})
+DEPTH_CASES = sorted({k.split("/")[0] for k in GOLD.files if k.startswith("depth")})
 
 
 def test_window_is_the_references():
@@ -40,3 +41,12 @@ def test_identical_images_and_finite_difference():
         d = np.zeros_like(y); d[idx] = 1e-6
         fd = (loss_oracle.l1_ssim(y + d, x)[1] - loss_oracle.l1_ssim(y - d, x)[1]) / 2e-6
         assert abs(fd - g[idx]) <= 1e-6 * max(1.0, abs(g[idx]) * 1e3), (idx, fd, g[idx])
+
+
+@pytest.mark.parametrize("case", DEPTH_CASES)
+def test_depth_loss_oracle_matches_reference(case):
+    loss, grad = loss_oracle.depth_loss(GOLD[case + "/pred"], GOLD[case + "/gt"], GOLD[case + "/mask"])
+    ref = float(GOLD[case + "/loss"])
+    assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)), (loss, ref)
+    gref = GOLD[case + "/g_pred"]
+    np.testing.assert_allclose(grad, gref, rtol=0, atol=2e-4 * max(np.abs(gref).max(), 1e-12))
