@@ -73,13 +73,12 @@ struct BinState {
 
 // ---- v2 (coarse-binned) state ----
 struct GeomStateV2 {
-	Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects;
+	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
 		Carver c(chunk); GeomStateV2 g;
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
-		g.cov3D = c.take<float>(P * 6);
 		g.rects = c.take<FilterRec>(P);
 		g.clamped = c.take<uint8_t>(P);
 		g.cells_touched = c.take<uint32_t>(P + 1);
@@ -277,7 +276,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy;
 		pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
 		pa.inv_depth = inv_depth;
-		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;
+		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = nullptr; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;     // cov3D: recomputed by the backward
 		pa.rects = geom.rects; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
@@ -488,7 +487,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		pa.P = P; pa.D = D; pa.M = M;
 		pa.means3D = means3D; pa.radii = radii; pa.shs = shs; pa.clamped = geom.clamped;
 		pa.scales = scales; pa.rotations = rotations; pa.scale_modifier = scale_modifier;
-		pa.cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+		pa.cov3D = cov3D_precomp;                // NULL: recomputed from scales / rotations
 		pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = campos;
 		pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
 		pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;

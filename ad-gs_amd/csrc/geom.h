@@ -1,0 +1,41 @@
+// Geometry helpers shared by the forward and backward preprocess kernels.
+#pragma once
+#include "common.h"
+
+namespace adgs {
+
+// computeCov3D (forward.cu:118-152): Sigma = (S R)^T (S R), S = diag(mod * scale), R from the UN-normalised (r,x,y,z),
+// upper triangle out.  Evaluated in glm's column-major order.  Contraction is pinned off inside this function (it is
+// self-contained for that reason) so that the forward preprocess and the v2 backward -- which recomputes Sigma instead of
+// reading it back -- produce the same bits whatever the flags of their translation units.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q, float* out) {
+#pragma clang fp contract(off)
+	const float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
+	const float r = q[0], x = q[1], y = q[2], z = q[3];
+	// R.v[col][row] (column-major, as glm stores mat3(...) given row by row in forward.cu:133-137)
+	const float Rm[3][3] = { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
+	                         { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
+	                         { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } };
+	const float Sd[3] = { sx, sy, sz };
+	// M = S * R : M.v[c][rr] = sum_k S.v[k][rr] * R.v[c][k]; S diagonal -> S.v[rr][rr] * R.v[c][rr] with the two zero terms
+	// added in glm's order (0*x + ... keeps the value; written out so the sums match m3mul bit for bit)
+	float M[3][3];
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++) {
+			const float a0 = (rr == 0 ? Sd[0] : 0.f) * Rm[c][0], a1 = (rr == 1 ? Sd[1] : 0.f) * Rm[c][1], a2 = (rr == 2 ? Sd[2] : 0.f) * Rm[c][2];
+			M[c][rr] = a0 + a1 + a2;
+		}
+	// Sigma = M^T * M : Sig.v[c][rr] = sum_k Mt.v[k][rr] * M.v[c][k],  Mt.v[k][rr] = M.v[rr][k]
+	float Sg[3][3];
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int rr = 0; rr < 3; rr++)
+			Sg[c][rr] = M[rr][0] * M[c][0] + M[rr][1] * M[c][1] + M[rr][2] * M[c][2];
+	out[0] = Sg[0][0]; out[1] = Sg[0][1]; out[2] = Sg[0][2];
+	out[3] = Sg[1][1]; out[4] = Sg[1][2]; out[5] = Sg[2][2];
+}
+
+} // namespace adgs

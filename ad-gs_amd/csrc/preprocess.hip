@@ -13,6 +13,7 @@
 // + 1 B clamp flags.
 #include "common.h"
 #include "kernels.h"
+#include "geom.h"
 #include <cstdlib>
 
 namespace adgs {
@@ -50,19 +51,6 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 	miny = (uint32_t)min(gy, max(0, (int)((py - radius) / TILE_Y)));
 	maxx = (uint32_t)min(gx, max(0, (int)((px + radius + TILE_X - 1) / TILE_X)));
 	maxy = (uint32_t)min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
-}
-
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q, float* out) {
-	M3 S = { { { 1.f, 0.f, 0.f }, { 0.f, 1.f, 0.f }, { 0.f, 0.f, 1.f } } };
-	S.v[0][0] = mod * s3[0]; S.v[1][1] = mod * s3[1]; S.v[2][2] = mod * s3[2];
-	const float r = q[0], x = q[1], y = q[2], z = q[3];     // un-normalised on purpose (forward.cu:127)
-	M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
-	           { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
-	           { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } } };
-	M3 Mm = m3mul(S, R);
-	M3 Sig = m3mul(m3t(Mm), Mm);
-	out[0] = Sig.v[0][0]; out[1] = Sig.v[0][1]; out[2] = Sig.v[0][2];
-	out[3] = Sig.v[1][1]; out[4] = Sig.v[1][2]; out[5] = Sig.v[2][2];
 }
 
 // SH basis evaluation, same association order as forward.cu:20-71.
@@ -147,8 +135,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
 	} else {
 		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
+		if (a.cov3D) {        // classic pipeline keeps it for the backward; v2 recomputes it there (same function, same rounding)
 #pragma unroll
-		for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = c3[k];
+			for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = c3[k];
+		}
 	}
 
 	// EWA 2D covariance (forward.cu:74-113)

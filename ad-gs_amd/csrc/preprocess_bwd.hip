@@ -12,6 +12,7 @@
 // dominates the writes.
 #include "common.h"
 #include "kernels.h"
+#include "geom.h"
 #include "func_eval.h"
 #include <cstdlib>
 
@@ -134,7 +135,12 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		gcol[0] = a.dL_dcolor[3 * (size_t)idx]; gcol[1] = a.dL_dcolor[3 * (size_t)idx + 1]; gcol[2] = a.dL_dcolor[3 * (size_t)idx + 2];
 	}
 	// ---------------- cov2D backward (backward.cu:144-274)
+	float c3_local[6];
 	const float* c3 = a.cov3D + 6 * (size_t)idx;
+	if (!a.cov3D) {           // v2 without cov3D_precomp: recomputed instead of stored by the forward (24 B written + read per Gaussian)
+		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3_local);
+		c3 = c3_local;
+	}
 	float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 	float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
 	const float tz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
