@@ -14,9 +14,10 @@
 // of Gaussians that pass the per-pixel tests, and removed entries are exactly those that fail
 // `alpha >= 1/255` on every pixel of the tile (or lie outside the reference's tile rectangle).
 //
-// One workgroup = one wave64 = one tile; each lane owns 4 pixels (column x = lane&15, rows
-// (lane>>4) + 4k).  Per-Gaussian data is broadcast from LDS once per 4 pixels, the backward's
-// cross-lane reductions (DPP row_shr/row_bcast adds, no LDS) are amortised over 256 pixels and
+// One workgroup = one wave64 = one tile (or half of one for small images: PPL = 2); each lane owns PPL pixels
+// (column x = lane&15, rows (lane>>4) + 4k).  Per-Gaussian data is broadcast from LDS once per PPL pixels, 16x4-pixel
+// strips an entry does not reach are skipped wave-uniformly, the backward's cross-lane reductions (a transposing
+// butterfly of permlane swaps and bank-masked DPP adds, no LDS) are amortised over the whole tile and
 // the 14 per-Gaussian partial sums go out as ONE atomic instruction onto one 64-byte line.
 // The consumed (tile, Gaussian) sequence is written to a chunk pool (linked 64-entry chunks) so
 // the backward replays exactly what the forward blended, back to front.
