@@ -31,13 +31,13 @@ def _flatten_bucket(tensors, max_bytes):
     return buckets
 
 
-def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 20):
+def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 20, in_place_bytes=32 << 20):
     """Sum `.grad` of every parameter over all ranks (missing grads count as zero).
 
-    Large tensors are reduced in place, one async collective each (no flatten copy: at
-    1M Gaussians the SH gradient alone is 192 MB and a copy would cost as much as the
-    reduction itself); small ones are coalesced into flat buckets.  xGMI is
-    point-to-point, so few large collectives are preferred over many small ones.
+    Tensors of at least `in_place_bytes` are reduced in place, one async collective each (no flatten
+    copy: at 1M Gaussians the SH gradient alone is 180 MB); the others are coalesced into flat buckets
+    (the copies are ~80 MB in total at C3, 0.03 ms).  xGMI is point-to-point, so few large collectives
+    are preferred over many small ones: C3 ends up with 6 in-place reductions and one bucket.
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
@@ -47,8 +47,8 @@ def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 2
         if p.grad is None:
             p.grad = torch.zeros_like(p)
         grads.append(p.grad)
-    big = [g for g in grads if g.numel() * g.element_size() >= (4 << 20)]
-    small = [g for g in grads if g.numel() * g.element_size() < (4 << 20)]
+    big = [g for g in grads if g.numel() * g.element_size() >= in_place_bytes]
+    small = [g for g in grads if g.numel() * g.element_size() < in_place_bytes]
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in big]
     flats = []
     for bucket in _flatten_bucket(small, bucket_bytes):
