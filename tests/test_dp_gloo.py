@@ -44,10 +44,18 @@ def _worker(rank, world, port, cams, out_dir):
     # densification statistics and shared RNG
     acc = torch.full((10, 1), float(rank + 1)); den = torch.full((10, 1), 1.0); rad = torch.arange(10, dtype=torch.float32) * (rank + 1)
     dp.allreduce_densification_stats(acc, den, rad)
+    # both reduction paths with explicit thresholds: in place (>= 1 MiB here), several flat buckets (16 KiB each), and a
+    # parameter that has a gradient on one rank only
+    extra = [torch.zeros(300_000, requires_grad=True), torch.zeros(3000, requires_grad=True), torch.zeros(5000, requires_grad=True),
+             torch.zeros(11, requires_grad=True)]
+    for i, p in enumerate(extra):
+        if not (i == 3 and rank == 1):
+            p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    dp.allreduce_gradients(extra, in_place_bytes=1 << 20, bucket_bytes=16 << 10)
     seed = dp.seed_all_ranks(1234 + rank)           # rank 0's value wins
     draw = torch.randn(4)
     torch.save(dict(grads=[p.grad.clone() for p in params], total=None if total is None else total.clone(), acc=acc, den=den, rad=rad,
-                    seed=seed, draw=draw, mine=dp.shard_cameras(cams, rank, world)), os.path.join(out_dir, "r%d.pt" % rank))
+                    seed=seed, draw=draw, mine=dp.shard_cameras(cams, rank, world), extra=[p.grad.clone() for p in extra]), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +82,10 @@ def test_sharded_cameras_equal_single_process_accumulation(tmp_path, cams):
     assert torch.equal(res[0]["acc"], torch.full((10, 1), 3.0)) and torch.equal(res[1]["den"], torch.full((10, 1), 2.0))
     assert torch.equal(res[0]["rad"], torch.arange(10, dtype=torch.float32) * 2)
     assert res[0]["seed"] == res[1]["seed"] == 1234 and torch.equal(res[0]["draw"], res[1]["draw"])
+    for r in range(world):
+        for i, g in enumerate(res[r]["extra"]):
+            want = 3.0 * (i + 1) if i != 3 else 4.0          # the last one only has rank 0's gradient (1 * 4)
+            assert torch.equal(g, torch.full_like(g, want)), (r, i)
 
 
 def test_single_process_is_a_no_op():
