@@ -576,11 +576,22 @@ extern "C" int adgs_raster_backward(
 		dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dflow, dL_dsemantic, grad_img_opacity, img_opacity, inv_depth, debug, stream);
 }
 
+// scene_dc != NULL is what switches the kernels to the raw-SH source, and an empty side (a model without scene or without
+// object Gaussians: its tensors have no storage) is never dereferenced: give it the other side's pointers.
 static ShSource to_sh_source(const adgs_sh_source* s) {
 	ShSource r;
 	r.Ns = s->Ns; r.scene_dc = s->scene_dc; r.obj_dc = s->obj_dc; r.scene_rest = s->scene_rest; r.obj_rest = s->obj_rest;
 	r.scene_sp = s->scene_deform; r.obj_sp = s->obj_deform; r.f = s->f;
+	if (!r.scene_dc) { r.scene_dc = r.obj_dc; r.scene_rest = r.obj_rest; }
+	if (!r.obj_dc) { r.obj_dc = r.scene_dc; r.obj_rest = r.scene_rest; }
 	return r;
+}
+static int check_sh_source(const adgs_sh_source* sh, int P, int M, const char* who) {
+	const bool need_scene = sh && sh->Ns > 0, need_obj = sh && sh->Ns < P;
+	if (!sh || sh->Ns < 0 || sh->Ns > P || (need_scene && (!sh->scene_dc || (M > 1 && !sh->scene_rest))) || (need_obj && (!sh->obj_dc || (M > 1 && !sh->obj_rest)))) {
+		set_error(std::string(who) + ": incomplete SH source"); return -1;
+	}
+	return 0;
 }
 
 extern "C" int adgs_raster_forward_rawsh(
@@ -591,7 +602,8 @@ extern "C" int adgs_raster_forward_rawsh(
 	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
 	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
 	int inv_depth, int* radii, int debug, void* stream) {
-	if (!sh || !sh->scene_dc || !sh->obj_dc || (M > 1 && (!sh->scene_rest || !sh->obj_rest))) { set_error("adgs_raster_forward_rawsh: incomplete SH source"); return -1; }
+	if (P > 0 && check_sh_source(sh, P, M, "adgs_raster_forward_rawsh") != 0) return -1;
+	if (P <= 0) return 0;
 	const ShSource src = to_sh_source(sh);
 	return raster_forward_impl(&src, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
 		width, height, means3D, nullptr, nullptr, flow_points, semantic, opacities, scales, scale_modifier, rotations, nullptr,
@@ -610,6 +622,7 @@ extern "C" int adgs_raster_backward_rawsh(
 	float* dL_dcov3D, const adgs_sh_grads* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dflow, float* dL_dsemantic,
 	const float* grad_img_opacity, const float* img_opacity, int inv_depth, int debug, void* stream) {
 	if (!sh || !dL_dsh) { set_error("adgs_raster_backward_rawsh: NULL SH source / gradients"); return -1; }
+	if (P > 0 && check_sh_source(sh, P, M, "adgs_raster_backward_rawsh") != 0) return -1;
 	const ShSource src = to_sh_source(sh);
 	ShGradDst dst;
 	dst.scene_dc = dL_dsh->scene_dc; dst.obj_dc = dL_dsh->obj_dc; dst.scene_rest = dL_dsh->scene_rest; dst.obj_rest = dL_dsh->obj_rest;
