@@ -73,13 +73,14 @@ struct BinState {
 
 // ---- v2 (coarse-binned) state ----
 struct GeomStateV2 {
-	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects;
+	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects; uint4* dupinfo;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
 		Carver c(chunk); GeomStateV2 g;
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
 		g.rects = c.take<FilterRec>(P);
+		g.dupinfo = c.take<uint4>(P);
 		g.clamped = c.take<uint8_t>(P);
 		g.cells_touched = c.take<uint32_t>(P + 1);
 		g.offsets = c.take<uint32_t>(P + 1);
@@ -277,7 +278,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
 		pa.inv_depth = inv_depth;
 		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = nullptr; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;     // cov3D: recomputed by the backward
-		pa.rects = geom.rects; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
+		pa.rects = geom.rects; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream) != 0) return -1; }
@@ -319,7 +320,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 				return 0;
 			}
 			{ StageTimer t(ST_DUPLICATE, stream);
-			  if (launch_duplicate_cells(P, geom.splats, geom.rects, geom.offsets, bin.keys_unsorted, bin.list_unsorted, (uint32_t)std::min<size_t>(cells, 0xffffffffu),
+			  if (launch_duplicate_cells(P, geom.dupinfo, geom.offsets, bin.keys_unsorted, bin.list_unsorted, (uint32_t)std::min<size_t>(cells, 0xffffffffu),
 			        cell_tiles, cgx, img.cell_ranges, (int)ncells, bin.pool_cursor, stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			{ StageTimer t(ST_SORT, stream);
@@ -385,7 +386,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.focal_x = width / (2.0f * tan_fovx);
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
-	pa.rects = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
+	pa.rects = nullptr; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }

@@ -19,6 +19,7 @@ struct PreprocessArgs {
 	// v2 (coarse-binned) extras; rects == nullptr selects the classic behaviour
 	FilterRec* rects;                // per-Gaussian tile-filter record (rectangle possibly empty)
 	uint32_t* fine_touched;          // #fine tiles covered per Gaussian (its sum bounds the chunk pool)
+	uint4* dupinfo;                  // (shrunk rect min, max, depth bits, -) per Gaussian: the binning kernel's only input
 	int cell_tiles, cgx, cgy;        // coarse cell = cell_tiles x cell_tiles fine tiles
 	ShSource sh_src;                 // raw SH source (sh_src.scene_dc != nullptr) instead of `shs`
 	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
@@ -85,7 +86,7 @@ constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
 constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumulators per Gaussian
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
-int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
+int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, hipStream_t stream);
 
 struct RenderV2FwdArgs {

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	}
 	a.radii[idx] = 0;
 	a.tiles_touched[idx] = 0;
-	if (a.rects) { a.rects[idx].rmin = 0u; a.rects[idx].rmax = 0u; a.fine_touched[idx] = 0; }
+	if (a.rects) { a.dupinfo[idx] = make_uint4(0u, 0u, 0u, 0u); a.fine_touched[idx] = 0; }      // culled: no cells
 
 	const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
 	const float* V = a.view; const float* PJ = a.proj;
@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		const uint32_t c0x = sminx / a.cell_tiles, c1x = (smaxx - 1) / a.cell_tiles, c0y = sminy / a.cell_tiles, c1y = (smaxy - 1) / a.cell_tiles;
 		ncell = (c1x - c0x + 1) * (c1y - c0y + 1);
 	}
+	a.dupinfo[idx] = make_uint4(sminx | (sminy << 16), smaxx | (smaxy << 16), __float_as_uint(vz), 0u);   // all the binning kernel needs, 16 B
 	a.tiles_touched[idx] = ncell;
 	a.fine_touched[idx] = nfine;     // scanned on the host side of the pipeline: chunk-pool capacity bound
 }
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat*
 }
 
 // v2: one (cell | depth) key per covered coarse cell.
-__global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat* __restrict__ splats, const FilterRec* __restrict__ rects,
+__global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const uint4* __restrict__ dupinfo,
 	const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap, int cell_tiles, int cgx,
 	uint2* __restrict__ cell_ranges, int ncells, uint32_t* __restrict__ pool_cursor) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,11 +298,11 @@ __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const Splat
 	for (int c = idx; c < ncells; c += gridDim.x * blockDim.x) cell_ranges[c] = make_uint2(0u, 0u);
 	if (idx == 0) *pool_cursor = 0u;
 	if (idx >= P) return;
-	const uint32_t rmin = rects[idx].rmin, rmax = rects[idx].rmax;
-	const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, maxx = rmax & 0xFFFFu, maxy = rmax >> 16;
+	const uint4 d = dupinfo[idx];                  // (rect min, rect max, depth bits, -): one coalesced 16-byte load
+	const uint32_t minx = d.x & 0xFFFFu, miny = d.x >> 16, maxx = d.y & 0xFFFFu, maxy = d.y >> 16;
 	if (maxx <= minx || maxy <= miny) return;
 	uint32_t off = offsets[idx];
-	const uint32_t dbits = __float_as_uint(splats[idx].zview);
+	const uint32_t dbits = d.z;
 	const uint32_t c0x = minx / cell_tiles, c1x = (maxx - 1) / cell_tiles, c0y = miny / cell_tiles, c1y = (maxy - 1) / cell_tiles;
 	for (uint32_t y = c0y; y <= c1y; y++)
 		for (uint32_t x = c0x; x <= c1x; x++) {
@@ -354,10 +355,10 @@ int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, c
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
-int launch_duplicate_cells(int P, const Splat* splats, const FilterRec* rects, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
+int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, hipStream_t stream) {
 	if (P == 0) return 0;
-	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, splats, rects, offsets, keys, vals, cap, cell_tiles, cgx,
+	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, dupinfo, offsets, keys, vals, cap, cell_tiles, cgx,
 		cell_ranges, ncells, pool_cursor);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
