@@ -608,9 +608,37 @@ static int check_func(const adgs_func_eval* f, const char* what) {
 
 namespace adgs {
 namespace {
-// coefficient 0 of the raw-SH path: sh0[n, c] = dc[n, c] + f_shs(t)(shs_deform_param[n, c, :]).  The block's parameter
-// rows (3 * n_params floats per Gaussian) are staged through LDS with coalesced loads; each thread then evaluates
-// its Gaussian's three channels from its own LDS row.
+// coefficient 0 of the raw-SH path: sh0[n, c] = dc[n, c] + f_shs(t)(shs_deform_param[n, c, :]).
+// Fast kernel (n_params a multiple of 4, at most 32): one thread per (Gaussian, channel) ROW, which it reads as 16-byte
+// words -- consecutive threads own consecutive rows, so the loads are perfectly coalesced without any staging -- and dots
+// with the dense basis vector (zero where the family has no term).  General kernel: rows staged through LDS.
+template <int NV4>
+__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out) {
+	__shared__ float s_w[NV4 * 4];
+	for (int k = threadIdx.x; k < NV4 * 4; k += 256) s_w[k] = 0.f;
+	__syncthreads();
+	const int total = s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2];
+	for (int i = threadIdx.x; i < total; i += 256) s_w[s.f.index[i]] = s.f.weight[i];
+	__syncthreads();
+	const int e = blockIdx.x * 256 + threadIdx.x;          // row = n * 3 + c
+	if (e >= N * 3) return;
+	const int n = e / 3;
+	const bool ob = n >= s.Ns;
+	const size_t r = ob ? (size_t)e - 3 * (size_t)s.Ns : (size_t)e;
+	float v = (ob ? s.obj_dc : s.scene_dc)[r];
+	const float* sp = ob ? s.obj_sp : s.scene_sp;
+	if (sp) {
+		const float4* row = reinterpret_cast<const float4*>(sp + r * (NV4 * 4));
+		float4 q[NV4];
+#pragma unroll
+		for (int k = 0; k < NV4; k++) q[k] = row[k];
+		float acc = 0.f;
+#pragma unroll
+		for (int k = 0; k < NV4; k++) acc += q[k].x * s_w[4 * k] + q[k].y * s_w[4 * k + 1] + q[k].z * s_w[4 * k + 2] + q[k].w * s_w[4 * k + 3];
+		v = v + acc;
+	}
+	out[e] = v;
+}
 __global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out) {
 	extern __shared__ float s_rows[];
 	const int tid = threadIdx.x, base = blockIdx.x * 256, count = min(256, N - base);
@@ -636,7 +664,25 @@ __global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __re
 } // namespace
 int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 	if (N <= 0) return 0;
-	const size_t lds = (size_t)256 * ((3 * s.f.n_params) | 1) * sizeof(float);
+	const int np = s.f.n_params;
+	const bool lin = (s.scene_sp || s.obj_sp) && (s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2]) > 0 && np > 0;
+	const bool aligned = ((reinterpret_cast<uintptr_t>(s.scene_sp) | reinterpret_cast<uintptr_t>(s.obj_sp)) & 15) == 0;
+	if (lin && np % 4 == 0 && np <= 32 && aligned) {
+		const unsigned blocks = (unsigned)(((size_t)N * 3 + 255) / 256);
+		switch (np / 4) {
+			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+		}
+		ADGS_HIP_CHECK(hipGetLastError());
+		return 0;
+	}
+	const size_t lds = (size_t)256 * ((3 * np) | 1) * sizeof(float);
 	if (lds > 64 * 1024) { set_error("launch_sh0: more than 5461 SH deformation parameters per channel are not supported"); return -1; }
 	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, stream, N, s, out);
 	ADGS_HIP_CHECK(hipGetLastError());
