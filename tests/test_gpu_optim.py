@@ -91,3 +91,48 @@ def test_densification_stats_match_the_reference_lines():
         denom[vis] += 1
     assert torch.equal(d_den.cpu(), denom) and torch.equal(d_max.cpu(), maxr)
     assert torch.allclose(d_acc.cpu(), accum, rtol=1e-6, atol=1e-7)
+
+
+def test_fused_adam_survives_the_references_optimizer_state_surgery():
+    """scene/gaussian_model.py:560-582 (_prune_optimizer) and :616-638 (cat_tensors_to_optimizer) edit optimizer.state and
+    param_groups in place; the same edits on FusedAdam (GPU) and torch.optim.Adam (CPU, float64) must keep them in step."""
+    from torch import nn
+    from adgs.optim import FusedAdam
+
+    def surgery(opt, mask, extension):
+        for group in opt.param_groups:
+            st = opt.state.get(group["params"][0], None)
+            # prune
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask.to(st["exp_avg"].device)], st["exp_avg_sq"][mask.to(st["exp_avg"].device)]
+            del opt.state[group["params"][0]]
+            group["params"][0] = nn.Parameter(group["params"][0][mask.to(group["params"][0].device)].requires_grad_(True))
+            opt.state[group["params"][0]] = st
+            # densify
+            ext = extension.to(group["params"][0].device, group["params"][0].dtype)
+            st = opt.state.get(group["params"][0], None)
+            st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0)
+            st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+            del opt.state[group["params"][0]]
+            group["params"][0] = nn.Parameter(torch.cat((group["params"][0], ext), dim=0).requires_grad_(True))
+            opt.state[group["params"][0]] = st
+
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(500, 3, generator=g)
+    grads = [torch.randn(500, 3, generator=g), torch.randn(470, 3, generator=g), torch.randn(470, 3, generator=g)]
+    mask = torch.rand(500, generator=g) > 0.1
+    n_keep = int(mask.sum())
+    ext = torch.randn(470 - n_keep, 3, generator=g) if n_keep < 470 else torch.zeros(0, 3)
+    grads[1], grads[2] = grads[1][: n_keep + ext.shape[0]], grads[2][: n_keep + ext.shape[0]]
+    results = []
+    for cls, dev, dt in ((FusedAdam, "cuda", torch.float32), (torch.optim.Adam, "cpu", torch.float64)):
+        p = nn.Parameter(p0.to(dev, dt).clone())
+        opt = cls([{"params": [p], "lr": 1e-2, "name": "scene_xyz"}], lr=0.0, eps=1e-15)
+        opt.param_groups[0]["params"][0].grad = grads[0].to(dev, dt)
+        opt.step()
+        surgery(opt, mask, ext)
+        for gr in grads[1:]:
+            opt.param_groups[0]["params"][0].grad = gr.to(dev, dt)
+            opt.step()
+        results.append(opt.param_groups[0]["params"][0].detach().cpu().double())
+    assert results[0].shape == results[1].shape
+    assert torch.allclose(results[0], results[1], rtol=1e-5, atol=1e-6)
