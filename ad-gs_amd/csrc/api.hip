@@ -8,6 +8,7 @@
 #include "../../include/adgs_rasterizer.h"
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <cstdlib>
@@ -170,15 +171,49 @@ struct StageTimer {
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
 static std::atomic<size_t> g_hint_cells{0}, g_hint_fine{0};      // speculative binning capacities (v2 forward)
-static hipEvent_t readback_event() {
-	static thread_local hipEvent_t e = nullptr;
-	if (!e) { if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr; }
-	return e;
-}
 static uint32_t* pinned_word() {
 	static thread_local uint32_t* p = nullptr;
 	if (!p) { if (hipHostMalloc((void**)&p, 1024, hipHostMallocDefault) != hipSuccess) p = nullptr; }
 	return p;
+}
+
+// Mailbox in pinned host memory, written by the GPU itself and polled by the host: the v2 forward needs two totals in the
+// middle of the frame, and a driver-level wait (hipEventSynchronize / hipStreamSynchronize) for them was measured to fall
+// back to a ~10 ms timeout per call in the first process on a freshly booted box (frames at 11 ms instead of 1.7 ms with
+// every kernel at its normal duration).  A volatile read of host memory has no such mode.
+struct Mailbox { volatile uint32_t seq; uint32_t pad; uint32_t r_cells; uint32_t pad2; unsigned long long r_fine; };
+struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; };
+static MailboxRef* mailbox() {
+	static thread_local MailboxRef m = { nullptr, nullptr, 0 };
+	if (!m.host) {
+		void* h = nullptr; void* d = nullptr;
+		if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+		memset(h, 0, 256);
+		m.host = (Mailbox*)h; m.dev = (Mailbox*)d; m.next_seq = 1;
+	}
+	return &m;
+}
+__global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, const unsigned long long* __restrict__ fine_slots, Mailbox* box, uint32_t seq) {
+	unsigned long long f = threadIdx.x < SCAN_AUX_SLOTS ? fine_slots[threadIdx.x] : 0ull;
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) f += __shfl_xor(f, off, WAVE);
+	if (threadIdx.x == 0) {
+		box->r_cells = *total_cells; box->r_fine = f;
+		__threadfence_system();
+		box->seq = seq;                       // published last: the host spins on it
+	}
+}
+// returns 0 when the GPU published `seq`; falls back to draining the stream if that takes implausibly long
+static int wait_mailbox(const MailboxRef* m, uint32_t seq, hipStream_t stream) {
+	const auto t0 = std::chrono::steady_clock::now();
+	for (unsigned spin = 0;; spin++) {
+		if (m->host->seq == seq) return 0;
+		if ((spin & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+	}
+	ADGS_HIP_CHECK(hipStreamSynchronize(stream));
+	if (m->host->seq == seq) return 0;
+	set_error("the device never published the binning counts"); return -1;
 }
 
 } // namespace adgs
@@ -296,12 +331,11 @@ static int raster_forward_impl(const ShSource* sh_src,
 		// (previous frames' counts + 25%) with the exact count read on the device; the host then waits only
 		// for the scan to finish -- the GPU keeps working on the speculative launches meanwhile -- and
 		// re-runs them with exact sizes in the rare case the capacity was too small.
-		uint32_t* hw = pinned_word();
-		hipEvent_t ev = readback_event();
-		if (!hw || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return -1; }
-		ADGS_HIP_CHECK(hipMemcpyAsync(hw, geom.offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		ADGS_HIP_CHECK(hipMemcpyAsync(hw + 2, geom.fine_total, SCAN_AUX_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		ADGS_HIP_CHECK(hipEventRecord(ev, stream));
+		MailboxRef* mb = mailbox();
+		if (!mb) { set_error("hipHostMalloc (mapped) failed"); return -1; }
+		const uint32_t seq = mb->next_seq++;
+		hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(WAVE), 0, stream, (const uint32_t*)(geom.offsets + P), (const unsigned long long*)geom.fine_total, mb->dev, seq);
+		ADGS_HIP_CHECK(hipGetLastError());
 		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
 		const bool speculate = env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99;
 		const int bit = (int)higher_msb((uint32_t)ncells);
@@ -332,10 +366,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 			return 0;
 		};
 		if (speculate && enqueue_binning(cap_cells, cap_fine, geom.offsets + P) != 0) return -1;
-		ADGS_HIP_CHECK(hipEventSynchronize(ev));
-		size_t R_fine = 0;
-		for (int i = 0; i < SCAN_AUX_SLOTS; i++) R_fine += (size_t)reinterpret_cast<unsigned long long*>(hw + 2)[i];
-		const size_t R_cells = hw[0];
+		if (wait_mailbox(mb, seq, stream) != 0) return -1;
+		const size_t R_cells = mb->host->r_cells, R_fine = (size_t)mb->host->r_fine;
 		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu\n", P, ncells, R_cells, R_fine);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
 		ADGS_DBG_STOP(0)
