@@ -62,6 +62,8 @@ SIGNATURES = {
     "adgs_adam_step": (c_i, [c_p, c_i, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_p]),
     "adgs_deform_forward_flow": (c_i, [c_p] * 10),
     "adgs_deform_backward_flow": (c_i, [c_p] * 15),
+    # include/adgs_exchange.h
+    "adgs_sh_grad_expand": (c_i, [c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p]),
     # include/adgs_testing.h
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),

@@ -660,6 +660,7 @@ extern "C" int adgs_raster_backward_rawsh(
 	ShGradDst dst;
 	dst.scene_dc = dL_dsh->scene_dc; dst.obj_dc = dL_dsh->obj_dc; dst.scene_rest = dL_dsh->scene_rest; dst.obj_rest = dL_dsh->obj_rest;
 	dst.scene_sp = dL_dsh->scene_deform; dst.obj_sp = dL_dsh->obj_deform;
+	dst.rgb_factor = dL_dsh->rgb_factor;
 	return raster_backward_impl(&src, &dst, P, D, M, R, D_S, background, width, height, means3D, nullptr, nullptr, flow_points, semantic,
 		scales, scale_modifier, rotations, nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
 		img_buffer, dL_dpix, dL_dpix_depth, dL_dpix_flow, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,

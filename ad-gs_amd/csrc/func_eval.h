@@ -114,6 +114,7 @@ struct ShSource {
 };
 struct ShGradDst {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_sp, *obj_sp;
+	float *rgb_factor;   // [P,3] clamp-masked colour gradient: the per-camera factor every SH gradient row is a multiple of
 };
 
 } // namespace adgs

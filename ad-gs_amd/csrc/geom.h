@@ -38,4 +38,35 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod,
 	out[3] = Sg[1][1]; out[4] = Sg[1][2]; out[5] = Sg[2][2];
 }
 
+// d colour / d SH coefficient k for the unit view direction (x, y, z): the per-coefficient factors of
+// computeColorFromSH's backward (backward.cu:44-112), coefficient 0 included; entries above the active degree are 0.
+// Shared by the preprocess backward (which multiplies them by one camera's colour gradient) and by the multi-camera
+// gradient expansion (exchange.hip), so that both produce the same rows.
+__device__ __forceinline__ void sh_coef_factors(int deg, float x, float y, float z, float* coef) {
+	const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+	const float C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
+	const float C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+		-0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+#pragma unroll
+	for (int k = 0; k < 16; k++) coef[k] = 0.f;
+	coef[0] = C0;
+	if (deg > 0) {
+		coef[1] = -C1 * y; coef[2] = C1 * z; coef[3] = -C1 * x;
+		if (deg > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+			coef[4] = C2[0] * xy; coef[5] = C2[1] * yz; coef[6] = C2[2] * (2.f * zz - xx - yy);
+			coef[7] = C2[3] * xz; coef[8] = C2[4] * (xx - yy);
+			if (deg > 2) {
+				coef[9] = C3[0] * y * (3.f * xx - yy);
+				coef[10] = C3[1] * xy * z;
+				coef[11] = C3[2] * y * (4.f * zz - xx - yy);
+				coef[12] = C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+				coef[13] = C3[4] * x * (4.f * zz - xx - yy);
+				coef[14] = C3[5] * z * (xx - yy);
+				coef[15] = C3[6] * x * (xx - 3.f * yy);
+			}
+		}
+	}
+}
+
 } // namespace adgs

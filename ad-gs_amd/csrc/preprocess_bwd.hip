@@ -86,7 +86,8 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 				float* gdc = (is_obj ? a.sh_dst.obj_dc : a.sh_dst.scene_dc);
 				float* gre = (is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest);
 				if (gdc) { gdc[3 * m] = 0.f; gdc[3 * m + 1] = 0.f; gdc[3 * m + 2] = 0.f; }
-				if (STAGED) { for (int i = 0; i < SH_ROW_REST; i++) s_sh[tid * SH_ROW_REST + i] = 0.f; }
+				if (a.sh_dst.rgb_factor) { float* rf = a.sh_dst.rgb_factor + 3 * (size_t)idx; rf[0] = 0.f; rf[1] = 0.f; rf[2] = 0.f; }
+				if (STAGED) { if (gre) for (int i = 0; i < SH_ROW_REST; i++) s_sh[tid * SH_ROW_REST + i] = 0.f; }
 				else if (gre) for (int i = 0; i < (a.M - 1) * 3; i++) gre[m * (size_t)(a.M - 1) * 3 + i] = 0.f;
 			} else if (a.shs) {
 				if (STAGED) { for (int i = 0; i < SH_ROW_FULL; i++) s_sh[tid * SH_ROW_FULL_LDS + i] = 0.f; }
@@ -232,15 +233,18 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		// STAGED: sh and dsh are the SAME LDS row, so every read of sh happens before any write of dsh.
 		const float* sh; float* dsh; float* dsh0;
 		float dummy0[3];
+		bool want_rows = true;       // raw path: false when the caller did not ask for the gradient of the `rest` coefficients
 		if (raw) {
 			const bool is_obj = idx >= a.sh_src.Ns;
 			const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
 			float* gdc = is_obj ? a.sh_dst.obj_dc : a.sh_dst.scene_dc;
+			float* gre = is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest;
 			dsh0 = gdc ? gdc + 3 * m : dummy0;
+			want_rows = gre != nullptr;
 			if (STAGED) { dsh = s_sh + tid * SH_ROW_REST - 3; sh = dsh; }
 			else {
 				sh = (is_obj ? a.sh_src.obj_rest : a.sh_src.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
-				dsh = (is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
+				dsh = gre + m * (size_t)(a.M - 1) * 3 - 3;
 			}
 		} else if (STAGED) {
 			dsh = s_sh + tid * SH_ROW_FULL_LDS; sh = dsh; dsh0 = dsh;
@@ -288,27 +292,16 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			}
 		}
 		// ---- pass B: gradients w.r.t. the coefficients (WRITES; may alias the row read above)
-#define SETSH(k, coef) { const float _c = (coef); dsh[(k) * 3 + 0] = _c * g[0]; dsh[(k) * 3 + 1] = _c * g[1]; dsh[(k) * 3 + 2] = _c * g[2]; }
 		dsh0[0] = C0 * g[0]; dsh0[1] = C0 * g[1]; dsh0[2] = C0 * g[2];
-		if (deg > 0) {
-			SETSH(1, -C1 * y); SETSH(2, C1 * z); SETSH(3, -C1 * x);
-			if (deg > 1) {
-				SETSH(4, C2[0] * xy); SETSH(5, C2[1] * yz); SETSH(6, C2[2] * (2.f * zz - xx - yy));
-				SETSH(7, C2[3] * xz); SETSH(8, C2[4] * (xx - yy));
-				if (deg > 2) {
-					SETSH(9, C3[0] * y * (3.f * xx - yy));
-					SETSH(10, C3[1] * xy * z);
-					SETSH(11, C3[2] * y * (4.f * zz - xx - yy));
-					SETSH(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-					SETSH(13, C3[4] * x * (4.f * zz - xx - yy));
-					SETSH(14, C3[5] * z * (xx - yy));
-					SETSH(15, C3[6] * x * (xx - 3.f * yy));
-				}
-			}
+		if (raw && a.sh_dst.rgb_factor) { float* rf = a.sh_dst.rgb_factor + 3 * (size_t)idx; rf[0] = g[0]; rf[1] = g[1]; rf[2] = g[2]; }
+		if (want_rows) {
+			float coef[16];
+			sh_coef_factors(deg, x, y, z, coef);
+			// coefficients above the active degree receive no gradient (their factor is 0)
+#pragma unroll
+			for (int k = 1; k < 16; k++)
+				if (k < a.M) { dsh[k * 3] = coef[k] * g[0]; dsh[k * 3 + 1] = coef[k] * g[1]; dsh[k * 3 + 2] = coef[k] * g[2]; }
 		}
-#undef SETSH
-		// coefficients above the active degree receive no gradient
-		for (int k = (deg + 1) * (deg + 1); k < a.M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
 		const float ddx = dx3[0] * g[0] + dx3[1] * g[1] + dx3[2] * g[2];
 		const float ddy = dy3[0] * g[0] + dy3[1] * g[1] + dy3[2] * g[2];
 		const float ddz = dz3[0] * g[0] + dz3[1] * g[1] + dz3[2] * g[2];

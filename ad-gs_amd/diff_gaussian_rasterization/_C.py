@@ -164,7 +164,8 @@ class ShSource(ctypes.Structure):
 
 
 class ShGrads(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform")]
+    """adgs_sh_grads (include/adgs_rasterizer.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor")]
 
 
 def _sh_source(raw, dev):
@@ -217,7 +218,9 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
 def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_semantic, semantic, flow_points, sh_raw,
                                        sh_needs_grad, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, img_opacity, grad_img_opacity,
-                                       inv_depth, debug):
+                                       inv_depth, debug, want_rgb_factor=False):
+    """With want_rgb_factor the result carries one more entry: the [P,3] clamp-masked colour gradient every SH gradient row is a
+    multiple of (include/adgs_exchange.h); combined with sh_needs_grad all False the SH rows are not materialised at all."""
     lib = _lib.lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -236,11 +239,18 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     need = list(sh_needs_grad)
     need[0], need[1] = need[0] or need[4], need[1] or need[5]      # the deform-param gradients are derived from the dc gradients
     sh_grads = [torch.empty_like(t) if (nd and t is not None and t.numel() != 0) else None for t, nd in zip(sh_raw[:6], need)]
+    if torch.is_tensor(want_rgb_factor):           # the caller's own [P,3] destination (adgs.dp.FactoredSHExchange's send buffer)
+        rgb_factor = want_rgb_factor
+        if rgb_factor.shape != (P, 3) or rgb_factor.dtype != torch.float32 or not rgb_factor.is_contiguous() or rgb_factor.device != dev:
+            raise RuntimeError("rgb_factor destination must be a contiguous float32 [P,3] tensor on the rasterizer's device")
+    else:
+        rgb_factor = (e(P, 3) if P != 0 else torch.zeros((0, 3), dtype=torch.float32, device=dev)) if want_rgb_factor else None
     if P != 0:
         src, keep_sh = _sh_source(sh_raw, dev)
         gs = ShGrads()
         for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
             setattr(gs, name, _ptr(t))
+        gs.rgb_factor = _ptr(rgb_factor)
         keep = [_prep(t, dev, n) for t, n in (
             (background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"), (scales, "scales"),
             (rotations, "rotations"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"),
@@ -257,4 +267,6 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
                 ctypes.byref(gs), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dflow_points), _ptr(dL_dsemantic), _ptr(go_), _ptr(io_),
                 int(bool(inv_depth)), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_backward_rawsh")
     sh_grads = [g if nd else None for g, nd in zip(sh_grads, sh_needs_grad)]
+    if rgb_factor is not None:
+        return dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic, rgb_factor
     return dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic

@@ -101,17 +101,21 @@ class RawSH(NamedTuple):
 
 
 class _RasterizeGaussiansRawSH(torch.autograd.Function):
-    """Same operator as _RasterizeGaussians with the SH input/gradients in the raw tensors' layout."""
+    """Same operator as _RasterizeGaussians with the SH input/gradients in the raw tensors' layout.
+
+    With a `factor_sink` (a list) the backward does not materialise the six SH parameter gradients: it appends the
+    [P,3] clamp-masked colour gradient they are all multiples of (include/adgs_exchange.h) to the list and returns None
+    for them; adgs.dp.FactoredSHExchange turns the factors of all cameras of an iteration into the summed gradients."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, scales, rotations, flow_points, semantic, scene_dc, obj_dc, scene_rest, obj_rest,
-                scene_deform, obj_deform, func_eval, raster_settings):
+                scene_deform, obj_deform, func_eval, raster_settings, factor_sink=None):
         s = raster_settings
         raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval)
         (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow, img_semantic) = _C.rasterize_gaussians_rawsh(
             s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
             s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
-        ctx.raster_settings, ctx.num_rendered, ctx.func_eval = s, num_rendered, func_eval
+        ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink = s, num_rendered, func_eval, factor_sink
         ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
                               scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform)
         return color, radii, depth, img_opacity, img_flow, img_semantic
@@ -122,11 +126,17 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         (means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
          scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform) = ctx.saved_tensors
         raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval)
-        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem) = _C.rasterize_gaussians_backward_rawsh(
+        factored = ctx.factor_sink is not None
+        need = (False,) * 6 if factored else ctx.needs_input_grad[7:13]
+        res = _C.rasterize_gaussians_backward_rawsh(
             s.bg, means3D, radii, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
-            grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, ctx.needs_input_grad[7:13], s.sh_degree, s.campos,
-            geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug)
-        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None)
+            grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, need, s.sh_degree, s.campos,
+            geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
+            want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False)
+        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem) = res[:8]
+        if factored:
+            ctx.factor_sink.append(res[8])
+        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
@@ -146,12 +156,13 @@ class GaussianRasterizer(nn.Module):
             s = self.raster_settings
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
-    def forward_rawsh(self, means3D, means2D, opacities, sh_raw, scales, rotations, flow_points=None, semantic=None):
-        """Extension (no reference counterpart): like forward(), with the SH coefficients given as a RawSH."""
+    def forward_rawsh(self, means3D, means2D, opacities, sh_raw, scales, rotations, flow_points=None, semantic=None, factor_sink=None):
+        """Extension (no reference counterpart): like forward(), with the SH coefficients given as a RawSH.
+        factor_sink: see _RasterizeGaussiansRawSH (factored SH gradients for data-parallel training)."""
         empty = lambda t: torch.Tensor([]) if t is None else t
         return _RasterizeGaussiansRawSH.apply(means3D, means2D, opacities, scales, rotations, empty(flow_points), empty(semantic),
                                               sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest, sh_raw.obj_rest, sh_raw.scene_deform,
-                                              sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings)
+                                              sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings, factor_sink)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, flow_points=None, semantic=None):

@@ -193,7 +193,8 @@ class DeformFrame:
     def zero_grad(self):
         self.model.zero_grad()
 
-    def forward(self):
+    def forward(self, sink_for=None):
+        """sink_for: adgs.dp.FactoredSHExchange.sink_for -- the backward then leaves the SH gradients in factored form."""
         import torch
         m = self.model
         if self.use_fs and self.fused_flow:
@@ -209,7 +210,8 @@ class DeformFrame:
                 rotations=pkg["rotation"], flow_points=flow, semantic=self.sem)
         else:
             color, radii, depth, op, fl, sem = self.rast.forward_rawsh(pkg["xyz"], means2D, pkg["opacity"], pkg["shs"], pkg["scales"],
-                                                                       pkg["rotation"], flow_points=flow, semantic=self.sem)
+                                                                       pkg["rotation"], flow_points=flow, semantic=self.sem,
+                                                                       factor_sink=None if sink_for is None else sink_for(pkg["xyz"]))
         self.last_radii = radii
         return [color, depth, op] + ([fl, sem] if self.use_fs else [])
 
@@ -299,11 +301,31 @@ def main():
     up = synthetic.make_upstream_grads(sc, 0)
     up_list = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
 
+    # Gradient exchange of the multi-GPU step.  Default on the raw-SH path: the SH gradients travel in
+    # factored form (one all-gather of 12 B per Gaussian and camera + a dense all-reduce of the rest + a local expansion);
+    # ADGS_DP_EXCHANGE=dense all-reduces every materialised gradient instead.  ADGS_BENCH_FACTORED=1 runs the factored
+    # step on one GPU as well (one camera; measures the backward without SH rows + the expansion).
+    factored = (isinstance(frame, DeformFrame) and frame.model.raw_sh and os.environ.get("ADGS_DP_EXCHANGE", "factored") != "dense"
+                and (world > 1 or os.environ.get("ADGS_BENCH_FACTORED") == "1"))
+    exchange = "none"
+    if factored:
+        ex = dp.FactoredSHExchange(frame.model)
+        cam_times = [frame.t] * world
+        cam_positions = [synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if world == 1 else r)["campos"].tolist() for r in range(world)]
+        exchange = "factored SH gradients: all-gather of the colour-gradient factors + dense all-reduce of the rest + local expansion"
+    elif world > 1:
+        exchange = "dense all-reduce of every parameter gradient"
+
     def step():
-        outs = frame.forward()
-        torch.autograd.backward(outs, up_list)
-        if world > 1:
-            dp.allreduce_gradients(frame.parameters())
+        if factored:
+            outs = frame.forward(sink_for=ex.sink_for)
+            torch.autograd.backward(outs, up_list)
+            ex.reduce(cam_times, cam_positions)
+        else:
+            outs = frame.forward()
+            torch.autograd.backward(outs, up_list)
+            if world > 1:
+                dp.allreduce_gradients(frame.parameters())
         frame.zero_grad()
 
     # Settle phase (setup, not a measurement): a fresh process on a fresh box shows one-off stalls of 0.1-0.6 s in its first
@@ -407,7 +429,7 @@ def main():
             "config": dict({"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, 1 camera/GPU/step" % (
                 args.config, P, W, H, cfg["sh_degree"], cfg["n_objects"], ", flow+semantic outputs" if use_fs else ""),
                 "P": P, "P_visible": V, "tiles": T, "deformation": frame.deform_desc,
-                "parallelism": "dp%d (camera-parallel, RCCL gradient all-reduce)" % world if world > 1 else "single GPU",
+                "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
                 "alg_bytes_per_frame": int(frame_bytes),
                 "frame_hbm_frac_of_8TBs": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4),
                 "reference_alg_bytes_per_frame": int(ref_bytes),

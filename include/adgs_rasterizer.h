@@ -135,6 +135,9 @@ typedef struct adgs_sh_source {
 } adgs_sh_source;
 typedef struct adgs_sh_grads {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_deform, *obj_deform;   /* NULL = not wanted */
+	float *rgb_factor;   /* [P,3] or NULL: the clamp-masked colour gradient dL/dRGB * (1 - clamped) (backward.cu:20-139), 0 for
+	                        Gaussians with radii == 0 -- the one per-camera vector every SH gradient row above is a multiple of
+	                        (adgs_exchange.h: data-parallel ranks exchange this instead of the expanded rows) */
 } adgs_sh_grads;
 
 int adgs_raster_forward_rawsh(

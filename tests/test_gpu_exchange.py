@@ -1,0 +1,143 @@
+"""GPU parity of the factored SH-gradient exchange (include/adgs_exchange.h): the expansion kernel vs the NumPy oracle, the
+rgb_factor output of the raw-SH backward vs the CPU raster oracle, and the whole factored path (several cameras, world 1) vs
+conventional gradient accumulation over the same cameras.  Tolerance 1e-4 (north_star); observed ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import exchange_oracle as xo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(name, a, b, tol=TOL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * 1e-2 * scale, err_msg=name)
+
+
+@pytest.mark.parametrize("Ns,No,M,C,D,row0_mode,n", [(700, 301, 16, 12, 3, "scene", 3), (700, 301, 16, 12, 2, "none", 2), (0, 513, 16, 12, 3, "scene", 1),
+                                                     (1000, 0, 16, 0, 3, "scene", 4), (257, 255, 4, 7, 1, "scene", 8), (300, 11, 1, 12, 0, "none", 2),
+                                                     (5000, 3000, 16, 12, 3, "scene", 32)])
+def test_expand_kernel_vs_numpy_oracle(Ns, No, M, C, D, row0_mode, n):
+    from adgs import dp
+    rng = np.random.default_rng(Ns + No + n)
+    P = Ns + No
+    row0 = Ns if row0_mode == "scene" else 0
+    head = (rng.normal(size=(Ns, 3)) + [0, 0, 6.0]).astype(np.float32)
+    cams = []
+    for c in range(n):
+        rgb = rng.normal(size=(P, 3)).astype(np.float32)
+        rgb[rng.random(P) < 0.35] = 0.0
+        tail = (rng.normal(size=(P - row0, 3)) + [0, 0, 6.0]).astype(np.float32)
+        if row0 == 0 and Ns:
+            tail[:Ns] = head
+        cams.append((rgb, tail if P - row0 > 0 else None, rng.normal(size=3).astype(np.float32)))
+    W = rng.normal(size=(n, max(C, 1))).astype(np.float32)
+    want = xo.expand(cams, W, C, P, Ns, row0, head, D, M)
+    d = lambda a: None if a is None else torch.tensor(a, device="cuda")
+    shapes = [(Ns, 1, 3), (No, 1, 3), (Ns, M - 1, 3), (No, M - 1, 3), (Ns, 3, C), (No, 3, C)]
+    outs = [torch.full(s, float("nan"), device="cuda") if int(np.prod(s)) else None for s in shapes]
+    dp.hip_sh_grad_expand([(d(r), d(t), cp.tolist()) for r, t, cp in cams], d(W) if C else None, C, P, Ns, row0, d(head) if row0 else None, D, M, outs)
+    torch.cuda.synchronize()
+    for name, o, w in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), outs, want):
+        if o is not None:
+            close(name, o.cpu().numpy(), w.reshape(o.shape))
+
+
+def test_expand_rejects_bad_arguments():
+    from adgs import dp
+    z = torch.zeros(4, 3, device="cuda")
+    with pytest.raises(RuntimeError):
+        dp.hip_sh_grad_expand([(z, None, [0, 0, 0])] * 33, None, 0, 4, 4, 4, z, 3, 16, [None] * 6)
+    with pytest.raises(RuntimeError):
+        dp.hip_sh_grad_expand([(z, None, [0, 0, 0])], None, 0, 4, 4, 2, z, 3, 16, [torch.zeros(4, 1, 3, device="cuda")] + [None] * 5)   # missing tail
+    with pytest.raises(RuntimeError):
+        dp.hip_sh_grad_expand([(z.cpu(), None, [0, 0, 0])], None, 0, 4, 4, 4, z, 3, 16, [None] * 6)
+
+
+def _render_cam(model, cam, t, ups, sink):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    d = lambda x: x.to("cuda")
+    s = GaussianRasterizationSettings(cam["H"], cam["W"], cam["tanfovx"], cam["tanfovy"], torch.zeros(3, device="cuda"), 1.0, d(cam["viewmatrix"]),
+                                      d(cam["projmatrix"]), model.active_sh_degree, d(cam["campos"]), False, True, False)
+    pkg = model.get_deformed_pkg(t, flow_time=t + 0.05)
+    means2D = torch.zeros_like(pkg["xyz"], requires_grad=True)
+    sem = model.get_obj_mask.float()[:, None].contiguous()
+    outs = GaussianRasterizer(s).forward_rawsh(pkg["xyz"], means2D, pkg["opacity"], pkg["shs"], pkg["scales"], pkg["rotation"], flow_points=pkg["flow_xyz"],
+                                               semantic=sem, factor_sink=None if sink is None else sink(pkg["xyz"]))
+    color, radii, depth, op, flow, semi = outs
+    torch.autograd.backward([color, depth, op, flow, semi], ups)
+    return radii
+
+
+@pytest.mark.parametrize("background", [False, True])
+def test_factored_multi_camera_gradients_equal_conventional_accumulation(background):
+    from adgs import dp, synthetic
+    from adgs.model import SyntheticGaussianModel, DEFAULT_ORDER_ARGS
+    sc = synthetic.make_scene(6000, 208, 128, 150.0, sh_degree=3, seed=5, n_objects=2)
+    oa = dict(DEFAULT_ORDER_ARGS)
+    if background:
+        oa["background"] = [0, 0, 2, 0, 0, 0]
+    times = [0.1, 0.45, 0.8]
+    cams = [synthetic.make_camera(208, 128, 150.0, cam_seed=c) for c in range(3)]
+    up = synthetic.make_upstream_grads(sc, 2)
+    ups = [up[k].cuda() for k in ("color", "depth", "img_opacity", "flow", "semantic")]
+
+    def run(factored):
+        model = SyntheticGaussianModel.from_scene(sc, torch.device("cuda", 0), seed=1, order_args=oa)
+        model.raw_sh = True
+        ex = dp.FactoredSHExchange(model) if factored else None
+        vis = 0
+        for cam, t in zip(cams, times):
+            vis += int((_render_cam(model, cam, t, ups, ex.sink_for if factored else None) > 0).sum())
+        if factored:
+            assert all(getattr(model, n).grad is None for n in dp._SH_PARAMS), "the backward must not materialise SH gradients"
+            ex.reduce(times, [c["campos"].tolist() for c in cams])
+        torch.cuda.synchronize()
+        assert vis > 3000
+        return {n: getattr(model, n).grad.detach().cpu().numpy() for n in
+                ("_scene_xyz", "_obj_xyz", "_scene_shs_dc", "_obj_shs_dc", "_scene_shs_rest", "_obj_shs_rest", "shs_deform_param_scene",
+                 "shs_deform_param_obj", "_scene_opacity", "_obj_scaling", "xyz_deform_param", "rotation_deform_param", "background_deform_param")
+                if getattr(model, n).grad is not None}
+
+    a, b = run(False), run(True)
+    assert set(a) == set(b)
+    for k in a:
+        assert np.abs(a[k]).max() > 0, k
+        close(k, b[k], a[k])
+
+
+def test_rgb_factor_equals_oracle_masked_colour_gradient():
+    """adgs_sh_grads.rgb_factor vs the CPU raster oracle: dL_dcolors * (1 - clamped), 0 where radii == 0."""
+    from adgs import synthetic
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, RawSH
+    from adgs.deform import make_func_eval
+    from oracle import oracle
+    sc = synthetic.make_scene(3000, 160, 96, 120.0, sh_degree=3, seed=11, n_objects=0)
+    g = synthetic.make_upstream_grads(sc, 3)
+    d = lambda x: x.to("cuda")
+    s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], d(sc["bg"]), 1.0, d(sc["viewmatrix"]), d(sc["projmatrix"]), 3,
+                                      d(sc["campos"]), False, True, False)
+    Ns = 2000
+    leaf = lambda t: d(t).contiguous().requires_grad_(True)
+    shs = sc["shs"]
+    raw = RawSH(leaf(shs[:Ns, :1]), leaf(shs[Ns:, :1]), leaf(shs[:Ns, 1:]), leaf(shs[Ns:, 1:]), torch.zeros(Ns, 3, 0, device="cuda"),
+                torch.zeros(sc["P"] - Ns, 3, 0, device="cuda"), make_func_eval(0.3, [0] * 6, 0))
+    L = {k: leaf(sc[k]) for k in ("means3D", "opacities", "scales", "rotations")}
+    sink = []
+    color, radii, depth, op, _, _ = GaussianRasterizer(s).forward_rawsh(L["means3D"], torch.zeros(sc["P"], 3, device="cuda", requires_grad=True), L["opacities"],
+                                                                        raw, L["scales"], L["rotations"], factor_sink=sink)
+    torch.autograd.backward([color, depth, op], [d(g["color"]), d(g["depth"]), d(g["img_opacity"])])
+    torch.cuda.synchronize()
+    assert len(sink) == 1 and raw.scene_rest.grad is None and raw.scene_dc.grad is None
+    o = oracle.RasterOracle("f32")
+    o.forward(sc["bg"], sc["means3D"], None, sc["opacities"], sc["scales"], sc["rotations"], 1.0, None, sc["viewmatrix"], sc["projmatrix"], sc["tanfovx"],
+              sc["tanfovy"], sc["H"], sc["W"], sc["shs"], None, None, 3, sc["campos"], False, True)
+    st = o.state()
+    rg = o.backward(g["color"], g["depth"], np.zeros((3, sc["H"], sc["W"]), np.float32), None, g["img_opacity"])
+    want = rg["dL_dcolors"] * (1 - st["clamped"].astype(np.float32)) * (radii.cpu().numpy() > 0)[:, None]
+    assert st["clamped"].sum() > 0
+    close("rgb_factor", sink[0].cpu().numpy(), want)
+    close("dL_dmeans3D", L["means3D"].grad.cpu().numpy(), rg["dL_dmeans3D"])
