@@ -31,7 +31,7 @@ def _flatten_bucket(tensors, max_bytes):
     return buckets
 
 
-def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 20, in_place_bytes=32 << 20):
+def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 20, in_place_bytes=32 << 20, force=False):
     """Sum `.grad` of every parameter over all ranks (missing grads count as zero).
 
     Tensors of at least `in_place_bytes` are reduced in place, one async collective each (no flatten
@@ -39,8 +39,8 @@ def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 2
     (the copies are ~80 MB in total at C3, 0.03 ms).  xGMI is point-to-point, so few large collectives
     are preferred over many small ones: C3 ends up with 6 in-place reductions and one bucket.
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return                                   # force: issue the collectives even in a one-rank group (RCCL self-test on a 1-GPU box)
     world = dist.get_world_size(group)
     grads = []
     for p in params:
@@ -197,6 +197,7 @@ class FactoredSHExchange:
         self.model, self.group = model, group
         self.expand = expand
         self.sink = _FactorSink(self)
+        self.force_collectives = False           # tools/rccl_selftest.py: run the collectives in a one-rank group too
         self.n_means = 0
         self.send = self.recv = None
         self._w_cache, self._cam_cache = {}, {}
@@ -261,7 +262,8 @@ class FactoredSHExchange:
         for j in range(n_local, k_max):
             send[j].zero_()                          # this rank has no j-th camera: an all-zero factor contributes nothing
         work = None
-        if world > 1:
+        coll = world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
+        if coll:
             if self.recv is None or self.recv.shape != (world, k_max, send.shape[1]):
                 self.recv = torch.empty(world, k_max, send.shape[1], dtype=torch.float32, device=send.device)
             recv = self.recv
@@ -270,10 +272,10 @@ class FactoredSHExchange:
             recv = send[:k_max].unsqueeze(0)
         # the dense remainder: every parameter except the six SH tensors
         sh = [getattr(m, n, None) for n in _SH_PARAMS]
-        if world > 1:
+        if coll:
             if dense_params is None:
                 dense_params = [p for p in m.parameters() if not any(p is s for s in sh)]
-            allreduce_gradients(dense_params, group=self.group)
+            allreduce_gradients(dense_params, group=self.group, force=self.force_collectives)
         if work is not None:
             work.wait()
         cams = []
