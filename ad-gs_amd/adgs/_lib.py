@@ -64,6 +64,13 @@ SIGNATURES = {
     "adgs_deform_backward_flow": (c_i, [c_p] * 15),
     # include/adgs_exchange.h
     "adgs_sh_grad_expand": (c_i, [c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p]),
+    # include/adgs_densify.h
+    "adgs_densify_workspace_bytes": (ctypes.c_size_t, [c_i]),
+    "adgs_densify_select": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_densify_plan": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_densify_gather_rows": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "adgs_densify_split_rows": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_reset_opacity": (c_i, [c_i, c_p, c_p]),
     # include/adgs_testing.h
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),
