@@ -2,12 +2,17 @@
 (scene/gaussian_model.py:27-231): the same attribute names for the raw parameters and the same
 getters (`get_xyz`, `get_scaling`, `get_obj_mask`, `get_deformed_xyz(t)`, `get_deformed_pkg(t)`,
 `active_sh_degree`), with the per-frame work done by the fused HIP deformation kernels
-(adgs.deform) instead of ~30 small PyTorch kernels.  Training-side machinery of the reference
-(densify, optimizer surgery, PLY I/O) is out of scope.
+(adgs.deform) instead of ~30 small PyTorch kernels.  The training-side methods that sit next to the hot
+path keep their reference names too: training_setup (fused Adam with the reference's group names),
+add_densification_stats, densify_and_prune, reset_opacity, set_obj_near_idx (adgs.densify / adgs.knn: HIP),
+save_ply / load_ply (adgs.io: the reference's point_cloud.ply + deform.pth).
 """
 import torch
 
 from . import deform
+from . import densify as _densify
+from . import io as _io
+from . import knn as _knn
 
 DEFAULT_ORDER_ARGS = dict(xyz=[6, 5, 0, 6, 0, 0], rotation=[0, 0, 0, 0, 6, 5], shs=[0, 0, 0, 6, 0, 0], background=[0] * 6)
 
@@ -108,3 +113,57 @@ class SyntheticGaussianModel:
         n = sum(getattr(self, k).numel() for k in ("xyz_deform_param", "rotation_deform_param", "shs_deform_param_scene",
                                                    "shs_deform_param_obj", "background_deform_param"))
         return 2 * 4 * n
+
+    # ---- training-side methods under their reference names (scene/gaussian_model.py:338-400, 413-541, 825-867) ----
+    percent_dense, scene_extent, object_extent = 0.01, 1.0, 1.0
+    use_near_idx, near_num, obj_near_idx, optimizer = False, 0, None, None
+
+    def training_setup(self, lrs=None, percent_dense=0.01, scene_extent=None, object_extent=None, near_num=0):
+        """The optimizer of GaussianModel.training_setup (:338-372): one group per raw tensor, the reference's group names,
+        Adam(lr=0, eps=1e-15) -- here the fused HIP Adam.  `lrs`: {group name: lr} (default 1e-3 each)."""
+        from .optim import FusedAdam
+        lrs = lrs or {}
+        self.percent_dense = percent_dense
+        self.scene_extent = self.scene_extent if scene_extent is None else scene_extent
+        self.object_extent = self.object_extent if object_extent is None else object_extent
+        dev = self._scene_xyz.device
+        N = self.get_pts_num
+        self.xyz_gradient_accum = torch.zeros((N, 1), device=dev)
+        self.denom = torch.zeros((N, 1), device=dev)
+        self.max_radii2D = torch.zeros((N,), device=dev)
+        order = ["scene_xyz", "scene_shs_dc", "scene_shs_rest", "scene_opacity", "scene_scaling", "scene_rotation", "obj_xyz", "obj_shs_dc",
+                 "obj_shs_rest", "obj_opacity", "obj_scaling", "obj_rotation", "deform_rotation", "deform_shs_scene", "deform_shs_obj", "deform_xyz",
+                 "deform_background", "time_sigma"]
+        groups = []
+        for name in order:
+            attr = _densify.GROUP_ATTR[name]
+            t = getattr(self, attr)
+            if not isinstance(t, torch.nn.Parameter):
+                t = torch.nn.Parameter(t.detach().requires_grad_(True))
+                setattr(self, attr, t)
+            groups.append({"params": [t], "lr": float(lrs.get(name, 1e-3)), "name": name})
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        self.near_num, self.use_near_idx = near_num, near_num > 0
+        self.set_obj_near_idx()
+        return self.optimizer
+
+    def add_densification_stats(self, render_pkg):
+        from .optim import add_densification_stats
+        add_densification_stats(self.xyz_gradient_accum, self.denom, self.max_radii2D, render_pkg["viewspace_points"].grad, render_pkg["radii"])
+
+    def densify_and_prune(self, max_scene_grad, max_obj_grad, min_opacity, prune_big_points):
+        info = _densify.densify_and_prune(self, max_scene_grad, max_obj_grad, min_opacity, prune_big_points)
+        self.set_obj_near_idx()
+        return info
+
+    def reset_opacity(self):
+        _densify.reset_opacity(self)
+
+    def set_obj_near_idx(self, K=None):
+        return _knn.set_obj_near_idx(self, K)
+
+    def save_ply(self, path):
+        _io.save_ply(self, path)
+
+    def load_ply(self, path):
+        _io.load_ply(self, path, device=self._scene_xyz.device if torch.is_tensor(getattr(self, "_scene_xyz", None)) else "cuda")

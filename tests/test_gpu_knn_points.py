@@ -1,0 +1,51 @@
+"""GPU parity of the HIP K-nearest-neighbour index (adgs.knn.knn_points / set_obj_near_idx) vs the NumPy oracle: index
+lists bit-exact (same float32 distance arithmetic, same tie rule), distances bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_points_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,A,D,K", [(20000, 2500, 3, 8), (20000, 2500, 4, 8), (1000, 1000, 3, 1), (5000, 77, 4, 16), (3000, 300, 3, 32), (64, 8, 3, 8),
+                                     (100_000, 12_500, 4, 8)])
+def test_knn_points_vs_oracle(N, A, D, K):
+    from adgs.knn import knn_points
+    rng = np.random.default_rng(N + A + D + K)
+    pts = rng.normal(size=(N, D)).astype(np.float32)
+    pts[N // 2:N // 2 + 20] = pts[:20]                      # exact duplicates: ties must resolve to the lower index
+    anchors = pts[rng.permutation(N)[:A]]
+    res = knn_points(torch.tensor(anchors, device="cuda")[None], torch.tensor(pts, device="cuda")[None], K=K)
+    torch.cuda.synchronize()
+    assert res.idx.shape == (1, A, K) and res.idx.dtype == torch.int64 and res.dists.shape == (1, A, K)
+    dist, idx = ko.knn_points(anchors, pts, K)
+    assert np.array_equal(res.idx[0].cpu().numpy(), idx)
+    assert np.array_equal(res.dists[0].cpu().numpy(), dist)
+
+
+def test_set_obj_near_idx_and_errors():
+    from adgs.knn import knn_points, set_obj_near_idx
+
+    class M:
+        pass
+    m = M()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    m._obj_xyz = torch.randn(4000, 3, device="cuda", generator=g)
+    m.gs_time = torch.rand(4000, 1, device="cuda", generator=g)
+    m.scene_extent, m.use_time_mask, m.use_near_idx, m.near_num = 20.0, True, True, 8
+    torch.manual_seed(3)
+    idx = set_obj_near_idx(m)
+    assert idx.shape == (500, 8) and idx.dtype == torch.int64 and int(idx.min()) >= 0 and int(idx.max()) < 4000
+    torch.manual_seed(3)
+    perm = torch.randperm(4000, device="cuda")[:500]
+    assert torch.equal(idx[:, 0], perm)                      # every anchor's nearest neighbour is itself
+    xyz4 = torch.cat([m._obj_xyz, m.gs_time * 20.0], -1).cpu().numpy()
+    assert np.array_equal(idx.cpu().numpy(), ko.knn_points(xyz4[perm.cpu().numpy()], xyz4, 8)[1])
+    m.use_near_idx = False
+    assert set_obj_near_idx(m) is None
+    with pytest.raises(RuntimeError):
+        knn_points(torch.zeros(1, 4, 3), torch.zeros(1, 9, 3), K=2)
+    with pytest.raises(RuntimeError):
+        knn_points(torch.zeros(1, 4, 3, device="cuda"), torch.zeros(1, 9, 3, device="cuda"), K=33)

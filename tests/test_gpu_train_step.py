@@ -30,3 +30,50 @@ def test_a_few_training_iterations_run_and_reduce_the_loss():
     for p in model.parameters():
         assert torch.isfinite(p).all()
     assert torch.isfinite(env_map.grid_map).all() and float(env_map.grid_map.abs().max()) > 1e-4
+
+
+def test_densification_cycle_on_the_model_class():
+    """training_setup -> a few render/backward/stats/Adam iterations -> densify_and_prune -> reset_opacity -> neighbour index ->
+    save_ply/load_ply, all through SyntheticGaussianModel's reference-named methods, then the renderer again on the new set."""
+    import tempfile
+    import types
+    from adgs import synthetic
+    from adgs.model import SyntheticGaussianModel
+    from gaussian_renderer import render
+    dev = torch.device("cuda", 0)
+    sc = synthetic.make_scene(5000, 208, 130, 150.0, sh_degree=3, seed=4, n_objects=2)
+    model = SyntheticGaussianModel.from_scene(sc, dev, seed=2)
+    model.raw_sh = True
+    model.training_setup(percent_dense=0.01, scene_extent=20.0, object_extent=4.0, near_num=8)
+    assert model.obj_near_idx.shape == (model.get_obj_pts_num // 8, 8)
+    cam = synthetic.camera_object(sc, time=0.4)
+    pipe = types.SimpleNamespace(inv_depth=True, debug=False)
+    for it in range(3):
+        pkg = render(cam, model, None, pipe, flow_pkg=(0.45,) + (None,) * 5, render_objmask=True)
+        (pkg["render"].mean() + pkg["depth"].mean() * 0.1).backward()
+        model.add_densification_stats(pkg)
+        model.optimizer.step()
+        model.optimizer.zero_grad(set_to_none=True)
+    assert float(model.denom.sum()) > 0
+    n0 = model.get_pts_num
+    thr = float((model.xyz_gradient_accum / model.denom.clamp_min(1)).quantile(0.9))
+    torch.manual_seed(0)
+    info = model.densify_and_prune(thr, thr, 0.005, True)
+    n1 = model.get_pts_num
+    assert n1 != n0 and n1 == info["scene"][2] + info["obj"][2]
+    assert model.xyz_gradient_accum.shape == (n1, 1) and model.max_radii2D.shape == (n1,) and model.gs_time.shape[0] == model.get_obj_pts_num
+    assert model.obj_near_idx.shape == (model.get_obj_pts_num // 8, 8)
+    model.reset_opacity()
+    assert float(torch.sigmoid(model._scene_opacity).max()) <= 0.0100001
+    pkg = render(cam, model, None, pipe, flow_pkg=(0.45,) + (None,) * 5, render_objmask=True)
+    pkg["render"].mean().backward()
+    model.optimizer.step()
+    assert pkg["radii"].shape[0] == n1 and torch.isfinite(pkg["render"]).all()
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
+    with tempfile.TemporaryDirectory() as d:
+        model.save_ply(d + "/point_cloud.ply")
+        other = SyntheticGaussianModel(3, model.order_args)
+        other._scene_xyz = torch.zeros(0, 3, device=dev)
+        other.load_ply(d + "/point_cloud.ply")
+        assert torch.equal(other._obj_shs_rest, model._obj_shs_rest) and torch.equal(other.xyz_deform_param, model.xyz_deform_param)
