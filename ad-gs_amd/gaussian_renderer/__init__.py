@@ -36,18 +36,23 @@ def _deformed_state(pc, t, flow_pkg):
     return pc.get_deformed_pkg(t), pc.get_deformed_xyz(flow_t)
 
 
-def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic):
+def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic, sh_factor_sink=None):
     scales = pkg["scales"] if "scales" in pkg else pc.get_scaling
     shs = None if override_color is not None else pkg["shs"]
     if shs is not None and not torch.is_tensor(shs):
         # a RawSH: the rasterizer reads dc / rest / deformation rows in place, the [N,16,3] tensor is never built
         return rasterizer.forward_rawsh(pkg["xyz"], means2D, pkg["opacity"], shs, scales, pkg["rotation"], flow_points=flow_points,
-                                        semantic=semantic)
+                                        semantic=semantic, factor_sink=None if sh_factor_sink is None else sh_factor_sink(pkg["xyz"]))
+    if sh_factor_sink is not None:
+        raise RuntimeError("sh_factor_sink needs the raw-SH path (a model whose get_deformed_pkg hands out a RawSH)")
     return rasterizer(means3D=pkg["xyz"], means2D=means2D, opacities=pkg["opacity"], shs=shs, colors_precomp=override_color, scales=scales,
                       rotations=pkg["rotation"], flow_points=flow_points, semantic=semantic)
 
 
-def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_color=None, flow_pkg=None, render_objmask=False):
+def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_color=None, flow_pkg=None, render_objmask=False,
+           sh_factor_sink=None):
+    """sh_factor_sink (extension, default off): adgs.dp.FactoredSHExchange.sink_for -- data-parallel training exchanges the SH
+    gradients in factored form; the backward of this render then leaves them to FactoredSHExchange.reduce()."""
     device = pc.get_xyz.device
     # the densification statistics read the gradient of the screen-space means from this tensor (.grad[:, :2])
     means2D = torch.zeros_like(pc.get_xyz, requires_grad=True)
@@ -55,7 +60,8 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
     rasterizer = GaussianRasterizer(raster_settings=_camera_settings(viewpoint_camera, pc, pipe, scaling_modifier, device))
     pkg, flow_points = _deformed_state(pc, viewpoint_camera.time, flow_pkg)
     semantic = pc.get_obj_mask.float()[..., None] if render_objmask else None
-    foreground, radii, depth, img_opacity, img_flow, img_semantic = _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic)
+    foreground, radii, depth, img_opacity, img_flow, img_semantic = _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic,
+                                                                                sh_factor_sink)
 
     background = env_map.get_image_background(viewpoint_camera) if env_map is not None else torch.zeros_like(foreground)
     out = dict(pkg)                                             # the reference also hands back xyz / rotation / shs / opacity

@@ -77,3 +77,20 @@ def test_densification_cycle_on_the_model_class():
         other._scene_xyz = torch.zeros(0, 3, device=dev)
         other.load_ply(d + "/point_cloud.ply")
         assert torch.equal(other._obj_shs_rest, model._obj_shs_rest) and torch.equal(other.xyz_deform_param, model.xyz_deform_param)
+
+
+def test_data_parallel_training_example_on_one_gpu(monkeypatch):
+    """examples/train_dp.py with three cameras accumulated on one GPU through the factored exchange, including a densify step."""
+    import sys
+    spec = importlib.util.spec_from_file_location("train_dp", os.path.join(ROOT, "examples", "train_dp.py"))
+    td = importlib.util.module_from_spec(spec); spec.loader.exec_module(td)
+    from adgs import synthetic
+    synthetic.CONFIGS["T1"] = dict(P=6000, W=208, H=130, focal=150.0, sh_degree=3, n_objects=2, seed=9)
+    monkeypatch.setattr(sys, "argv", ["train_dp.py", "--config", "T1", "--iters", "6", "--cams", "3", "--densify-every", "4"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    try:
+        losses, same = td.main()
+    finally:
+        del synthetic.CONFIGS["T1"]
+    assert same and all(l == l for l in losses) and len(losses) == 9
