@@ -38,11 +38,14 @@ class _Buffer:
     rasterize_points.cu:27-33)."""
 
     def __init__(self, device):
-        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+        t = torch.empty(0, dtype=torch.uint8, device=device)
+        self.t = t
 
+        # the callback closes over the tensor, NOT over self: self -> cb -> closure -> self would be a reference cycle that
+        # keeps every frame's buffers (0.4 GB at C3) alive until the cyclic garbage collector runs
         def cb(_user, nbytes):
-            self.t.resize_(int(nbytes))
-            return self.t.data_ptr()
+            t.resize_(int(nbytes))
+            return t.data_ptr()
         self.cb = _lib.ALLOC_FN(cb)
 
 

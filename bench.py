@@ -262,8 +262,8 @@ def parity_vs_oracle(hip_outs, oracle_fwd):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flow-sem", action="store_true", help="render without the flow / semantic outputs")
