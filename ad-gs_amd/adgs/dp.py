@@ -18,11 +18,11 @@ def shard_cameras(cameras, rank, world_size):
     return [c for i, c in enumerate(cameras) if i % world_size == rank]
 
 
-def _flatten_bucket(tensors, max_bytes):
-    """Greedy bucketing of tensors into groups of at most max_bytes (one collective per group)."""
+def _flatten_bucket(params, max_bytes):
+    """Greedy bucketing of parameters (by gradient size) into groups of at most max_bytes (one collective per group)."""
     buckets, cur, size = [], [], 0
-    for t in tensors:
-        nbytes = t.numel() * t.element_size()
+    for t in params:
+        nbytes = t.grad.numel() * t.grad.element_size()
         if cur and size + nbytes > max_bytes:
             buckets.append(cur); cur, size = [], 0
         cur.append(t); size += nbytes
@@ -36,34 +36,39 @@ def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 2
 
     Tensors of at least `in_place_bytes` are reduced in place, one async collective each (no flatten
     copy: at 1M Gaussians the SH gradient alone is 180 MB); the others are coalesced into flat buckets
-    (the copies are ~80 MB in total at C3, 0.03 ms).  xGMI is point-to-point, so few large collectives
-    are preferred over many small ones: C3 ends up with 6 in-place reductions and one bucket.
+    (one `cat`; afterwards every `.grad` of the bucket is re-pointed at its slice of the reduced flat buffer, so
+    nothing is copied back).  xGMI is point-to-point, so few large collectives are preferred over many small ones:
+    C3 ends up with 6 in-place reductions and one bucket.
     """
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return                                   # force: issue the collectives even in a one-rank group (RCCL self-test on a 1-GPU box)
     world = dist.get_world_size(group)
-    grads = []
+    params = list(params)
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-        grads.append(p.grad)
-    big = [g for g in grads if g.numel() * g.element_size() >= in_place_bytes]
-    small = [g for g in grads if g.numel() * g.element_size() < in_place_bytes]
-    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in big]
+    big = [p for p in params if p.grad.numel() * p.grad.element_size() >= in_place_bytes]
+    small = [p for p in params if p.grad.numel() * p.grad.element_size() < in_place_bytes]
+    works = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True) for p in big]
     flats = []
     for bucket in _flatten_bucket(small, bucket_bytes):
-        flat = torch.cat([g.reshape(-1) for g in bucket])
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
         works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
         flats.append((flat, bucket))
     for w in works:
         w.wait()
     for flat, bucket in flats:
+        if average:
+            flat.div_(world)
+        # the reduced gradients ARE slices of the flat buffer from here on (no copy back: one launch per tensor saved)
         off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad = flat[off:off + n].view(p.grad.shape)
+            off += n
     if average:
-        for g in grads:
-            g.div_(world)
+        for p in big:
+            p.grad.div_(world)
 
 
 def allreduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None):

@@ -68,6 +68,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          img_semantic) = _call_with_dump(_C.rasterize_gaussians, native_args, s.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
+        ctx.set_materialize_grads(False)     # outputs the loss does not use arrive as None (NULL for the kernels), not as zero fills
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
                               img_buf, img_opacity, flow_points, semantic)
         return color, radii, depth, img_opacity, img_flow, img_semantic
@@ -77,6 +78,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf,
          img_opacity, flow_points, semantic) = ctx.saved_tensors
+        if grad_out_color is None:           # the C binding takes H, W from this tensor
+            grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
         native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_depth, grad_img_flow,
                        grad_img_semantic, semantic, flow_points, sh, s.sh_degree, s.campos, geom_buf, ctx.num_rendered,
@@ -116,6 +119,7 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
             s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
             s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
         ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink = s, num_rendered, func_eval, factor_sink
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
                               scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform)
         return color, radii, depth, img_opacity, img_flow, img_semantic
@@ -126,6 +130,8 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         (means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
          scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform) = ctx.saved_tensors
         raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval)
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
         factored = ctx.factor_sink is not None
         need = (False,) * 6 if factored else ctx.needs_input_grad[7:13]
         res = _C.rasterize_gaussians_backward_rawsh(

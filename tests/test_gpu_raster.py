@@ -290,3 +290,38 @@ def test_c2_sized_scene_properties_and_parity():
     h2 = run_hip(sc, grads=g2)
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         assert_close("lin_" + k, h2["grads"][k].cpu().numpy(), 2.0 * h["grads"][k].cpu().numpy(), tol=2e-5, max_frac=0)
+
+
+@pytest.mark.parametrize("mode", ["classic", "v2"])
+@pytest.mark.parametrize("used", [("color",), ("depth",), ("img_opacity", "img_flow"), ("img_semantic",)])
+def test_outputs_the_loss_does_not_use(monkeypatch, mode, used):
+    """A loss built from a subset of the six outputs: the unused ones reach the kernels as absent (NULL) gradients -- no zero
+    fills -- and the result equals the oracle's with zero upstream gradients there."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    monkeypatch.setenv("ADGS_RASTER_MODE", mode)
+    sc = synthetic.make_scene(1500, 112, 80, 90.0, sh_degree=3, seed=21)
+    g = synthetic.make_upstream_grads(sc, 4)
+    s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], dev(sc["bg"]), 1.0, dev(sc["viewmatrix"]), dev(sc["projmatrix"]), 3,
+                                      dev(sc["campos"]), False, True, False)
+    L = {k: sc[k].cuda().clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations", "flow_points", "semantic")}
+    m2 = torch.zeros(sc["P"], 3, device="cuda", requires_grad=True)
+    out = GaussianRasterizer(s)(means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"], rotations=L["rotations"],
+                                flow_points=L["flow_points"], semantic=L["semantic"])
+    outs = dict(zip(("color", "radii", "depth", "img_opacity", "img_flow", "img_semantic"), out))
+    up = dict(color=g["color"], depth=g["depth"], img_opacity=g["img_opacity"], img_flow=g["flow"], img_semantic=g["semantic"])
+    sum((outs[k] * up[k].cuda()).sum() for k in used).backward()
+    torch.cuda.synchronize()
+    z = lambda k: up[k].numpy() if k in used else np.zeros_like(up[k].numpy())
+    o = oracle.RasterOracle("f32")
+    o.forward(sc["bg"], sc["means3D"], None, sc["opacities"], sc["scales"], sc["rotations"], 1.0, None, sc["viewmatrix"], sc["projmatrix"], sc["tanfovx"],
+              sc["tanfovy"], sc["H"], sc["W"], sc["shs"], sc["flow_points"], sc["semantic"], 3, sc["campos"], False, True)
+    og = o.backward(z("color"), z("depth"), z("img_flow"), z("img_semantic"), z("img_opacity"))
+    for hk, ok in (("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                   ("flow_points", "dL_dflow_points"), ("semantic", "dL_dsemantic")):
+        got = L[hk].grad
+        want = og[ok].reshape(L[hk].shape)
+        if got is None:
+            assert not want.any(), hk
+        else:
+            assert_close("grad_" + hk, got.cpu().numpy(), want, max_frac=2e-4)
+    assert_close("grad_means2D", m2.grad.cpu().numpy(), og["dL_dmeans2D"], max_frac=2e-4)
