@@ -283,7 +283,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_coll = world == 1 and os.environ.get("ADGS_BENCH_FORCE_COLLECTIVES") == "1"   # 1-GPU dry run of the N-GPU step: the
+    if world > 1 or force_coll:                                                          # collectives run in a one-rank RCCL group
+        if force_coll:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
     if _lib.lib().adgs_device_check() != 0:
         raise SystemExit(_lib.last_error())
@@ -306,10 +309,11 @@ def main():
     # ADGS_DP_EXCHANGE=dense all-reduces every materialised gradient instead.  ADGS_BENCH_FACTORED=1 runs the factored
     # step on one GPU as well (one camera; measures the backward without SH rows + the expansion).
     factored = (isinstance(frame, DeformFrame) and frame.model.raw_sh and os.environ.get("ADGS_DP_EXCHANGE", "factored") != "dense"
-                and (world > 1 or os.environ.get("ADGS_BENCH_FACTORED") == "1"))
+                and (world > 1 or force_coll or os.environ.get("ADGS_BENCH_FACTORED") == "1"))
     exchange = "none"
     if factored:
         ex = dp.FactoredSHExchange(frame.model)
+        ex.force_collectives = force_coll
         cam_times = [frame.t] * world
         cam_positions = [synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if world == 1 else r)["campos"].tolist() for r in range(world)]
         exchange = "factored SH gradients: all-gather of the colour-gradient factors + dense all-reduce of the rest + local expansion"
@@ -324,8 +328,8 @@ def main():
         else:
             outs = frame.forward()
             torch.autograd.backward(outs, up_list)
-            if world > 1:
-                dp.allreduce_gradients(frame.parameters())
+            if world > 1 or force_coll:
+                dp.allreduce_gradients(frame.parameters(), force=force_coll)
         frame.zero_grad()
 
     # Settle phase (setup, not a measurement): a fresh process on a fresh box shows one-off stalls of 0.1-0.6 s in its first
@@ -446,8 +450,16 @@ def main():
                 sc_cpu = sc
             result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, cam, cfg, use_fs, up)
             result["parity"] = parity_vs_oracle(outs, oracle_fwd)
+        # RCCL prints a version banner through C stdio, which (on a pipe) would only be flushed at exit, i.e. AFTER the JSON
+        # line: flush it first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.barrier()
         dist.destroy_process_group()
 
