@@ -57,6 +57,10 @@ SIGNATURES = {
     "adgs_l1_ssim_backward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_depth_loss_forward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_depth_loss_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_flow_loss_forward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "adgs_flow_loss_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_bce_clip_forward": (c_i, [c_i, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p]),
+    "adgs_bce_clip_backward": (c_i, [c_i, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p]),
     # include/adgs_optim.h
     "adgs_densification_stats": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_adam_step": (c_i, [c_p, c_i, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_p]),

@@ -121,3 +121,96 @@ def get_depth_loss(pred, gt, mask=None):
     squares) and the target, averaged over the mask; differentiable w.r.t. `pred` through the scale and the shift.  No host
     synchronisation (the reference's `if det == 0` is one)."""
     return _DepthLoss.apply(pred, gt.detach(), None if mask is None else mask.detach())
+
+
+AUX_WORK_DOUBLES = 256 * 2 + 2           # ADGS_AUX_WORK_DOUBLES
+
+
+class _FlowLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img_flow, img_opacity, flow, flow_vis, K, R, T, dist):
+        if not img_flow.is_cuda:
+            raise RuntimeError("get_flow_loss: tensors must be on a HIP device; there is no CPU path")
+        f = img_flow.contiguous().float()
+        fl, vis = flow.contiguous().float(), flow_vis.contiguous().float()
+        op = None if img_opacity is None else img_opacity.contiguous().float()
+        H, W = fl.shape[1], fl.shape[2]
+        if f.shape != (3, H, W) or fl.shape[0] != 2 or vis.shape != (H, W) or (op is not None and op.numel() != H * W):
+            raise ValueError("get_flow_loss: expected img_flow [3,H,W], flow [2,H,W], flow_vis [H,W], img_opacity [H,W]")
+        cam = [(ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()]) for t, n in ((K, 9), (R, 9), (T, 3))]
+        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=f.device)
+        out = torch.zeros(1, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device):
+            _lib.check(_lib.lib().adgs_flow_loss_forward(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
+                                                         cam[0], cam[1], cam[2], float(dist), work.data_ptr(), out.data_ptr(), _stream(f.device)),
+                       "adgs_flow_loss_forward")
+        ctx.save_for_backward(f, fl, vis, work, *([op] if op is not None else []))
+        ctx.cam, ctx.dist, ctx.op_shape = cam, float(dist), None if img_opacity is None else img_opacity.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        f, fl, vis, work, *rest = ctx.saved_tensors
+        op = rest[0] if rest else None
+        H, W = fl.shape[1], fl.shape[2]
+        g_f = torch.empty_like(f)
+        g_op = torch.empty(H, W, dtype=torch.float32, device=f.device) if op is not None else None
+        gl = g_loss.reshape(1).float().contiguous()
+        with torch.cuda.device(f.device):
+            _lib.check(_lib.lib().adgs_flow_loss_backward(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
+                                                          ctx.cam[0], ctx.cam[1], ctx.cam[2], ctx.dist, work.data_ptr(), gl.data_ptr(), g_f.data_ptr(),
+                                                          g_op.data_ptr() if g_op is not None else None, _stream(f.device)), "adgs_flow_loss_backward")
+        return g_f, (g_op.reshape(ctx.op_shape) if g_op is not None else None), None, None, None, None, None, None
+
+
+def get_flow_loss(img_flow, flow_pkg, img_opacity=None, dist=1e-3):
+    """utils/loss_utils.py:86-106: mean over the pixels with a valid flow target of the normalised L1 distance between the
+    re-projected rendered flow point and the target, weighted by the accumulated opacity; flow_pkg = (_, K, R, T, flow, flow_vis)
+    as in the reference (train.py:68-71).  One reduction pass + one elementwise backward; the reference's nonzero() (a host
+    synchronisation) and gathers are gone.  Always returns a tensor: 0 with zero gradients where the reference returns 0.0."""
+    _, K, R, T, flow, flow_vis = flow_pkg
+    return _FlowLoss.apply(img_flow, img_opacity, flow.detach(), flow_vis.detach(), K, R, T, dist)
+
+
+class _BceClip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, lo, hi, invert, positive_target):
+        if not pred.is_cuda:
+            raise RuntimeError("bce_clip_loss: tensors must be on a HIP device; there is no CPU path")
+        p, t = pred.contiguous().float(), target.contiguous().float()
+        if p.numel() != t.numel():
+            raise ValueError("bce_clip_loss: prediction and target must have the same number of elements")
+        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=p.device)
+        out = torch.zeros(1, dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().adgs_bce_clip_forward(p.numel(), p.data_ptr(), t.data_ptr(), float(lo), float(hi), int(bool(invert)),
+                                                        int(bool(positive_target)), work.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_bce_clip_forward")
+        ctx.save_for_backward(p, t)
+        ctx.args, ctx.shape = (float(lo), float(hi), int(bool(invert)), int(bool(positive_target))), pred.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        p, t = ctx.saved_tensors
+        out = torch.empty_like(p)
+        gl = g_loss.reshape(1).float().contiguous()
+        lo, hi, inv, pos = ctx.args
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().adgs_bce_clip_backward(p.numel(), p.data_ptr(), t.data_ptr(), lo, hi, inv, pos, gl.data_ptr(), out.data_ptr(),
+                                                         _stream(p.device)), "adgs_bce_clip_backward")
+        return out.reshape(ctx.shape), None, None, None, None, None
+
+
+def bce_clip_loss(pred, target, lo=1e-3, hi=1.0 - 1e-3, invert=False, positive_target=False):
+    """mean BCE(q, t) with q = clip(pred, lo, hi) (1 - clip(...) with `invert`) and t = target ((target > 0) with `positive_target`)."""
+    return _BceClip.apply(pred, target.detach(), lo, hi, invert, positive_target)
+
+
+def obj_loss(img_semantic, gt_semantic):
+    """train.py:95-98: binary_cross_entropy(clip(img_semantic, 1e-3, 1 - 1e-3)[0], (gt_semantic > 0).float())."""
+    return bce_clip_loss(img_semantic[0] if img_semantic.dim() == 3 else img_semantic, gt_semantic, positive_target=True)
+
+
+def sky_loss(img_opacity, gt_sky):
+    """train.py:100-103: binary_cross_entropy(1 - clip(img_opacity, 1e-3, 1 - 1e-3), gt_sky)."""
+    return bce_clip_loss(img_opacity, gt_sky, invert=True)

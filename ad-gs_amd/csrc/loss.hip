@@ -224,6 +224,118 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(int n, const float* __re
 	(void)a00;
 }
 
+// ---------------------------------------------------------------- flow re-projection loss and clipped BCE
+// Pixel-wise losses of train.py:88-103 that the reference builds from nonzero() (a host synchronisation), gathers and half a
+// dozen elementwise kernels each.  Here: one reduction pass (double partial sums in AUX_SLOTS slots) + a one-thread finish,
+// and one elementwise backward.  aux work layout (doubles): [slot][2] = (sum, count), then [2*AUX_SLOTS] = sum, [+1] = count.
+constexpr int AUX_SLOTS = 256;
+struct FlowCam { float M[9]; float KT[3]; float dist; };          // M = K R, KT = K T (3x3 row-major products formed on the host in fp32)
+
+struct FlowPix { bool sel; float w, u, v, z, px, py; bool front; };
+__device__ __forceinline__ FlowPix flow_pixel(int i, int HW, int W, int H, const float* __restrict__ f, const float* __restrict__ fl,
+	const float* __restrict__ vis, const float* __restrict__ op, const FlowCam& c) {
+	FlowPix r;
+	const float t0 = fl[i], t1 = fl[HW + i];
+	r.sel = (vis[i] > 0.5f) && (t0 <= (float)W - 1.0f) && (t0 >= 0.f) && (t1 <= (float)H - 1.0f) && (t1 >= 0.f);       // loss_utils.py:90
+	r.w = 0.f; r.u = r.v = r.z = r.px = r.py = 0.f; r.front = false;
+	if (!r.sel) return r;
+	const float x = f[i], y = f[HW + i], z = f[2 * HW + i];
+	r.px = c.M[0] * x + c.M[1] * y + c.M[2] * z + c.KT[0];
+	r.py = c.M[3] * x + c.M[4] * y + c.M[5] * z + c.KT[1];
+	const float pz = c.M[6] * x + c.M[7] * y + c.M[8] * z + c.KT[2];
+	r.front = pz > c.dist;                                         // flow_utils.py:8
+	r.z = fmaxf(pz, c.dist);                                       // clamp_min, :9
+	r.u = r.px / r.z; r.v = r.py / r.z;
+	r.w = (op ? op[i] : 1.f) * (r.front ? 1.f : 0.f);
+	return r;
+}
+__global__ void __launch_bounds__(256) flow_loss_sum_kernel(int H, int W, const float* __restrict__ f, const float* __restrict__ fl,
+	const float* __restrict__ vis, const float* __restrict__ op, FlowCam c, double* __restrict__ work) {
+	const int HW = H * W;
+	double sum = 0, cnt = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+		const FlowPix p = flow_pixel(i, HW, W, H, f, fl, vis, op, c);
+		if (p.sel) {
+			cnt += 1.0;
+			sum += (double)((fabsf(p.u - fl[i]) / (float)W + fabsf(p.v - fl[HW + i]) / (float)H) * p.w);      // :103-105
+		}
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) { sum += __shfl_xor(sum, off, WAVE); cnt += __shfl_xor(cnt, off, WAVE); }
+	if ((threadIdx.x & (WAVE - 1)) == 0) {
+		const size_t slot = (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % AUX_SLOTS) * 2;
+		atomicAdd(work + slot, sum); atomicAdd(work + slot + 1, cnt);
+	}
+}
+__global__ void __launch_bounds__(256) aux_finish_kernel(double* __restrict__ work, float* __restrict__ loss) {
+	__shared__ double s[2][256 / WAVE];
+	double a = work[(size_t)threadIdx.x * 2], b = work[(size_t)threadIdx.x * 2 + 1];
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) { a += __shfl_xor(a, off, WAVE); b += __shfl_xor(b, off, WAVE); }
+	if ((threadIdx.x & (WAVE - 1)) == 0) { s[0][threadIdx.x / WAVE] = a; s[1][threadIdx.x / WAVE] = b; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double ta = 0, tb = 0;
+		for (int w = 0; w < 256 / WAVE; w++) { ta += s[0][w]; tb += s[1][w]; }
+		work[2 * AUX_SLOTS] = ta; work[2 * AUX_SLOTS + 1] = tb;
+		loss[0] = tb > 0 ? (float)(ta / tb) : 0.f;                   // mean over the selected pixels; 0.0 when none (:92-93)
+	}
+}
+__global__ void __launch_bounds__(256) flow_loss_bwd_kernel(int H, int W, const float* __restrict__ f, const float* __restrict__ fl,
+	const float* __restrict__ vis, const float* __restrict__ op, FlowCam c, const double* __restrict__ work, const float* __restrict__ g_loss,
+	float* __restrict__ g_f, float* __restrict__ g_op) {
+	const int HW = H * W;
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= HW) return;
+	const double n = work[2 * AUX_SLOTS + 1];
+	const FlowPix p = flow_pixel(i, HW, W, H, f, fl, vis, op, c);
+	float gx = 0.f, gy = 0.f, gz = 0.f, go = 0.f;
+	if (p.sel && n > 0) {
+		const float gl = (float)((double)g_loss[0] / n);
+		const float du = p.u - fl[i], dv = p.v - fl[HW + i];
+		go = gl * (fabsf(du) / (float)W + fabsf(dv) / (float)H) * (p.front ? 1.f : 0.f);
+		const float su = du > 0.f ? 1.f : (du < 0.f ? -1.f : 0.f), sv = dv > 0.f ? 1.f : (dv < 0.f ? -1.f : 0.f);
+		const float gu = gl * su * p.w / (float)W, gv = gl * sv * p.w / (float)H;
+		// u = px / z, v = py / z; z = max(pz, dist) passes the gradient where pz > dist (the weight is 0 elsewhere)
+		const float gpx = gu / p.z, gpy = gv / p.z, gpz = -(gu * p.px + gv * p.py) / (p.z * p.z);
+		gx = c.M[0] * gpx + c.M[3] * gpy + c.M[6] * gpz;
+		gy = c.M[1] * gpx + c.M[4] * gpy + c.M[7] * gpz;
+		gz = c.M[2] * gpx + c.M[5] * gpy + c.M[8] * gpz;
+	}
+	g_f[i] = gx; g_f[HW + i] = gy; g_f[2 * HW + i] = gz;
+	if (g_op) g_op[i] = go;
+}
+
+// mean BCE of q = clip(pred, lo, hi) (or 1 - clip) against t = target (or target > 0): train.py:95-103
+__device__ __forceinline__ float bce_target(float t, int positive) { return positive ? (t > 0.f ? 1.f : 0.f) : t; }
+__global__ void __launch_bounds__(256) bce_clip_sum_kernel(int n, const float* __restrict__ pred, const float* __restrict__ target, float lo, float hi,
+	int invert, int positive, double* __restrict__ work) {
+	double sum = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const float c = fminf(fmaxf(pred[i], lo), hi);
+		const float q = invert ? 1.0f - c : c;
+		const float t = bce_target(target[i], positive);
+		sum += (double)(-(t * fmaxf(logf(q), -100.f) + (1.f - t) * fmaxf(logf(1.f - q), -100.f)));     // torch clamps the logs at -100
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
+	if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(work + (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % AUX_SLOTS) * 2, sum);
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(work + 1, (double)n);      // the "count" of the shared finish kernel
+}
+__global__ void __launch_bounds__(256) bce_clip_bwd_kernel(int n, const float* __restrict__ pred, const float* __restrict__ target, float lo, float hi,
+	int invert, int positive, const float* __restrict__ g_loss, float* __restrict__ out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float x = pred[i];
+	const float c = fminf(fmaxf(x, lo), hi);
+	const float q = invert ? 1.0f - c : c;
+	const float t = bce_target(target[i], positive);
+	// d BCE / dq = (q - t) / (q (1 - q)) with torch's eps-clamped denominator; clamp passes the gradient on [lo, hi]
+	const float dq = (q - t) / fmaxf(q * (1.f - q), 1e-12f);
+	const bool inside = x >= lo && x <= hi;
+	out[i] = inside ? g_loss[0] * (invert ? -dq : dq) / (float)n : 0.f;
+}
+
 } // namespace
 } // namespace adgs
 
@@ -272,6 +384,57 @@ extern "C" int adgs_l1_ssim_backward(int planes, int H, int W, const float* imag
 	const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
 	const float inv_n = (float)(1.0 / ((double)planes * H * W));
 	hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(TS * TS), 0, (hipStream_t)stream, H, W, image, gt, win, d_mu1, d_e11, d_e12, g_l1, g_ssim, inv_n, dL_dimage);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+static FlowCam make_flow_cam(const float* K, const float* R, const float* T, float dist) {
+	FlowCam c;
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 3; j++) c.M[3 * i + j] = K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j] + K[3 * i + 2] * R[6 + j];
+		c.KT[i] = K[3 * i] * T[0] + K[3 * i + 1] * T[1] + K[3 * i + 2] * T[2];
+	}
+	c.dist = dist;
+	return c;
+}
+extern "C" int adgs_flow_loss_forward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, double* work, float* loss, void* stream_) {
+	if (H <= 0 || W <= 0) return 0;
+	if (!img_flow || !flow || !flow_vis || !K || !R || !T || !work || !loss) { set_error("adgs_flow_loss_forward: NULL pointer"); return -1; }
+	hipStream_t stream = (hipStream_t)stream_;
+	const int n = H * W;
+	hipLaunchKernelGGL(flow_loss_sum_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, stream, H, W, img_flow, flow, flow_vis, img_opacity,
+		make_flow_cam(K, R, T, dist), work);
+	hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_flow_loss_backward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
+	void* stream_) {
+	if (H <= 0 || W <= 0) return 0;
+	if (!img_flow || !flow || !flow_vis || !K || !R || !T || !work || !g_loss || !dL_dimg_flow) { set_error("adgs_flow_loss_backward: NULL pointer"); return -1; }
+	const int n = H * W;
+	hipLaunchKernelGGL(flow_loss_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, H, W, img_flow, flow, flow_vis, img_opacity,
+		make_flow_cam(K, R, T, dist), work, g_loss, dL_dimg_flow, dL_dimg_opacity);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_bce_clip_forward(int n, const float* pred, const float* target, float lo, float hi, int invert, int positive_target,
+	double* work, float* loss, void* stream_) {
+	if (n <= 0) return 0;
+	if (!pred || !target || !work || !loss) { set_error("adgs_bce_clip_forward: NULL pointer"); return -1; }
+	hipStream_t stream = (hipStream_t)stream_;
+	hipLaunchKernelGGL(bce_clip_sum_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, stream, n, pred, target, lo, hi, invert, positive_target, work);
+	hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_bce_clip_backward(int n, const float* pred, const float* target, float lo, float hi, int invert, int positive_target,
+	const float* g_loss, float* dL_dpred, void* stream_) {
+	if (n <= 0) return 0;
+	if (!pred || !target || !g_loss || !dL_dpred) { set_error("adgs_bce_clip_backward: NULL pointer"); return -1; }
+	hipLaunchKernelGGL(bce_clip_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, n, pred, target, lo, hi, invert, positive_target, g_loss, dL_dpred);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

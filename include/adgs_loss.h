@@ -45,6 +45,33 @@ int adgs_depth_loss_forward(int n, const float* prediction, const float* target,
 int adgs_depth_loss_backward(int n, const float* prediction, const float* target, const float* mask, const double* work, const float* g_loss,
 	float* dL_dprediction, void* stream);
 
+/*
+ * Flow re-projection loss: utils/loss_utils.py:86-106 get_flow_loss over utils/flow_utils.py:5-10 flow_points_project.
+ * img_flow [3,H,W] are the rendered 3-D flow points, flow [2,H,W] the target pixel coordinates, flow_vis [H,W] the visibility
+ * score (selected iff > 0.5 and the target lies inside the image), img_opacity [H,W] an optional weight (NULL = 1).
+ * K, R, T: HOST pointers to the 3x3 / 3x3 / 3 camera of the flow target (row-major).  Per selected pixel
+ *   p = K (R f + T); (u, v) = p.xy / max(p.z, dist); loss += (|u - flow_x| / W + |v - flow_y| / H) * opacity * [p.z > dist]
+ * and loss = sum / #selected, 0 when nothing is selected -- decided on the device (the reference's nonzero() synchronises).
+ * work: ADGS_AUX_WORK_DOUBLES device doubles, zero-initialised by the caller, kept for the backward.
+ */
+#define ADGS_AUX_WORK_DOUBLES (256 * 2 + 2)
+int adgs_flow_loss_forward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, double* work, float* loss, void* stream);
+/* dL_dimg_flow [3,H,W] (fully written), dL_dimg_opacity [H,W] or NULL; g_loss is a DEVICE scalar. */
+int adgs_flow_loss_backward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
+	void* stream);
+
+/*
+ * Clipped binary cross entropy (train.py:95-103): mean BCE of q against t, q = clip(pred, lo, hi) or, with invert,
+ * 1 - clip(pred, lo, hi) (the sky term); t = target or, with positive_target, (target > 0) (the object-mask term).
+ * Same work buffer convention as above.
+ */
+int adgs_bce_clip_forward(int n, const float* pred, const float* target, float lo, float hi, int invert, int positive_target,
+	double* work, float* loss, void* stream);
+int adgs_bce_clip_backward(int n, const float* pred, const float* target, float lo, float hi, int invert, int positive_target,
+	const float* g_loss, float* dL_dpred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,3 +72,49 @@ def depth_loss(pred, gt, mask=None, dtype=np.float64):
     t_a00, t_a01, t_b0 = (b1 - t * a11) / det, (-b0 + 2 * a01 * t) / det, -a01 / det
     grad = m * (sg * s + (A * s_a00 + B * t_a00) * 2 * p + (A * s_a01 + B * t_a01) + (A * s_b0 + B * t_b0) * g) / a11
     return loss, grad
+
+
+def flow_loss(img_flow, flow, flow_vis, opacity, K, R, T, dist, dtype=np.float64):
+    """utils/loss_utils.py:86-106 (get_flow_loss) over utils/flow_utils.py:5-10 (flow_points_project).
+    img_flow [3,H,W] rendered 3-D flow points, flow [2,H,W] target pixel coordinates, flow_vis [H,W], opacity [H,W] or None.
+    Returns (loss, d loss / d img_flow, d loss / d opacity or None); loss 0 when no pixel is selected (:92-93)."""
+    f = np.asarray(img_flow, dtype); fl = np.asarray(flow, dtype); vis = np.asarray(flow_vis, dtype)
+    K, R, T = np.asarray(K, dtype), np.asarray(R, dtype), np.asarray(T, dtype)
+    _, H, W = f.shape
+    sel = (vis > 0.5) & (fl[0] <= W - 1.0) & (fl[0] >= 0.0) & (fl[1] <= H - 1.0) & (fl[1] >= 0.0)
+    n = int(sel.sum())
+    g_f = np.zeros_like(f); g_o = None if opacity is None or np.size(opacity) == 0 else np.zeros((H, W), dtype)
+    if n == 0:
+        return 0.0, g_f, g_o
+    w = sel.astype(dtype)
+    if g_o is not None:
+        w = w * np.asarray(opacity, dtype)
+    M = K @ R
+    p = np.einsum("ij,jhw->ihw", M, f) + (K @ T)[:, None, None]
+    mask = p[2] > dist
+    z = np.maximum(p[2], dist)
+    u, v = p[0] / z, p[1] / z
+    w = w * mask
+    du, dv = u - fl[0], v - fl[1]
+    per = (np.abs(du) / W + np.abs(dv) / H)
+    loss = (per * w).sum() / n
+    if g_o is not None:
+        g_o = per * sel * mask / n
+    # d/dp of u = x / z (z > dist where the weight is non-zero): (1/z, 0, -x/z^2)
+    gu, gv = np.sign(du) * w / (W * n), np.sign(dv) * w / (H * n)
+    gp = np.stack([gu / z, gv / z, -(gu * p[0] + gv * p[1]) / (z * z)])
+    g_f = np.einsum("ij,ihw->jhw", M, gp)
+    return loss, g_f, g_o
+
+
+def bce_clip_loss(pred, target, lo=1e-3, hi=1.0 - 1e-3, invert=False, dtype=np.float64):
+    """train.py:95-103: mean binary cross entropy of clip(pred, lo, hi) (or 1 - clip(...) when `invert`) against `target`;
+    log terms clamped at -100 like torch.  Returns (loss, d loss / d pred)."""
+    x = np.asarray(pred, dtype); t = np.asarray(target, dtype)
+    c = np.clip(x, dtype(lo), dtype(hi))
+    inside = (x >= dtype(lo)) & (x <= dtype(hi))
+    q = 1.0 - c if invert else c
+    lq, l1q = np.maximum(np.log(q), -100.0), np.maximum(np.log(1.0 - q), -100.0)
+    loss = -(t * lq + (1.0 - t) * l1q).mean()
+    dq = -(t / q - (1.0 - t) / (1.0 - q)) / x.size
+    return loss, (-dq if invert else dq) * inside

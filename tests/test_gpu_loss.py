@@ -91,3 +91,51 @@ def test_depth_loss_full_resolution_against_oracle():
     o_loss, o_grad = loss_oracle.depth_loss(pred, gt, mask)
     assert abs(float(val) - o_loss) <= 1e-4 * o_loss
     np.testing.assert_allclose(p.grad.cpu().numpy(), o_grad, rtol=0, atol=1e-3 * np.abs(o_grad).max())
+
+
+GOLD2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss2_golden.npz"))
+
+
+@pytest.mark.parametrize("name", ["flow_24x40", "flow_noopacity_17x23", "flow_none_selected_8x8"])
+def test_flow_loss_vs_reference_golden(name):
+    from adgs.loss import get_flow_loss
+    g = lambda k: GOLD2[name + "/" + k]
+    d = lambda a: torch.tensor(a, device="cuda")
+    f = d(g("img_flow")).requires_grad_(True)
+    op = d(g("opacity")).requires_grad_(True) if g("opacity").size else None
+    loss = get_flow_loss(f, (None, d(g("K")), d(g("R")), d(g("T")), d(g("flow")), d(g("vis"))), op, dist=0.02)
+    (loss * 1.0).backward()
+    np.testing.assert_allclose(float(loss), float(g("loss")), rtol=1e-5, atol=1e-8)
+    scale = max(np.abs(g("g_img_flow")).max(), 1e-30)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), g("g_img_flow"), rtol=1e-4, atol=1e-4 * scale)
+    if op is not None:
+        np.testing.assert_allclose(op.grad.cpu().numpy(), g("g_opacity"), rtol=1e-4, atol=1e-4 * max(np.abs(g("g_opacity")).max(), 1e-30))
+
+
+def test_flow_loss_full_size_vs_oracle_and_bce_terms():
+    from adgs.loss import get_flow_loss, obj_loss, sky_loss
+    from oracle import loss_oracle as lo
+    rng = np.random.default_rng(5)
+    H, W = 320, 480
+    K = np.array([[400.0, 0, W / 2], [0, 410.0, H / 2], [0, 0, 1]], np.float32); R = np.eye(3, dtype=np.float32); T = np.array([0.2, 0.0, 0.1], np.float32)
+    pts = (rng.normal(size=(3, H, W)) * [[[3.0]], [[2.0]], [[6.0]]] + [[[0.0]], [[0.0]], [[8.0]]]).astype(np.float32)
+    flow = np.stack([rng.random((H, W)) * (W + 20) - 10, rng.random((H, W)) * (H + 20) - 10]).astype(np.float32)
+    vis, op = rng.random((H, W)).astype(np.float32), rng.random((H, W)).astype(np.float32)
+    d = lambda a: torch.tensor(a, device="cuda")
+    f, o = d(pts).requires_grad_(True), d(op).requires_grad_(True)
+    loss = get_flow_loss(f, (None, d(K), d(R), d(T), d(flow), d(vis)), o, dist=0.02)
+    (loss * 3.0).backward()
+    want, g_f, g_o = lo.flow_loss(pts, flow, vis, op, K, R, T, 0.02)
+    np.testing.assert_allclose(float(loss), want, rtol=1e-5)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), 3.0 * g_f, rtol=1e-4, atol=1e-4 * np.abs(g_f).max() * 3)
+    np.testing.assert_allclose(o.grad.cpu().numpy(), 3.0 * g_o, rtol=1e-4, atol=1e-4 * np.abs(g_o).max() * 3)
+    # the two clipped BCE terms of train.py:95-103 vs golden values from the torch expression
+    g = lambda k: GOLD2["bce_19x31/" + k]
+    p1 = d(g("pred")).requires_grad_(True)
+    l1 = obj_loss(p1[None], d(g("gt_sem"))); l1.backward()
+    np.testing.assert_allclose(float(l1), float(g("obj")), rtol=1e-5); np.testing.assert_allclose(p1.grad.cpu().numpy(), g("g_obj"), rtol=1e-4, atol=1e-8)
+    p2 = d(g("pred")).requires_grad_(True)
+    l2 = sky_loss(p2, d(g("gt_sky"))); l2.backward()
+    np.testing.assert_allclose(float(l2), float(g("sky")), rtol=1e-5); np.testing.assert_allclose(p2.grad.cpu().numpy(), g("g_sky"), rtol=1e-4, atol=1e-8)
+    with pytest.raises(RuntimeError):
+        sky_loss(torch.zeros(4, 4), torch.zeros(4, 4))

@@ -50,3 +50,31 @@ def test_depth_loss_oracle_matches_reference(case):
     assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)), (loss, ref)
     gref = GOLD[case + "/g_pred"]
     np.testing.assert_allclose(grad, gref, rtol=0, atol=2e-4 * max(np.abs(gref).max(), 1e-12))
+
+
+lo = loss_oracle
+GOLD2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss2_golden.npz"))
+
+
+@pytest.mark.parametrize("name", ["flow_24x40", "flow_noopacity_17x23", "flow_none_selected_8x8"])
+def test_flow_loss_oracle_vs_reference_golden(name):
+    """get_flow_loss of the reference (values and autograd gradients) vs the NumPy restatement."""
+    g = lambda k: GOLD2[name + "/" + k]
+    op = g("opacity") if g("opacity").size else None
+    loss, g_f, g_o = lo.flow_loss(g("img_flow"), g("flow"), g("vis"), op, g("K"), g("R"), g("T"), 0.02)
+    np.testing.assert_allclose(loss, float(g("loss")), rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(g_f, g("g_img_flow"), rtol=2e-4, atol=2e-7)
+    if op is not None:
+        np.testing.assert_allclose(g_o, g("g_opacity"), rtol=2e-4, atol=2e-8)
+    if name.startswith("flow_none"):
+        assert loss == 0.0
+    else:
+        assert np.abs(g("g_img_flow")).max() > 0 and (g("img_flow")[2] < 0.5).any()
+
+
+def test_bce_clip_oracle_vs_train_py_expression():
+    g = lambda k: GOLD2["bce_19x31/" + k]
+    loss, grad = lo.bce_clip_loss(g("pred"), (g("gt_sem") > 0).astype(np.float64))
+    np.testing.assert_allclose(loss, float(g("obj")), rtol=1e-6); np.testing.assert_allclose(grad, g("g_obj"), rtol=2e-5, atol=1e-9)
+    loss, grad = lo.bce_clip_loss(g("pred"), g("gt_sky"), invert=True)
+    np.testing.assert_allclose(loss, float(g("sky")), rtol=1e-6); np.testing.assert_allclose(grad, g("g_sky"), rtol=2e-5, atol=1e-9)
