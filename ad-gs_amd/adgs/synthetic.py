@@ -17,6 +17,8 @@ CONFIGS = {
     "C3": dict(P=1_000_000, W=1920, H=1280, focal=2050.0, sh_degree=3, n_objects=8, seed=2),
     "C4": dict(P=1_000_000, W=1920, H=1280, focal=2050.0, sh_degree=3, n_objects=8, seed=3),
     "C5": dict(P=3_000_000, W=1920, H=1280, focal=2050.0, sh_degree=3, n_objects=16, seed=4),
+    # not a BASELINE.json config: a small dynamic scene for multi-rank dry runs of bench.py (tests/test_gpu_bench_multirank.py)
+    "T3": dict(P=20_000, W=320, H=208, focal=340.0, sh_degree=3, n_objects=2, seed=7),
 }
 
 
