@@ -178,6 +178,10 @@ class _FactorSink(list):
     def next_target(self, P):
         return self.owner._target(len(self), P)
 
+    def append(self, factor):
+        super().append(factor)
+        self.owner._factor_added()
+
 
 class FactoredSHExchange:
     """Gradient exchange of one camera-parallel iteration with the SH gradients in factored form.
@@ -205,11 +209,49 @@ class FactoredSHExchange:
         self.force_collectives = False           # tools/rccl_selftest.py: run the collectives in a one-rank group too
         self.n_means = 0
         self.send = self.recv = None
+        self._work = self._expect = None
         self._w_cache, self._cam_cache = {}, {}
 
-    def begin(self):
+    def begin(self, n_cameras=None):
+        """Start an iteration.  With the iteration's total camera count the all-gather of the factors is issued as soon as this
+        rank's last backward has produced its factor -- from inside the autograd backward, so it overlaps with the rest of
+        the backward (the deformation kernels) instead of starting in reduce()."""
         del self.sink[:]
         self.n_means = 0
+        self._work = None
+        self._expect = None
+        if n_cameras is not None:
+            world, rank = self._world()
+            k_max = (n_cameras + world - 1) // world
+            n_local = len(range(rank, n_cameras, world))
+            self._expect = (int(n_cameras), k_max, n_local)
+            send, _, _ = self._buffers(k_max)
+            for j in range(n_local, k_max):
+                send[j].zero_()                      # this rank has no j-th camera: an all-zero factor contributes nothing
+
+    def _collectives(self, world):
+        return world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
+
+    def _start_gather(self, k_max):
+        world, _ = self._world()
+        send = self.send
+        if self.recv is None or self.recv.shape != (world, k_max, send.shape[1]):
+            self.recv = torch.empty(world, k_max, send.shape[1], dtype=torch.float32, device=send.device)
+        self._work = dist.all_gather_into_tensor(self.recv.view(-1), send[:k_max].reshape(-1), group=self.group, async_op=True)
+
+    def _factor_added(self):
+        if getattr(self, "_expect", None) is None or getattr(self, "_work", None) is not None:
+            return
+        n_total, k_max, n_local = self._expect
+        world, _ = self._world()
+        if len(self.sink) != n_local or self.n_means != n_local or not self._collectives(world):
+            return
+        send, P, _ = self._buffers(k_max)
+        for j, f in enumerate(self.sink):
+            if f.data_ptr() != send[j].data_ptr():
+                send[j, :3 * P].copy_(f.reshape(-1))
+                self.sink[j] = send[j, :3 * P].view(P, 3)
+        self._start_gather(k_max)
 
     def _world(self):
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -261,20 +303,20 @@ class FactoredSHExchange:
                                % (rank, self.n_means, len(self.sink), n_local))
         send, P, row0 = self._buffers(k_max)
         Ns = m.get_scene_pts_num
-        for j, f in enumerate(self.sink):            # a backward that could not write in place (foreign sink use): copy now
-            if f.data_ptr() != send[j].data_ptr():
-                send[j, :3 * P].copy_(f.reshape(-1))
-        for j in range(n_local, k_max):
-            send[j].zero_()                          # this rank has no j-th camera: an all-zero factor contributes nothing
-        work = None
-        coll = world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
-        if coll:
-            if self.recv is None or self.recv.shape != (world, k_max, send.shape[1]):
-                self.recv = torch.empty(world, k_max, send.shape[1], dtype=torch.float32, device=send.device)
-            recv = self.recv
-            work = dist.all_gather_into_tensor(recv.view(-1), send[:k_max].reshape(-1), group=self.group, async_op=True)
-        else:
-            recv = send[:k_max].unsqueeze(0)
+        if self._expect is not None and self._expect != (n_total, k_max, n_local):
+            raise RuntimeError("FactoredSHExchange: begin() announced %d cameras, reduce() got %d" % (self._expect[0], n_total))
+        coll = self._collectives(world)
+        work = self._work                            # already in flight when begin(n_cameras) was used
+        if work is None:
+            for j, f in enumerate(self.sink):        # a backward that could not write in place (foreign sink use): copy now
+                if f.data_ptr() != send[j].data_ptr():
+                    send[j, :3 * P].copy_(f.reshape(-1))
+            for j in range(n_local, k_max):
+                send[j].zero_()                      # this rank has no j-th camera: an all-zero factor contributes nothing
+            if coll:
+                self._start_gather(k_max)
+                work = self._work
+        recv = self.recv if coll else send[:k_max].unsqueeze(0)
         # the dense remainder: every parameter except the six SH tensors
         sh = [getattr(m, n, None) for n in _SH_PARAMS]
         if coll:

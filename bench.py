@@ -329,6 +329,7 @@ def main():
 
     def step():
         if factored:
+            ex.begin(world)                      # the all-gather starts from inside the backward, as soon as the factor exists
             outs = frame.forward(sink_for=ex.sink_for)
             torch.autograd.backward(outs, up_list)
             ex.reduce(cam_times, cam_positions)

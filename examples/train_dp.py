@@ -39,6 +39,7 @@ def iteration(model, ex, cameras, targets, it, rank, world, densify_every=0, lam
     from gaussian_renderer import render
     pipe = types.SimpleNamespace(inv_depth=True, debug=False)
     total = torch.zeros((), device=model._scene_xyz.device)
+    ex.begin(len(cameras))
     for cam in dp.shard_cameras(cameras, rank, world):
         pkg = render(cam, model, None, pipe, flow_pkg=(cam.time + 0.05,) + (None,) * 5, render_objmask=True, sh_factor_sink=ex.sink_for)
         l, _, _ = loss.photometric_loss(pkg["render"], targets["image"], lambda_dssim)

@@ -118,6 +118,8 @@ def _worker(rank, world, port, n_cams, background, out_dir):
     model = _Model(50, 30, 16, 12, background)
     ex = dp.FactoredSHExchange(model, expand=_oracle_expand)
     cams = [_camera(model, c) for c in range(n_cams)]
+    if n_cams == 3:
+        ex.begin(n_cams)                      # announced camera count: the gather is issued by the last local append
     for c in dp.shard_cameras(list(range(n_cams)), rank, world):
         t, campos, xyz, rgb, dense = cams[c]
         sink = ex.sink_for(xyz)               # what forward_rawsh(factor_sink=...) + backward do on the HIP path
