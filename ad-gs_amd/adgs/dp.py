@@ -40,8 +40,14 @@ def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 2
     nothing is copied back).  xGMI is point-to-point, so few large collectives are preferred over many small ones:
     C3 ends up with 6 in-place reductions and one bucket.
     """
+    allreduce_gradients_finish(allreduce_gradients_start(params, group, average, bucket_bytes, in_place_bytes, force))
+
+
+def allreduce_gradients_start(params, group=None, average=False, bucket_bytes=256 << 20, in_place_bytes=32 << 20, force=False):
+    """Issue the collectives of allreduce_gradients and return a handle for allreduce_gradients_finish: work enqueued in
+    between runs concurrently with the reduction (it must not touch the gradients being reduced)."""
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
-        return                                   # force: issue the collectives even in a one-rank group (RCCL self-test on a 1-GPU box)
+        return None                              # force: issue the collectives even in a one-rank group (RCCL self-test on a 1-GPU box)
     world = dist.get_world_size(group)
     params = list(params)
     for p in params:
@@ -55,20 +61,26 @@ def allreduce_gradients(params, group=None, average=False, bucket_bytes=256 << 2
         flat = torch.cat([p.grad.reshape(-1) for p in bucket])
         works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
         flats.append((flat, bucket))
-    for w in works:
+    return dict(works=works, flats=flats, big=big, average=average, world=world)
+
+
+def allreduce_gradients_finish(handle):
+    if handle is None:
+        return
+    for w in handle["works"]:
         w.wait()
-    for flat, bucket in flats:
-        if average:
-            flat.div_(world)
+    for flat, bucket in handle["flats"]:
+        if handle["average"]:
+            flat.div_(handle["world"])
         # the reduced gradients ARE slices of the flat buffer from here on (no copy back: one launch per tensor saved)
         off = 0
         for p in bucket:
             n = p.grad.numel()
             p.grad = flat[off:off + n].view(p.grad.shape)
             off += n
-    if average:
-        for p in big:
-            p.grad.div_(world)
+    if handle["average"]:
+        for p in handle["big"]:
+            p.grad.div_(handle["world"])
 
 
 def allreduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
@@ -324,7 +336,9 @@ class FactoredSHExchange:
                 dense_params = [p for p in m.parameters() if not any(p is s for s in sh)]
             # one flat bucket for the whole dense remainder (108 MB at C3): one collective instead of one per large tensor --
             # xGMI is point-to-point and every extra collective costs a launch + synchronisation round
-            allreduce_gradients(dense_params, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40)
+            dense = allreduce_gradients_start(dense_params, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40)
+        else:
+            dense = None
         if work is not None:
             work.wait()
         cams = []
@@ -354,4 +368,5 @@ class FactoredSHExchange:
             self.expand(cams, W, C, P, Ns, row0, head, int(m.active_sh_degree), M, outs)
         else:
             hip_sh_grad_expand(cams, W, C, P, Ns, row0, head, int(m.active_sh_degree), M, outs, _cache=self._cam_cache)
+        allreduce_gradients_finish(dense)            # the expansion above ran while the dense all-reduce was on the links
         self.begin()
