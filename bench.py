@@ -456,6 +456,11 @@ def main():
                 "reference_alg_hbm_frac_of_8TBs": round(ref_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4)}, **measured_frame_traffic(args.config, use_fs and v2, fps / world), **extra),
             "roofline": roof,
             "stages_ms": {k: round(v[0], 4) for k, v in stages_all.items()},    # all stages timed: from the last warm-up steps
+            # every stage against the HBM roofline (algorithmic bytes of DESIGN.md section 5 / its HIP-event time in the last warm-up
+            # steps): the streaming stages sit at 45-70 % of the 8 TB/s peak, the two blend stages are VALU-bound (see "roofline")
+            "stage_rooflines": {k: {"alg_bytes": int(ab.get(k, 0)), "GB/s": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9, 1),
+                                    "frac_of_8TBs": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                for k, v in stages_all.items() if v[0] > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             if isinstance(frame, DeformFrame):
