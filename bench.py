@@ -259,6 +259,38 @@ def parity_vs_oracle(hip_outs, oracle_fwd):
             "frac_color_outside_1e-4": float(np.mean(np.abs(color - oc) > 1e-4 * (1.0 + np.abs(oc))))}
 
 
+def quick_measure(config, steps, device, use_fs):
+    """frames/s of another BASELINE.json config in the same process (single GPU, `steps` timed steps after a short warm-up):
+    reported next to the headline as secondary information, never as `value`."""
+    import torch
+    from adgs import synthetic
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cfg = synthetic.CONFIGS[config]
+    sc = synthetic.make_config_scene(config)
+    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
+    d = lambda t: t.to(device)
+    settings = GaussianRasterizationSettings(cfg["H"], cfg["W"], cam["tanfovx"], cam["tanfovy"], d(sc["bg"]), 1.0, d(cam["viewmatrix"]),
+                                             d(cam["projmatrix"]), cfg["sh_degree"], d(cam["campos"]), False, True, False)
+    rast = GaussianRasterizer(settings)
+    frame = DeformFrame(sc, rast, device, use_fs) if cfg["n_objects"] > 0 else StaticFrame(sc, rast, device, use_fs)
+    up = synthetic.make_upstream_grads(sc, 0)
+    ups = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
+
+    def step():
+        torch.autograd.backward(frame.forward(), ups)
+        frame.zero_grad()
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects" % (config, cfg["P"], cfg["W"], cfg["H"], cfg["sh_degree"], cfg["n_objects"]),
+            "frames_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,6 +299,7 @@ def main():
     ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flow-sem", action="store_true", help="render without the flow / semantic outputs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements of the other configs")
     args = ap.parse_args()
 
     import torch
@@ -462,6 +495,9 @@ def main():
                                     "frac_of_8TBs": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                                 for k, v in stages_all.items() if v[0] > 0},
         }
+        if world == 1 and not force_coll and not args.no_secondary and args.config == "C3":
+            # the other single-GPU configs of BASELINE.json, same build, same process (secondary: `value` stays the C3 headline)
+            result["other_configs"] = [quick_measure(c, 300, device, use_fs) for c in ("C1", "C2")]
         if world == 1 and not args.no_cpu_baseline:
             if isinstance(frame, DeformFrame):
                 pkg, flow = frame.activated()
