@@ -197,7 +197,7 @@ class _DeformPkgFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
-        t, order_args, use_time_mask, want, flow_t = meta
+        t, order_args, use_time_mask, want, flow_t = meta[:5]
         ts = [None if x is None else x.contiguous() for x in tensors]
         named = dict(zip(_PTRS, ts))
         dev = named["scene_xyz"].device
@@ -242,7 +242,8 @@ class _DeformPkgFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_xyz, g_rot, g_shs, g_op, g_sc, g_flow):
-        t, order_args, use_time_mask, want, flow_t = ctx.meta
+        t, order_args, use_time_mask, want, flow_t = ctx.meta[:5]
+        arena = ctx.meta[5] if len(ctx.meta) > 5 else None
         saved = list(ctx.saved_tensors)
         ts = [saved.pop(0) if pr else None for pr in ctx.present]
         named = dict(zip(_PTRS, ts))
@@ -275,7 +276,10 @@ class _DeformPkgFn(torch.autograd.Function):
             elif n == "background_deform_param":          # accumulated with atomics
                 grads[n] = torch.zeros_like(src)
             else:
-                grads[n] = torch.empty_like(src)
+                # a gradient arena (adgs.dp.GradArena) hands out slices of ONE persistent flat buffer, so that the data-parallel
+                # all-reduce runs on that buffer directly instead of on a concatenated copy of these tensors
+                g = arena.take(n, src) if arena is not None else None
+                grads[n] = g if g is not None else torch.empty_like(src)
             setattr(gs, n, _dp(grads[n]))
         fe = ctx.fe
         with torch.cuda.device(dev):
@@ -303,7 +307,7 @@ def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scale
         return out
     tensors = [getattr(model, _MODEL_ATTRS[n], None) for n in _PTRS]
     meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want),
-            None if flow_time is None else float(flow_time))
+            None if flow_time is None else float(flow_time), getattr(model, "grad_arena", None))
     xyz, rot, shs, op, sc, flow = _DeformPkgFn.apply(meta, *tensors)
     out = {}
     if flow_time is not None:

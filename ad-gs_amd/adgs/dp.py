@@ -181,6 +181,49 @@ def hip_sh_grad_expand(cams, W, C, P, Ns, row0, xyz_head, D, M, outs, _cache=Non
                    "adgs_sh_grad_expand")
 
 
+class GradArena:
+    """ONE persistent flat buffer for the dense parameter gradients of a model.  The deformation backward (adgs.deform) asks
+    `take(name, like)` for the tensor it writes a parameter's gradient into and gets a slice of the buffer; autograd then
+    installs that slice as `.grad` without a copy, and the data-parallel reduction is a single in-place all-reduce of the buffer
+    (no `cat`, no copy back).  Each slice is handed out once per iteration (`reset()`): a second backward of the same iteration
+    allocates normally and autograd accumulates into the slice."""
+
+    def __init__(self, named_params):
+        self.names = [n for n, p in named_params if p is not None and p.numel() > 0]
+        self.shapes = {n: tuple(p.shape) for n, p in named_params if p is not None and p.numel() > 0}
+        self.offsets, off = {}, 0
+        for n in self.names:
+            numel = 1
+            for d in self.shapes[n]:
+                numel *= d
+            self.offsets[n] = (off, numel)
+            off += (numel + 63) // 64 * 64                       # 256-byte aligned slices
+        ref = next(p for n, p in named_params if p is not None and p.numel() > 0)
+        self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=ref.device)
+        self.handed = set()
+
+    def matches(self, named_params):
+        return all(self.shapes.get(n) == tuple(p.shape) for n, p in named_params if p is not None and p.numel() > 0) and \
+            len(self.shapes) == sum(1 for n, p in named_params if p is not None and p.numel() > 0)
+
+    def reset(self):
+        self.handed.clear()
+
+    def take(self, name, like):
+        if name not in self.offsets or name in self.handed or tuple(like.shape) != self.shapes[name] or like.device != self.flat.device:
+            return None
+        self.handed.add(name)
+        off, numel = self.offsets[name]
+        return self.flat[off:off + numel].view(self.shapes[name])
+
+    def holds(self, name, grad):
+        """True when `grad` is this arena's slice for `name` (autograd installed it without a copy)."""
+        if grad is None or name not in self.offsets:
+            return False
+        off, numel = self.offsets[name]
+        return grad.data_ptr() == self.flat.data_ptr() + 4 * off and grad.numel() == numel and grad.is_contiguous()
+
+
 class _FactorSink(list):
     """What forward_rawsh(factor_sink=...) receives: the backward asks `next_target(P)` for the [P,3] destination of its colour-gradient
     factor (a slice of the exchange's send buffer: no copy afterwards) and appends the tensor it wrote."""
@@ -225,6 +268,23 @@ class FactoredSHExchange:
         self.send = self.recv = None
         self._work = self._expect = None
         self._w_cache, self._cam_cache = {}, {}
+        self.arena = None
+        self._arena_setup()
+
+    def _dense_named(self):
+        from . import deform
+        sh = set(_SH_PARAMS)
+        return [(field, getattr(self.model, attr, None)) for field, attr in deform._MODEL_ATTRS.items()
+                if attr not in sh and field in deform._GRADS and field != "background_deform_param"]
+
+    def _arena_setup(self):
+        """(Re)build the gradient arena when the model's dense parameters changed shape (densification)."""
+        named = self._dense_named()
+        if not any(p is not None and p.numel() > 0 and p.is_cuda for _, p in named):
+            self.arena = None                      # CPU tensors (the gloo tests): plain path
+        elif self.arena is None or not self.arena.matches(named):
+            self.arena = GradArena(named)
+        self.model.grad_arena = self.arena
 
     def begin(self, n_cameras=None):
         """Start an iteration.  With the iteration's total camera count the all-gather of the factors is issued as soon as this
@@ -234,6 +294,9 @@ class FactoredSHExchange:
         self.n_means = 0
         self._work = None
         self._expect = None
+        self._arena_setup()
+        if self.arena is not None:
+            self.arena.reset()
         if n_cameras is not None:
             world, rank = self._world()
             k_max = (n_cameras + world - 1) // world
@@ -338,7 +401,17 @@ class FactoredSHExchange:
                 dense_params = [p for p in m.parameters() if not any(p is s for s in sh)]
             # one flat bucket for the whole dense remainder (108 MB at C3): one collective instead of one per large tensor --
             # xGMI is point-to-point and every extra collective costs a launch + synchronisation round
-            dense = allreduce_gradients_start(dense_params, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40)
+            named = self._dense_named() if self.arena is not None else []
+            in_arena = [p for n, p in named if p is not None and p.numel() > 0 and self.arena.holds(n, p.grad)]
+            if self.arena is not None and len(in_arena) == len(self.arena.names):
+                # every dense gradient of the deformation backward sits in the arena: ONE in-place all-reduce, nothing to copy
+                rest = [p for p in dense_params if not any(p is q for q in in_arena)]
+                w = dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                dense = allreduce_gradients_start(rest, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40) \
+                    if rest else dict(works=[], flats=[], big=[], average=False, world=world)
+                dense["works"].append(w)
+            else:
+                dense = allreduce_gradients_start(dense_params, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40)
         else:
             dense = None
         if work is not None:

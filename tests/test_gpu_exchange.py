@@ -94,6 +94,9 @@ def test_factored_multi_camera_gradients_equal_conventional_accumulation(backgro
             vis += int((_render_cam(model, cam, t, ups, ex.sink_for if factored else None) > 0).sum())
         if factored:
             assert all(getattr(model, n).grad is None for n in dp._SH_PARAMS), "the backward must not materialise SH gradients"
+            # the dense gradients of the first backward live in the exchange's arena (one flat all-reduce buffer, installed by
+            # autograd without a copy); the later cameras were accumulated into the same slices
+            assert ex.arena is not None and all(ex.arena.holds(f, p.grad) for f, p in ex._dense_named() if p is not None and p.numel() > 0)
             ex.reduce(times, [c["campos"].tolist() for c in cams])
         torch.cuda.synchronize()
         assert vis > 3000
