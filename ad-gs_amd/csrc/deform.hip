@@ -484,6 +484,8 @@ struct ParamGradArgs {
 	const float* g;                                   // g[(n0 + m) * gstride + d]
 	float* out;                                       // [count, D, n_params]
 	adgs_func_eval f;
+	// optional second segment in the same launch (blocks >= nb0): the object side after the scene side
+	int nb0, n0_b, count_b; const float* g_b; float* out_b;
 };
 constexpr int PG_ITEMS = 8;                          // consecutive outputs per thread (two 16-byte stores)
 __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
@@ -494,15 +496,20 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 	const int total = a.f.n_terms[0] + a.f.n_terms[1] + a.f.n_terms[2];
 	for (int i = threadIdx.x; i < total; i += blockDim.x) s_w[a.f.index[i]] = a.f.weight[i];
 	__syncthreads();
-	const size_t tot = (size_t)a.count * a.D * np;
-	const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * PG_ITEMS;
+	// the segment's fields go into locals: writing to the by-value argument struct would move all of it into scratch memory
+	const bool second = a.nb0 > 0 && (int)blockIdx.x >= a.nb0;
+	const int seg_n0 = second ? a.n0_b : a.n0, seg_count = second ? a.count_b : a.count;
+	const float* __restrict__ seg_g = second ? a.g_b : a.g;
+	float* __restrict__ seg_out = second ? a.out_b : a.out;
+	const size_t tot = (size_t)seg_count * a.D * np;
+	const size_t e0 = ((size_t)(blockIdx.x - (second ? a.nb0 : 0)) * 256 + threadIdx.x) * PG_ITEMS;
 	if (e0 >= tot) return;
 	// (Gaussian m, channel d, column k) of the first output; then advanced incrementally
 	size_t row; int k;
 	if (tot <= 0xffffffffull) { const uint32_t r32 = (uint32_t)e0 / (uint32_t)np; row = r32; k = (int)((uint32_t)e0 - r32 * (uint32_t)np); }
 	else { row = e0 / np; k = (int)(e0 - row * np); }
 	size_t m = row / a.D; int d = (int)(row - m * a.D);
-	float gv = a.g[(a.n0 + m) * (size_t)a.gstride + d];
+	float gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
 	float v[PG_ITEMS];
 #pragma unroll
 	for (int it = 0; it < PG_ITEMS; it++) {
@@ -510,14 +517,14 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 		if (++k == np) {
 			k = 0;
 			if (++d == a.D) { d = 0; m++; }
-			if (e0 + it + 1 < tot) gv = a.g[(a.n0 + m) * (size_t)a.gstride + d];
+			if (e0 + it + 1 < tot) gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
 		}
 	}
 	if (e0 + PG_ITEMS <= tot) {
-		float4* o = reinterpret_cast<float4*>(a.out + e0);
+		float4* o = reinterpret_cast<float4*>(seg_out + e0);
 		o[0] = make_float4(v[0], v[1], v[2], v[3]); o[1] = make_float4(v[4], v[5], v[6], v[7]);
 	} else {
-		for (int it = 0; it < PG_ITEMS && e0 + it < tot; it++) a.out[e0 + it] = v[it];
+		for (int it = 0; it < PG_ITEMS && e0 + it < tot; it++) seg_out[e0 + it] = v[it];
 	}
 }
 
@@ -910,11 +917,32 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
+int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);
+// two segments (scene side, object side) in ONE launch: a kernel boundary costs ~5 us, as much as a quarter of one side's work
+int launch_lin_param_grad2(int count_a, const float* g_a, float* out_a, int count_b, const float* g_b, float* out_b, int D, int gstride,
+	const adgs_func_eval& f, hipStream_t stream) {
+	if (f.n_params <= 0) return 0;
+	if (!(out_a && count_a > 0) || !(out_b && count_b > 0)) {          // at most one side: the plain launcher
+		if (out_a && count_a > 0) return launch_lin_param_grad(count_a, D, g_a, gstride, out_a, f, stream);
+		if (out_b && count_b > 0) return launch_lin_param_grad(count_b, D, g_b, gstride, out_b, f, stream);
+		return 0;
+	}
+	if (!g_a || !g_b) { set_error("launch_lin_param_grad2: NULL gradient buffer"); return -1; }
+	ParamGradArgs pg;
+	pg.n0 = 0; pg.count = count_a; pg.D = D; pg.gstride = gstride; pg.g = g_a; pg.out = out_a; pg.f = f;
+	const size_t per_block = (size_t)256 * PG_ITEMS;
+	const size_t nb_a = ((size_t)count_a * D * f.n_params + per_block - 1) / per_block, nb_b = ((size_t)count_b * D * f.n_params + per_block - 1) / per_block;
+	pg.nb0 = (int)nb_a; pg.n0_b = 0; pg.count_b = count_b; pg.g_b = g_b; pg.out_b = out_b;
+	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)(nb_a + nb_b)), dim3(256), f.n_params * sizeof(float), stream, pg);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream) {
 	if (count <= 0 || f.n_params <= 0) return 0;
 	if (!g || !out) { set_error("launch_lin_param_grad: NULL gradient buffer"); return -1; }
 	ParamGradArgs pg;
 	pg.n0 = 0; pg.count = count; pg.D = D; pg.gstride = gstride; pg.g = g; pg.out = out; pg.f = f;
+	pg.nb0 = 0; pg.n0_b = 0; pg.count_b = 0; pg.g_b = nullptr; pg.out_b = nullptr;
 	const size_t tot = (size_t)count * D * f.n_params;
 	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((tot + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), f.n_params * sizeof(float), stream, pg);
 	ADGS_HIP_CHECK(hipGetLastError());
@@ -1077,6 +1105,7 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 			if (!out || count == 0 || fs.n_params == 0) continue;
 			ParamGradArgs pg;
 			pg.n0 = part == 0 ? 0 : p->Ns; pg.count = count; pg.D = 3; pg.gstride = M * 3; pg.g = dL_dshs; pg.out = out; pg.f = fs;
+			pg.nb0 = 0; pg.n0_b = 0; pg.count_b = 0; pg.g_b = nullptr; pg.out_b = nullptr;
 			const size_t t2 = (size_t)count * 3 * fs.n_params;
 			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), fs.n_params * sizeof(float), stream, pg);
 			ADGS_HIP_CHECK(hipGetLastError());

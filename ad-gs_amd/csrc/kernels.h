@@ -113,6 +113,8 @@ int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream);
 
 // flat coalesced d/dparam[m, d, k] = w_k * g[m * gstride + d] for the linear families (deform.hip)
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);
+int launch_lin_param_grad2(int count_a, const float* g_a, float* out_a, int count_b, const float* g_b, float* out_b, int D, int gstride,
+	const adgs_func_eval& f, hipStream_t stream);
 int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream);   // sh0[N,3] = dc + f_shs(t)
 inline bool has_lin_host(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0 && f.n_params > 0; }
 

@@ -136,11 +136,13 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		gcol[0] = a.dL_dcolor[3 * (size_t)idx]; gcol[1] = a.dL_dcolor[3 * (size_t)idx + 1]; gcol[2] = a.dL_dcolor[3 * (size_t)idx + 2];
 	}
 	// ---------------- cov2D backward (backward.cu:144-274)
-	float c3_local[6];
-	const float* c3 = a.cov3D + 6 * (size_t)idx;
-	if (!a.cov3D) {           // v2 without cov3D_precomp: recomputed instead of stored by the forward (24 B written + read per Gaussian)
-		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3_local);
-		c3 = c3_local;
+	// in registers either way: a pointer that may refer to a local array would put that array into scratch memory
+	float c3[6];
+	if (a.cov3D) {
+#pragma unroll
+		for (int i = 0; i < 6; i++) c3[i] = a.cov3D[6 * (size_t)idx + i];
+	} else {                  // v2 without cov3D_precomp: recomputed instead of stored by the forward (24 B written + read per Gaussian)
+		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
 	}
 	float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 	float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
@@ -232,14 +234,13 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		// `sh[k*3+c]` / `dsh[k*3+c]` are used for k >= 1 only; coefficient 0 goes through dsh0.
 		// STAGED: sh and dsh are the SAME LDS row, so every read of sh happens before any write of dsh.
 		const float* sh; float* dsh; float* dsh0;
-		float dummy0[3];
 		bool want_rows = true;       // raw path: false when the caller did not ask for the gradient of the `rest` coefficients
 		if (raw) {
 			const bool is_obj = idx >= a.sh_src.Ns;
 			const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
 			float* gdc = is_obj ? a.sh_dst.obj_dc : a.sh_dst.scene_dc;
 			float* gre = is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest;
-			dsh0 = gdc ? gdc + 3 * m : dummy0;
+			dsh0 = gdc ? gdc + 3 * m : nullptr;
 			want_rows = gre != nullptr;
 			if (STAGED) { dsh = s_sh + tid * SH_ROW_REST - 3; sh = dsh; }
 			else {
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			}
 		}
 		// ---- pass B: gradients w.r.t. the coefficients (WRITES; may alias the row read above)
-		dsh0[0] = C0 * g[0]; dsh0[1] = C0 * g[1]; dsh0[2] = C0 * g[2];
+		if (dsh0) { dsh0[0] = C0 * g[0]; dsh0[1] = C0 * g[1]; dsh0[2] = C0 * g[2]; }
 		if (raw && a.sh_dst.rgb_factor) { float* rf = a.sh_dst.rgb_factor + 3 * (size_t)idx; rf[0] = g[0]; rf[1] = g[1]; rf[2] = g[2]; }
 		if (want_rows) {
 			float coef[16];
@@ -382,8 +383,7 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
 	// raw-SH path: d/d(shs_deform_param[m, c, k]) = w_k * dL/d(dc[m, c]) as flat coalesced passes
 	if (raw && has_lin_host(a.sh_src.f)) {
 		const int No = a.P - a.sh_src.Ns;
-		if (a.sh_dst.scene_sp && a.sh_src.Ns > 0 && launch_lin_param_grad(a.sh_src.Ns, 3, a.sh_dst.scene_dc, 3, a.sh_dst.scene_sp, a.sh_src.f, stream) != 0) return -1;
-		if (a.sh_dst.obj_sp && No > 0 && launch_lin_param_grad(No, 3, a.sh_dst.obj_dc, 3, a.sh_dst.obj_sp, a.sh_src.f, stream) != 0) return -1;
+		if (launch_lin_param_grad2(a.sh_src.Ns, a.sh_dst.scene_dc, a.sh_dst.scene_sp, No, a.sh_dst.obj_dc, a.sh_dst.obj_sp, 3, 3, a.sh_src.f, stream) != 0) return -1;
 	}
 	return 0;
 }

@@ -289,7 +289,9 @@ def test_c2_sized_scene_properties_and_parity():
     g2 = {k: 2.0 * v for k, v in g.items()}
     h2 = run_hip(sc, grads=g2)
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-        assert_close("lin_" + k, h2["grads"][k].cpu().numpy(), 2.0 * h["grads"][k].cpu().numpy(), tol=2e-5, max_frac=0)
+        # two separate backward runs: the per-Gaussian sums are accumulated with float atomics in a different order each time, so
+        # "exactly twice" holds to accumulation rounding only (observed 2.3e-5 of the tensor's scale on 1 of 1.2 M elements)
+        assert_close("lin_" + k, h2["grads"][k].cpu().numpy(), 2.0 * h["grads"][k].cpu().numpy(), tol=5e-5, max_frac=0)
 
 
 @pytest.mark.parametrize("mode", ["classic", "v2"])
