@@ -49,13 +49,30 @@ def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semant
                       rotations=pkg["rotation"], flow_points=flow_points, semantic=semantic)
 
 
+_ZEROS = {}
+
+
+def screenspace_points(n, device):
+    """The reference's `torch.zeros_like(pc.get_xyz, requires_grad=True)` (gaussian_renderer/__init__.py:27-31): a fresh autograd
+    leaf of zeros whose only purpose is to receive dL/dmeans2D in `.grad`.  Nothing ever writes to it, so every call hands out a
+    new leaf over the SAME zero-filled storage: no `cat` of the positions and no fill kernel per frame."""
+    key = (int(n), str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 8:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros((int(n), 3), dtype=torch.float32, device=device)
+    return z.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_color=None, flow_pkg=None, render_objmask=False,
            sh_factor_sink=None):
     """sh_factor_sink (extension, default off): adgs.dp.FactoredSHExchange.sink_for -- data-parallel training exchanges the SH
     gradients in factored form; the backward of this render then leaves them to FactoredSHExchange.reduce()."""
-    device = pc.get_xyz.device
+    n_pts = pc.get_pts_num if hasattr(pc, "get_pts_num") else pc.get_xyz.shape[0]
+    device = (pc._scene_xyz if hasattr(pc, "_scene_xyz") else pc.get_xyz).device
     # the densification statistics read the gradient of the screen-space means from this tensor (.grad[:, :2])
-    means2D = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    means2D = screenspace_points(n_pts, device)
 
     rasterizer = GaussianRasterizer(raster_settings=_camera_settings(viewpoint_camera, pc, pipe, scaling_modifier, device))
     pkg, flow_points = _deformed_state(pc, viewpoint_camera.time, flow_pkg)

@@ -203,7 +203,8 @@ class DeformFrame:
         else:
             pkg = m.get_deformed_pkg(self.t)
             flow = m.get_deformed_xyz(self.t + 0.05) if self.use_fs else None
-        means2D = torch.zeros_like(pkg["xyz"], requires_grad=True)
+        from gaussian_renderer import screenspace_points
+        means2D = screenspace_points(pkg["xyz"].shape[0], pkg["xyz"].device)      # what render() uses: a fresh leaf over cached zeros
         if torch.is_tensor(pkg["shs"]):
             color, radii, depth, op, fl, sem = self.rast(
                 means3D=pkg["xyz"], means2D=means2D, opacities=pkg["opacity"], shs=pkg["shs"], scales=pkg["scales"],
