@@ -68,6 +68,7 @@ SIGNATURES = {
     "adgs_deform_backward_flow": (c_i, [c_p] * 15),
     # include/adgs_exchange.h
     "adgs_sh_grad_expand": (c_i, [c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p]),
+    "adgs_lin_grad_expand": (c_i, [c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     # include/adgs_densify.h
     "adgs_densify_workspace_bytes": (ctypes.c_size_t, [c_i]),
     "adgs_densify_select": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -266,12 +266,19 @@ class _DeformPkgFn(torch.autograd.Function):
                "shs_deform_param_scene": "shs", "shs_deform_param_obj": "shs",
                "scene_opacity": "opacity", "obj_opacity": "opacity", "gs_time_sigma": "opacity",
                "scene_scaling": "scales", "obj_scaling": "scales"}
+        # factored exchange (adgs.dp.FactoredSHExchange): xyz_deform_param's gradient is w(t) (x) g_xyz + w(t_flow) (x) g_flow of the
+        # object range -- the two upstream tensors go to the exchange and the [No,3,Cx] rows are not materialised here
+        xyz_factored = False
+        sink = getattr(arena, "xyz_sink", None) if arena is not None else None
+        if sink is not None and named["xyz_deform_param"] is not None and named["xyz_deform_param"].numel() > 0 and \
+                ctx.needs_input_grad[1 + _PTRS.index("xyz_deform_param")] and (up["xyz"] is not None or up["flow"] is not None):
+            xyz_factored = bool(sink(None if up["xyz"] is None else up["xyz"][Ns:], None if up["flow"] is None else up["flow"][Ns:]))
         grads, gs = {}, DeformGrads()
         for n in _GRADS:
             src = named[n]
             has_up = up[dep[n]] is not None or (dep[n] == "xyz" and up["flow"] is not None)
             need = (src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)] and has_up)
-            if not need:
+            if not need or (xyz_factored and n == "xyz_deform_param"):
                 grads[n] = None
             elif n == "background_deform_param":          # accumulated with atomics
                 grads[n] = torch.zeros_like(src)

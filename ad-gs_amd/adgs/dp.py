@@ -201,6 +201,7 @@ class GradArena:
         ref = next(p for n, p in named_params if p is not None and p.numel() > 0)
         self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=ref.device)
         self.handed = set()
+        self.xyz_sink = None                 # set by FactoredSHExchange: receives the upstream position gradients of the object range
 
     def matches(self, named_params):
         return all(self.shapes.get(n) == tuple(p.shape) for n, p in named_params if p is not None and p.numel() > 0) and \
@@ -222,6 +223,20 @@ class GradArena:
             return False
         off, numel = self.offsets[name]
         return grad.data_ptr() == self.flat.data_ptr() + 4 * off and grad.numel() == numel and grad.is_contiguous()
+
+
+def hip_lin_grad_expand(terms, W, C, count, scale, out):
+    """adgs_lin_grad_expand (include/adgs_exchange.h): out[m, d, j] = scale * sum_e W[e][j] * terms[e][m, d]; HIP only."""
+    from . import _lib
+    if not out.is_cuda:
+        raise RuntimeError("adgs_lin_grad_expand needs HIP tensors; there is no CPU path")
+    arr = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    for t in terms:
+        if not (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == 3 * count):
+            raise RuntimeError("adgs_lin_grad_expand: factors must be contiguous float32 [count,3]")
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().adgs_lin_grad_expand(len(terms), arr, W.data_ptr(), int(C), int(count), float(scale), out.data_ptr(),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), "adgs_lin_grad_expand")
 
 
 class _FactorSink(list):
@@ -259,9 +274,11 @@ class FactoredSHExchange:
     across iterations: the per-iteration host work is a handful of launches.
     """
 
-    def __init__(self, model, group=None, expand=None):
+    def __init__(self, model, group=None, expand=None, factor_xyz=False):
         self.model, self.group = model, group
         self.expand = expand
+        self.want_factor_xyz = bool(factor_xyz)
+        self.n_xyz = 0
         self.sink = _FactorSink(self)
         self.force_collectives = False           # tools/rccl_selftest.py: run the collectives in a one-rank group too
         self.n_means = 0
@@ -275,7 +292,16 @@ class FactoredSHExchange:
         from . import deform
         sh = set(_SH_PARAMS)
         return [(field, getattr(self.model, attr, None)) for field, attr in deform._MODEL_ATTRS.items()
-                if attr not in sh and field in deform._GRADS and field != "background_deform_param"]
+                if attr not in sh and field in deform._GRADS and field != "background_deform_param"
+                and not (field == "xyz_deform_param" and self.factor_xyz())]
+
+    def factor_xyz(self):
+        """xyz_deform_param's gradient also travels in factored form (two [No,3] upstream gradients per camera instead of the
+        [No,3,Cx] rows: 43 MB of the 108 MB dense remainder at C3) -- opt-in (`factor_xyz=True`), on the HIP path with object
+        Gaussians only, and it needs ONE deformation backward per camera: positions and flow points from the same
+        get_deformed_pkg(t, flow_time=...) call (what gaussian_renderer.render() does for adgs.model), flow_times given to reduce()."""
+        p = getattr(self.model, "xyz_deform_param", None)
+        return self.want_factor_xyz and self.expand is None and p is not None and p.numel() > 0 and p.is_cuda
 
     def _arena_setup(self):
         """(Re)build the gradient arena when the model's dense parameters changed shape (densification)."""
@@ -284,6 +310,8 @@ class FactoredSHExchange:
             self.arena = None                      # CPU tensors (the gloo tests): plain path
         elif self.arena is None or not self.arena.matches(named):
             self.arena = GradArena(named)
+        if self.arena is not None:
+            self.arena.xyz_sink = self._xyz_sink if self.factor_xyz() else None
         self.model.grad_arena = self.arena
 
     def begin(self, n_cameras=None):
@@ -292,6 +320,7 @@ class FactoredSHExchange:
         the backward (the deformation kernels) instead of starting in reduce()."""
         del self.sink[:]
         self.n_means = 0
+        self.n_xyz = 0
         self._work = None
         self._expect = None
         self._arena_setup()
@@ -321,7 +350,7 @@ class FactoredSHExchange:
             return
         n_total, k_max, n_local = self._expect
         world, _ = self._world()
-        if len(self.sink) != n_local or self.n_means != n_local or not self._collectives(world):
+        if len(self.sink) != n_local or self.n_means != n_local or not self._collectives(world) or (self.factor_xyz() and self.n_xyz != n_local):
             return
         send, P, _ = self._buffers(k_max)
         for j, f in enumerate(self.sink):
@@ -342,7 +371,7 @@ class FactoredSHExchange:
         """send [k, blob] / recv [world, k, blob], blob = [factor P*3 | means (P-row0)*3]; grown on demand, kept across iterations."""
         m = self.model
         P, row0 = m.get_pts_num, self._row0()
-        blob = 3 * P + 3 * (P - row0)
+        blob = 3 * P + 3 * (P - row0) + (6 * m.get_obj_pts_num if self.factor_xyz() else 0)     # [factor | means | g_xyz, g_flow of the objects]
         ref = m._scene_xyz if m._scene_xyz.numel() else m._obj_xyz
         if self.send is None or self.send.shape[1] != blob or self.send.shape[0] < k_need or self.send.device != ref.device:
             k = max(k_need, 1 if self.send is None else self.send.shape[0])
@@ -364,11 +393,32 @@ class FactoredSHExchange:
         j = self.n_means
         send, P, row0 = self._buffers(j + 1)
         if row0 < P:
-            send[j, 3 * P:].copy_(xyz.detach()[row0:].reshape(-1))
+            send[j, 3 * P:3 * P + 3 * (P - row0)].copy_(xyz.detach()[row0:].reshape(-1))
         self.n_means = j + 1
         return self.sink
 
-    def reduce(self, cam_times, cam_positions, dense_params=None):
+    def _xyz_sink(self, g_xyz, g_flow):
+        """Called by the deformation backward (through the arena) with the upstream gradients of the object positions at the camera
+        time and at the flow time; stores them in the send buffer.  The all-gather of an announced iteration starts here, when
+        the last local camera has delivered both its colour factor and these."""
+        m = self.model
+        j = self.n_xyz
+        send, P, row0 = self._buffers(j + 1)
+        No = m.get_obj_pts_num
+        base = 3 * P + 3 * (P - row0)
+        for k, g in enumerate((g_xyz, g_flow)):
+            dst = send[j, base + 3 * No * k: base + 3 * No * (k + 1)]
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g.reshape(-1))
+        self.n_xyz = j + 1
+        self._factor_added()
+        return True
+
+    def reduce(self, cam_times, cam_positions, dense_params=None, flow_times=None):
+        """flow_times: per camera, the time stamp its flow points were evaluated at (get_deformed_pkg(t, flow_time=...)) or None;
+        needed to expand xyz_deform_param's gradient when it travels in factored form."""
         m = self.model
         world, rank = self._world()
         n_total = len(cam_times)
@@ -380,6 +430,10 @@ class FactoredSHExchange:
                                % (rank, self.n_means, len(self.sink), n_local))
         send, P, row0 = self._buffers(k_max)
         Ns = m.get_scene_pts_num
+        fx = self.factor_xyz()
+        if fx and self.n_xyz != n_local:
+            raise RuntimeError("FactoredSHExchange: %d of this rank's %d backward passes delivered the object position gradients (the "
+                               "deformation must go through adgs.deform with this model's grad_arena)" % (self.n_xyz, n_local))
         if self._expect is not None and self._expect != (n_total, k_max, n_local):
             raise RuntimeError("FactoredSHExchange: begin() announced %d cameras, reduce() got %d" % (self._expect[0], n_total))
         coll = self._collectives(world)
@@ -398,7 +452,8 @@ class FactoredSHExchange:
         sh = [getattr(m, n, None) for n in _SH_PARAMS]
         if coll:
             if dense_params is None:
-                dense_params = [p for p in m.parameters() if not any(p is s for s in sh)]
+                skip = sh + ([m.xyz_deform_param] if fx else [])
+                dense_params = [p for p in m.parameters() if not any(p is s for s in skip)]
             # one flat bucket for the whole dense remainder (108 MB at C3): one collective instead of one per large tensor --
             # xGMI is point-to-point and every extra collective costs a launch + synchronisation round
             named = self._dense_named() if self.arena is not None else []
@@ -419,7 +474,7 @@ class FactoredSHExchange:
         cams = []
         for g in range(n_total):                     # global camera order: identical summation order on every rank
             r, j = g % world, g // world
-            cams.append((recv[r, j, :3 * P].view(P, 3), recv[r, j, 3 * P:].view(P - row0, 3) if row0 < P else None, cam_positions[g]))
+            cams.append((recv[r, j, :3 * P].view(P, 3), recv[r, j, 3 * P:3 * P + 3 * (P - row0)].view(P - row0, 3) if row0 < P else None, cam_positions[g]))
         C = int(m.shs_deform_param_scene.shape[-1]) if getattr(m, "shs_deform_param_scene", None) is not None else 0
         M = 1 + int(m._scene_shs_rest.shape[1])
         W = None
@@ -443,5 +498,29 @@ class FactoredSHExchange:
             self.expand(cams, W, C, P, Ns, row0, head, int(m.active_sh_degree), M, outs)
         else:
             hip_sh_grad_expand(cams, W, C, P, Ns, row0, head, int(m.active_sh_degree), M, outs, _cache=self._cam_cache)
-        allreduce_gradients_finish(dense)            # the expansion above ran while the dense all-reduce was on the links
+        if fx:
+            from . import deform
+            xp = m.xyz_deform_param
+            No, Cx = xp.shape[0], int(xp.shape[-1])
+            base = 3 * P + 3 * (P - row0)
+            ft = [None] * n_total if flow_times is None else list(flow_times)
+            key = ("xyz", tuple(float(t) for t in cam_times), tuple(None if t is None else float(t) for t in ft), tuple(m.order_args["xyz"]), Cx, str(send.device))
+            Wx = self._w_cache.get(key)
+            if Wx is None:
+                rows = []
+                for g in range(n_total):
+                    for t in (cam_times[g], ft[g]):
+                        if t is not None:
+                            rows.append(_dense_basis_weights((float(t),), m.order_args["xyz"], Cx, "cpu")[0])
+                Wx = self._w_cache[key] = torch.stack(rows).contiguous().to(send.device)
+            terms = []
+            for g in range(n_total):
+                r, j = g % world, g // world
+                terms.append(recv[r, j, base:base + 3 * No])
+                if ft[g] is not None:
+                    terms.append(recv[r, j, base + 3 * No:base + 6 * No])
+            if xp.grad is None or xp.grad.shape != xp.shape:
+                xp.grad = torch.empty_like(xp)
+            hip_lin_grad_expand(terms, Wx, Cx, No, 1.0, xp.grad)
+        allreduce_gradients_finish(dense)            # the expansions above ran while the dense all-reduce was on the links
         self.begin()

@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(EX_THREADS) sh_expand_rows_kernel(ExpandArgs a
 constexpr int EX_ITEMS = 8;
 struct ExpandDeformArgs {
 	int n, C, count, n0;
+	float scale;                 // SH_C0 for the SH deformation rows (the factor is dL/dRGB), 1 for plain linear families
 	const float* W; float* out;
 	const float* rgb[ADGS_EXPAND_MAX_CAMS];
 };
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(EX_THREADS) sh_expand_deform_kernel(ExpandDefo
 	const size_t tot = (size_t)a.count * 3 * np;
 	const size_t e0 = ((size_t)blockIdx.x * EX_THREADS + threadIdx.x) * EX_ITEMS;
 	if (e0 >= tot) return;
-	const float C0 = 0.28209479177387814f;
+	const float C0 = a.scale;
 	const size_t row0 = e0 / np;                     // (Gaussian, channel) row of the first output
 	const int k0 = (int)(e0 - row0 * np);
 	float v[EX_ITEMS];
@@ -147,7 +148,7 @@ extern "C" int adgs_sh_grad_expand(int n_cams, const adgs_sh_expand_cam* cams, c
 		if (!W) { set_error("adgs_sh_grad_expand: W is NULL"); return -1; }
 		if ((size_t)n_cams * C * sizeof(float) > 48 * 1024) { set_error("adgs_sh_grad_expand: n_cams * C too large"); return -1; }
 		ExpandDeformArgs d;
-		d.n = n_cams; d.C = C; d.W = W;
+		d.n = n_cams; d.C = C; d.W = W; d.scale = 0.28209479177387814f;
 		for (int c = 0; c < n_cams; c++) d.rgb[c] = cams[c].rgb;
 		for (int side = 0; side < 2; side++) {
 			d.out = side == 0 ? a.out.scene_sp : a.out.obj_sp;
@@ -160,5 +161,21 @@ extern "C" int adgs_sh_grad_expand(int n_cams, const adgs_sh_expand_cam* cams, c
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}
+	return 0;
+}
+
+// out[m, d, j] = scale * sum_e W[e][j] * g_e[m, d]: the gradient of a parameter tensor [count, 3, C] that enters linearly
+// (utils/func_utils.py:121-156) summed over n_terms (camera, time stamp) factors -- xyz_deform_param in the factored exchange
+extern "C" int adgs_lin_grad_expand(int n_terms, const float* const* g, const float* W, int C, int count, float scale, float* out, void* stream_) {
+	if (count <= 0 || C <= 0) return 0;
+	if (!g || !W || !out || n_terms < 1 || n_terms > ADGS_EXPAND_MAX_CAMS) { set_error("adgs_lin_grad_expand: need 1.." + std::to_string(ADGS_EXPAND_MAX_CAMS) + " factors"); return -1; }
+	if ((size_t)n_terms * C * sizeof(float) > 48 * 1024) { set_error("adgs_lin_grad_expand: n_terms * C too large"); return -1; }
+	ExpandDeformArgs d;
+	d.n = n_terms; d.C = C; d.count = count; d.n0 = 0; d.scale = scale; d.W = W; d.out = out;
+	for (int e = 0; e < n_terms; e++) { if (!g[e]) { set_error("adgs_lin_grad_expand: NULL factor"); return -1; } d.rgb[e] = g[e]; }
+	const size_t tot = (size_t)count * 3 * C, per_block = (size_t)EX_THREADS * EX_ITEMS;
+	hipLaunchKernelGGL(sh_expand_deform_kernel, dim3((unsigned)((tot + per_block - 1) / per_block)), dim3(EX_THREADS), (size_t)n_terms * C * sizeof(float),
+		(hipStream_t)stream_, d);
+	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

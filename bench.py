@@ -353,11 +353,12 @@ def main():
                 and (world > 1 or force_coll or os.environ.get("ADGS_BENCH_FACTORED") == "1"))
     exchange = "none"
     if factored:
-        ex = dp.FactoredSHExchange(frame.model)
+        ex = dp.FactoredSHExchange(frame.model, factor_xyz=(frame.fused_flow or not use_fs) and os.environ.get("ADGS_DP_FACTOR_XYZ", "1") != "0")
         ex.force_collectives = force_coll
+        flow_times = [frame.t + 0.05 if use_fs else None] * world
         cam_times = [frame.t] * world
         cam_positions = [synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if world == 1 else r)["campos"].tolist() for r in range(world)]
-        exchange = "factored SH gradients: all-gather of the colour-gradient factors + dense all-reduce of the rest + local expansion"
+        exchange = "factored SH%s gradients: all-gather of the factors + dense all-reduce of the rest + local expansion" % (" and xyz-deformation" if ex.factor_xyz() else "")
     elif world > 1:
         exchange = "dense all-reduce of every parameter gradient"
 
@@ -366,7 +367,7 @@ def main():
             ex.begin(world)                      # the all-gather starts from inside the backward, as soon as the factor exists
             outs = frame.forward(sink_for=ex.sink_for)
             torch.autograd.backward(outs, up_list)
-            ex.reduce(cam_times, cam_positions)
+            ex.reduce(cam_times, cam_positions, flow_times=flow_times)
         else:
             outs = frame.forward()
             torch.autograd.backward(outs, up_list)

@@ -48,7 +48,7 @@ def iteration(model, ex, cameras, targets, it, rank, world, densify_every=0, lam
         with torch.no_grad():
             model.add_densification_stats(pkg)
         total += l.detach()
-    ex.reduce([c.time for c in cameras], [c.camera_center.tolist() for c in cameras])
+    ex.reduce([c.time for c in cameras], [c.camera_center.tolist() for c in cameras], flow_times=[c.time + 0.05 for c in cameras])
     with torch.no_grad():
         model.optimizer.step(zero_grad=False)
         model.zero_grad()
@@ -89,7 +89,7 @@ def main():
     cameras = make_cameras(cfg, args.cams or world)
     g = torch.Generator().manual_seed(11)
     targets = dict(image=torch.rand(3, cfg["H"], cfg["W"], generator=g).to(dev), depth=torch.rand(cfg["H"], cfg["W"], generator=g).to(dev) * 0.3)
-    ex = dp.FactoredSHExchange(model)
+    ex = dp.FactoredSHExchange(model, factor_xyz=True)       # render() evaluates positions and flow points in one deformation pass
     losses = []
     for it in range(args.iters + 3):
         if it == 3:

@@ -49,6 +49,12 @@ typedef struct adgs_sh_expand_cam {
 int adgs_sh_grad_expand(int n_cams, const adgs_sh_expand_cam* cams, const float* W, int C,
 	int P, int Ns, int row0, const float* xyz_head, int D, int M, const adgs_sh_grads* out, void* stream);
 
+/* The same for a parameter tensor [count, 3, C] that enters its output linearly (f_xyz: utils/func_utils.py:121-156,
+ * scene/gaussian_model.py:173-185): out[m, d, j] = scale * sum_e W[e][j] * g[e][m, d] over n_terms <= ADGS_EXPAND_MAX_CAMS factors.
+ * In the factored exchange: xyz_deform_param's gradient from every camera's two upstream position gradients of the object range
+ * (camera time and flow time), g = HOST array of n_terms device pointers to [count,3], W device [n_terms, C] (dense basis rows). */
+int adgs_lin_grad_expand(int n_terms, const float* const* g, const float* W, int C, int count, float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,8 +72,8 @@ def _render_cam(model, cam, t, ups, sink):
     return radii
 
 
-@pytest.mark.parametrize("background,sh_degree", [(False, 3), (True, 3), (False, 1), (False, 0)])
-def test_factored_multi_camera_gradients_equal_conventional_accumulation(background, sh_degree):
+@pytest.mark.parametrize("background,sh_degree,factor_xyz", [(False, 3, False), (True, 3, True), (False, 1, True), (False, 0, False), (False, 3, True)])
+def test_factored_multi_camera_gradients_equal_conventional_accumulation(background, sh_degree, factor_xyz):
     from adgs import dp, synthetic
     from adgs.model import SyntheticGaussianModel, DEFAULT_ORDER_ARGS
     sc = synthetic.make_scene(6000, 208, 128, 150.0, sh_degree=sh_degree, seed=5, n_objects=2)
@@ -88,7 +88,7 @@ def test_factored_multi_camera_gradients_equal_conventional_accumulation(backgro
     def run(factored):
         model = SyntheticGaussianModel.from_scene(sc, torch.device("cuda", 0), seed=1, order_args=oa)
         model.raw_sh = True
-        ex = dp.FactoredSHExchange(model) if factored else None
+        ex = dp.FactoredSHExchange(model, factor_xyz=factor_xyz) if factored else None
         vis = 0
         for cam, t in zip(cams, times):
             vis += int((_render_cam(model, cam, t, ups, ex.sink_for if factored else None) > 0).sum())
@@ -97,7 +97,9 @@ def test_factored_multi_camera_gradients_equal_conventional_accumulation(backgro
             # the dense gradients of the first backward live in the exchange's arena (one flat all-reduce buffer, installed by
             # autograd without a copy); the later cameras were accumulated into the same slices
             assert ex.arena is not None and all(ex.arena.holds(f, p.grad) for f, p in ex._dense_named() if p is not None and p.numel() > 0)
-            ex.reduce(times, [c["campos"].tolist() for c in cams])
+            if factor_xyz:
+                assert model.xyz_deform_param.grad is None, "the deformation backward must not materialise the xyz rows"
+            ex.reduce(times, [c["campos"].tolist() for c in cams], flow_times=[t + 0.05 for t in times])
         torch.cuda.synchronize()
         assert vis > 3000
         return {n: getattr(model, n).grad.detach().cpu().numpy() for n in
