@@ -499,7 +499,6 @@ class FactoredSHExchange:
         else:
             hip_sh_grad_expand(cams, W, C, P, Ns, row0, head, int(m.active_sh_degree), M, outs, _cache=self._cam_cache)
         if fx:
-            from . import deform
             xp = m.xyz_deform_param
             No, Cx = xp.shape[0], int(xp.shape[-1])
             base = 3 * P + 3 * (P - row0)
