@@ -347,3 +347,11 @@ def test_c3_full_size_two_independent_pipelines_agree(monkeypatch):
         assert_close("grad_" + k, a["grads"][k].cpu().numpy(), b["grads"][k].cpu().numpy(), max_frac=2e-4)
     op = a["img_opacity"]
     assert float(op.min()) >= 0.0 and float(op.max()) <= 1.0 + 1e-6
+
+
+def test_c3_full_size_vs_oracle():
+    """BASELINE.json configs[2] at full size against the CPU oracle (the line-by-line restatement of the reference kernels):
+    radii bit-exact, the five images and all gradients within 1e-4 (about 10 s of oracle time on the GPU box's host cores)."""
+    sc = synthetic.make_config_scene("C3")
+    h, o = compare(sc, grads=synthetic.make_upstream_grads(sc, 2))
+    assert o["num_rendered"] > 40_000_000                       # the reference's (tile, Gaussian) pair count of this frame
