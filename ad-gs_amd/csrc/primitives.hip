@@ -7,6 +7,7 @@
 //   sort : per 8-bit pass reads keys twice + values once, writes both
 //          (u64 key + u32 value: 8 + 12 + 12 = 32 B/item/pass)
 #include "common.h"
+#include <cstdlib>
 
 namespace adgs {
 
@@ -26,7 +27,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 	return v;
 }
 
-// mode 0: write per-block sums only.  mode 1: write exclusive scan (+ block offset).
+// mode 0: write per-block sums only.  mode 1: write exclusive scan (+ block offset).  mode 2: as mode 1, with block_offsets
+// holding the UNSCANNED block sums (each block sums its predecessors itself).
 template <int MODE>
 __global__ void __launch_bounds__(PB) scan_tile_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
 	size_t n, const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ block_sums,
@@ -77,7 +79,21 @@ __global__ void __launch_bounds__(PB) scan_tile_kernel(const uint32_t* __restric
 		if (tid == 0) block_sums[blockIdx.x] = block_total;
 		return;
 	}
-	uint32_t run = (block_offsets ? block_offsets[blockIdx.x] : 0u) + wave_prefix + (incl - tsum);
+	uint32_t block_off = 0;
+	if (MODE == 2) {
+		// every block adds up the sums of the blocks before it by itself (a few hundred values from the L2): no separate
+		// launch for the scan of the block sums
+		__shared__ uint32_t s_part[PB / WAVE];
+		uint32_t p = 0;
+		for (uint32_t b = tid; b < blockIdx.x; b += PB) p += block_offsets[b];
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) p += __shfl_xor(p, off, WAVE);
+		if (lane == 0) s_part[wid] = p;
+		__syncthreads();
+#pragma unroll
+		for (int w = 0; w < PB / WAVE; w++) block_off += s_part[w];
+	} else if (block_offsets) block_off = block_offsets[blockIdx.x];
+	uint32_t run = block_off + wave_prefix + (incl - tsum);
 	uint32_t o[SCAN_ITEMS];
 #pragma unroll
 	for (int k = 0; k < SCAN_ITEMS; k++) { o[k] = run; run += v[k]; }
@@ -124,6 +140,12 @@ int exclusive_scan_u32_sum(const uint32_t* in, uint32_t* out, size_t n, char* te
 	char* next_temp = temp + align_up(nb * sizeof(uint32_t), 256);
 	hipLaunchKernelGGL(scan_tile_kernel<0>, dim3((unsigned)nb), dim3(PB), 0, stream, in, (uint32_t*)nullptr, n, (const uint32_t*)nullptr, sums, aux_in, aux_total);
 	ADGS_HIP_CHECK(hipGetLastError());
+	static const bool three_launch = getenv("ADGS_SCAN3") != nullptr;
+	if (nb <= 4096 && !three_launch) {            // two launches: the blocks of the second pass add up the preceding block sums themselves
+		hipLaunchKernelGGL(scan_tile_kernel<2>, dim3((unsigned)nb), dim3(PB), 0, stream, in, out, n, (const uint32_t*)sums, (uint32_t*)nullptr, no_aux, no_tot);
+		ADGS_HIP_CHECK(hipGetLastError());
+		return 0;
+	}
 	if (exclusive_scan_u32(sums, sums, nb, next_temp, stream) != 0) return -1;
 	hipLaunchKernelGGL(scan_tile_kernel<1>, dim3((unsigned)nb), dim3(PB), 0, stream, in, out, n, (const uint32_t*)sums, (uint32_t*)nullptr, no_aux, no_tot);
 	ADGS_HIP_CHECK(hipGetLastError());
