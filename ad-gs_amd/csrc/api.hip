@@ -139,6 +139,12 @@ static bool use_v2(int D_S) {
 // Pixels per lane of the v2 blend kernels: one wave per 16x16 tile (4 px/lane) when that already gives the chip enough
 // waves; 16x8 half tiles (2 px/lane) for small images (KITTI-sized frames have < 2 waves per SIMD otherwise).
 // ADGS_V2_PPL=2|4 overrides; forward and backward of a frame must see the same value.
+// Edge of a coarse cell in 16x16 tiles.  Larger cells mean fewer (cell, Gaussian) pairs to sort but longer candidate lists for
+// every tile to filter; measured on MI355X (frames/s, cell edge 8 / 10 / 12 tiles): C3 1920x1280 (9600 tiles) 636 / 640 / 643,
+// C5 395 / 400 / 405, C2 1242x375 (1872 tiles) 1324 / 1279 / 1152 -- so 12 for large tile grids, 8 otherwise.
+static int v2_cell_tiles(size_t ntiles16) {
+	return std::max(1, env_int("ADGS_CELL_TILES", ntiles16 >= 4096 ? 12 : 8));
+}
 static int v2_pixels_per_lane(size_t ntiles16) {
 	const int e = env_int("ADGS_V2_PPL", 0);
 	if (e == 2 || e == 4) return e;
@@ -287,7 +293,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (gx > 65535 || gy > 65535) { set_error("image too large"); return -1; }
 
 	if (use_v2(D_S)) {
-		const int cell_tiles = std::max(1, env_int("ADGS_CELL_TILES", 8));
+		const int cell_tiles = v2_cell_tiles(ntiles);
 		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
 		const size_t ncells = (size_t)cgx * cgy;
 		size_t gb = 0, ib = 0;
@@ -488,7 +494,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	if (use_v2(D_S)) {
-		const int cell_tiles = std::max(1, env_int("ADGS_CELL_TILES", 8));
+		const int cell_tiles = v2_cell_tiles(ntiles);
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr);
 		const int ppl = v2_pixels_per_lane(ntiles);
