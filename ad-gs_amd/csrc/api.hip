@@ -94,13 +94,14 @@ struct GeomStateV2 {
 	}
 };
 struct ImgStateV2 {
-	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed;
+	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order;
 	static ImgStateV2 carve(char* chunk, size_t npix, size_t ntiles, size_t ncells, size_t* bytes) {
 		Carver c(chunk); ImgStateV2 s;
 		s.n_contrib = c.take<uint32_t>(npix);
 		s.cell_ranges = c.take<uint2>(ncells);
 		s.tile_last_chunk = c.take<uint32_t>(ntiles);
 		s.tile_consumed = c.take<uint32_t>(ntiles);
+		s.tile_order = c.take<uint32_t>(ntiles);
 		if (bytes) *bytes = c.size();
 		return s;
 	}
@@ -515,8 +516,13 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		ra.do_depth = dL_dpix_depth != nullptr;
 		ra.do_opacity = grad_img_opacity != nullptr;
 		ra.gacc = geom.gacc;
+		ra.tile_order = nullptr;
 		{
 			StageTimer t(ST_RENDER_BWD, stream);
+			if (wtiles >= 2048 && env_int("ADGS_TILE_ORDER", 1) != 0) {      // fewer tiles than wave slots: nothing to balance
+				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream) != 0) return -1;
+				ra.tile_order = img.tile_order;
+			}
 			// geom.gacc lines of the visible Gaussians were zeroed by the forward preprocess (and are re-zeroed
 			// by the preprocess backward after it consumed them)
 			if (binning_buffer && launch_render_bwd_v2(ra, stream) != 0) return -1;

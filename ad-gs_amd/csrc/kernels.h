@@ -108,8 +108,11 @@ struct RenderV2BwdArgs {
 	const float* dL_dpix; const float* dL_dpix_depth; const float* dL_dpix_flow; const float* dL_dpix_sem; const float* dL_dpix_opacity;
 	bool do_color, do_flow, do_sem, do_depth, do_opacity;
 	float* gacc;                     // [P][GACC_STRIDE], zero-initialised
+	const uint32_t* tile_order;      // workgroup -> tile, longest lists first (launch_tile_order); nullptr: identity
 };
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream);
+// order[i] = tile with the i-th largest number of consumed entries (bucketed): the backward starts the long tiles first
+int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream);
 
 // flat coalesced d/dparam[m, d, k] = w_k * g[m * gstride + d] for the linear families (deform.hip)
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);
