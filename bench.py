@@ -129,7 +129,9 @@ def pmc_annotations(stage, config, measured_case):
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_blend_kernels.json")))["kernels"].get(kname)
         if pm:
             out["valu_busy_frac"] = pm["valu_busy_frac"]
-            out["valu_note"] = "fp32-VALU-bound kernel (SURVEY.md 8(d)): SQ_ACTIVE_INST_VALU / (SIMDs x kernel cycles), profiles/r01/pmc_blend_kernels.json"
+            out["valu_insts_per_simd_cycle"] = pm.get("valu_insts_per_simd_cycle")
+            out["valu_note"] = ("fp32-VALU-bound kernel (SURVEY.md 8(d)): valu_busy_frac = min(1, 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles)); "
+                                "valu_insts_per_simd_cycle against a full-rate peak of 0.5 (quarter-rate exp / rcp included); profiles/r01/pmc_blend_kernels.json")
     except (OSError, ValueError, KeyError):
         pass
     return out
