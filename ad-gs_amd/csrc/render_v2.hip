@@ -121,6 +121,16 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	}
 	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
+	// prefetched batch (see the refill loop)
+	uint32_t pf_id = 0;
+	float4 pf_f0 = make_float4(0.f, 0.f, 0.f, 0.f), pf_f1 = pf_f0;
+	if (pos + lane < range.y) {
+		pf_id = a.cell_list[pos + lane];
+		if (PPL == 2) {
+			const float4* fr = reinterpret_cast<const float4*>(a.rects + pf_id);
+			pf_f0 = fr[0]; pf_f1 = fr[1];
+		}
+	}
 
 	while (true) {
 		bool mine_done = true;
@@ -130,17 +140,32 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		if (all_done) break;
 		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction)
 		while (qcount < WAVE && pos < range.y) {
-			const uint32_t e = pos + lane;
-			bool pass = false; uint32_t id = 0;
-			if (e < range.y) {
-				id = a.cell_list[e];
+			// Software prefetch, one batch ahead.  PPL == 2 (84 -> 98 registers would cost the PPL == 4 kernel a wave of occupancy):
+			// list entry AND filter record of batch k+1 are requested before batch k is tested, so both dependent round trips
+			// overlap the test and, after the last refill, the blend loop.  PPL == 4: only the list entry travels ahead (one
+			// register): the filter records are fetched at once, one round trip on the critical path instead of two.
+			const uint32_t id = pf_id;
+			const bool have = pos + lane < range.y;
+			float4 f0 = pf_f0, f1 = pf_f1;
+			if (PPL != 2 && have) {
 				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
-				float4 f0 = fr[0], f1 = fr[1];
-				// both halves of the record are requested together (otherwise the compiler sinks the first
-				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
-				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
-				pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
+				f0 = fr[0]; f1 = fr[1];
 			}
+			{
+				const uint32_t e2 = pos + WAVE + lane;
+				if (e2 < range.y) {
+					pf_id = a.cell_list[e2];
+					if (PPL == 2) {
+						const float4* fr = reinterpret_cast<const float4*>(a.rects + pf_id);
+						pf_f0 = fr[0]; pf_f1 = fr[1];
+					}
+				}
+			}
+			// both halves of the record are requested together (otherwise the compiler sinks the first
+			// load behind the rectangle test and the survivors pay a third dependent memory round trip)
+			if (PPL != 2) asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
+			bool pass = false;
+			if (have) pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
 			qcount += __popcll(m);
