@@ -397,6 +397,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
 		ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 		ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
+		ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
 		{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;

@@ -42,6 +42,7 @@ struct RenderFwdArgs {
 	float* final_T;                  // img_opacity output (holds 1 - T)
 	uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
+	int order_mode;
 };
 int launch_render_fwd(const RenderFwdArgs& a, hipStream_t stream);
 
@@ -98,6 +99,7 @@ struct RenderV2FwdArgs {
 	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed;
 	float* final_T; uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
+	int order_mode;                         // 1: workgroups walk the tiles bottom-up (default), 0: top-down
 };
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
 

@@ -99,7 +99,11 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
 	const int lane = threadIdx.x;
-	const uint32_t tile = blockIdx.x;
+	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
+	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
+	// objects of the synthetic configs) the lower image rows carry the long lists, and tiles dispatched last run on a draining
+	// machine.  Measured at C3: 0.409 -> 0.400 ms; a strided permutation of the tiles: 0.412 ms.  ADGS_FWD_ORDER=0: top-down.
+	const uint32_t tile = a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	const uint32_t ty16 = ty / SUB;                           // row of the 16x16 tile grid the binning works on
 	const uint32_t cell = (ty16 / a.cell_tiles) * a.cgx + (tx / a.cell_tiles);
