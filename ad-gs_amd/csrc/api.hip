@@ -349,6 +349,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 		size_t cap_cells = std::max<size_t>(g_hint_cells.load(), (size_t)P + 4096);
 		size_t cap_fine = std::max<size_t>(g_hint_fine.load(), (size_t)8 * P + 4096);
 		BinStateV2 bin;
+		// rectangle-coverage masks in the key bits above (cell | depth): one bit per tile row and per tile column of a cell
+		const int mask_shift = (2 * cell_tiles + bit <= 32 && env_int("ADGS_KEY_MASKS", 1) != 0) ? 32 + bit : -1;
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
 			BinStateV2::carve(nullptr, cells, fine * sub, wtiles, &bb);        // a Gaussian can enter both halves of a tile
@@ -362,13 +364,13 @@ static int raster_forward_impl(const ShSource* sh_src,
 			}
 			{ StageTimer t(ST_DUPLICATE, stream);
 			  if (launch_duplicate_cells(P, geom.dupinfo, geom.offsets, bin.keys_unsorted, bin.list_unsorted, (uint32_t)std::min<size_t>(cells, 0xffffffffu),
-			        cell_tiles, cgx, img.cell_ranges, (int)ncells, bin.pool_cursor, stream) != 0) return -1; }
+			        cell_tiles, cgx, img.cell_ranges, (int)ncells, bin.pool_cursor, mask_shift, stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			{ StageTimer t(ST_SORT, stream);
 			  if (radix_sort_pairs_u64_dn(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, cells, d_count, 32 + bit, bin.sort_temp, stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			{ StageTimer t(ST_RANGES, stream);
-			  if (launch_tile_ranges((int)cells, d_count, bin.keys, img.cell_ranges, stream) != 0) return -1; }
+			  if (launch_tile_ranges((int)cells, d_count, bin.keys, img.cell_ranges, bit >= 32 ? 0xffffffffu : ((1u << bit) - 1u), stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
 		};
@@ -390,6 +392,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		}
 		RenderV2FwdArgs ra;
 		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
+		ra.cell_keys = bin.keys; ra.mask_shift = mask_shift;
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
 		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
@@ -460,7 +463,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	ADGS_LAUNCH_CHECK(debug, stream);
 	{ StageTimer t(ST_RANGES, stream);
 	  ADGS_HIP_CHECK(hipMemsetAsync(img.ranges, 0, ntiles * sizeof(uint2), stream));
-	  if (launch_tile_ranges(num_rendered, nullptr, bin.keys, img.ranges, stream) != 0) return -1; }
+	  if (launch_tile_ranges(num_rendered, nullptr, bin.keys, img.ranges, 0xffffffffu, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
 	RenderFwdArgs ra;

@@ -31,7 +31,7 @@ int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
 int launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, const int* radii, uint64_t* keys, uint32_t* vals,
 	int gx, int gy, hipStream_t stream);
-int launch_tile_ranges(int L, const uint32_t* d_L, const uint64_t* keys, uint2* ranges, hipStream_t stream);
+int launch_tile_ranges(int L, const uint32_t* d_L, const uint64_t* keys, uint2* ranges, uint32_t id_mask, hipStream_t stream);
 
 struct RenderFwdArgs {
 	const uint2* ranges; const uint32_t* point_list; const Splat* splats;
@@ -88,10 +88,11 @@ constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumula
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
 int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
-	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, hipStream_t stream);
+	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, int mask_shift, hipStream_t stream);
 
 struct RenderV2FwdArgs {
 	const uint2* cell_ranges; const uint32_t* cell_list; const FilterRec* rects; const Splat* splats;
+	const uint64_t* cell_keys; int mask_shift;   // sorted keys with the rectangle-coverage masks at bit mask_shift (-1: keys carry no masks)
 	int W, H, gx, gy, cell_tiles, cgx;      // gy: rows of WAVE tiles (16 x 4*ppl pixels), not of 16x16 tiles
 	int ppl;                                // pixels per lane: 4 or 2 (v2_pixels_per_lane)
 	bool has_color, has_flow, has_sem;

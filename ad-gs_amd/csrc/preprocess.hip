@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat*
 // v2: one (cell | depth) key per covered coarse cell.
 __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const uint4* __restrict__ dupinfo,
 	const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap, int cell_tiles, int cgx,
-	uint2* __restrict__ cell_ranges, int ncells, uint32_t* __restrict__ pool_cursor) {
+	uint2* __restrict__ cell_ranges, int ncells, uint32_t* __restrict__ pool_cursor, int mask_shift) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	// bookkeeping resets for the stages that follow on this stream (tile_ranges, blend forward)
 	for (int c = idx; c < ncells; c += gridDim.x * blockDim.x) cell_ranges[c] = make_uint2(0u, 0u);
@@ -308,20 +308,32 @@ __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const uint4
 		for (uint32_t x = c0x; x <= c1x; x++) {
 			uint64_t key = (uint64_t)(y * cgx + x);
 			key <<= 32; key |= dbits;
+			if (mask_shift >= 0) {
+				// The key bits above (cell | depth) are not sorted on but travel with the key: they carry which tile rows and tile
+				// columns OF THIS CELL the Gaussian's rectangle covers, so that the blend forward can run the rectangle test on the
+				// sorted key stream alone (8 sequential bytes per candidate) and gathers the 32-byte filter record only for
+				// candidates that pass it.
+				const uint32_t ty0 = y * cell_tiles, tx0 = x * cell_tiles;
+				const uint32_t r0 = max(miny, ty0) - ty0, r1 = min(maxy, ty0 + cell_tiles) - ty0;      // [r0, r1) within the cell
+				const uint32_t q0 = max(minx, tx0) - tx0, q1 = min(maxx, tx0 + cell_tiles) - tx0;
+				const uint64_t rows = ((1ull << r1) - 1ull) & ~((1ull << r0) - 1ull), cols = ((1ull << q1) - 1ull) & ~((1ull << q0) - 1ull);
+				key |= (rows << mask_shift) | (cols << (mask_shift + cell_tiles));
+			}
 			if (off < cap) { keys[off] = key; vals[off] = (uint32_t)idx; }    // cap: speculative capacity (the host re-runs on overflow)
 			off++;
 		}
 }
 
 // rasterizer_impl.cu:116-138
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* __restrict__ d_L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* __restrict__ d_L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges,
+	uint32_t id_mask) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (d_L) L = (int)min((uint32_t)L, *d_L);      // device-side count, L is the capacity
 	if (idx >= L) return;
-	const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+	const uint32_t currtile = (uint32_t)(keys[idx] >> 32) & id_mask;      // v2 keys carry coverage masks above the cell id
 	if (idx == 0) ranges[currtile].x = 0;
 	else {
-		const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+		const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32) & id_mask;
 		if (currtile != prevtile) { ranges[prevtile].y = idx; ranges[currtile].x = idx; }
 	}
 	if (idx == L - 1) ranges[currtile].y = L;
@@ -356,16 +368,16 @@ int launch_duplicate_keys(int P, const Splat* splats, const uint32_t* offsets, c
 	return 0;
 }
 int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
-	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, hipStream_t stream) {
+	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, int mask_shift, hipStream_t stream) {
 	if (P == 0) return 0;
 	hipLaunchKernelGGL(duplicate_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, dupinfo, offsets, keys, vals, cap, cell_tiles, cgx,
-		cell_ranges, ncells, pool_cursor);
+		cell_ranges, ncells, pool_cursor, mask_shift);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
-int launch_tile_ranges(int L, const uint32_t* d_L, const uint64_t* keys, uint2* ranges, hipStream_t stream) {
+int launch_tile_ranges(int L, const uint32_t* d_L, const uint64_t* keys, uint2* ranges, uint32_t id_mask, hipStream_t stream) {
 	if (L == 0) return 0;
-	hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, L, d_L, keys, ranges);
+	hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, L, d_L, keys, ranges, id_mask);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
+	__shared__ uint32_t s_cand[2 * WAVE];
 	const int lane = threadIdx.x;
 	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
 	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
@@ -125,16 +126,13 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	}
 	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
-	// prefetched batch (see the refill loop)
+	// stage-1 state: candidates whose rectangle holds this tile (ring buffer), the prefetched next batch of the key stream
+	uint32_t chead = 0, ccount = 0;
+	const bool masks = a.mask_shift >= 0;
+	const int row_bit = a.mask_shift + (int)(ty16 % a.cell_tiles), col_bit = a.mask_shift + a.cell_tiles + (int)(tx % a.cell_tiles);
+	unsigned long long pf_key = 0ull;
 	uint32_t pf_id = 0;
-	float4 pf_f0 = make_float4(0.f, 0.f, 0.f, 0.f), pf_f1 = pf_f0;
-	if (pos + lane < range.y) {
-		pf_id = a.cell_list[pos + lane];
-		if (PPL == 2) {
-			const float4* fr = reinterpret_cast<const float4*>(a.rects + pf_id);
-			pf_f0 = fr[0]; pf_f1 = fr[1];
-		}
-	}
+	if (pos + lane < range.y) { pf_key = a.cell_keys[pos + lane]; pf_id = a.cell_list[pos + lane]; }
 
 	while (true) {
 		bool mine_done = true;
@@ -142,38 +140,43 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		for (int k = 0; k < PPL; k++) mine_done = mine_done && (pyf[k] == PIXEL_DONE);
 		const bool all_done = __all(mine_done);
 		if (all_done) break;
-		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction)
-		while (qcount < WAVE && pos < range.y) {
-			// Software prefetch, one batch ahead.  PPL == 2 (84 -> 98 registers would cost the PPL == 4 kernel a wave of occupancy):
-			// list entry AND filter record of batch k+1 are requested before batch k is tested, so both dependent round trips
-			// overlap the test and, after the last refill, the blend loop.  PPL == 4: only the list entry travels ahead (one
-			// register): the filter records are fetched at once, one round trip on the critical path instead of two.
-			const uint32_t id = pf_id;
-			const bool have = pos + lane < range.y;
-			float4 f0 = pf_f0, f1 = pf_f1;
-			if (PPL != 2 && have) {
-				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
-				f0 = fr[0]; f1 = fr[1];
-			}
-			{
-				const uint32_t e2 = pos + WAVE + lane;
-				if (e2 < range.y) {
-					pf_id = a.cell_list[e2];
-					if (PPL == 2) {
-						const float4* fr = reinterpret_cast<const float4*>(a.rects + pf_id);
-						pf_f0 = fr[0]; pf_f1 = fr[1];
-					}
+		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction), in two stages.
+		// Stage 1 scans the sorted KEY stream: the key bits above (cell | depth) say which tile rows and columns of the cell the
+		// Gaussian's rectangle covers (duplicate_cells), so the rectangle test costs 8 sequential, prefetched bytes and two
+		// shifts per candidate -- at C3 a tile scans ~2100 candidates to blend ~180 entries.  Only candidates whose rectangle
+		// holds the tile go on to stage 2, 64 at a time: gather of the 32-byte filter record + the exact ellipse test.
+		while (qcount < WAVE && (pos < range.y || ccount > 0)) {
+			while (ccount < WAVE && pos < range.y) {
+				const unsigned long long key = pf_key;
+				const uint32_t id = pf_id;
+				const bool have = pos + lane < range.y;
+				{
+					const uint32_t e2 = pos + WAVE + lane;
+					if (e2 < range.y) { pf_key = a.cell_keys[e2]; pf_id = a.cell_list[e2]; }
 				}
+				const bool rp = have && (!masks || (((key >> row_bit) & (key >> col_bit)) & 1ull));
+				const uint64_t m = __ballot(rp);
+				if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
+				ccount += __popcll(m);
+				pos += WAVE;
 			}
-			// both halves of the record are requested together (otherwise the compiler sinks the first
-			// load behind the rectangle test and the survivors pay a third dependent memory round trip)
-			if (PPL != 2) asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
-			bool pass = false;
-			if (have) pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
+			const uint32_t nc = min(ccount, (uint32_t)WAVE);
+			if (nc == 0) break;
+			__syncthreads();
+			bool pass = false; uint32_t id = 0;
+			if ((uint32_t)lane < nc) {
+				id = s_cand[(chead + lane) & (2 * WAVE - 1)];
+				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
+				float4 f0 = fr[0], f1 = fr[1];
+				// both halves of the record are requested together (otherwise the compiler sinks the first
+				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
+				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
+				pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
+			}
+			chead = (chead + nc) & (2 * WAVE - 1); ccount -= nc;
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
 			qcount += __popcll(m);
-			pos += WAVE;
 		}
 		const uint32_t n = min(qcount, (uint32_t)WAVE);
 		if (n == 0) break;
