@@ -191,18 +191,15 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			s_splat[lane * 4 + 3] = src[3];
 		}
 		qhead = (qhead + n) & (2 * WAVE - 1); qcount -= n;
-		// ---- publish the chunk for the backward replay
+		// the chunk slot is drawn now, so that the atomic's round trip hides behind the blend loop (a batch without a live
+		// entry leaves its slot unused)
 		uint32_t chunk = 0;
 		if (lane == 0) chunk = atomicAdd(a.pool_cursor, 1u);
-		chunk = __shfl(chunk, 0, WAVE);
-		{
-			uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
-			if (lane == 0) { c[0] = prev_chunk; c[1] = n; }
-			if ((uint32_t)lane < n) c[2 + lane] = myid;
-		}
-		prev_chunk = chunk;
 		__syncthreads();
-		// ---- blend
+		// ---- blend.  `live` collects the entries at least one pixel evaluates as contributing: only those are published for
+		// the backward replay (at C3 22 % of the entries that pass the tile test are blended by no pixel -- the test is a bound
+		// over the tile rectangle, and pixels saturate), and positions (n_contrib) count live entries only.
+		uint64_t live = 0ull;
 		for (uint32_t j = 0; j < n; j++) {
 			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
 			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
@@ -217,6 +214,8 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 				any_act = any_act || act[k];
 			}
 			if (!__any(any_act)) continue;
+			const uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
+			live |= 1ull << j;
 			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
 			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview pad
 #pragma unroll
@@ -231,10 +230,19 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
 				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
 				T[k] = up ? test_T : T[k];
-				last_contrib[k] = up ? consumed + j + 1 : last_contrib[k];
+				last_contrib[k] = up ? position : last_contrib[k];
 			}
 		}
-		consumed += n;
+		// ---- publish the live entries of this batch, in order, as one chunk of the backward's replay list
+		const uint32_t nlive = (uint32_t)__popcll(live);
+		if (nlive > 0) {
+			chunk = __shfl(chunk, 0, WAVE);
+			uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
+			if (lane == 0) { c[0] = prev_chunk; c[1] = nlive; }
+			if ((live >> lane) & 1ull) c[2 + __popcll(live & lt_mask)] = myid;
+			prev_chunk = chunk;
+			consumed += nlive;
+		}
 	}
 	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; }
 	const size_t HW = (size_t)a.H * a.W;
