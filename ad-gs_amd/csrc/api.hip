@@ -700,6 +700,21 @@ extern "C" int adgs_knn_dist2(int P, const float* points, float* meanDists, char
 
 // ---- test-only hooks (include/adgs_testing.h) ----
 #include "../../include/adgs_testing.h"
+extern "C" long long adgs_test_v2_published_entries(const char* img_buffer, int width, int height, void* stream_) {
+	if (!img_buffer || width <= 0 || height <= 0) return -1;
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	const int cell_tiles = v2_cell_tiles(ntiles), ppl = v2_pixels_per_lane(ntiles);
+	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
+	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
+	std::vector<uint32_t> h(wtiles);
+	if (hipMemcpyAsync(h.data(), img.tile_consumed, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	long long total = 0;
+	for (uint32_t v : h) total += v;
+	return total;
+}
 extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
 extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {
 	return exclusive_scan_u32(in, out, n, temp, (hipStream_t)stream);

@@ -45,7 +45,7 @@ def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     }
 
 
-def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, n_obj_rows):
+def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, n_obj_rows, E_pub=None):
     """Algorithmic bytes per launch of the default (v2, coarse-binned) pipeline -- DESIGN.md section 5.
     Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries actually blended."""
     pay = 12 + 4 + 12 * F + 4 * D_S
@@ -57,15 +57,15 @@ def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, n_obj_rows):
         "radix_sort": passes * Rc * 24 + Rc * 8,
         "tile_ranges": Rc * 8,
         "render_fwd": E * (4 + 64 + 4) + out,
-        "render_bwd": E * (4 + 64) + E * 56 + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),
+        "render_bwd": (E if E_pub is None else E_pub) * (4 + 64 + 56) + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),      # replays the published entries only
         "preprocess_bwd": P * (12 + 12 + 16 + 4 + 12 * M) + V * (64 + 32 + 24 + 1) + V * 64 + P * (12 + 12 * M + 12 + 16 + 12 + 16 + 4 + 12 + 4 + 24),
     }
 
 
 def blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device):
-    """(E, R): E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published; the last
+    """(E, R, E_pub): E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published; the last
     chunk of a tile is partly empty, so this is an upper bound within #tiles x 63), R = the reference's num_rendered for the
-    same frame (one extra forward in classic mode)."""
+    same frame (one extra forward in classic mode), E_pub = the entries at least one pixel blends, i.e. what the backward replays."""
     import torch
     from diff_gaussian_rasterization import _C
     from adgs import deform
@@ -86,6 +86,10 @@ def blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device):
                                               s.campos, s.prefiltered, s.inv_depth, False)
         out = call()
         chunks = int(out[6][:4].view(torch.int32)[0].item())      # BinStateV2 starts with the chunk-pool cursor
+        import ctypes
+        from adgs import _lib
+        published = int(_lib.lib().adgs_test_v2_published_entries(out[7].data_ptr(), int(s.image_width), int(s.image_height),
+                                                                  ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
         old = os.environ.get("ADGS_RASTER_MODE")
         os.environ["ADGS_RASTER_MODE"] = "classic"
         try:
@@ -95,7 +99,7 @@ def blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device):
                 del os.environ["ADGS_RASTER_MODE"]
             else:
                 os.environ["ADGS_RASTER_MODE"] = old
-    return chunks * 64, r_ref
+    return chunks * 64, r_ref, published
 
 
 def measured_frame_traffic(config, measured_case, fps_per_gpu):
@@ -452,12 +456,12 @@ def main():
         if v2:
             # scene-level work figures: the reference's pair count R and what v2 actually blends
             if os.environ.get("ADGS_BENCH_SKIP_STATS"):           # PMC passes: keep foreign launches out of the counter totals
-                E, R_ref = 0, 0
+                E, R_ref, E_pub = 0, 0, 0
             else:
-                E, R_ref = blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device)
-            ab = alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], 0)
+                E, R_ref, E_pub = blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device)
+            ab = alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], 0, E_pub)
             extra = {"pipeline": "v2 (coarse cells + lazy per-tile filtering)", "reference_pairs_R": R_ref, "R_over_P": round(R_ref / max(P, 1), 2),
-                     "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E,
+                     "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E, "published_entries": E_pub,
                      "mean_entries_per_tile": round(E / max(T, 1), 1)}
         else:
             ab = alg_bytes(P, V, Rc, X, T, M, F, D_S, stats["sort_passes"])
@@ -477,7 +481,7 @@ def main():
                 "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4)}
         roof.update(pmc_annotations(dom, args.config, use_fs and v2))
         if v2 and dom in ("render_fwd", "render_bwd"):
-            roof["pixel_entry_evals_per_s"] = round(extra["blended_entries"] * 256 / (dom_ms * 1e-3), 1)
+            roof["pixel_entry_evals_per_s"] = round((extra["published_entries"] if dom == "render_bwd" else extra["blended_entries"]) * 256 / (dom_ms * 1e-3), 1)
         result = {
             "metric": "fwd+bwd frames/s",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

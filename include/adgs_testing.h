@@ -17,6 +17,10 @@ size_t adgs_test_sort_temp_bytes(size_t n);
 /* stable LSD radix sort on key bits [0,end_bit); *_in are clobbered */
 int adgs_test_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit, char* temp, void* stream);
 int adgs_test_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit, char* temp, void* stream);
+/* Number of (tile, Gaussian) entries the default (v2) forward published for the backward replay of a frame: the sum of the
+ * per-tile counts in the forward's image-state buffer.  Synchronises the stream; statistics only (bench.py). */
+long long adgs_test_v2_published_entries(const char* img_buffer, int width, int height, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
