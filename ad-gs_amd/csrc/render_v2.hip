@@ -507,16 +507,41 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 // (For the forward the counts are not known yet; ordering by the length of the tile's cell list was measured and does not help.)
 namespace {
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order) {
-	__shared__ uint32_t hist[256];
-	__shared__ uint32_t start[256];
+	// 1024 buckets of one entry: the LDS atomics of the histogram and of the scatter are what this kernel costs, and they
+	// serialise per address -- with coarse buckets most tiles of a frame fall into a handful of them
+	constexpr int NB = 1024, PER = 16;            // tiles per thread kept in registers: one round of loads (T <= 16384), else the generic loops
+	__shared__ uint32_t hist[NB];
+	__shared__ uint32_t start[NB];
 	const int tid = threadIdx.x;
-	if (tid < 256) hist[tid] = 0;
+	hist[tid] = 0;
 	__syncthreads();
-	for (int t = tid; t < T; t += 1024) atomicAdd(&hist[255u - min(consumed[t] >> 3, 255u)], 1u);
+	uint32_t b[PER];
+	const bool fits = T <= 1024 * PER;
+	if (fits) {
+#pragma unroll
+		for (int k = 0; k < PER; k++) { const int t = tid + k * 1024; b[k] = t < T ? (uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1)) : 0xffffffffu; }
+#pragma unroll
+		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) atomicAdd(&hist[b[k]], 1u);
+	} else {
+		for (int t = tid; t < T; t += 1024) atomicAdd(&hist[(uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1))], 1u);
+	}
 	__syncthreads();
-	if (tid == 0) { uint32_t run = 0; for (int b = 0; b < 256; b++) { start[b] = run; run += hist[b]; } }
+	if (tid < WAVE) {                                // exclusive scan of the buckets by one wave (16 buckets per lane)
+		uint32_t s16 = 0;
+		for (int q = 0; q < NB / WAVE; q++) s16 += hist[(NB / WAVE) * tid + q];
+		uint32_t incl = s16;
+#pragma unroll
+		for (int off = 1; off < WAVE; off <<= 1) { const uint32_t o = __shfl_up(incl, off, WAVE); if (tid >= off) incl += o; }
+		uint32_t run = incl - s16;
+		for (int q = 0; q < NB / WAVE; q++) { start[(NB / WAVE) * tid + q] = run; run += hist[(NB / WAVE) * tid + q]; }
+	}
 	__syncthreads();
-	for (int t = tid; t < T; t += 1024) order[atomicAdd(&start[255u - min(consumed[t] >> 3, 255u)], 1u)] = (uint32_t)t;
+	if (fits) {
+#pragma unroll
+		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) order[atomicAdd(&start[b[k]], 1u)] = (uint32_t)(tid + k * 1024);
+	} else {
+		for (int t = tid; t < T; t += 1024) order[atomicAdd(&start[(uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1))], 1u)] = (uint32_t)t;
+	}
 }
 } // namespace
 int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream) {
