@@ -505,7 +505,10 @@ def main():
         }
         if world == 1 and not force_coll and not args.no_secondary and args.config == "C3":
             # the other single-GPU configs of BASELINE.json, same build, same process (secondary: `value` stays the C3 headline)
-            result["other_configs"] = [quick_measure(c, 300, device, use_fs) for c in ("C1", "C2")]
+            try:
+                result["other_configs"] = [quick_measure(c, 300, device, use_fs) for c in ("C1", "C2")]
+            except Exception as exc:                     # secondary information must never cost the headline line
+                result["other_configs"] = "failed: %r" % (exc,)
         if world == 1 and not args.no_cpu_baseline:
             if isinstance(frame, DeformFrame):
                 pkg, flow = frame.activated()
@@ -513,8 +516,11 @@ def main():
                               shs=pkg["shs"], flow_points=flow)
             else:
                 sc_cpu = sc
-            result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, cam, cfg, use_fs, up)
-            result["parity"] = parity_vs_oracle(outs, oracle_fwd)
+            try:
+                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, cam, cfg, use_fs, up)
+                result["parity"] = parity_vs_oracle(outs, oracle_fwd)
+            except Exception as exc:                     # e.g. the oracle library could not be built on this host
+                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (exc,)}
         # RCCL prints a version banner through C stdio, which (on a pipe) would only be flushed at exit, i.e. AFTER the JSON
         # line: flush it first so that the JSON line is the last line of stdout
         try:
