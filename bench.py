@@ -458,7 +458,11 @@ def main():
             if os.environ.get("ADGS_BENCH_SKIP_STATS"):           # PMC passes: keep foreign launches out of the counter totals
                 E, R_ref, E_pub = 0, 0, 0
             else:
-                E, R_ref, E_pub = blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device)
+                try:
+                    E, R_ref, E_pub = blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device)
+                except Exception as exc:                 # statistics only
+                    print("bench: scene statistics failed: %r" % (exc,), file=sys.stderr)
+                    E, R_ref, E_pub = 0, 0, 0
             ab = alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], 0, E_pub)
             extra = {"pipeline": "v2 (coarse cells + lazy per-tile filtering)", "reference_pairs_R": R_ref, "R_over_P": round(R_ref / max(P, 1), 2),
                      "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E, "published_entries": E_pub,
