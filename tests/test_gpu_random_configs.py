@@ -58,3 +58,50 @@ def test_v2_matches_classic_and_oracle_on_random_configs(seed):
             continue
         a, b = gv.cpu().numpy(), cl["grads"][k].cpu().numpy()
         assert_close("grad " + k + " v2~classic", a, b, max_frac=max(2e-4, 1.5 / max(a.size, 1)))
+
+
+def _large_case(seed):
+    """Images large enough for the longest-tiles-first backward order (>= 2048 wave tiles) and the 12-tile cells."""
+    rng = np.random.RandomState(5000 + seed)
+    P = int(rng.choice([4000, 15000, 40000]))
+    W, H = int(rng.randint(700, 1300)), int(rng.randint(500, 900))
+    sc = synthetic.make_scene(P, W, H, float(rng.uniform(500, 1400)), sh_degree=3, seed=100 + seed, n_objects=int(rng.randint(0, 4)),
+                              scale_mult=float(rng.choice([0.004, 0.012])))
+    opts = dict(flow=bool(rng.randint(2)), sem=bool(rng.randint(2)), inv_depth=bool(rng.randint(2)), degree=int(rng.randint(0, 4)))
+    env = dict(ADGS_CELL_TILES=str(int(rng.choice([4, 8, 12]))), ADGS_V2_PPL=str(int(rng.choice([2, 4]))), ADGS_FWD_ORDER=str(int(rng.randint(2))))
+    return sc, opts, env
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_LARGE_SEEDS", "6"))))
+def test_v2_matches_classic_and_oracle_on_large_random_configs(seed):
+    sc, opts, env = _large_case(seed)
+    g = synthetic.make_upstream_grads(sc, seed)
+    saved = {k: os.environ.get(k) for k in list(env) + ["ADGS_RASTER_MODE"]}
+    try:
+        os.environ.update(env)
+        os.environ.pop("ADGS_RASTER_MODE", None)
+        v2 = run_hip(sc, grads=g, **opts)
+        os.environ["ADGS_RASTER_MODE"] = "classic"
+        cl = run_hip(sc, grads=g, **opts)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ref = run_oracle(sc, grads=g, **opts)
+    assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
+    for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
+        a = v2[k].detach().cpu().numpy()
+        assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), max_frac=2e-5)
+        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), max_frac=2e-5)
+    names = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations",
+                 flow="dL_dflow_points", sem="dL_dsemantic")
+    for k, gv in v2["grads"].items():
+        if gv is None:
+            continue
+        a = gv.cpu().numpy()
+        frac = max(2e-4, 4.5 / max(a.size, 1))          # one gate-flipped Gaussian moves all (<= 4) components of its row
+        assert_close("grad " + k + " v2~classic", a, cl["grads"][k].cpu().numpy(), max_frac=frac)
+        if k in names:
+            assert_close("grad " + k + " v2~oracle", a, np.asarray(ref["grads"][names[k]]).reshape(a.shape), max_frac=frac)
