@@ -983,7 +983,9 @@ extern "C" int adgs_func_eval_backward(int N, int D, const float* param, const a
 	return 0;
 }
 
-// block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB
+// block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB; one-wave blocks may take up to
+// MAX_STAGING_LDS of the CU's 160 KiB (very long parameter rows: B-spline + polynomial + Fourier + quaternion parts together)
+constexpr size_t MAX_STAGING_LDS = 156 * 1024;
 static int pick_block(int row_floats, size_t* lds) {
 	for (int B = 256; B >= 64; B >>= 1) {
 		const size_t bytes = (size_t)B * row_floats * sizeof(float);
@@ -1022,13 +1024,14 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 				p->obj_xyz && getenv("ADGS_NO_XYZ_ROWS") == nullptr;
 			const int B = p->No > 0 ? pick_block(a.xyz_rows ? a.stride_r : std::max(a.stride_x, a.stride_r), &lds) : 256;
 			if (a.xyz_rows) lds = std::max(lds, (size_t)2 * np_x * sizeof(float));
-			if (lds > 64 * 1024) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
+			if (lds > MAX_STAGING_LDS) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
 			a.scene4 = scene4_ok({ p->scene_xyz, p->scene_rotation, p->scene_opacity, p->scene_scaling, a.o.xyz, a.flow_xyz, a.o.rotation, a.o.opacity, a.o.scales });
 			const int nb_o = (p->No + B - 1) / B, nb_scene = a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B;
 			const int nb_rot = (a.o.rotation || a.o.opacity || a.o.scales) ? nb_o : 0;
 			const int nb_xyz = (a.o.xyz || a.flow_xyz) ? (a.xyz_rows ? (int)((3 * (size_t)p->No + B - 1) / B) : nb_o) : 0;
 			a.n_begin = 0; a.n_end = N;
-#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_fwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz)
+#define ADGS_CALL(NQ) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+				hipLaunchKernelGGL((deform_fwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz); } while (0)
 			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
 #undef ADGS_CALL
 			ADGS_HIP_CHECK(hipGetLastError());
@@ -1079,13 +1082,14 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 				B = pick_block(std::max(a.stride_x, 2 * a.stride_r), &lds);
 				lds = std::max(lds, (size_t)B * a.stride_x * sizeof(float) + 2 * (size_t)np_x * sizeof(float));     // + dense basis rows of the two time stamps
 			}
-			if (lds > 64 * 1024) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
+			if (lds > MAX_STAGING_LDS) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }
 			const int nb_o = (p->No + B - 1) / B;
 			a.scene4 = scene4_ok({ p->scene_xyz, p->scene_rotation, p->scene_opacity, p->scene_scaling, dL_dxyz, dL_dflow_xyz, dL_drotation, dL_dopacity, dL_dscales,
 				grads->scene_xyz, grads->scene_rotation, grads->scene_opacity, grads->scene_scaling });
 			const int nb_rot = dL_drotation ? nb_o : 0, nb_xyz = want_rest ? nb_o : 0, nb_scene = a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B;
 			a.n_begin = 0; a.n_end = N;
-#define ADGS_CALL(NQ) hipLaunchKernelGGL((deform_bwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz)
+#define ADGS_CALL(NQ) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_bwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+				hipLaunchKernelGGL((deform_bwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz); } while (0)
 			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
 #undef ADGS_CALL
 			ADGS_HIP_CHECK(hipGetLastError());

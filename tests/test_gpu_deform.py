@@ -246,3 +246,68 @@ def test_flow_only_gradient_reaches_xyz_parameters():
     (deform.get_deformed_xyz(ref, 0.7) * w).sum().backward()
     for n in ("_scene_xyz", "_obj_xyz", "xyz_deform_param"):
         close(n, getattr(model, n).grad.cpu().numpy(), getattr(ref, n).grad.cpu().numpy(), tol=1e-6)
+
+
+def _random_order(rng, quat):
+    """A random get_func_result order list: B-spline [n, k], polynomial, Fourier, and (rotation only) a quaternion spline."""
+    oa = [0] * 6
+    if rng.randint(3) > 0:
+        oa[1] = int(rng.randint(1, 6)); oa[0] = int(rng.randint(oa[1] + 1, oa[1] + 12))
+    if rng.randint(3) == 0:
+        oa[2] = int(rng.randint(1, 5))
+    if rng.randint(2) == 0:
+        oa[3] = int(rng.randint(1, 7))
+    if quat and rng.randint(4) > 0:
+        oa[5] = int(rng.randint(1, 6)); oa[4] = int(rng.randint(oa[5] + 1, oa[5] + 10))
+    return oa
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_DEFORM_SEEDS", "16"))))
+def test_random_order_args_forward_vs_oracle_and_backward_vs_float64_autograd(seed):
+    """Random basis mixes / row lengths / scene-object splits / time stamps (incl. both ends of the sequence): forward against the
+    NumPy oracle, the fused flow points against the oracle's positions at the flow time, every gradient against float64 autograd."""
+    from adgs.deform import get_deformed_pkg, get_param_num
+    rng = np.random.RandomState(7000 + seed)
+    Ns, No = int(rng.choice([0, 5, 300, 1111])), int(rng.choice([1, 64, 257, 700]))
+    oa = dict(xyz=_random_order(rng, False), rotation=_random_order(rng, True), shs=_random_order(rng, False), background=_random_order(rng, False))
+    use_mask = bool(rng.randint(2))
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    raw = dict(scene_xyz=r(Ns, 3) * 10, obj_xyz=r(No, 3) * 10, scene_shs_dc=r(Ns, 1, 3), obj_shs_dc=r(No, 1, 3),
+               scene_shs_rest=r(Ns, 15, 3) * 0.1, obj_shs_rest=r(No, 15, 3) * 0.1, scene_scaling=r(Ns, 3) * 0.3 - 2,
+               obj_scaling=r(No, 3) * 0.3 - 2, scene_rotation=r(Ns, 4), obj_rotation=r(No, 4), scene_opacity=r(Ns, 1), obj_opacity=r(No, 1),
+               xyz_deform_param=r(No, 3, get_param_num(oa["xyz"])) * 0.1, rotation_deform_param=r(No, 4, get_param_num(oa["rotation"])) * 0.3,
+               shs_deform_param_scene=r(Ns, 3, get_param_num(oa["shs"])) * 0.1, shs_deform_param_obj=r(No, 3, get_param_num(oa["shs"])) * 0.1,
+               background_deform_param=r(1, 3, get_param_num(oa["background"])) * 0.1, gs_time=torch.rand(No, 1, generator=g),
+               gs_time_sigma=r(No, 2) * 0.3 - 1.0)
+    attr_of = lambda k: k if k.endswith("deform_param") or k.startswith("shs_deform") or k.startswith("gs_") else "_" + k
+    npm = {k: v.numpy() for k, v in raw.items()}
+    npm["order_args"], npm["use_time_mask"] = oa, use_mask
+    for t, tf in ((float(rng.rand()), float(rng.rand())), (float(rng.choice([0.0, 1.0])), None)):
+        m = _Model()
+        for k, v in raw.items():
+            setattr(m, attr_of(k), v.cuda().requires_grad_(k != "gs_time"))
+        m.order_args, m.use_time_mask = oa, use_mask
+        pkg = get_deformed_pkg(m, t, flow_time=tf)
+        ref = do.get_deformed_pkg(npm, t)
+        for key in ("xyz", "rotation", "shs", "opacity", "scales"):
+            close("%s %s t=%g" % (oa, key, t), pkg[key].detach().cpu().numpy(), ref[key])
+        if tf is not None:
+            close("%s flow_xyz t=%g" % (oa, tf), pkg["flow_xyz"].detach().cpu().numpy(), do.get_deformed_pkg(npm, tf)["xyz"])
+        keys = [k for k in ("xyz", "rotation", "shs", "opacity", "scales", "flow_xyz") if k in pkg and torch.is_tensor(pkg[k])]
+        ws = {k: torch.randn(pkg[k].shape, generator=g) for k in keys}
+        sum((pkg[k] * ws[k].cuda()).sum() for k in keys).backward()
+        m64 = {k: v.double().requires_grad_(k != "gs_time") for k, v in raw.items()}
+        r64 = tr.get_deformed_pkg(m64, t, oa, use_mask)
+        if tf is not None:
+            r64["flow_xyz"] = tr.get_deformed_pkg(m64, tf, oa, use_mask)["xyz"]
+        sum((r64[k] * ws[k].double()).sum() for k in keys).backward()
+        for name, t64 in m64.items():
+            if name == "gs_time" or t64.numel() == 0:
+                continue
+            got, want = getattr(m, attr_of(name)).grad, t64.grad
+            if want is None or float(want.abs().max()) == 0.0:
+                assert got is None or float(got.abs().max()) == 0.0, (name, oa)
+            else:
+                assert got is not None, (name, oa)
+                close("%s grad %s t=%g" % (oa, name, t), got.cpu().numpy(), want.numpy(), tol=2e-4)
