@@ -1,5 +1,7 @@
 """GPU parity of the HIP K-nearest-neighbour index (adgs.knn.knn_points / set_obj_near_idx) vs the NumPy oracle: index
 lists bit-exact (same float32 distance arithmetic, same tie rule), distances bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -23,6 +25,25 @@ def test_knn_points_vs_oracle(N, A, D, K):
     dist, idx = ko.knn_points(anchors, pts, K)
     assert np.array_equal(res.idx[0].cpu().numpy(), idx)
     assert np.array_equal(res.dists[0].cpu().numpy(), dist)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_KNN_SEEDS", "12"))))
+def test_knn_points_fuzz(seed):
+    """Random sizes (fewer points than a block, K = N, heavy duplication on a coarse lattice -> many exact distance ties)."""
+    from adgs.knn import knn_points
+    rng = np.random.default_rng(6000 + seed)
+    N = int(rng.choice([1, 2, 33, 64, 257, 1000, 4097, 9000]))
+    D = int(rng.choice([3, 4]))
+    K = int(min(N, rng.choice([1, 2, 7, 8, 16, 32])))
+    A = int(rng.integers(1, N + 1))
+    pts = rng.normal(size=(N, D)).astype(np.float32)
+    if rng.integers(2):
+        pts = np.round(pts * 2) / 2                       # lattice: many points coincide, many distances tie exactly
+    anchors = pts[rng.permutation(N)[:A]] if rng.integers(2) else rng.normal(size=(A, D)).astype(np.float32)
+    res = knn_points(torch.tensor(anchors, device="cuda")[None], torch.tensor(pts, device="cuda")[None], K=K)
+    dist, idx = ko.knn_points(anchors, pts, K)
+    assert np.array_equal(res.idx[0].cpu().numpy(), idx), (N, A, D, K)
+    assert np.array_equal(res.dists[0].cpu().numpy(), dist), (N, A, D, K)
 
 
 def test_set_obj_near_idx_and_errors():

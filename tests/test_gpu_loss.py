@@ -139,3 +139,41 @@ def test_flow_loss_full_size_vs_oracle_and_bce_terms():
     np.testing.assert_allclose(float(l2), float(g("sky")), rtol=1e-5); np.testing.assert_allclose(p2.grad.cpu().numpy(), g("g_sky"), rtol=1e-4, atol=1e-8)
     with pytest.raises(RuntimeError):
         sky_loss(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_LOSS_SEEDS", "12"))))
+def test_random_image_shapes_vs_oracle(seed):
+    """L1 + SSIM, the depth loss and the flow loss on random image shapes (smaller than the 11x11 window, one row / one column,
+    sizes that are no multiple of any block shape) against the NumPy oracle: values and gradients."""
+    from adgs import loss
+    rng = np.random.default_rng(9000 + seed)
+    H = int(rng.choice([1, 2, 5, 11, 12, 16, 17, 31, 33, 64, 100, 131]))
+    W = int(rng.choice([1, 3, 10, 11, 16, 31, 32, 33, 63, 65, 128, 257]))
+    gt_np = rng.random((3, H, W)).astype(np.float32)
+    img_np = np.clip(gt_np + float(rng.choice([0.0, 0.02, 0.3])) * rng.standard_normal(gt_np.shape), 0, 1).astype(np.float32)
+    img = torch.tensor(img_np).cuda().requires_grad_(True)
+    l1, s = loss.l1_ssim(img, torch.tensor(gt_np).cuda())
+    a, b = float(rng.uniform(0.5, 2)), float(rng.uniform(-2, 2))
+    (a * l1 + b * s).backward()
+    o_l1, o_s, og_l1, og_s = loss_oracle.l1_ssim(img_np, gt_np)
+    assert abs(float(l1) - o_l1) <= 1e-6 and abs(float(s) - o_s) <= 1e-5, (H, W)
+    want = a * og_l1 + b * og_s
+    # identical images: the exact gradient is 0 and fp32 leaves rounding noise -> the floor is the scale of a mean's gradient
+    np.testing.assert_allclose(img.grad.cpu().numpy(), want, rtol=0, atol=1e-4 * max(np.abs(want).max(), 1.0 / gt_np.size), err_msg=str((H, W)))
+    # depth loss: scale/shift-invariant fit over a random mask (incl. the empty mask and the degenerate single-pixel fit)
+    gtd = (rng.random((H, W)) * 60 + 1).astype(np.float32)
+    pred = (0.02 * gtd + 0.3 + 0.1 * rng.standard_normal(gtd.shape)).astype(np.float32)
+    mask = (rng.random(gtd.shape) > float(rng.choice([0.0, 0.3, 0.9]))).astype(np.float32)
+    mask[0, 0] = 1.0                                   # an empty mask is 0/0 in the reference as well
+    use_mask = bool(rng.random() < 0.8)
+    p = torch.tensor(pred).cuda().requires_grad_(True)
+    val = loss.get_depth_loss(p, torch.tensor(gtd).cuda(), torch.tensor(mask).cuda() if use_mask else None)
+    val.backward()
+    if (mask.sum() if use_mask else H * W) < 8:         # (near-)rank-deficient fits: conditioning, not parity -- only "does not trap"
+        return
+    o_loss, o_grad = loss_oracle.depth_loss(pred, gtd, mask if use_mask else None)
+    assert np.isfinite(o_loss) and torch.isfinite(val) and torch.isfinite(p.grad).all(), (H, W)
+    assert abs(float(val) - o_loss) <= 2e-4 * max(abs(o_loss), 1e-3), (H, W, float(val), o_loss)
+    # |s p + t - g| has a kink: a residual within rounding of zero takes the other sign in fp32 (seen once in 300 seeds)
+    bad = np.abs(p.grad.cpu().numpy() - o_grad) > 2e-3 * max(np.abs(o_grad).max(), 1e-9)
+    assert bad.sum() <= max(2, 1e-4 * bad.size), (H, W, int(bad.sum()))
