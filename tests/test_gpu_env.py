@@ -49,3 +49,33 @@ def test_environment_map_class_full_resolution_and_adam():
     before = e.grid_map.detach().clone()
     e.optimizer.step(zero_grad=True)
     assert float((e.grid_map.detach() - before).abs().max()) > 0 and float(e.grid_map.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_ENV_SEEDS", "10"))))
+def test_random_maps_cameras_and_image_shapes_vs_oracle(seed):
+    """Random map resolutions (down to 2x2, non-square), image shapes, focal lengths and rotations (incl. rays that look
+    backwards / straight up): forward and the map gradient against the NumPy oracle."""
+    from adgs import env
+    rng = np.random.default_rng(8000 + seed)
+    Hm, Wm = int(rng.choice([2, 3, 7, 16, 33, 128])), int(rng.choice([2, 3, 5, 16, 64, 129]))      # (maps below 2x2 are rejected)
+    H, W = int(rng.choice([1, 3, 16, 37, 90])), int(rng.choice([1, 5, 16, 33, 121]))
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float32)
+    focal = float(rng.uniform(0.3, 3.0) * W)
+    gm_np = rng.normal(size=(3, Hm, Wm)).astype(np.float32)
+    gm = torch.tensor(gm_np)[None].cuda().requires_grad_(True)
+    bg = env.image_background(gm, H, W, focal, R.tolist())
+    wts = rng.normal(size=(3, H, W)).astype(np.float32)
+    (bg * torch.tensor(wts).cuda()).sum().backward()
+    ref = env_oracle.background(gm_np, H, W, focal, R)
+    gref = env_oracle.background_grad(gm_np, H, W, focal, R, wts)
+    # fp32 ray arithmetic moves a sample by ~1e-6 of the map; on a white-noise map that is ~1e-6 * resolution * contrast
+    tol = 3e-5 + 4e-6 * max(Hm, Wm)
+    got = bg.detach().cpu().numpy()
+    bad = np.abs(got - ref) > tol
+    assert bad.sum() <= max(3, 1e-3 * bad.size), (Hm, Wm, H, W, int(bad.sum()), float(np.abs(got - ref).max()))   # a sample on a texel edge may round across it
+    gbad = np.abs(gm.grad.cpu().numpy()[0] - gref) > 1e-4 * max(np.abs(gref).max(), 1.0) + tol * np.abs(wts).max() * 4
+    assert gbad.sum() <= max(6, 2e-3 * gbad.size), (Hm, Wm, H, W, int(gbad.sum()))

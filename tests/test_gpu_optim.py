@@ -136,3 +136,47 @@ def test_fused_adam_survives_the_references_optimizer_state_surgery():
         results.append(opt.param_groups[0]["params"][0].detach().cpu().double())
     assert results[0].shape == results[1].shape
     assert torch.allclose(results[0], results[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ADGS_TEST_SEED_BASE", "0")), int(__import__("os").environ.get("ADGS_TEST_SEED_BASE", "0")) + int(__import__("os").environ.get("ADGS_TEST_ADAM_SEEDS", "8"))))
+def test_fused_adam_fuzz(seed):
+    """Random tensor shapes (empty, one element, sizes around the kernel's vector width), learning rates incl. 0, betas,
+    gradients that are None on random steps: parameters and both moments against float64 torch.optim.Adam."""
+    from adgs.optim import FusedAdam
+    rng = np.random.default_rng(2000 + seed)
+    n_groups = int(rng.integers(1, 7))
+    shapes = [tuple(int(v) for v in rng.choice([0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 1000], size=int(rng.integers(1, 4)))) for _ in range(n_groups)]
+    lrs = [float(rng.choice([0.0, 1e-4, 1e-2, 0.3])) for _ in range(n_groups)]
+    betas = (float(rng.choice([0.9, 0.5, 0.0])), float(rng.choice([0.999, 0.9])))
+    steps = int(rng.integers(1, 6))
+    init = [rng.normal(size=s) for s in shapes]
+    grads = [[None if rng.random() < 0.2 else rng.normal(size=s) * 10.0 ** float(rng.integers(-3, 3)) for s in shapes] for _ in range(steps)]
+
+    def run(cls, dtype, device):
+        ps = [torch.tensor(a, dtype=dtype, device=device).requires_grad_(True) for a in init]
+        opt = cls([{"params": [p], "lr": lr, "name": "g%d" % i} for i, (p, lr) in enumerate(zip(ps, lrs))], lr=0.0, eps=1e-15, betas=betas)
+        for gs in grads:
+            for p, g in zip(ps, gs):
+                p.grad = None if g is None else torch.tensor(g, dtype=dtype, device=device)
+            opt.step()
+        return ps, opt
+    pf, of = run(FusedAdam, torch.float32, "cuda")
+    p64, o64 = run(torch.optim.Adam, torch.float64, "cpu")
+    p32, _ = run(torch.optim.Adam, torch.float32, "cpu")
+    for a, b, c, s in zip(pf, p64, p32, shapes):
+        if a.numel() == 0:
+            continue
+        x, y, z = a.detach().cpu().double().numpy(), b.detach().numpy(), c.detach().double().numpy()
+        scale = max(np.abs(y).max(), 1e-30)
+        err, err32 = np.abs(x - y).max() / scale, np.abs(z - y).max() / scale
+        assert err <= max(3e-6, 4 * err32), (s, err, err32)
+        assert (a in of.state) == (b in o64.state), s
+        if b in o64.state:
+            assert float(of.state[a]["step"]) == float(o64.state[b]["step"])
+            # the moments are updated as m += (1 - beta) (g - m) (torch's lerp): in fp32 the absolute error is a few ulp of the
+            # LARGEST gradient the moment has seen, not of its final value
+            idx = shapes.index(s) if shapes.count(s) == 1 else [j for j, q in enumerate(pf) if q is a][0]
+            hist = max([float(np.abs(gs[idx]).max()) for gs in grads if gs[idx] is not None] + [1e-30])
+            for k, bound in (("exp_avg", hist), ("exp_avg_sq", hist * hist)):
+                u, v = of.state[a][k].cpu().double().numpy(), o64.state[b][k].numpy()
+                np.testing.assert_allclose(u, v, rtol=2e-5, atol=1e-6 * bound, err_msg=str(s) + k)

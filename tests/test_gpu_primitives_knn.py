@@ -1,6 +1,7 @@
 """GPU tests of the hand-written scan / radix sort (bit-exact vs numpy) and the HIP 3-NN
 kernel (bit-exact vs the CPU oracle, which itself is checked against brute force)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -100,3 +101,22 @@ def test_knn_duplicates_and_tiny_inputs():
     np.testing.assert_array_equal(small, oracle.knn_dist2(_cloud(3, 1).numpy()))
     with pytest.raises(RuntimeError):
         distCUDA2(pts)                 # CPU tensor: loud failure
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_SIMPLE_KNN_SEEDS", "10"))))
+def test_dist2_fuzz_bit_exact(seed):
+    """distCUDA2 on random sizes around the 1024-point box size, lattice clouds (coincident points, equal Morton codes, exact
+    distance ties), flat clouds (one coordinate constant) and wildly different scales."""
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.choice([1, 2, 3, 4, 7, 1023, 1024, 1025, 2048, 3000, 5121, 20_000]))
+    p = rng.normal(size=(n, 3)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 1e3]))
+    kind = int(rng.integers(4))
+    if kind == 1:
+        p = (np.round(p / np.abs(p).max() * 6) / 6).astype(np.float32)
+    elif kind == 2:
+        p[:, int(rng.integers(3))] = 0.25
+    elif kind == 3:
+        p[: n // 2] = p[: n // 2] * 0.001 + p[0]
+    got = distCUDA2(torch.tensor(p).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.knn_dist2(p), err_msg=str((n, kind)))
