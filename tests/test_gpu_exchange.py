@@ -1,6 +1,8 @@
 """GPU parity of the factored SH-gradient exchange (include/adgs_exchange.h): the expansion kernel vs the NumPy oracle, the
 rgb_factor output of the raw-SH backward vs the CPU raster oracle, and the whole factored path (several cameras, world 1) vs
 conventional gradient accumulation over the same cameras.  Tolerance 1e-4 (north_star); observed ~1e-6."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,8 +23,25 @@ def close(name, a, b, tol=TOL):
                                                      (1000, 0, 16, 0, 3, "scene", 4), (257, 255, 4, 7, 1, "scene", 8), (300, 11, 1, 12, 0, "none", 2),
                                                      (5000, 3000, 16, 12, 3, "scene", 32)])
 def test_expand_kernel_vs_numpy_oracle(Ns, No, M, C, D, row0_mode, n):
+    _expand_case(Ns, No, M, C, D, row0_mode, n, Ns + No + n)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_EXPAND_SEEDS", "10"))))
+def test_expand_kernel_fuzz(seed):
+    """Random scene/object splits (one-sided, single rows), SH layouts (M = 1, 4, 9, 16 with every active degree that fits), deformation
+    row lengths (0, odd, even), camera counts 1..32 and both ways of passing the means."""
+    rng = np.random.default_rng(1000 + seed)
+    Ns, No = int(rng.choice([0, 1, 63, 256, 1001])), int(rng.choice([0, 1, 65, 255, 700]))
+    if Ns + No == 0:
+        No = 5
+    md = int(rng.integers(0, 4))
+    _expand_case(Ns, No, (md + 1) ** 2, int(rng.choice([0, 1, 4, 7, 12, 13])), int(rng.integers(0, md + 1)), str(rng.choice(["scene", "none"])),
+                 int(rng.choice([1, 2, 3, 8, 31, 32])), 5000 + seed)
+
+
+def _expand_case(Ns, No, M, C, D, row0_mode, n, seed):
     from adgs import dp
-    rng = np.random.default_rng(Ns + No + n)
+    rng = np.random.default_rng(seed)
     P = Ns + No
     row0 = Ns if row0_mode == "scene" else 0
     head = (rng.normal(size=(Ns, 3)) + [0, 0, 6.0]).astype(np.float32)
