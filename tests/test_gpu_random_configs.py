@@ -109,3 +109,50 @@ def test_v2_matches_classic_and_oracle_on_large_random_configs(seed):
         assert_close("grad " + k + " v2~classic", a, cl["grads"][k].cpu().numpy(), max_frac=frac)
         if k in names:
             assert_close("grad " + k + " v2~oracle", a, np.asarray(ref["grads"][names[k]]).reshape(a.shape), max_frac=frac)
+
+
+def _cov3d(sc):
+    q = sc["rotations"].double()
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    Mm = R @ torch.diag_embed(sc["scales"].double())
+    Sg = Mm @ Mm.transpose(1, 2)
+    return torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).float().contiguous()
+
+
+@pytest.mark.parametrize("seed", range(_BASE, _BASE + int(os.environ.get("ADGS_TEST_VARIANT_SEEDS", "12"))))
+def test_input_variants_match_oracle_on_random_configs(seed):
+    """The optional inputs of GaussianRasterizer.forward in random combination -- precomputed colours or SH or neither, precomputed 3-D
+    covariances or scales + rotations, 1..32 semantic channels, background colour, scale modifier -- default pipeline vs the oracle."""
+    from test_gpu_raster import compare
+    rng = np.random.RandomState(3000 + seed)
+    P = int(rng.choice([3, 200, 1500, 4000]))
+    W, H = int(rng.randint(20, 260)), int(rng.randint(12, 170))
+    sc = synthetic.make_scene(P, W, H, float(rng.uniform(50, 220)), sh_degree=3, seed=500 + seed, n_objects=int(rng.randint(0, 3)))
+    g = torch.Generator().manual_seed(seed)
+    kw = dict(flow=bool(rng.randint(2)), inv_depth=bool(rng.randint(2)), degree=int(rng.randint(0, 4)), scale_modifier=float(rng.choice([1.0, 0.6, 1.3])))
+    colour = int(rng.randint(3))
+    if colour == 0:
+        kw["colors"] = torch.rand(P, 3, generator=g)
+    elif colour == 1:
+        kw["use_sh"] = False
+    if rng.randint(2):
+        kw["cov3D"] = _cov3d(sc)
+    D_S = int(rng.choice([0, 1, 2, 5, 32]))
+    kw["sem"] = D_S > 0
+    if D_S > 1:
+        kw["semantic"] = torch.rand(P, D_S, generator=g)
+    if rng.randint(2):
+        kw["bg"] = torch.rand(3, generator=g)
+    env = dict(ADGS_V2_PPL=str(int(rng.choice([2, 4]))))
+    saved = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        compare(sc, grads=synthetic.make_upstream_grads(sc, seed, D_S=max(D_S, 1)), **kw)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
