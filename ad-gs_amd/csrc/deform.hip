@@ -870,11 +870,11 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 }
 __global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out) {
 	extern __shared__ float s_rows[];
-	const int tid = threadIdx.x, base = blockIdx.x * 256, count = min(256, N - base);
+	const int tid = threadIdx.x, B = blockDim.x, base = blockIdx.x * B, count = min(B, N - base);
 	const int np = s.f.n_params, L = 3 * np, stride = L | 1;
 	const bool lin = (s.scene_sp || s.obj_sp) && has_lin(s.f);
 	if (lin) {
-		stage_rows<true>(s_rows, stride, L, base, count, s.Ns, s.scene_sp, s.obj_sp, tid, 256);
+		stage_rows<true>(s_rows, stride, L, base, count, s.Ns, s.scene_sp, s.obj_sp, tid, B);
 		__syncthreads();
 	}
 	if (tid >= count) return;
@@ -891,6 +891,17 @@ __global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __re
 	}
 }
 } // namespace
+constexpr size_t MAX_STAGING_LDS = 156 * 1024;
+// block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB; one-wave blocks may take up to
+// MAX_STAGING_LDS of the CU's 160 KiB (very long parameter rows: B-spline + polynomial + Fourier + quaternion parts together)
+static int pick_block(int row_floats, size_t* lds) {
+	for (int B = 256; B >= 64; B >>= 1) {
+		const size_t bytes = (size_t)B * row_floats * sizeof(float);
+		if (bytes <= 48 * 1024 || B == 64) { *lds = bytes; return B; }
+	}
+	return 64;
+}
+
 int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 	if (N <= 0) return 0;
 	const int np = s.f.n_params;
@@ -911,9 +922,11 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 		ADGS_HIP_CHECK(hipGetLastError());
 		return 0;
 	}
-	const size_t lds = (size_t)256 * ((3 * np) | 1) * sizeof(float);
-	if (lds > 64 * 1024) { set_error("launch_sh0: more than 5461 SH deformation parameters per channel are not supported"); return -1; }
-	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, stream, N, s, out);
+	size_t lds = 0;
+	const int B = pick_block((3 * np) | 1, &lds);
+	if (lds > MAX_STAGING_LDS) { set_error("launch_sh0: SH deformation rows too large for the LDS staging buffer (more than 207 parameters per channel)"); return -1; }
+	if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -981,17 +994,6 @@ extern "C" int adgs_func_eval_backward(int N, int D, const float* param, const a
 	}
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
-}
-
-// block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB; one-wave blocks may take up to
-// MAX_STAGING_LDS of the CU's 160 KiB (very long parameter rows: B-spline + polynomial + Fourier + quaternion parts together)
-constexpr size_t MAX_STAGING_LDS = 156 * 1024;
-static int pick_block(int row_floats, size_t* lds) {
-	for (int B = 256; B >= 64; B >>= 1) {
-		const size_t bytes = (size_t)B * row_floats * sizeof(float);
-		if (bytes <= 48 * 1024 || B == 64) { *lds = bytes; return B; }
-	}
-	return 64;
 }
 
 extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_func_eval* f_xyz, const adgs_func_eval* f_rotation,

@@ -156,20 +156,41 @@ def test_render_entry_runs_on_fused_pkg():
 def test_raw_sh_path_matches_materialised_sh_path(seed):
     """GaussianRasterizer.forward_rawsh (SH read from / gradients written to the raw scene||object tensors)
     == get_deformed_pkg + GaussianRasterizer.forward, forward and backward."""
+    from adgs import synthetic
+    sc = synthetic.make_scene(6000, 208, 130, 150.0, sh_degree=3, seed=seed, n_objects=2 if seed < 2 else 0)      # seed 2: a model without objects
+    _raw_vs_materialised(sc, seed, max(3 - seed, 2), None, 0.37, 0.42)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_RAWSH_SEEDS", "8"))))
+def test_raw_sh_path_fuzz(seed):
+    """The same over random scene sizes, image shapes, active SH degrees, object counts, basis mixes of every deformation function
+    (incl. no SH deformation at all) and time stamps."""
+    from adgs import synthetic
+    rng = np.random.RandomState(11000 + seed)
+    sc = synthetic.make_scene(int(rng.choice([40, 900, 5000])), int(rng.randint(40, 300)), int(rng.randint(30, 200)), float(rng.uniform(80, 250)),
+                              sh_degree=3, seed=700 + seed, n_objects=int(rng.randint(0, 4)))
+    oa = dict(xyz=_random_order(rng, False), rotation=_random_order(rng, True), shs=_random_order(rng, False), background=_random_order(rng, False))
+    if rng.randint(4) == 0:
+        oa["shs"] = [0] * 6
+    if rng.randint(2):
+        oa["background"] = [0] * 6
+    _raw_vs_materialised(sc, seed, int(rng.randint(0, 4)), oa, float(rng.rand()), float(rng.rand()))
+
+
+def _raw_vs_materialised(sc, seed, degree, order_args, t, t_flow):
     from adgs import synthetic, deform
     from adgs.model import SyntheticGaussianModel
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    sc = synthetic.make_scene(6000, 208, 130, 150.0, sh_degree=3, seed=seed, n_objects=2 if seed < 2 else 0)      # seed 2: a model without objects
     g = synthetic.make_upstream_grads(sc, seed)
     d = lambda x: x.cuda()
     s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], d(sc["bg"]), 1.0, d(sc["viewmatrix"]), d(sc["projmatrix"]),
-                                      max(3 - seed, 2), d(sc["campos"]), False, True, False)
+                                      degree, d(sc["campos"]), False, True, False)
     rast = GaussianRasterizer(s)
     res = []
     for raw in (False, True):
-        model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3)
-        pkg = deform.get_deformed_pkg(model, 0.37, raw_sh=raw)
-        flow = model.get_deformed_xyz(0.42)
+        model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3, order_args=order_args)
+        pkg = deform.get_deformed_pkg(model, t, raw_sh=raw)
+        flow = model.get_deformed_xyz(t_flow)
         m2 = torch.zeros_like(pkg["xyz"], requires_grad=True)
         sem = model.get_obj_mask.float()[:, None].contiguous()
         if raw:
