@@ -35,8 +35,24 @@ def test_expand_kernel_fuzz(seed):
     if Ns + No == 0:
         No = 5
     md = int(rng.integers(0, 4))
-    _expand_case(Ns, No, (md + 1) ** 2, int(rng.choice([0, 1, 4, 7, 12, 13])), int(rng.integers(0, md + 1)), str(rng.choice(["scene", "none"])),
+    _expand_case(Ns, No, (md + 1) ** 2, int(rng.choice([0, 1, 4, 7, 12, 13, 32, 47])), int(rng.integers(0, md + 1)), str(rng.choice(["scene", "none"])),
                  int(rng.choice([1, 2, 3, 8, 31, 32])), 5000 + seed)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_EXPAND_SEEDS", "10"))))
+def test_lin_grad_expand_fuzz(seed):
+    """adgs_lin_grad_expand: out[m, d, j] = scale * sum_e W[e][j] * g[e][m, d] for random counts, row lengths and factor counts (1..32)."""
+    from adgs import dp
+    rng = np.random.default_rng(12000 + seed)
+    count, C, n = int(rng.choice([1, 2, 63, 64, 65, 1000, 4099])), int(rng.choice([1, 2, 5, 12, 18, 33, 64])), int(rng.choice([1, 2, 3, 16, 31, 32]))
+    scale = float(rng.choice([1.0, 0.5, -2.0]))
+    g = [rng.normal(size=(count, 3)).astype(np.float32) for _ in range(n)]
+    W = rng.normal(size=(n, C)).astype(np.float32)
+    W[rng.random((n, C)) < 0.5] = 0.0                         # B-spline rows are mostly zero outside the active window
+    out = torch.full((count, 3, C), float("nan"), device="cuda")
+    dp.hip_lin_grad_expand([torch.tensor(a, device="cuda") for a in g], torch.tensor(W, device="cuda"), C, count, scale, out)
+    want = scale * sum(a.astype(np.float64)[:, :, None] * W[e].astype(np.float64)[None, None, :] for e, a in enumerate(g))
+    close("lin_grad_expand %s" % ((count, C, n),), out.cpu().numpy(), want)
 
 
 def _expand_case(Ns, No, M, C, D, row0_mode, n, seed):
