@@ -2,6 +2,7 @@
 rgb_factor output of the raw-SH backward vs the CPU raster oracle, and the whole factored path (several cameras, world 1) vs
 conventional gradient accumulation over the same cameras.  Tolerance 1e-4 (north_star); observed ~1e-6."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -13,10 +14,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def close(name, a, b, tol=TOL):
+def close(name, a, b, tol=TOL, atol_frac=1e-2):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     scale = max(np.abs(b).max(), 1e-30)
-    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * 1e-2 * scale, err_msg=name)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * atol_frac * scale, err_msg=name)
 
 
 @pytest.mark.parametrize("Ns,No,M,C,D,row0_mode,n", [(700, 301, 16, 12, 3, "scene", 3), (700, 301, 16, 12, 2, "none", 2), (0, 513, 16, 12, 3, "scene", 1),
@@ -109,14 +110,35 @@ def _render_cam(model, cam, t, ups, sink):
 
 @pytest.mark.parametrize("background,sh_degree,factor_xyz", [(False, 3, False), (True, 3, True), (False, 1, True), (False, 0, False), (False, 3, True)])
 def test_factored_multi_camera_gradients_equal_conventional_accumulation(background, sh_degree, factor_xyz):
-    from adgs import dp, synthetic
-    from adgs.model import SyntheticGaussianModel, DEFAULT_ORDER_ARGS
-    sc = synthetic.make_scene(6000, 208, 128, 150.0, sh_degree=sh_degree, seed=5, n_objects=2)
+    from adgs.model import DEFAULT_ORDER_ARGS
     oa = dict(DEFAULT_ORDER_ARGS)
     if background:
         oa["background"] = [0, 0, 2, 0, 0, 0]
-    times = [0.1, 0.45, 0.8]
-    cams = [synthetic.make_camera(208, 128, 150.0, cam_seed=c) for c in range(3)]
+    _factored_vs_conventional(oa, sh_degree, factor_xyz, 6000, [0.1, 0.45, 0.8], 5)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_FACTORED_SEEDS", "6"))))
+def test_factored_exchange_fuzz(seed):
+    """Random basis mixes of every deformation function (row lengths of the SH / xyz deformation tensors), SH degrees, camera
+    counts and time stamps: the factored path (with and without the factored xyz rows) against conventional accumulation."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_deform import _random_order
+    rng = np.random.RandomState(13000 + seed)
+    oa = dict(xyz=_random_order(rng, False), rotation=_random_order(rng, True), shs=_random_order(rng, False), background=_random_order(rng, False))
+    if rng.randint(2):
+        oa["background"] = [0] * 6
+    if sum(oa["xyz"]) == 0:
+        oa["xyz"] = [0, 0, 2, 0, 0, 0]
+    n = int(rng.choice([1, 2, 4]))
+    _factored_vs_conventional(oa, int(rng.randint(0, 4)), bool(rng.randint(2)), int(rng.choice([3000, 6000])), [float(t) for t in rng.rand(n) * 0.9], 20 + seed,
+                              min_visible=300 * n, fuzz=True)
+
+
+def _factored_vs_conventional(oa, sh_degree, factor_xyz, P, times, scene_seed, min_visible=3000, fuzz=False):
+    from adgs import dp, synthetic
+    from adgs.model import SyntheticGaussianModel
+    sc = synthetic.make_scene(P, 208, 128, 150.0, sh_degree=sh_degree, seed=scene_seed, n_objects=2)
+    cams = [synthetic.make_camera(208, 128, 150.0, cam_seed=c) for c in range(len(times))]
     up = synthetic.make_upstream_grads(sc, 2)
     ups = [up[k].cuda() for k in ("color", "depth", "img_opacity", "flow", "semantic")]
 
@@ -136,7 +158,7 @@ def test_factored_multi_camera_gradients_equal_conventional_accumulation(backgro
                 assert model.xyz_deform_param.grad is None, "the deformation backward must not materialise the xyz rows"
             ex.reduce(times, [c["campos"].tolist() for c in cams], flow_times=[t + 0.05 for t in times])
         torch.cuda.synchronize()
-        assert vis > 3000
+        assert vis > min_visible
         return {n: getattr(model, n).grad.detach().cpu().numpy() for n in
                 ("_scene_xyz", "_obj_xyz", "_scene_shs_dc", "_obj_shs_dc", "_scene_shs_rest", "_obj_shs_rest", "shs_deform_param_scene",
                  "shs_deform_param_obj", "_scene_opacity", "_obj_scaling", "xyz_deform_param", "rotation_deform_param", "background_deform_param")
@@ -145,8 +167,10 @@ def test_factored_multi_camera_gradients_equal_conventional_accumulation(backgro
     a, b = run(False), run(True)
     assert set(a) == set(b)
     for k in a:
-        assert np.abs(a[k]).max() > 0, k
-        close(k, b[k], a[k])
+        # fuzz: the objects may be masked out at a random time stamp (all-zero gradients on both sides), and the two runs differ by the
+        # order of the rasterizer's fp32 atomics, which shows on near-cancelling elements -> absolute part at 0.3 of the 1e-4 budget
+        assert fuzz or np.abs(a[k]).max() > 0, k
+        close(k, b[k], a[k], atol_frac=0.3 if fuzz else 1e-2)
 
 
 def test_rgb_factor_equals_oracle_masked_colour_gradient():
