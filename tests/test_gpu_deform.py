@@ -332,3 +332,65 @@ def test_random_order_args_forward_vs_oracle_and_backward_vs_float64_autograd(se
             else:
                 assert got is not None, (name, oa)
                 close("%s grad %s t=%g" % (oa, name, t), got.cpu().numpy(), want.numpy(), tol=2e-4)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_RENDER_SEEDS", "8"))))
+def test_render_entry_fuzz(seed):
+    """gaussian_renderer.render() under random option combinations (flow target, object mask, colour override, environment map,
+    scale modifier, inverse depth, time mask, models without objects, random basis mixes): the raw-SH model and the model that
+    materialises the SH tensor must give the same package and the same gradients on every parameter and on the map."""
+    import types
+    from adgs import synthetic
+    from adgs.env import EnvironmentMap
+    from adgs.model import SyntheticGaussianModel
+    from gaussian_renderer import render
+    rng = np.random.RandomState(14000 + seed)
+    sc = synthetic.make_scene(int(rng.choice([60, 1500, 5000])), int(rng.randint(40, 280)), int(rng.randint(30, 180)), float(rng.uniform(80, 250)),
+                              sh_degree=int(rng.randint(0, 4)), seed=900 + seed, n_objects=int(rng.randint(0, 4)))
+    oa = dict(xyz=_random_order(rng, False), rotation=_random_order(rng, True), shs=_random_order(rng, False), background=_random_order(rng, False))
+    if rng.randint(2):
+        oa["background"] = [0] * 6
+    t = float(rng.rand())
+    cam = synthetic.camera_object(sc, time=t)
+    flow_pkg = ((float(rng.rand()),) + (None,) * 5) if rng.randint(2) else None
+    objmask, use_env, use_mask = bool(rng.randint(2)), bool(rng.randint(2)), bool(rng.randint(2))
+    override = torch.rand(sc["P"], 3, generator=torch.Generator().manual_seed(seed)).cuda() if rng.randint(4) == 0 else None
+    pipe = types.SimpleNamespace(inv_depth=bool(rng.randint(2)), debug=False)
+    smod = float(rng.choice([1.0, 0.8]))
+    gen = torch.Generator().manual_seed(100 + seed)
+    H, W = sc["H"], sc["W"]
+    ws = dict(render=torch.randn(3, H, W, generator=gen).cuda(), depth=torch.randn(H, W, generator=gen).cuda(), img_opacity=torch.randn(H, W, generator=gen).cuda(),
+              img_flow=torch.randn(3, H, W, generator=gen).cuda(), img_semantic=torch.randn(1, H, W, generator=gen).cuda())
+    res = []
+    for raw in (False, True):
+        model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=3, order_args=oa, use_time_mask=use_mask)
+        model.raw_sh = raw
+        env = None
+        if use_env:
+            env = EnvironmentMap(64, 3)
+            with torch.no_grad():
+                env.grid_map.copy_(torch.randn(env.grid_map.shape, generator=torch.Generator().manual_seed(7)).cuda())
+        pkg = render(cam, model, env, pipe, scaling_modifier=smod, override_color=override, flow_pkg=flow_pkg, render_objmask=objmask)
+        assert (pkg["img_flow"] is not None) == (flow_pkg is not None) and (pkg["img_semantic"] is not None) == objmask
+        loss = sum((pkg[k] * w).sum() for k, w in ws.items() if pkg.get(k) is not None)
+        loss.backward()
+        res.append((pkg, model, env))
+    (p0, m0, e0), (p1, m1, e1) = res
+    assert torch.equal(p0["radii"], p1["radii"])
+    for k in ("render", "depth", "img_opacity", "img_flow", "img_semantic", "foreground", "background"):
+        if p0.get(k) is not None:
+            close(k, p1[k].detach().cpu().numpy(), p0[k].detach().cpu().numpy(), tol=2e-5)
+    close("means2D", p1["viewspace_points"].grad.cpu().numpy(), p0["viewspace_points"].grad.cpu().numpy(), tol=1e-4)
+    names = __import__("adgs.model", fromlist=["_RAW"])._RAW
+    for name in names:
+        a, b = getattr(m0, name, None), getattr(m1, name, None)
+        if a is None or a.numel() == 0:
+            continue
+        ga, gb = a.grad, b.grad
+        za = ga is None or float(ga.abs().max()) == 0.0
+        zb = gb is None or float(gb.abs().max()) == 0.0
+        assert za == zb, (name, za, zb)
+        if not za:
+            close(name, gb.cpu().numpy(), ga.cpu().numpy(), tol=1e-4)
+    if use_env:
+        close("grid_map", e1.grid_map.grad.cpu().numpy(), e0.grid_map.grad.cpu().numpy(), tol=1e-4)
