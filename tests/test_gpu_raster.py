@@ -73,8 +73,8 @@ def run_hip(sc, colors=None, cov3D=None, use_sh=True, flow=True, sem=True, inv_d
 
 
 def run_oracle(sc, colors=None, cov3D=None, use_sh=True, flow=True, sem=True, inv_depth=True, scale_modifier=1.0, degree=None,
-               semantic=None, bg=None, grads=None):
-    o = oracle.RasterOracle("f32")
+               semantic=None, bg=None, grads=None, precision="f32"):
+    o = oracle.RasterOracle(precision)
     semt = (sc["semantic"] if semantic is None else semantic) if sem else None
     out = o.forward(sc["bg"] if bg is None else bg, sc["means3D"], colors, sc["opacities"],
                     None if cov3D is not None else sc["scales"], None if cov3D is not None else sc["rotations"], scale_modifier, cov3D,
