@@ -94,3 +94,43 @@ def test_data_parallel_training_example_on_one_gpu(monkeypatch):
     finally:
         del synthetic.CONFIGS["T1"]
     assert same and all(l == l for l in losses) and len(losses) == 9
+
+
+def test_side_stream_gives_the_same_results_as_the_default_stream():
+    """Every launch, copy and allocation of the path follows torch's CURRENT stream (the library takes the stream as an argument, the
+    mailbox read-back waits on it): the rasterizer and a few whole training iterations under `torch.cuda.stream(side)` must reproduce
+    the default-stream run -- a launch that slipped onto the null stream would race with its neighbours here."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_raster import assert_close, run_hip
+    from adgs import synthetic
+    sc = synthetic.make_scene(5000, 310, 190, 170.0, sh_degree=3, seed=21, n_objects=2)
+    g = synthetic.make_upstream_grads(sc, 21)
+    ref = run_hip(sc, grads=g)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            got = run_hip(sc, grads=g)
+        assert torch.equal(got["radii"], ref["radii"])
+        for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
+            assert torch.equal(got[k], ref[k]), k                    # the forward is deterministic
+        for k, v in ref["grads"].items():
+            if v is not None:
+                assert_close("grad " + k, got["grads"][k].cpu().numpy(), v.cpu().numpy(), max_frac=2e-4)
+
+    spec = importlib.util.spec_from_file_location("train_iteration", os.path.join(ROOT, "examples", "train_iteration.py"))
+    ti = importlib.util.module_from_spec(spec); spec.loader.exec_module(ti)
+    synthetic.CONFIGS["T2"] = dict(P=6000, W=208, H=130, focal=150.0, sh_degree=3, n_objects=2, seed=9)
+    try:
+        runs = []
+        for stream in (None, side):
+            ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream())
+            with ctx:
+                cfg, model, cam, env_map, stats, targets = ti.build("T2", 256, torch.device("cuda", 0))
+                losses = [float(ti.iteration(model, cam, env_map, stats, targets)[1]) for _ in range(6)]
+                torch.cuda.current_stream().synchronize()
+            runs.append(losses)
+    finally:
+        del synthetic.CONFIGS["T2"]
+    assert np.allclose(runs[0], runs[1], rtol=2e-4, atol=1e-7), runs
