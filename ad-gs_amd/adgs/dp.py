@@ -457,8 +457,24 @@ class FactoredSHExchange:
             # one flat bucket for the whole dense remainder (108 MB at C3): one collective instead of one per large tensor --
             # xGMI is point-to-point and every extra collective costs a launch + synchronisation round
             named = self._dense_named() if self.arena is not None else []
-            in_arena = [p for n, p in named if p is not None and p.numel() > 0 and self.arena.holds(n, p.grad)]
-            if self.arena is not None and len(in_arena) == len(self.arena.names):
+            in_arena = []
+            if self.arena is not None:
+                # Which collectives a rank issues must not depend on what ITS cameras produced (a rank that got no camera in this
+                # iteration, a parameter without gradient, a gradient autograd allocated elsewhere): every rank reduces the arena,
+                # after moving into its slice whatever is not there yet (zeros for a missing gradient).
+                for n, p in named:
+                    if p is None or p.numel() == 0:
+                        continue
+                    if not self.arena.holds(n, p.grad):
+                        off, numel = self.arena.offsets[n]
+                        view = self.arena.flat[off:off + numel].view(self.arena.shapes[n])
+                        if p.grad is None:
+                            view.zero_()
+                        else:
+                            view.copy_(p.grad)
+                        p.grad = view
+                    in_arena.append(p)
+            if self.arena is not None:
                 # every dense gradient of the deformation backward sits in the arena: ONE in-place all-reduce, nothing to copy
                 rest = [p for p in dense_params if not any(p is q for q in in_arena)]
                 w = dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

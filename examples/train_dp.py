@@ -76,10 +76,17 @@ def main():
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("needs MI355X GPUs: there is no CPU fallback")
+    # ADGS_DP_BACKEND=gloo: control-flow / bit-identity check of the multi-rank loop on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives go through the host) -- never a measurement
+    backend = os.environ.get("ADGS_DP_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)       # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     cfg = synthetic.CONFIGS[args.config]
     sc = synthetic.make_config_scene(args.config)
     model = SyntheticGaussianModel.from_scene(sc, dev, seed=0)            # same seed on every rank: identical replicas
@@ -110,6 +117,7 @@ def main():
     if rank == 0:
         print("%s on %d GPU(s), %d cameras/iteration: %.2f ms/iteration = %.1f cameras/s; %d Gaussians at the end; loss %.5f -> %.5f; "
               "replicas identical: %s" % (args.config, world, len(cameras), dt * 1e3, len(cameras) / dt, model.get_pts_num, losses[0], losses[-1], same))
+        print("LOSSES " + " ".join("%.9g" % l for l in losses))
     if world > 1:
         dist.destroy_process_group()
     return losses, same

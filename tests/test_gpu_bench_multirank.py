@@ -32,3 +32,26 @@ def test_two_ranks_finish_and_print_one_json_line(config, exchange):
     assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3          # whole-job frames / max-over-ranks time
     want = "factored" if (exchange == "factored" and config == "T3") else "dense"               # static configs have no raw-SH path
     assert d["config"]["gradient_exchange"].startswith(want), d["config"]["gradient_exchange"]
+
+
+@pytest.mark.parametrize("world,cams", [(2, 2), (3, 4), (3, 2)])
+def test_multi_rank_training_loop_keeps_replicas_identical_and_matches_one_process(world, cams):
+    """examples/train_dp.py (render -> losses -> backward -> factored exchange -> fused Adam -> densify/prune with a seeded sampler) as TWO
+    or THREE ranks sharing the GPU (collectives on gloo) against ONE process accumulating the same cameras: every rank ends with
+    bit-identical parameters, and the loss sequence of the multi-rank run follows the one-process run through the densification step.
+    (3, 4): an uneven deal (2 + 1 + 1 cameras); (3, 2): one rank has NO camera in the iteration and still takes part in every collective."""
+    env = dict(os.environ, ADGS_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--config", "T3", "--iters", "7", "--cams", str(cams), "--densify-every", "5"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+                          str(_free_port()), os.path.join(ROOT, "examples", "train_dp.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert two.returncode == 0, two.stderr[-2000:]
+    assert "replicas identical: True" in two.stdout, two.stdout[-2000:]
+    env1 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_dp.py")] + args, env=env1, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert one.returncode == 0, one.stderr[-2000:]
+    get = lambda out: [float(x) for x in [l for l in out.splitlines() if l.startswith("LOSSES ")][0].split()[1:]]
+    a, b = get(two.stdout), get(one.stdout)
+    assert len(a) == len(b) == 10
+    assert all(abs(x - y) <= 2e-4 * abs(y) + 1e-7 for x, y in zip(a, b)), (a, b)
+    size = lambda out: [l for l in out.splitlines() if "Gaussians at the end" in l][0].split(";")[1]
+    assert size(two.stdout) == size(one.stdout)                       # the same rows were cloned / split / pruned
