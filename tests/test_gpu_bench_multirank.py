@@ -34,7 +34,7 @@ def test_two_ranks_finish_and_print_one_json_line(config, exchange):
     assert d["config"]["gradient_exchange"].startswith(want), d["config"]["gradient_exchange"]
 
 
-@pytest.mark.parametrize("world,cams", [(2, 2), (3, 4), (3, 2)])
+@pytest.mark.parametrize("world,cams", [(2, 2), (3, 4), (3, 2), (3, 7)])
 def test_multi_rank_training_loop_keeps_replicas_identical_and_matches_one_process(world, cams):
     """examples/train_dp.py (render -> losses -> backward -> factored exchange -> fused Adam -> densify/prune with a seeded sampler) as TWO
     or THREE ranks sharing the GPU (collectives on gloo) against ONE process accumulating the same cameras: every rank ends with
