@@ -448,6 +448,11 @@ class FactoredSHExchange:
                 self._start_gather(k_max)
                 work = self._work
         recv = self.recv if coll else send[:k_max].unsqueeze(0)
+        if coll and work is not None and dist.get_backend(self.group) == "gloo":
+            # gloo (the host-side dry runs; RCCL executes a communicator's collectives in issue order) hangs with four or more ranks when
+            # an all-gather and all-reduces of device tensors are in flight together (reproduced without any of this code): finish the
+            # gather before the reductions start
+            work.wait()
         # the dense remainder: every parameter except the six SH tensors
         sh = [getattr(m, n, None) for n in _SH_PARAMS]
         if coll:

@@ -314,6 +314,9 @@ def main():
     from adgs import _lib, synthetic, dp
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
+    if os.environ.get("ADGS_BENCH_WATCHDOG"):              # debugging aid: dump every thread's stack and exit if the run takes longer than N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["ADGS_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -18,18 +18,18 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("config,exchange", [("T3", "factored"), ("T3", "dense"), ("C1", "factored")])
-def test_two_ranks_finish_and_print_one_json_line(config, exchange):
+@pytest.mark.parametrize("config,exchange,world", [("T3", "factored", 2), ("T3", "dense", 2), ("C1", "factored", 2), ("T3", "factored", 4)])
+def test_ranks_finish_and_print_one_json_line(config, exchange, world):
     env = dict(os.environ, ADGS_BENCH_BACKEND="gloo", ADGS_DP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--config", config]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--config", config]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3          # whole-job frames / max-over-ranks time
+    assert d["n_gpus"] == world and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - world * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3          # whole-job frames / max-over-ranks time
     want = "factored" if (exchange == "factored" and config == "T3") else "dense"               # static configs have no raw-SH path
     assert d["config"]["gradient_exchange"].startswith(want), d["config"]["gradient_exchange"]
 
