@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements of the other configs")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the hosts only support dmabuf IPC: RCCL across processes needs this (set before HIP initialises)
     import torch
     import torch.distributed as dist
     from adgs import _lib, synthetic, dp

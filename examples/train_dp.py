@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--cams", type=int, default=0, help="cameras per iteration (default: one per rank)")
     ap.add_argument("--densify-every", type=int, default=20)
     args = ap.parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL across processes (set before HIP initialises)
     import torch
     import torch.distributed as dist
     from adgs import dp, synthetic
