@@ -8,7 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libadgs_hip.so")
+# ADGS_LIB: another build of the same library (e.g. lib/libadgs_hip_precise.so, `make -C ad-gs_amd/csrc precise`: expf instead of
+# v_exp_f32 in the blend kernels -- used by tests/test_gpu_gate_flips.py and tools/parity_stats.py)
+LIB_PATH = os.environ.get("ADGS_LIB") or os.path.join(PKG_ROOT, "lib", "libadgs_hip.so")
 
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 

@@ -211,7 +211,12 @@ class GradArena:
         self.handed.clear()
 
     def take(self, name, like):
-        if name not in self.offsets or name in self.handed or tuple(like.shape) != self.shapes[name] or like.device != self.flat.device:
+        # A parameter that still has a gradient installed (accumulation over several backward passes, or gradients zero-filled in
+        # place: optimizer.zero_grad(set_to_none=False) / FusedAdam.step(zero_grad="zeros")) must not get its slice: that `.grad`
+        # may BE the slice, the kernels overwrite their destination, and autograd's AccumulateGrad would then add the slice to
+        # itself (2 g).  The backward writes a fresh tensor instead and autograd accumulates it into the installed gradient.
+        if name not in self.offsets or name in self.handed or tuple(like.shape) != self.shapes[name] or like.device != self.flat.device \
+                or like.grad is not None:
             return None
         self.handed.add(name)
         off, numel = self.offsets[name]

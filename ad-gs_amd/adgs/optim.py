@@ -34,8 +34,15 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
-        """One Adam step over every parameter that has a gradient.  zero_grad=True also zeroes the gradients in the same
-        pass (the reference calls optimizer.zero_grad(set_to_none=True) right after, train.py:165)."""
+        """One Adam step over every parameter that has a gradient.
+        zero_grad=True: the reference's `optimizer.zero_grad(set_to_none=True)` right after the step (train.py:165) -- the
+        gradients are dropped (`p.grad = None`), so a parameter that receives no gradient in a later iteration is skipped by the
+        next step exactly as torch.optim.Adam skips it (no moment-driven update, `step` not incremented).
+        zero_grad="zeros": `zero_grad(set_to_none=False)` -- the gradients stay installed and are zero-filled by the same kernel
+        pass (for callers that accumulate into persistent gradient buffers)."""
+        if zero_grad not in (False, True, "zeros"):
+            raise ValueError("zero_grad must be False, True (set to None) or 'zeros' (zero-fill in place)")
+        fill = zero_grad == "zeros"
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -75,10 +82,12 @@ class FusedAdam(torch.optim.Optimizer):
                 for i in range(0, len(items), MAX_GROUPS):
                     chunk = items[i:i + MAX_GROUPS]
                     arr = (AdamGroup * len(chunk))(*[c[0] for c in chunk])
-                    _lib.check(lib.adgs_adam_step(arr, len(chunk), b1, b2, eps, int(bool(zero_grad)), stream), "adgs_adam_step")
+                    _lib.check(lib.adgs_adam_step(arr, len(chunk), b1, b2, eps, int(fill), stream), "adgs_adam_step")
             for _, p, g in items:
-                if zero_grad and g is not p.grad:
+                if fill and g is not p.grad:
                     p.grad.zero_()          # the kernel zeroed the contiguous copy
+                elif zero_grad is True:
+                    p.grad = None
         return loss
 
 

@@ -47,8 +47,10 @@ def test_environment_map_class_full_resolution_and_adam():
     assert abs(float(e.grid_map.grad.double().sum()) - mass) <= 1e-4 * mass
     e.training_setup(types.SimpleNamespace(env_lr=1e-2))
     before = e.grid_map.detach().clone()
-    e.optimizer.step(zero_grad=True)
+    e.optimizer.step(zero_grad="zeros")
     assert float((e.grid_map.detach() - before).abs().max()) > 0 and float(e.grid_map.grad.abs().max()) == 0.0
+    e.optimizer.step(zero_grad=True)
+    assert e.grid_map.grad is None
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_ENV_SEEDS", "10"))))

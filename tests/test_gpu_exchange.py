@@ -205,3 +205,48 @@ def test_rgb_factor_equals_oracle_masked_colour_gradient():
     assert st["clamped"].sum() > 0
     close("rgb_factor", sink[0].cpu().numpy(), want)
     close("dL_dmeans3D", L["means3D"].grad.cpu().numpy(), rg["dL_dmeans3D"])
+
+
+@pytest.mark.parametrize("zero_mode", ["zeros", True, "torch_zero_fill"])
+def test_arena_gradients_with_in_place_zeroed_or_dropped_gradients(zero_mode):
+    """Three iterations of render -> factored exchange -> FusedAdam.step(zero_grad=...) on one model: after reduce() every dense
+    `.grad` IS a slice of the exchange's gradient arena.  When the gradients are then zero-filled in place (zero_grad="zeros",
+    optimizer.zero_grad(set_to_none=False)) the next backward must not write into the slice the installed gradient aliases
+    (autograd would add the slice to itself: 2 g).  The gradients of every iteration equal those of a fresh model without arena."""
+    from adgs import dp, synthetic
+    from adgs.model import SyntheticGaussianModel
+    sc = synthetic.make_scene(5000, 208, 128, 150.0, sh_degree=3, seed=31, n_objects=2)
+    cams = [synthetic.make_camera(208, 128, 150.0, cam_seed=c) for c in range(2)]
+    up = synthetic.make_upstream_grads(sc, 3)
+    ups = [up[k].cuda() for k in ("color", "depth", "img_opacity", "flow", "semantic")]
+    names = ("_scene_xyz", "_obj_xyz", "_scene_shs_dc", "_obj_shs_rest", "shs_deform_param_obj", "_scene_opacity", "_obj_opacity", "_scene_scaling",
+             "_obj_scaling", "_scene_rotation", "xyz_deform_param", "rotation_deform_param", "gs_time_sigma")
+    model = SyntheticGaussianModel.from_scene(sc, torch.device("cuda", 0), seed=1)
+    model.raw_sh = True
+    from adgs import densify
+    model.training_setup(lrs={n: 0.0 for n in densify.GROUP_ATTR})          # lr 0: the parameters stay put, the moments move
+    ex = dp.FactoredSHExchange(model, factor_xyz=True)
+    for it in range(3):
+        times = [0.15 + 0.2 * it, 0.5 + 0.1 * it]
+        for cam, t in zip(cams, times):
+            _render_cam(model, cam, t, ups, ex.sink_for)
+        ex.reduce(times, [c["campos"].tolist() for c in cams], flow_times=[t + 0.05 for t in times])
+        got = {n: getattr(model, n).grad.detach().clone() for n in names}
+        assert ex.arena.holds("scene_xyz", model._scene_xyz.grad)
+        fresh = SyntheticGaussianModel.from_scene(sc, torch.device("cuda", 0), seed=1)
+        fresh.raw_sh = True
+        for cam, t in zip(cams, times):
+            _render_cam(fresh, cam, t, ups, None)
+        torch.cuda.synchronize()
+        for n in names:
+            assert float(got[n].abs().max()) > 0, n
+            close("iteration %d %s" % (it, n), got[n].cpu().numpy(), getattr(fresh, n).grad.cpu().numpy(), atol_frac=1e-2)
+        if zero_mode == "torch_zero_fill":
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=False)
+        else:
+            model.optimizer.step(zero_grad=zero_mode)
+        if zero_mode is True:
+            assert all(p.grad is None for p in model.parameters())
+        else:
+            assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in model.parameters())

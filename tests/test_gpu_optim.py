@@ -61,8 +61,20 @@ def test_fused_adam_zero_grad_and_state_keys():
     opt = FusedAdam([{"params": [p], "lr": 1e-2, "name": "p"}, {"params": [q], "lr": 0.0, "name": "q"}], lr=0.0, eps=1e-15)
     p.grad, q.grad = torch.randn_like(p), torch.randn_like(q)
     q0 = q.detach().clone()
-    opt.step(zero_grad=True)
+    opt.step(zero_grad="zeros")                                      # zero_grad(set_to_none=False): zero-filled by the same kernel pass
     assert float(p.grad.abs().max()) == 0.0 and float(q.grad.abs().max()) == 0.0
+    p.grad.copy_(torch.randn_like(p))
+    q.grad = None
+    steps = (float(opt.state[p]["step"]), float(opt.state[q]["step"]))
+    opt.step(zero_grad=True)                                         # the reference's zero_grad(set_to_none=True), train.py:165
+    assert p.grad is None and q.grad is None
+    # a parameter without gradient is skipped like torch.optim.Adam skips it: no step count, no moment-driven update
+    assert (float(opt.state[p]["step"]), float(opt.state[q]["step"])) == (steps[0] + 1, steps[1])
+    with pytest.raises(ValueError):
+        opt.step(zero_grad="none")
+    p.grad, q.grad = torch.randn_like(p), torch.randn_like(q)
+    q0 = q.detach().clone()
+    opt.step()
     assert torch.equal(q.detach(), q0)                               # lr = 0 leaves the parameter untouched, but the moments move
     st = opt.state[q]
     assert set(st.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st["exp_avg"].abs().max()) > 0

@@ -21,19 +21,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_abs=2e-2):
-    got = np.asarray(got, dtype=np.float64)
-    ref = np.asarray(ref, dtype=np.float64)
-    assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    if got.size == 0:
-        return
-    scale = max(np.abs(ref).max(), 1e-30)
-    err = np.abs(got - ref)
-    bad = err > tol * np.abs(ref) + tol * scale
-    frac = bad.mean()
-    assert frac <= max_frac, "%s: %.3g of elements outside tol (max err %.3g, scale %.3g)" % (name, frac, err.max(), scale)
-    if bad.any():
-        assert (err[bad] <= outlier_abs * scale + outlier_abs).all(), "%s: gate-flip outlier too large: %g" % (name, err.max())
+from tests.parity import assert_close  # noqa: E402  (element-wise 1e-4 + relative L2 + per-row relative error; tests/parity.py)
 
 
 def dev(t):
