@@ -181,6 +181,38 @@ def hip_sh_grad_expand(cams, W, C, P, Ns, row0, xyz_head, D, M, outs, _cache=Non
                    "adgs_sh_grad_expand")
 
 
+ARENA_QUANTUM = 64 * 840
+
+
+def reduce_flat(flat, group=None, shard_cache=None):
+    """Sum ONE flat fp32 buffer over the ranks, asynchronously; returns the list of work handles to wait on.
+    ADGS_DP_COLLECTIVE=all_reduce (default): one RCCL all-reduce.  ADGS_DP_COLLECTIVE=rs_ag: reduce-scatter + all-gather, each rank
+    owning 1/world of the buffer -- on a fully connected xGMI node every rank then exchanges S/n with every peer directly in
+    both phases whatever algorithm RCCL picks for all-reduce; which of the two is faster is for the first
+    multi-GPU run to measure (bench.py prints exchange_ms for either).  gloo (host-side dry runs) has no reduce-scatter: there the
+    rs_ag form is all-reduce + an all-gather of the owned shard, i.e. the same sequence of collectives on the same buffers."""
+    import os
+    mode = os.environ.get("ADGS_DP_COLLECTIVE", "all_reduce")
+    world = dist.get_world_size(group)
+    if mode != "rs_ag" or flat.numel() % world != 0 or world == 1:
+        return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)]
+    n = flat.numel() // world
+    rank = dist.get_rank(group)
+    shard = None if shard_cache is None else shard_cache.get("shard")
+    if shard is None or shard.numel() != n or shard.device != flat.device:
+        shard = torch.empty(n, dtype=flat.dtype, device=flat.device)
+        if shard_cache is not None:
+            shard_cache["shard"] = shard
+    if dist.get_backend(group) == "gloo":
+        w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        w.wait()
+        shard.copy_(flat[rank * n:(rank + 1) * n])
+        return [dist.all_gather_into_tensor(flat, shard, group=group, async_op=True)]
+    w1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    w2 = dist.all_gather_into_tensor(flat, shard, group=group, async_op=True)      # a communicator runs its collectives in issue order
+    return [w1, w2]
+
+
 class GradArena:
     """ONE persistent flat buffer for the dense parameter gradients of a model.  The deformation backward (adgs.deform) asks
     `take(name, like)` for the tensor it writes a parameter's gradient into and gets a slice of the buffer; autograd then
@@ -199,7 +231,9 @@ class GradArena:
             self.offsets[n] = (off, numel)
             off += (numel + 63) // 64 * 64                       # 256-byte aligned slices
         ref = next(p for n, p in named_params if p is not None and p.numel() > 0)
-        self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=ref.device)
+        # sized to a multiple of 64 * lcm(1..8) floats: every world size up to 8 splits it into equal, 256-byte aligned shards
+        # (the reduce-scatter + all-gather form of the exchange, ADGS_DP_COLLECTIVE=rs_ag)
+        self.flat = torch.zeros((max(off, 1) + ARENA_QUANTUM - 1) // ARENA_QUANTUM * ARENA_QUANTUM, dtype=torch.float32, device=ref.device)
         self.handed = set()
         self.xyz_sink = None                 # set by FactoredSHExchange: receives the upstream position gradients of the object range
 
@@ -290,6 +324,8 @@ class FactoredSHExchange:
         self.send = self.recv = None
         self._work = self._expect = None
         self._w_cache, self._cam_cache = {}, {}
+        self._shard_cache = {}
+        self.timing = None                       # a list: reduce() appends (t0, t_gathered, t_expanded, t_reduced) HIP events per call (bench.py)
         self.arena = None
         self._arena_setup()
 
@@ -442,6 +478,9 @@ class FactoredSHExchange:
         if self._expect is not None and self._expect != (n_total, k_max, n_local):
             raise RuntimeError("FactoredSHExchange: begin() announced %d cameras, reduce() got %d" % (self._expect[0], n_total))
         coll = self._collectives(world)
+        tm = self.timing
+        stamp = (lambda: None) if tm is None else self._stamp
+        ev = [stamp()]
         work = self._work                            # already in flight when begin(n_cameras) was used
         if work is None:
             for j, f in enumerate(self.sink):        # a backward that could not write in place (foreign sink use): copy now
@@ -487,16 +526,17 @@ class FactoredSHExchange:
             if self.arena is not None:
                 # every dense gradient of the deformation backward sits in the arena: ONE in-place all-reduce, nothing to copy
                 rest = [p for p in dense_params if not any(p is q for q in in_arena)]
-                w = dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                ws = reduce_flat(self.arena.flat, self.group, self._shard_cache)
                 dense = allreduce_gradients_start(rest, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40) \
                     if rest else dict(works=[], flats=[], big=[], average=False, world=world)
-                dense["works"].append(w)
+                dense["works"].extend(ws)
             else:
                 dense = allreduce_gradients_start(dense_params, group=self.group, force=self.force_collectives, in_place_bytes=1 << 40, bucket_bytes=1 << 40)
         else:
             dense = None
         if work is not None:
             work.wait()
+        ev.append(stamp())
         cams = []
         for g in range(n_total):                     # global camera order: identical summation order on every rank
             r, j = g % world, g // world
@@ -547,5 +587,15 @@ class FactoredSHExchange:
             if xp.grad is None or xp.grad.shape != xp.shape:
                 xp.grad = torch.empty_like(xp)
             hip_lin_grad_expand(terms, Wx, Cx, No, 1.0, xp.grad)
+        ev.append(stamp())
         allreduce_gradients_finish(dense)            # the expansions above ran while the dense all-reduce was on the links
+        ev.append(stamp())
+        if tm is not None:
+            tm.append(tuple(ev))
         self.begin()
+
+    @staticmethod
+    def _stamp():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e

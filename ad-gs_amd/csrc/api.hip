@@ -94,7 +94,7 @@ struct GeomStateV2 {
 	}
 };
 struct ImgStateV2 {
-	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order;
+	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order; uint32_t* tile_scanned;
 	static ImgStateV2 carve(char* chunk, size_t npix, size_t ntiles, size_t ncells, size_t* bytes) {
 		Carver c(chunk); ImgStateV2 s;
 		s.n_contrib = c.take<uint32_t>(npix);
@@ -102,6 +102,7 @@ struct ImgStateV2 {
 		s.tile_last_chunk = c.take<uint32_t>(ntiles);
 		s.tile_consumed = c.take<uint32_t>(ntiles);
 		s.tile_order = c.take<uint32_t>(ntiles);
+		s.tile_scanned = c.take<uint32_t>(ntiles);          // candidates of the cell list the tile's walk went through (statistics)
 		if (bytes) *bytes = c.size();
 		return s;
 	}
@@ -152,13 +153,12 @@ static int v2_pixels_per_lane(size_t ntiles16) {
 	return ntiles16 < 4096 ? 2 : 4;
 }
 
-// ---- optional per-stage timing with HIP events on the launch stream (bench.py) ----
-enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+// ---- optional per-stage timing with HIP events on the launch stream (bench.py); Stage / StageTimer are declared in common.h ----
 static const char* const kStageNames[ST_COUNT] = { "preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
-	"render_fwd", "render_bwd", "preprocess_bwd" };
+	"render_fwd", "render_bwd", "preprocess_bwd", "deform_fwd", "deform_bwd", "grad_expand" };
 struct ProfRec { int stage; hipEvent_t a, b; };
 // process-wide: torch.autograd calls the backward from its own worker thread
-static unsigned g_prof_mask = 0;          // bit i: stage i is timed
+static std::atomic<unsigned> g_prof_mask{0};          // bit i: stage i is timed
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -167,13 +167,12 @@ static hipEvent_t prof_event() {
 	if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
 	hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
-struct StageTimer {
-	bool on; ProfRec r; hipStream_t s;
-	StageTimer(int stage, hipStream_t stream) : on((g_prof_mask >> stage) & 1u), s(stream) {
-		if (on) { r.stage = stage; r.a = prof_event(); r.b = prof_event(); (void)hipEventRecord(r.a, s); }
-	}
-	~StageTimer() { if (on) { (void)hipEventRecord(r.b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back(r); } }
-};
+StageTimer::StageTimer(int stage_, hipStream_t stream) : on((g_prof_mask.load(std::memory_order_relaxed) >> stage_) & 1u), stage(stage_), a(nullptr), b(nullptr), s(stream) {
+	if (on) { a = prof_event(); b = prof_event(); (void)hipEventRecord(a, s); }
+}
+StageTimer::~StageTimer() {
+	if (on) { (void)hipEventRecord(b, s); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back(ProfRec{ stage, a, b }); }
+}
 
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
@@ -235,7 +234,7 @@ extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_
 // atomics-into-outputs pipeline; also the reference's contract), 0 if every element is written.
 extern "C" int adgs_raster_needs_zero_init(int D_S) { return use_v2(D_S) ? 0 : 1; }
 
-extern "C" void adgs_profile_enable(int stage_mask) { g_prof_mask = (unsigned)stage_mask; }
+extern "C" void adgs_profile_enable(int stage_mask) { g_prof_mask.store((unsigned)stage_mask); }
 // Pre-creates event objects so that a measurement loop never calls hipEventCreate (a driver call that can block).
 extern "C" int adgs_profile_reserve(int n_events) {
 	std::vector<hipEvent_t> fresh;
@@ -397,7 +396,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
 		ra.bg = background;
-		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
+		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned;
 		ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 		ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
 		ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
@@ -710,6 +709,22 @@ extern "C" long long adgs_test_v2_published_entries(const char* img_buffer, int 
 	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
 	std::vector<uint32_t> h(wtiles);
 	if (hipMemcpyAsync(h.data(), img.tile_consumed, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	long long total = 0;
+	for (uint32_t v : h) total += v;
+	return total;
+}
+// sum over the wave tiles of the candidates of the cell list each tile's walk went through before all its pixels were saturated
+extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream_) {
+	if (!img_buffer || width <= 0 || height <= 0) return -1;
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	const int cell_tiles = v2_cell_tiles(ntiles), ppl = v2_pixels_per_lane(ntiles);
+	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
+	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
+	std::vector<uint32_t> h(wtiles);
+	if (hipMemcpyAsync(h.data(), img.tile_scanned, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
 	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
 	long long total = 0;
 	for (uint32_t v : h) total += v;

@@ -75,6 +75,17 @@ struct Carver {
 	size_t size() const { return align_up(off, 256) + 256; }
 };
 
+// ---- optional per-stage timing with HIP events on the launch stream (bench.py; implemented in api.hip) ----
+enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM_FWD, ST_DEFORM_BWD,
+	ST_EXPAND, ST_COUNT };
+struct StageTimer {
+	bool on; int stage; hipEvent_t a, b; hipStream_t s;
+	StageTimer(int stage, hipStream_t stream);
+	~StageTimer();
+	StageTimer(const StageTimer&) = delete;
+	StageTimer& operator=(const StageTimer&) = delete;
+};
+
 // ---- device primitives (primitives.hip) ----
 size_t scan_temp_bytes(size_t n);
 // out[i] = sum_{j<i} in[j]  (in == out allowed)

@@ -1013,6 +1013,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 	if (flow_xyz && !f_xyz_flow) a.fx2.n_params = a.fx.n_params;
 	const adgs_func_eval fs = f_shs ? *f_shs : empty_func();
 	hipStream_t stream = (hipStream_t)stream_;
+	StageTimer timer(ST_DEFORM_FWD, stream);
 	float* shs_out = a.o.shs;
 	a.o.shs = nullptr;                       // SH rows go through the flat coalesced kernel below
 	if (a.o.xyz || a.flow_xyz || a.o.rotation || a.o.opacity || a.o.scales) {
@@ -1071,6 +1072,7 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 	a.fx2 = f_xyz_flow ? *f_xyz_flow : empty_func(); a.fb2 = f_background_flow ? *f_background_flow : empty_func();
 	const adgs_func_eval fs = f_shs ? *f_shs : empty_func();
 	hipStream_t stream = (hipStream_t)stream_;
+	StageTimer timer(ST_DEFORM_BWD, stream);
 	a.g_xyz = dL_dxyz; a.g_flow = dL_dflow_xyz; a.g_rot = dL_drotation; a.g_op = dL_dopacity; a.g_sc = dL_dscales;
 	if (dL_dxyz || dL_dflow_xyz || dL_drotation || dL_dopacity || dL_dscales) {
 		const int np_x = std::max(a.fx.n_params, a.fx2.n_params);

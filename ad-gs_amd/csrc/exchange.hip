@@ -122,6 +122,7 @@ using namespace adgs;
 extern "C" int adgs_sh_grad_expand(int n_cams, const adgs_sh_expand_cam* cams, const float* W, int C,
 	int P, int Ns, int row0, const float* xyz_head, int D, int M, const adgs_sh_grads* out, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
+	StageTimer timer(ST_EXPAND, stream);
 	if (P <= 0) return 0;
 	if (!cams || !out || n_cams < 1 || n_cams > ADGS_EXPAND_MAX_CAMS) { set_error("adgs_sh_grad_expand: need 1.." + std::to_string(ADGS_EXPAND_MAX_CAMS) + " cameras"); return -1; }
 	if (Ns < 0 || Ns > P || row0 < 0 || row0 > P || D < 0 || D > 3 || M < 1 || M > 16 || (D + 1) * (D + 1) > M || C < 0) {
@@ -174,6 +175,7 @@ extern "C" int adgs_lin_grad_expand(int n_terms, const float* const* g, const fl
 	d.n = n_terms; d.C = C; d.count = count; d.n0 = 0; d.scale = scale; d.W = W; d.out = out;
 	for (int e = 0; e < n_terms; e++) { if (!g[e]) { set_error("adgs_lin_grad_expand: NULL factor"); return -1; } d.rgb[e] = g[e]; }
 	const size_t tot = (size_t)count * 3 * C, per_block = (size_t)EX_THREADS * EX_ITEMS;
+	StageTimer timer(ST_EXPAND, (hipStream_t)stream_);
 	hipLaunchKernelGGL(sh_expand_deform_kernel, dim3((unsigned)((tot + per_block - 1) / per_block)), dim3(EX_THREADS), (size_t)n_terms * C * sizeof(float),
 		(hipStream_t)stream_, d);
 	ADGS_HIP_CHECK(hipGetLastError());

@@ -97,7 +97,7 @@ struct RenderV2FwdArgs {
 	int ppl;                                // pixels per lane: 4 or 2 (v2_pixels_per_lane)
 	bool has_color, has_flow, has_sem;
 	const float* bg;
-	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed;
+	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_scanned;
 	float* final_T; uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
 	int order_mode;                         // 1: workgroups walk the tiles bottom-up (default), 0: top-down

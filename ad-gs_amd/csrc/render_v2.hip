@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			consumed += nlive;
 		}
 	}
-	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; }
+	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; }
 	const size_t HW = (size_t)a.H * a.W;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {

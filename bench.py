@@ -3,22 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W [--config C3]
 
-One "step" = one frame = per-frame deformation (when the config has dynamic objects)
-+ GaussianRasterizer forward + backward with non-zero upstream gradients on colour,
-depth, accumulated opacity, flow and semantic; loss and optimizer are
-excluded, as in BASELINE.md.  Inputs are synthetic (seeded) and resident
-in HBM before the timed region.  With N > 1 every rank (one process per GPU, launched by
-torch.distributed.run) renders its own camera of the same replicated scene and the
-parameter gradients are all-reduced over RCCL inside the step (weak scaling).
+One "frame" = per-frame deformation (when the config has dynamic objects) + GaussianRasterizer forward + backward with
+non-zero upstream gradients on colour, depth, accumulated opacity, flow and semantic; loss and optimizer are
+excluded, as in BASELINE.md.  Inputs are synthetic (seeded) and resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra
-objects: "roofline" for the dominant kernel (algorithmic bytes per launch / HIP-event
-time of that kernel) and "cpu_baseline" (the CPU oracle timed on the host cores).
+Workloads (BASELINE.json configs):
+  * C1 / C2 / C3 (default C3 = the configuration `value` is quoted on): one step = one frame per GPU.  With N > 1 every rank (one
+    process per GPU over RCCL) renders its own camera of the same replicated scene and the parameter gradients are summed over
+    the ranks inside the step ("scaling": "weak").  `python bench.py --gpus N` without a launcher starts the N ranks itself.
+  * C4 (1 M Gaussians, 3 cameras per iteration) and C5 (3 M Gaussians, 16 objects, 5 cameras per iteration + densify/prune):
+    one step = one ITERATION: the cameras are dealt round-robin to the ranks (with 4 ranks and 3 cameras one rank idles and still
+    takes part in the exchange), then one gradient exchange; C5 additionally runs adgs.densify.densify_and_prune every
+    `--densify-every` iterations inside the timed loop (reported separately as densify_ms).  `value` = cameras rendered per
+    second ("scaling": "strong": the iteration's work is fixed as N grows).  On one GPU the same code accumulates the cameras.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with "roofline" for the dominant kernel (algorithmic bytes per
+launch / HIP-event time of that kernel), "cpu_baseline" (the CPU oracle timed on the host cores), per-step HIP-event statistics
+(median / p10 / p90), the GPU-idle share of a step, per-step exchange times for N > 1, and secondary single-GPU measurements.
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,10 +36,12 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, densify_every=10)}
 
 
 def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
-    """Algorithmic bytes per launch of every stage."""
+    """Algorithmic bytes per launch of every stage of the reference-order ("classic") pipeline."""
     pay = 12 + 4 + 12 * F + 4 * D_S
     return {
         "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 4 + V * 68,
@@ -45,10 +55,9 @@ def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     }
 
 
-def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, n_obj_rows, E_pub=None):
+def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None):
     """Algorithmic bytes per launch of the default (v2, coarse-binned) pipeline -- DESIGN.md section 5.
-    Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries actually blended."""
-    pay = 12 + 4 + 12 * F + 4 * D_S
+    Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries blended, E_pub = entries the backward replays."""
     out = X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4)
     return {
         "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 32 + 24 + 1 + 64),
@@ -57,90 +66,37 @@ def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, n_obj_rows, E_pub=None):
         "radix_sort": passes * Rc * 24 + Rc * 8,
         "tile_ranges": Rc * 8,
         "render_fwd": E * (4 + 64 + 4) + out,
-        "render_bwd": (E if E_pub is None else E_pub) * (4 + 64 + 56) + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),      # replays the published entries only
+        "render_bwd": (E if E_pub is None else E_pub) * (4 + 64 + 56) + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),
         "preprocess_bwd": P * (12 + 12 + 16 + 4 + 12 * M) + V * (64 + 32 + 24 + 1) + V * 64 + P * (12 + 12 * M + 12 + 16 + 12 + 16 + 4 + 12 + 4 + 24),
     }
 
 
-def blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device):
-    """(E, R, E_pub): E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published; the last
-    chunk of a tile is partly empty, so this is an upper bound within #tiles x 63), R = the reference's num_rendered for the
-    same frame (one extra forward in classic mode), E_pub = the entries at least one pixel blends, i.e. what the backward replays."""
+# ------------------------------------------------------------------ scenes
+def build_scene(config, variant="default"):
+    """BASELINE.json config scene, or one of two C3-sized stress variants for the scene-sensitivity lines:
+    'translucent' (opacity x 0.05 + 0.01: no pixel saturates, every tile walks its whole list) and 'sky' (the upper 40 % of the
+    image is empty; the Gaussians that were there lie on the road plane y = +1.5 m instead: long lists around the horizon)."""
     import torch
-    from diff_gaussian_rasterization import _C
-    from adgs import deform
-    with torch.no_grad():
-        if isinstance(frame, DeformFrame):
-            pkg = deform.get_deformed_pkg(frame.model, frame.t)
-            flow = frame.model.get_deformed_xyz(frame.t + 0.05) if use_fs else torch.empty(0, device=device)
-            t = dict(means3D=pkg["xyz"], opacities=pkg["opacity"], scales=pkg["scales"], rotations=pkg["rotation"], shs=pkg["shs"])
-            sem = frame.sem if use_fs else torch.empty(0, device=device)
-        else:
-            t = {k: v.detach() for k, v in frame.leaf.items()}
-            flow = frame.flow if use_fs else torch.empty(0, device=device)
-            sem = frame.sem if use_fs else torch.empty(0, device=device)
-        e = torch.empty(0, device=device)
-        s = settings
-        call = lambda: _C.rasterize_gaussians(s.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], s.scale_modifier, e, s.viewmatrix,
-                                              s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, t["shs"], flow, sem, s.sh_degree,
-                                              s.campos, s.prefiltered, s.inv_depth, False)
-        out = call()
-        chunks = int(out[6][:4].view(torch.int32)[0].item())      # BinStateV2 starts with the chunk-pool cursor
-        import ctypes
-        from adgs import _lib
-        published = int(_lib.lib().adgs_test_v2_published_entries(out[7].data_ptr(), int(s.image_width), int(s.image_height),
-                                                                  ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
-        old = os.environ.get("ADGS_RASTER_MODE")
-        os.environ["ADGS_RASTER_MODE"] = "classic"
-        try:
-            r_ref = int(call()[0])
-        finally:
-            if old is None:
-                del os.environ["ADGS_RASTER_MODE"]
-            else:
-                os.environ["ADGS_RASTER_MODE"] = old
-    return chunks * 64, r_ref, published
+    from adgs import synthetic
+    sc = synthetic.make_config_scene(config)
+    if variant == "translucent":
+        sc["opacities"] = (sc["opacities"] * 0.05 + 0.01).contiguous()
+    elif variant == "sky":
+        xyz = sc["means3D"].clone()
+        z = xyz[:, 2].clamp_min(0.3)
+        up = (xyz[:, 1] / z) < -0.2 * sc["tanfovy"]              # projects into the upper 40 % of the image
+        up &= ~sc["obj_mask"]
+        g = torch.Generator().manual_seed(77)
+        n = int(up.sum())
+        xyz[up, 1] = 1.5 + 0.05 * torch.randn(n, generator=g)    # the road plane, 1.5 m below the camera (y points down)
+        sc["means3D"] = xyz.contiguous()
+        sc["flow_points"] = (xyz + 0.05 * torch.randn(xyz.shape, generator=g)).float().contiguous()
+    elif variant != "default":
+        raise ValueError(variant)
+    return sc
 
 
-def measured_frame_traffic(config, measured_case, fps_per_gpu):
-    """HBM bytes per frame summed over every kernel of the frame, from the committed PMC passes (profiles/r01/)."""
-    if config != "C3" or not measured_case:
-        return {}
-    try:
-        tot = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_per_frame.json")))
-        return {"measured_hbm_bytes_per_frame": int(tot["hbm_bytes_per_frame"]),
-                "measured_hbm_frac_of_8TBs": round(tot["hbm_bytes_per_frame"] * fps_per_gpu / 1e9 / HBM_PEAK_GBS, 4)}
-    except (OSError, ValueError, KeyError):
-        return {}
-
-
-def pmc_annotations(stage, config, measured_case):
-    """HBM traffic / VALU occupancy of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01/, collected
-    with this same command line; counters cannot be read from inside the process).  Only attached for the case they were
-    measured on (C3, flow+semantic, default pipeline)."""
-    if config != "C3" or not measured_case:
-        return {}
-    kname = {"render_bwd": "render_bwd_v2_kernel", "render_fwd": "render_fwd_v2_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
-             "preprocess_fwd": "preprocess_fwd_kernel"}.get(stage)
-    out = {}
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_per_kernel.json")))
-        for k, v in tr.items():
-            if kname and kname in k:
-                out["traffic"] = v["hbm_bytes_per_launch"]
-                out["traffic_source"] = "profiles/r01/hbm_traffic_per_kernel.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
-                break
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_blend_kernels.json")))["kernels"].get(kname)
-        if pm:
-            out["valu_busy_frac"] = pm["valu_busy_frac"]
-            out["valu_insts_per_simd_cycle"] = pm.get("valu_insts_per_simd_cycle")
-            out["valu_note"] = ("fp32-VALU-bound kernel (SURVEY.md 8(d)): valu_busy_frac = min(1, 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles)); "
-                                "valu_insts_per_simd_cycle against a full-rate peak of 0.5 (quarter-rate exp / rcp included); profiles/r01/pmc_blend_kernels.json")
-    except (OSError, ValueError, KeyError):
-        pass
-    return out
-
-
+# ------------------------------------------------------------------ per-frame work
 class StaticFrame:
     """Per-frame work on already-deformed parameters: rasterizer forward (+ autograd backward)."""
 
@@ -164,7 +120,7 @@ class StaticFrame:
             p.grad = None
         self.means2D.grad = None
 
-    def forward(self):
+    def forward(self, sink_for=None):
         L = self.leaf
         color, radii, depth, op, flow, sem = self.rast(
             means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
@@ -174,24 +130,32 @@ class StaticFrame:
 
 
 class DeformFrame:
-    """Per-frame work of the dynamic configs (C3-C5): fused B-spline/Fourier/quaternion-spline
-    deformation of the raw parameters at the camera time (+ the flow points at t+0.05), then the
-    rasterizer; the backward runs through both into every raw parameter."""
+    """Per-frame work of the dynamic configs (C3-C5): fused B-spline/Fourier/quaternion-spline deformation of the raw parameters at
+    the camera time (+ the flow points at t+0.05), then the rasterizer; the backward runs through both into every raw parameter.
+    Several frames (cameras) may share one model."""
 
-    def __init__(self, sc, rasterizer, device, use_flow_sem, t=0.37):
+    def __init__(self, sc, rasterizer, device, use_flow_sem, t=0.37, model=None):
         from adgs.model import SyntheticGaussianModel
         self.rast, self.t, self.use_fs = rasterizer, t, use_flow_sem
-        self.model = SyntheticGaussianModel.from_scene(sc, device, seed=0)
+        self.model = model if model is not None else SyntheticGaussianModel.from_scene(sc, device, seed=0)
         self.model.raw_sh = os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0"     # SH read straight from the raw parameters
         self.fused_flow = os.environ.get("ADGS_BENCH_FUSED_FLOW", "1") != "0"      # flow-time xyz in the same deformation pass
-        self.means2D = None
-        self.sem = self.model.get_obj_mask.float()[:, None].contiguous() if use_flow_sem else None
+        self._sem = None
         self.last_radii = None
+        self.last_means2D = None
         self.deform_bytes = self.model.deform_bytes_per_frame()
         oa = self.model.order_args
         self.deform_desc = "fused HIP: xyz %s, rotation %s (quaternion spline), shs %s%s, time-masked opacity; %d object Gaussians" % (
             oa["xyz"], oa["rotation"], oa["shs"], " (read in place by the preprocess: raw-SH path)" if self.model.raw_sh else "",
             self.model.get_obj_pts_num)
+
+    @property
+    def sem(self):
+        if not self.use_fs:
+            return None
+        if self._sem is None or self._sem.shape[0] != self.model.get_pts_num:      # densification changes the point count
+            self._sem = self.model.get_obj_mask.float()[:, None].contiguous()
+        return self._sem
 
     def parameters(self):
         return self.model.parameters()
@@ -219,7 +183,7 @@ class DeformFrame:
             color, radii, depth, op, fl, sem = self.rast.forward_rawsh(pkg["xyz"], means2D, pkg["opacity"], pkg["shs"], pkg["scales"],
                                                                        pkg["rotation"], flow_points=flow, semantic=self.sem,
                                                                        factor_sink=None if sink_for is None else sink_for(pkg["xyz"]))
-        self.last_radii = radii
+        self.last_radii, self.last_means2D = radii, means2D
         return [color, depth, op] + ([fl, sem] if self.use_fs else [])
 
     def activated(self):
@@ -232,24 +196,127 @@ class DeformFrame:
         return {k: v.detach().cpu() for k, v in pkg.items()}, flow.cpu()
 
 
-def cpu_baseline(sc, cam, cfg, use_fs, up):
-    """The CPU oracle (oracle/, a port of the reference kernels -- the reference has no CPU path)
-    timed on this host's cores for ONE frame of the same workload."""
+def make_settings(cfg, cam, sc, device):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    d = lambda t: t.to(device)
+    return GaussianRasterizationSettings(cfg["H"], cfg["W"], cam["tanfovx"], cam["tanfovy"], d(sc["bg"]), 1.0, d(cam["viewmatrix"]),
+                                         d(cam["projmatrix"]), cfg["sh_degree"], d(cam["campos"]), False, True, False)
+
+
+def make_frame(sc, cfg, cam, device, use_fs, t=0.37, model=None):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    rast = GaussianRasterizer(make_settings(cfg, cam, sc, device))
+    if cfg["n_objects"] > 0:
+        return DeformFrame(sc, rast, device, use_fs, t=t, model=model)
+    return StaticFrame(sc, rast, device, use_fs)
+
+
+# ------------------------------------------------------------------ scene statistics
+def frame_work_figures(frame, settings, use_fs, device):
+    """(E, R, E_pub, scanned): E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published: an
+    upper bound within #tiles x 63), R = the reference's num_rendered for the same frame (one extra forward in classic mode),
+    E_pub = the entries at least one pixel blends (what the backward replays), scanned = candidates of the cell lists that the
+    tiles' walks went through."""
+    import ctypes
+    import torch
+    from diff_gaussian_rasterization import _C
+    from adgs import deform, _lib
+    with torch.no_grad():
+        if isinstance(frame, DeformFrame):
+            pkg = deform.get_deformed_pkg(frame.model, frame.t)
+            flow = frame.model.get_deformed_xyz(frame.t + 0.05) if use_fs else torch.empty(0, device=device)
+            t = dict(means3D=pkg["xyz"], opacities=pkg["opacity"], scales=pkg["scales"], rotations=pkg["rotation"], shs=pkg["shs"])
+        else:
+            t = {k: v.detach() for k, v in frame.leaf.items()}
+            flow = frame.flow if use_fs else torch.empty(0, device=device)
+        sem = frame.sem if use_fs else torch.empty(0, device=device)
+        e = torch.empty(0, device=device)
+        s = settings
+        call = lambda: _C.rasterize_gaussians(s.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], s.scale_modifier, e, s.viewmatrix,
+                                              s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, t["shs"], flow, sem, s.sh_degree,
+                                              s.campos, s.prefiltered, s.inv_depth, False)
+        out = call()
+        chunks = int(out[6][:4].view(torch.int32)[0].item())      # BinStateV2 starts with the chunk-pool cursor
+        st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        published = int(_lib.lib().adgs_test_v2_published_entries(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
+        scanned = int(_lib.lib().adgs_test_v2_scanned_candidates(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
+        old = os.environ.get("ADGS_RASTER_MODE")
+        os.environ["ADGS_RASTER_MODE"] = "classic"
+        try:
+            r_ref = int(call()[0])
+        finally:
+            if old is None:
+                del os.environ["ADGS_RASTER_MODE"]
+            else:
+                os.environ["ADGS_RASTER_MODE"] = old
+    return chunks * 64, r_ref, published, scanned
+
+
+def committed_pmc(stage, config, measured_case):
+    """HBM traffic / VALU issue rate of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's build
+    (profiles/r02/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
+    the case they were measured on (C3, flow+semantic, default pipeline); absent files leave `traffic` null."""
+    if config != "C3" or not measured_case:
+        return {}
+    kname = {"render_bwd": "render_bwd_v2_kernel", "render_fwd": "render_fwd_v2_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
+             "preprocess_fwd": "preprocess_fwd_kernel"}.get(stage)
+    out = {}
+    try:
+        tr = json.load(open(os.path.join(PROFILE_DIR, "hbm_traffic_per_kernel.json")))
+        for k, v in tr.items():
+            if kname and kname in k:
+                out["traffic"] = v["hbm_bytes_per_launch"]
+                out["traffic_source"] = "profiles/r02/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, per launch)"
+                break
+        pm = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))["kernels"].get(kname)
+        if pm:
+            out["valu_insts_per_simd_cycle"] = pm.get("valu_insts_per_simd_cycle")
+            out["valu_issue_frac_of_peak"] = None if pm.get("valu_insts_per_simd_cycle") is None else round(pm["valu_insts_per_simd_cycle"] / 0.5, 3)
+            out["valu_note"] = ("the blend kernels are fp32-VALU-issue bound, not HBM bound (SURVEY.md 8(d)): wave64 VALU instructions per SIMD and "
+                                "cycle against the full-rate peak of 0.5; profiles/r02/pmc_blend_kernels.json")
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
+def committed_frame_traffic(config, measured_case, fps_per_gpu):
+    if config != "C3" or not measured_case:
+        return {}
+    try:
+        tot = json.load(open(os.path.join(PROFILE_DIR, "hbm_traffic_per_frame.json")))
+        return {"measured_hbm_bytes_per_frame": int(tot["hbm_bytes_per_frame"]),
+                "measured_hbm_frac_of_8TBs": round(tot["hbm_bytes_per_frame"] * fps_per_gpu / 1e9 / HBM_PEAK_GBS, 4)}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+# ------------------------------------------------------------------ CPU baseline / parity
+def cpu_baseline(sc, cam, cfg, use_fs, up, threads=None):
+    """The CPU oracle (oracle/, a port of the reference kernels -- the reference has no CPU path) timed on this host's cores
+    for ONE frame of the same workload."""
     import numpy as np
     from oracle import oracle
     H, W = cfg["H"], cfg["W"]
-    o = oracle.RasterOracle("f32")
-    t0 = time.perf_counter()
-    fwd = o.forward(sc["bg"], sc["means3D"], None, sc["opacities"], sc["scales"], sc["rotations"], 1.0, None, cam["viewmatrix"],
-                    cam["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, sc["shs"], sc["flow_points"] if use_fs else None,
-                    sc["semantic"] if use_fs else None, cfg["sh_degree"], cam["campos"], False, True)
-    t1 = time.perf_counter()
-    o.backward(up["color"], up["depth"], up["flow"] if use_fs else np.zeros((3, H, W), np.float32), up["semantic"] if use_fs else None,
-               up["img_opacity"])
-    t2 = time.perf_counter()
-    base = {"value": round(1.0 / (t2 - t0), 5), "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": "1 full frame (rasterizer fwd %.2f s + bwd %.2f s; the O(N) deformation is not included) of the same scene "
-                      "and camera, OpenMP over Gaussians/tiles, g++ -O3 -fno-fast-math -ffp-contract=off" % (t1 - t0, t2 - t1)}
+    all_threads = oracle.num_threads()
+    if threads is not None:
+        oracle.set_num_threads(threads)
+    try:
+        o = oracle.RasterOracle("f32")
+        t0 = time.perf_counter()
+        fwd = o.forward(sc["bg"], sc["means3D"], None, sc["opacities"], sc["scales"], sc["rotations"], 1.0, None, cam["viewmatrix"],
+                        cam["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, sc["shs"], sc["flow_points"] if use_fs else None,
+                        sc["semantic"] if use_fs else None, cfg["sh_degree"], cam["campos"], False, True)
+        t1 = time.perf_counter()
+        o.backward(up["color"], up["depth"], up["flow"] if use_fs else np.zeros((3, H, W), np.float32), up["semantic"] if use_fs else None,
+                   up["img_opacity"])
+        t2 = time.perf_counter()
+        cores = oracle.num_threads()
+    finally:
+        if threads is not None:
+            oracle.set_num_threads(all_threads)
+    base = {"value": round(1.0 / (t2 - t0), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 full frame (rasterizer fwd %.3f s + bwd %.3f s; the O(N) deformation is not included) of the same scene "
+                      "and camera, %s, g++ -O3 -fno-fast-math -ffp-contract=off" % (t1 - t0, t2 - t1, "OpenMP over Gaussians/tiles" if cores > 1 else "single thread")}
     return base, fwd
 
 
@@ -263,57 +330,123 @@ def parity_vs_oracle(hip_outs, oracle_fwd):
     return {"psnr_vs_oracle_db": round(20.0 * np.log10(1.0 / np.sqrt(mse)), 2) if mse > 0 else float("inf"),
             "max_abs_err_color": float(np.abs(color - oc).max()), "max_abs_err_depth": float(np.abs(depth - od).max()),
             "depth_scale": float(np.abs(od).max()),
-            "frac_color_outside_1e-4": float(np.mean(np.abs(color - oc) > 1e-4 * (1.0 + np.abs(oc))))}
+            "frac_color_outside_1e-4": float(np.mean(np.abs(color - oc) > 1e-4 * (1.0 + np.abs(oc)))),
+            "note": "gate flips at alpha = 1/255: tests/test_gpu_gate_flips.py shows the float32 oracle itself is this far from the float64 result"}
 
 
-def quick_measure(config, steps, device, use_fs):
-    """frames/s of another BASELINE.json config in the same process (single GPU, `steps` timed steps after a short warm-up):
-    reported next to the headline as secondary information, never as `value`."""
+# ------------------------------------------------------------------ timing helpers
+def percentile(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return 0.0
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+def timed_loop(step, steps, sync, barrier=None):
+    """EXACTLY `steps` calls of step(i) between barrier + synchronize on both sides; a HIP event on the launch stream after every
+    step gives the per-step GPU-side times.  Returns (elapsed_s, [step_ms])."""
     import torch
-    from adgs import synthetic
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    cfg = synthetic.CONFIGS[config]
-    sc = synthetic.make_config_scene(config)
-    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
-    d = lambda t: t.to(device)
-    settings = GaussianRasterizationSettings(cfg["H"], cfg["W"], cam["tanfovx"], cam["tanfovy"], d(sc["bg"]), 1.0, d(cam["viewmatrix"]),
-                                             d(cam["projmatrix"]), cfg["sh_degree"], d(cam["campos"]), False, True, False)
-    rast = GaussianRasterizer(settings)
-    frame = DeformFrame(sc, rast, device, use_fs) if cfg["n_objects"] > 0 else StaticFrame(sc, rast, device, use_fs)
-    up = synthetic.make_upstream_grads(sc, 0)
-    ups = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
-
-    def step():
-        torch.autograd.backward(frame.forward(), ups)
-        frame.zero_grad()
-    for _ in range(30):
-        step()
-    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync()
+    if barrier:
+        barrier()
+    sync()
+    gc.collect(); gc.disable()                              # no collector pauses inside the timed region
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects" % (config, cfg["P"], cfg["W"], cfg["H"], cfg["sh_degree"], cfg["n_objects"]),
-            "frames_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps}
+    evs[0].record()
+    for i in range(steps):
+        step(i)
+        evs[i + 1].record()
+    sync()
+    if barrier:
+        barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    return elapsed, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
 
 
+def step_stats(ms):
+    return {"median": round(percentile(ms, 0.5), 4), "p10": round(percentile(ms, 0.1), 4), "p90": round(percentile(ms, 0.9), 4),
+            "min": round(min(ms), 4), "max": round(max(ms), 4)} if ms else {}
+
+
+def quick_measure(config, steps, device, use_fs, variant="default", mode=None, with_stats=False, warm=15):
+    """frames/s of another workload in the same process (single GPU): secondary information next to the headline, never `value`."""
+    import torch
+    from adgs import synthetic, _lib
+    cfg = synthetic.CONFIGS[config]
+    sc = build_scene(config, variant)
+    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
+    old = os.environ.get("ADGS_RASTER_MODE")
+    if mode:
+        os.environ["ADGS_RASTER_MODE"] = mode
+    try:
+        frame = make_frame(sc, cfg, cam, device, use_fs)
+        up = synthetic.make_upstream_grads(sc, 0)
+        d = lambda t: t.to(device)
+        ups = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
+
+        def step(i=0):
+            torch.autograd.backward(frame.forward(), ups)
+            frame.zero_grad()
+        for _ in range(warm):
+            step()
+        elapsed, ms = timed_loop(step, steps, torch.cuda.synchronize)
+        res = {"workload": "%s%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects" % (config, "" if variant == "default" else "/" + variant, cfg["P"], cfg["W"],
+                                                                                         cfg["H"], cfg["sh_degree"], cfg["n_objects"]),
+               "pipeline": mode or "v2", "frames_per_s": round(steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+               "step_ms": step_stats(ms)}
+        if with_stats and not mode:
+            frame.forward()
+            st = _lib.frame_stats()
+            E, R, E_pub, scanned = frame_work_figures(frame, make_settings(cfg, cam, sc, device), use_fs, device)
+            T = st["tiles"]
+            res.update({"reference_pairs_R": R, "cell_pairs_sorted": st["num_rendered"], "blended_entries": E, "published_entries": E_pub,
+                        "E_over_R": round(E / max(R, 1), 4), "candidates_scanned_per_tile": round(scanned / max(T, 1), 1),
+                        "entries_per_tile": round(E / max(T, 1), 1)})
+        return res, frame, sc, cam, cfg, up
+    finally:
+        if mode:
+            if old is None:
+                os.environ.pop("ADGS_RASTER_MODE", None)
+            else:
+                os.environ["ADGS_RASTER_MODE"] = old
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks from here (this process has not touched the GPU), relay
+    their output and exit with their status."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+# ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C5")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C4, C5")
+    ap.add_argument("--cams-per-iter", type=int, default=0, help="iteration mode: cameras per iteration, dealt round-robin to the ranks (default: C4 3, C5 5)")
+    ap.add_argument("--densify-every", type=int, default=-1, help="iteration mode: densify/prune every k iterations inside the timed loop (default: C5 10, else off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flow-sem", action="store_true", help="render without the flow / semantic outputs")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements of the other configs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements (other configs, scene sensitivity)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the hosts only support dmabuf IPC: RCCL across processes needs this (set before HIP initialises)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     import torch
     import torch.distributed as dist
     from adgs import _lib, synthetic, dp
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
     if os.environ.get("ADGS_BENCH_WATCHDOG"):              # debugging aid: dump every thread's stack and exit if the run takes longer than N seconds
         import faulthandler
@@ -321,8 +454,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # ADGS_BENCH_BACKEND=gloo: control-flow dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
@@ -343,63 +474,135 @@ def main():
         raise SystemExit(_lib.last_error())
 
     cfg = synthetic.CONFIGS[args.config]
-    sc = synthetic.make_config_scene(args.config)
-    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if world == 1 else rank)
+    sc = build_scene(args.config)
     H, W, P = cfg["H"], cfg["W"], cfg["P"]
     use_fs = not args.no_flow_sem
     d = lambda t: t.to(device)
-    settings = GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], d(sc["bg"]), 1.0, d(cam["viewmatrix"]),
-                                             d(cam["projmatrix"]), cfg["sh_degree"], d(cam["campos"]), False, True, False)
-    rasterizer = GaussianRasterizer(settings)
-    frame = DeformFrame(sc, rasterizer, device, use_fs) if cfg["n_objects"] > 0 else StaticFrame(sc, rasterizer, device, use_fs)
     up = synthetic.make_upstream_grads(sc, 0)
     up_list = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
+    sync = torch.cuda.synchronize
+    barrier = dist.barrier if world > 1 else None
+
+    # ---- which cameras does a step render?
+    iteration_mode = args.config in ITERATION_CONFIGS or args.cams_per_iter > 0
+    if iteration_mode and cfg["n_objects"] == 0:
+        raise SystemExit("--cams-per-iter needs a dynamic config (C3, C4, C5)")
+    if iteration_mode:
+        n_cams = args.cams_per_iter or ITERATION_CONFIGS.get(args.config, {}).get("cams", world)
+        densify_every = args.densify_every if args.densify_every >= 0 else ITERATION_CONFIGS.get(args.config, {}).get("densify_every", 0)
+        cam_ids = list(range(n_cams))
+        cam_times = [0.37 if n_cams == 1 else 0.1 + 0.8 * c / (n_cams - 1) for c in cam_ids]
+    else:
+        n_cams, densify_every = world, 0
+        cam_ids = [None] if world == 1 else list(range(world))
+        cam_times = [0.37] * world
+    cams = [synthetic.make_camera(W, H, cfg["focal"], cam_seed=c) for c in cam_ids]
+    my = [i for i in range(len(cams)) if i % world == rank]
+    frames, model = [], None
+    for i in my:
+        f = make_frame(sc, cfg, cams[i], device, use_fs, t=cam_times[i], model=model)
+        model = getattr(f, "model", None)
+        frames.append(f)
+    if not frames:                                    # a rank without a camera in this deal (C4 on 4 GPUs) still owns a replica
+        from adgs.model import SyntheticGaussianModel
+        model = SyntheticGaussianModel.from_scene(sc, device, seed=0)
+        model.raw_sh = os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0"
+    frame = frames[0] if frames else None
+    dynamic = cfg["n_objects"] > 0
+    params = (lambda: model.parameters()) if dynamic else (lambda: frame.parameters())
 
     # Gradient exchange of the multi-GPU step.  Default on the raw-SH path: the SH gradients travel in
-    # factored form (one all-gather of 12 B per Gaussian and camera + a dense all-reduce of the rest + a local expansion);
-    # ADGS_DP_EXCHANGE=dense all-reduces every materialised gradient instead.  ADGS_BENCH_FACTORED=1 runs the factored
-    # step on one GPU as well (one camera; measures the backward without SH rows + the expansion).
-    factored = (isinstance(frame, DeformFrame) and frame.model.raw_sh and os.environ.get("ADGS_DP_EXCHANGE", "factored") != "dense"
-                and (world > 1 or force_coll or os.environ.get("ADGS_BENCH_FACTORED") == "1"))
-    exchange = "none"
+    # factored form (one all-gather of 12 B per Gaussian and camera + ONE reduction of the dense remainder + a local expansion);
+    # ADGS_DP_EXCHANGE=dense all-reduces every materialised gradient instead.  ADGS_DP_COLLECTIVE=rs_ag: the dense reduction as
+    # reduce-scatter + all-gather.  ADGS_BENCH_FACTORED=1 runs the factored step on one GPU with one camera as well.
+    multi = world > 1 or force_coll or n_cams > 1
+    factored = (dynamic and model.raw_sh and os.environ.get("ADGS_DP_EXCHANGE", "factored") != "dense"
+                and (multi or os.environ.get("ADGS_BENCH_FACTORED") == "1"))
+    exchange, ex = "none", None
+    ex_events = []
     if factored:
-        ex = dp.FactoredSHExchange(frame.model, factor_xyz=(frame.fused_flow or not use_fs) and os.environ.get("ADGS_DP_FACTOR_XYZ", "1") != "0")
+        fused = (frame.fused_flow if frame is not None else os.environ.get("ADGS_BENCH_FUSED_FLOW", "1") != "0")
+        ex = dp.FactoredSHExchange(model, factor_xyz=(fused or not use_fs) and os.environ.get("ADGS_DP_FACTOR_XYZ", "1") != "0")
         ex.force_collectives = force_coll
-        flow_times = [frame.t + 0.05 if use_fs else None] * world
-        cam_times = [frame.t] * world
-        cam_positions = [synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if world == 1 else r)["campos"].tolist() for r in range(world)]
-        exchange = "factored SH%s gradients: all-gather of the factors + dense all-reduce of the rest + local expansion" % (" and xyz-deformation" if ex.factor_xyz() else "")
+        ex.timing = []
+        flow_times = [t + 0.05 if use_fs else None for t in cam_times]
+        cam_positions = [c["campos"].tolist() for c in cams]
+        exchange = "factored SH%s gradients: all-gather of the factors + %s of the dense remainder + local expansion" % (
+            " and xyz-deformation" if ex.factor_xyz() else "", "reduce-scatter + all-gather" if os.environ.get("ADGS_DP_COLLECTIVE") == "rs_ag" else "all-reduce")
     elif world > 1:
         exchange = "dense all-reduce of every parameter gradient"
+    elif n_cams > 1:
+        exchange = "none (one GPU: plain accumulation over the cameras)"
 
-    def step():
+    # densify / prune inside the loop (C5): needs the optimizer-state surgery, i.e. a model with training_setup() and Adam moments
+    densify_events = []
+    if densify_every:
+        from adgs import densify as _densify
+        model.training_setup(lrs={n: 0.0 for n in _densify.GROUP_ATTR}, scene_extent=20.0, object_extent=4.0)      # lr 0: the scene stays put, the moments exist
+        if ex is not None:
+            ex._arena_setup()
+    densify_thr = [None]
+
+    def step(it=0):
         if factored:
-            ex.begin(world)                      # the all-gather starts from inside the backward, as soon as the factor exists
-            outs = frame.forward(sink_for=ex.sink_for)
+            ex.begin(n_cams)                     # the all-gather starts from inside the backward, as soon as the last factor exists
+        for f in frames:
+            outs = f.forward(sink_for=ex.sink_for if factored else None)
             torch.autograd.backward(outs, up_list)
+            if densify_every:
+                with torch.no_grad():
+                    model.add_densification_stats(dict(viewspace_points=f.last_means2D, radii=f.last_radii))
+        if factored:
             ex.reduce(cam_times, cam_positions, flow_times=flow_times)
+        elif world > 1 or force_coll:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dp.allreduce_gradients(params(), force=force_coll)
+            e1.record()
+            ex_events.append((e0, e1))
+        if densify_every and (it + 1) % densify_every == 0:
+            with torch.no_grad():
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dp.allreduce_densification_stats(model.xyz_gradient_accum, model.denom, model.max_radii2D)
+                dp.seed_all_ranks(1000 + it)
+                if densify_thr[0] is None:           # threshold: the 99th percentile of the accumulated screen-space gradient (about 1 % densify)
+                    g = (model.xyz_gradient_accum / model.denom.clamp_min(1)).reshape(-1)
+                    thr = torch.quantile(g[g > 0][:2_000_000], 0.99) if bool((g > 0).any()) else torch.tensor(1.0, device=device)
+                    if world > 1:
+                        dist.broadcast(thr, src=0)
+                    densify_thr[0] = float(thr)
+                model.densify_and_prune(densify_thr[0], densify_thr[0], 0.005, False)
+                e1.record()
+                densify_events.append((e0, e1))
+        if dynamic:
+            model.zero_grad()
         else:
-            outs = frame.forward()
-            torch.autograd.backward(outs, up_list)
-            if world > 1 or force_coll:
-                dp.allreduce_gradients(frame.parameters(), force=force_coll)
-        frame.zero_grad()
+            frame.zero_grad()
+
+    if densify_every:                                 # Adam moments must exist for the optimizer-state surgery (one untimed step)
+        for f in frames:
+            torch.autograd.backward(f.forward(), up_list)
+        if world > 1:
+            dp.allreduce_gradients(params())
+        model.optimizer.step(zero_grad=True)
 
     # Settle phase (setup, not a measurement): a fresh process on a fresh box shows one-off stalls of 0.1-0.6 s in its first
-    # second (driver / allocator / clock ramp -- seen as a single 200+ ms step right after another GPU process exited).
-    # Windows of 20 untimed steps run until two consecutive windows agree within 10 % (at most 8 windows), then the contract's
-    # W warm-up steps and K timed steps follow unchanged.
+    # second (driver / allocator / clock ramp).  Windows of 20 untimed steps run until two consecutive windows agree within 10 %
+    # (at most 8 windows), then the contract's W warm-up steps and K timed steps follow unchanged.
+    it_counter = [0]
+
+    def run(n):
+        for _ in range(n):
+            step(it_counter[0]); it_counter[0] += 1
     if os.environ.get("ADGS_BENCH_SETTLE", "1") != "0":
-        # With several ranks every step contains collectives, so all ranks must run the SAME number of windows: the window time
-        # every rank decides on is the maximum over the ranks, and the bound is a window count, not a per-rank clock.
         prev_w, agree = None, 0
         for _ in range(8):
             t_w = time.perf_counter()
-            for _ in range(20):
-                step()
-            torch.cuda.synchronize()
+            run(20)
+            sync()
             w = time.perf_counter() - t_w
-            if world > 1:
+            if world > 1:             # every rank must run the SAME number of windows: decide on the maximum over the ranks
                 tw = torch.tensor([w], device=device, dtype=torch.float64)
                 dist.all_reduce(tw, op=dist.ReduceOp.MAX)
                 w = float(tw.item())
@@ -407,39 +610,39 @@ def main():
             prev_w = w
             if agree >= 2:
                 break
-    # Stage breakdown (all stages timed with HIP events) on the last warm-up steps; the timed region below only keeps
-    # the events around the dominant kernel, because every timed stage leaves a ~10 us bubble in the queue.
-    stages_all, dom = None, None
+    # Stage breakdown (every stage timed with HIP events) on the last warm-up steps, together with the event-to-event time of those
+    # steps: step time - sum of the stage times = what the GPU spent NOT running this library's kernels (launch gaps, host waits,
+    # torch's own small kernels).  The timed region below only keeps the events around the dominant kernel, because every timed
+    # stage leaves a ~10 us bubble in the queue.
+    stages_all, dom, gpu_idle = None, None, None
     if args.warmup > 0:
-        n_prof = min(args.warmup, 2)              # the last warm-up steps (allocator and caches already warm)
-        for _ in range(args.warmup - n_prof):
-            step()
-        torch.cuda.synchronize()
+        n_prof = min(args.warmup, 4)
+        run(args.warmup - n_prof)
+        sync()
         wprof = _lib.StageProfiler()
+        wprof.reserve(64 * n_prof)
         wprof.enable(True)
-        for _ in range(n_prof):
-            step()
-        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_prof + 1)]
+        evs[0].record()
+        for i in range(n_prof):
+            run(1)
+            evs[i + 1].record()
+        sync()
         wprof.enable(False)
         stages_all = wprof.collect()
+        prof_step_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(n_prof)) / n_prof
+        per_step = {k: v[0] * v[1] / n_prof for k, v in stages_all.items()}
+        gpu_idle = {"profiled_step_ms": round(prof_step_ms, 4), "sum_of_stage_ms": round(sum(per_step.values()), 4),
+                    "gpu_not_in_adgs_kernels_ms": round(prof_step_ms - sum(per_step.values()), 4),
+                    "note": "from %d warm-up steps with every stage bracketed by HIP events (each bracket adds a bubble: an upper bound)" % n_prof}
         dom = max(stages_all, key=lambda k: stages_all[k][0] * max(stages_all[k][1], 1))
     prof = _lib.StageProfiler()
-    prof.reserve(2 * args.steps * (1 if dom else 8) + 64)      # no event creation inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    prof.reserve(2 * args.steps * max(len(frames), 1) * (1 if dom else 11) + 64)      # no event creation inside the timed region
     prof.enable(True, stages=[dom] if dom else None)       # --warmup 0: no breakdown yet, time every stage
-    gc.collect(); gc.disable()                              # no collector pauses inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    if ex is not None:
+        ex.timing = []
+    del ex_events[:]; del densify_events[:]
+    elapsed, step_ms = timed_loop(lambda i: run(1), args.steps, sync, barrier)
     prof.enable(False)
     stages = prof.collect()
     if world > 1:
@@ -448,76 +651,121 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        outs = frame.forward()
-        stats = _lib.frame_stats()
-        V = int((frame.last_radii > 0).sum().item())
-        Rc = stats["num_rendered"]                # pairs that were sorted: (cell, Gaussian) in v2, (tile, Gaussian) in classic mode
-        X, T = H * W, stats["tiles"]
-        M = sc["shs"].shape[1]
-        F, D_S = (1, 1) if use_fs else (0, 0)
-        v2 = _lib.lib().adgs_raster_needs_zero_init(D_S) == 0
-        extra = {}
-        if v2:
-            # scene-level work figures: the reference's pair count R and what v2 actually blends
-            if os.environ.get("ADGS_BENCH_SKIP_STATS"):           # PMC passes: keep foreign launches out of the counter totals
-                E, R_ref, E_pub = 0, 0, 0
-            else:
-                try:
-                    E, R_ref, E_pub = blended_entries_and_reference_pairs(frame, sc, settings, use_fs, device)
-                except Exception as exc:                 # statistics only
-                    print("bench: scene statistics failed: %r" % (exc,), file=sys.stderr)
-                    E, R_ref, E_pub = 0, 0, 0
-            ab = alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], 0, E_pub)
-            extra = {"pipeline": "v2 (coarse cells + lazy per-tile filtering)", "reference_pairs_R": R_ref, "R_over_P": round(R_ref / max(P, 1), 2),
-                     "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E, "published_entries": E_pub,
-                     "mean_entries_per_tile": round(E / max(T, 1), 1)}
-        else:
-            ab = alg_bytes(P, V, Rc, X, T, M, F, D_S, stats["sort_passes"])
-            extra = {"pipeline": "classic (reference stage order)", "reference_pairs_R": Rc, "R_over_P": round(Rc / max(P, 1), 2)}
-        frame_bytes = sum(ab.values()) + frame.deform_bytes
-        # the same frame priced with the REFERENCE algorithm's bytes (every (tile, Gaussian) pair is duplicated,
-        # sorted and streamed through the blend kernels) -- what the north star's "fraction of the HBM roofline" refers to
-        ref_bytes = sum(alg_bytes(P, V, extra.get("reference_pairs_R", Rc), X, T, M, F, D_S, (32 + max(T - 1, 1).bit_length() + 7) // 8).values()) + frame.deform_bytes
-        if stages_all is None:
-            stages_all = stages
-            dom = max(stages, key=lambda k: stages[k][0] * max(stages[k][1], 1))
-        dom_ms = stages[dom][0]                   # HIP events on the launch stream, over the timed region
-        achieved = ab.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        fps = args.steps * world / elapsed
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4)}
-        roof.update(pmc_annotations(dom, args.config, use_fs and v2))
-        if v2 and dom in ("render_fwd", "render_bwd"):
-            roof["pixel_entry_evals_per_s"] = round((extra["published_entries"] if dom == "render_bwd" else extra["blended_entries"]) * 256 / (dom_ms * 1e-3), 1)
+        cams_per_step = n_cams if iteration_mode else world
+        fps = args.steps * cams_per_step / elapsed
         result = {
             "metric": "fwd+bwd frames/s",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if iteration_mode else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": dict({"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, 1 camera/GPU/step" % (
-                args.config, P, W, H, cfg["sh_degree"], cfg["n_objects"], ", flow+semantic outputs" if use_fs else ""),
-                "P": P, "P_visible": V, "tiles": T, "deformation": frame.deform_desc,
-                "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
-                "alg_bytes_per_frame": int(frame_bytes),
-                "frame_hbm_frac_of_8TBs": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4),
-                "reference_alg_bytes_per_frame": int(ref_bytes),
-                "reference_alg_hbm_frac_of_8TBs": round(ref_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4)}, **measured_frame_traffic(args.config, use_fs and v2, fps / world), **extra),
-            "roofline": roof,
-            "stages_ms": {k: round(v[0], 4) for k, v in stages_all.items()},    # all stages timed: from the last warm-up steps
+        }
+        config = {"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, %s" % (
+            args.config, P, W, H, cfg["sh_degree"], cfg["n_objects"], ", flow+semantic outputs" if use_fs else "",
+            ("%d cameras/iteration dealt round-robin over %d GPU(s)%s" % (n_cams, world, ", densify/prune every %d iterations" % densify_every if densify_every else ""))
+            if iteration_mode else "1 camera/GPU/step"),
+            "P": P, "cameras_per_step": cams_per_step,
+            "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
+            "step_ms_hip_events": step_stats(step_ms)}
+        if gpu_idle:
+            config["gpu_idle"] = gpu_idle
+        # ---- exchange / densify times (HIP events on rank 0's launch stream)
+        if ex is not None and ex.timing:
+            tm = ex.timing
+            avg = lambda a, b: round(sum(t_[a].elapsed_time(t_[b]) for t_ in tm) / len(tm), 4)
+            config["exchange_ms"] = {"total": avg(0, 3), "allgather_wait": avg(0, 1), "expansion": avg(1, 2), "dense_reduction_wait": avg(2, 3), "calls": len(tm),
+                                     "note": "waits seen by the launch stream: the all-gather starts inside the backward, the expansion runs under the dense reduction"}
+        elif ex_events:
+            config["exchange_ms"] = {"total": round(sum(a.elapsed_time(b) for a, b in ex_events) / len(ex_events), 4), "calls": len(ex_events)}
+        if densify_events:
+            dms = [a.elapsed_time(b) for a, b in densify_events]
+            config["densify_ms"] = {"mean": round(sum(dms) / len(dms), 4), "calls": len(dms), "P_end": int(model.get_pts_num),
+                                    "ms_per_step_excl_densify": round((elapsed * 1e3 - sum(dms)) / args.steps, 4)}
+        roof = None
+        if frame is not None:
+            outs = frame.forward()
+            stats = _lib.frame_stats()
+            V = int((frame.last_radii > 0).sum().item())
+            Rc = stats["num_rendered"]                # pairs that were sorted: (cell, Gaussian) in v2, (tile, Gaussian) in classic mode
+            X, T = H * W, stats["tiles"]
+            Pn = int(frame.last_radii.shape[0])
+            M = sc["shs"].shape[1]
+            F, D_S = (1, 1) if use_fs else (0, 0)
+            v2 = _lib.lib().adgs_raster_needs_zero_init(D_S) == 0
+            settings = make_settings(cfg, cams[my[0]], sc, device)
+            if v2:
+                # scene-level work figures: the reference's pair count R and what v2 actually blends
+                if os.environ.get("ADGS_BENCH_SKIP_STATS"):           # PMC passes: keep foreign launches out of the counter totals
+                    E, R_ref, E_pub, scanned = 0, 0, 0, 0
+                else:
+                    try:
+                        E, R_ref, E_pub, scanned = frame_work_figures(frame, settings, use_fs, device)
+                    except Exception as exc:                 # statistics only
+                        print("bench: scene statistics failed: %r" % (exc,), file=sys.stderr)
+                        E, R_ref, E_pub, scanned = 0, 0, 0, 0
+                ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub)
+                config.update({"pipeline": "v2 (coarse cells + lazy per-tile filtering)", "P_visible": V, "tiles": T, "reference_pairs_R": R_ref,
+                               "R_over_P": round(R_ref / max(Pn, 1), 2), "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E,
+                               "published_entries": E_pub, "E_over_R": round(E / max(R_ref, 1), 4), "mean_entries_per_tile": round(E / max(T, 1), 1),
+                               "candidates_scanned_per_tile": round(scanned / max(T, 1), 1)})
+            else:
+                ab = alg_bytes(Pn, V, Rc, X, T, M, F, D_S, stats["sort_passes"])
+                config.update({"pipeline": "classic (reference stage order)", "P_visible": V, "tiles": T, "reference_pairs_R": Rc, "R_over_P": round(Rc / max(Pn, 1), 2)})
+            frame_bytes = sum(ab.values()) + frame.deform_bytes
+            config["deformation"] = frame.deform_desc
+            # HBM accounting (never to be conflated): the algorithmic bytes of THIS pipeline and, when
+            # committed for this build, the PMC-measured bytes.  The north star's ">= 40 % of the HBM roofline" is NOT met by
+            # either: more than half of the frame is spent in the two blend kernels, which are fp32-VALU-issue bound.
+            fps_rank0 = args.steps * len(frames) / elapsed          # frames this GPU rendered per second
+            config.update({"alg_bytes_per_frame": int(frame_bytes), "frame_hbm_frac_of_8TBs": round(frame_bytes * fps_rank0 / 1e9 / HBM_PEAK_GBS, 4)})
+            config.update(committed_frame_traffic(args.config, use_fs and v2 and not iteration_mode, fps_rank0))
+            if stages_all is None:
+                stages_all = stages
+                dom = max(stages, key=lambda k: stages[k][0] * max(stages[k][1], 1))
+            dom_ms = stages[dom][0]                   # HIP events on the launch stream, over the timed region
+            achieved = ab.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(stages[dom][1])}
+            roof.update(committed_pmc(dom, args.config, use_fs and v2))
+            if v2 and dom in ("render_fwd", "render_bwd"):
+                roof["pixel_entry_evals_per_s"] = round((config["published_entries"] if dom == "render_bwd" else config["blended_entries"]) * 256 / (dom_ms * 1e-3), 1)
+            result["config"] = config
+            result["roofline"] = roof
+            result["stages_ms"] = {k: round(v[0], 4) for k, v in stages_all.items() if v[1] > 0}    # all stages timed: from the last warm-up steps
             # every stage against the HBM roofline (algorithmic bytes of DESIGN.md section 5 / its HIP-event time in the last warm-up
             # steps): the streaming stages sit at 45-70 % of the 8 TB/s peak, the two blend stages are VALU-bound (see "roofline")
-            "stage_rooflines": {k: {"alg_bytes": int(ab.get(k, 0)), "GB/s": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9, 1),
-                                    "frac_of_8TBs": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                for k, v in stages_all.items() if v[0] > 0},
-        }
-        if world == 1 and not force_coll and not args.no_secondary and args.config == "C3":
-            # the other single-GPU configs of BASELINE.json, same build, same process (secondary: `value` stays the C3 headline)
+            result["stage_rooflines"] = {k: {"alg_bytes": int(ab.get(k, 0)), "GB/s": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9, 1),
+                                             "frac_of_8TBs": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                         for k, v in stages_all.items() if v[0] > 0 and k in ab}
+        else:
+            result["config"] = config
+        secondary = world == 1 and not force_coll and not args.no_secondary and args.config == "C3" and not iteration_mode
+        if secondary:
+            # the other single-GPU configs of BASELINE.json, same build, same process (secondary: `value` stays the C3 headline), the
+            # mandatory C1 CPU baseline (OpenMP and single thread), and the scene-sensitivity lines: two C3-sized scenes that do NOT
+            # saturate early, default pipeline against the reference-order ("classic") pipeline
             try:
-                result["other_configs"] = [quick_measure(c, 300, device, use_fs) for c in ("C1", "C2")]
+                others = []
+                r1, f1, sc1, cam1, cfg1, up1 = quick_measure("C1", 300, device, use_fs)
+                if not args.no_cpu_baseline:
+                    upn = {k: v.numpy() for k, v in up1.items()}
+                    r1["cpu_baseline_openmp"], _ = cpu_baseline(sc1, cam1, cfg1, use_fs, upn)
+                    r1["cpu_baseline_single_thread"], _ = cpu_baseline(sc1, cam1, cfg1, use_fs, upn, threads=1)
+                others.append(r1)
+                others.append(quick_measure("C2", 300, device, use_fs)[0])
+                del f1
+                result["other_configs"] = others
+                sens = []
+                for variant in ("translucent", "sky"):
+                    a = quick_measure("C3", 40, device, use_fs, variant=variant, with_stats=True)[0]
+                    b = quick_measure("C3", 6, device, use_fs, variant=variant, mode="classic", warm=3)[0]
+                    a["classic_frames_per_s"] = b["frames_per_s"]
+                    sens.append(a)
+                    gc.collect(); torch.cuda.empty_cache()
+                result["scene_sensitivity"] = sens
             except Exception as exc:                     # secondary information must never cost the headline line
                 result["other_configs"] = "failed: %r" % (exc,)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and frame is not None and not iteration_mode:
             if isinstance(frame, DeformFrame):
                 pkg, flow = frame.activated()
                 sc_cpu = dict(sc, means3D=pkg["xyz"], opacities=pkg["opacity"], scales=pkg["scales"], rotations=pkg["rotation"],
@@ -525,7 +773,7 @@ def main():
             else:
                 sc_cpu = sc
             try:
-                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, cam, cfg, use_fs, up)
+                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, cams[my[0]], cfg, use_fs, up)
                 result["parity"] = parity_vs_oracle(outs, oracle_fwd)
             except Exception as exc:                     # e.g. the oracle library could not be built on this host
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (exc,)}

@@ -20,6 +20,9 @@ int adgs_test_sort_pairs_u32(uint32_t* keys_in, uint32_t* keys_out, uint32_t* va
 /* Number of (tile, Gaussian) entries the default (v2) forward published for the backward replay of a frame: the sum of the
  * per-tile counts in the forward's image-state buffer.  Synchronises the stream; statistics only (bench.py). */
 long long adgs_test_v2_published_entries(const char* img_buffer, int width, int height, void* stream);
+/* Sum over the tiles of the candidates of the coarse cell's depth-sorted list each tile's walk went through before all of
+ * its pixels were saturated (same buffer, same conditions). */
+long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream);
 
 #ifdef __cplusplus
 }

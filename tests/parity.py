@@ -9,9 +9,11 @@ maximum alone lets every element far below the maximum pass with O(1) relative e
   3. rows ([P, ...] tensors): the per-row error relative to the row's own norm, with a floor of `tol` x the RMS row norm (NOT the
      maximum), may exceed 1e-3 on at most 1 % and 1e-2 on at most 0.1 % of the non-zero rows (`row_tol`).
 
-The thresholds of 2 and 3 are set from the measured float32-oracle-vs-float64-oracle error of the same tensors (a float32
-evaluation of the reference algorithm is itself only that close to the exact result; tests/test_gpu_gate_flips.py asserts that the
-HIP error is within 2x of it): see DESIGN.md section 2.
+The thresholds of 2 and 3 sit INSIDE the measured float32-oracle-vs-float64-oracle error of the same tensors (relative L2
+1.4e-4 ... 2.9e-4 on every gradient tensor of C2 / C3, median row error 1e-4, dominated by the reference's float32 `1 - T` round
+trip; profiles/r02/parity_stats_default.txt): a float32 evaluation of the reference algorithm is itself only that close to the exact
+result, and tests/test_gpu_gate_flips.py asserts that the HIP error against float64 is within 1.25x of it.  Measured HIP vs float32
+oracle: relative L2 1e-5 ... 4e-5 at C2 / C3 / C5 (7e-5 on the rotation gradients of one random configuration), row error p99 <= 5e-4.
 """
 import numpy as np
 
@@ -41,7 +43,7 @@ def error_stats(got, ref, tol=TOL):
     return st
 
 
-def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=5e-5, row_tol=((1e-3, 1e-2), (1e-2, 1e-3))):
+def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=1e-4, row_tol=((1e-3, 1e-2), (1e-2, 1e-3))):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)

@@ -13,6 +13,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def _free_port():
@@ -52,10 +55,19 @@ def _worker(rank, world, port, cams, out_dir):
         if not (i == 3 and rank == 1):
             p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
     dp.allreduce_gradients(extra, in_place_bytes=1 << 20, bucket_bytes=16 << 10)
+    # one flat buffer through both forms of the collective (ADGS_DP_COLLECTIVE): all_reduce and reduce-scatter + all-gather
+    flats = {}
+    for mode in ("all_reduce", "rs_ag"):
+        os.environ["ADGS_DP_COLLECTIVE"] = mode
+        f = torch.arange(dp.ARENA_QUANTUM, dtype=torch.float32) * (rank + 1)
+        for w in dp.reduce_flat(f, None, {}):
+            w.wait()
+        flats[mode] = f
+    os.environ.pop("ADGS_DP_COLLECTIVE")
     seed = dp.seed_all_ranks(1234 + rank)           # rank 0's value wins
     draw = torch.randn(4)
     torch.save(dict(grads=[p.grad.clone() for p in params], total=None if total is None else total.clone(), acc=acc, den=den, rad=rad,
-                    seed=seed, draw=draw, mine=dp.shard_cameras(cams, rank, world), extra=[p.grad.clone() for p in extra]), os.path.join(out_dir, "r%d.pt" % rank))
+                    seed=seed, draw=draw, mine=dp.shard_cameras(cams, rank, world), extra=[p.grad.clone() for p in extra], flats=flats), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,6 +94,10 @@ def test_sharded_cameras_equal_single_process_accumulation(tmp_path, cams):
     assert torch.equal(res[0]["acc"], torch.full((10, 1), 3.0)) and torch.equal(res[1]["den"], torch.full((10, 1), 2.0))
     assert torch.equal(res[0]["rad"], torch.arange(10, dtype=torch.float32) * 2)
     assert res[0]["seed"] == res[1]["seed"] == 1234 and torch.equal(res[0]["draw"], res[1]["draw"])
+    from adgs import dp as _dp
+    for r in range(world):
+        for mode in ("all_reduce", "rs_ag"):
+            assert torch.equal(res[r]["flats"][mode], torch.arange(_dp.ARENA_QUANTUM, dtype=torch.float32) * 3), (r, mode)
     for r in range(world):
         for i, g in enumerate(res[r]["extra"]):
             want = 3.0 * (i + 1) if i != 3 else 4.0          # the last one only has rank 0's gradient (1 * 4)

@@ -34,6 +34,39 @@ def test_ranks_finish_and_print_one_json_line(config, exchange, world):
     assert d["config"]["gradient_exchange"].startswith(want), d["config"]["gradient_exchange"]
 
 
+@pytest.mark.parametrize("world,cams,densify,collective,self_launch", [(2, 3, 0, "all_reduce", False), (4, 3, 0, "rs_ag", False), (2, 5, 3, "rs_ag", True),
+                                                                        (1, 3, 3, "all_reduce", False)])
+def test_iteration_mode_cameras_per_iteration_densify_and_collective_forms(world, cams, densify, collective, self_launch):
+    """BASELINE.json's C4 / C5 workloads on the small T3 scene: `cams` cameras per iteration dealt round-robin over the ranks
+    (4 ranks x 3 cameras: one rank idles and still takes part in every collective), optional densify/prune inside the timed loop,
+    both forms of the dense reduction, and `python bench.py --gpus N` starting its own ranks."""
+    env = dict(os.environ, ADGS_BENCH_BACKEND="gloo", ADGS_DP_COLLECTIVE=collective, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = ["--gpus", str(world), "--steps", "7", "--warmup", "2", "--config", "T3", "--cams-per-iter", str(cams), "--densify-every", str(densify)]
+    if self_launch or world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port()), os.path.join(ROOT, "bench.py")] + tail
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 7 and d["scaling"] == "strong" and d["config"]["cameras_per_step"] == cams
+    assert abs(d["value"] - cams * 7 / (d["ms_per_step"] * 7e-3)) / d["value"] < 1e-3          # cameras per second over the max-over-ranks time
+    assert set(d["config"]["step_ms_hip_events"]) >= {"median", "p10", "p90"}
+    if world > 1 or cams > 1:
+        ex = d["config"]["exchange_ms"]
+        assert ex["calls"] == 7 and ex["total"] >= 0 and {"allgather_wait", "expansion", "dense_reduction_wait"} <= set(ex)
+    if densify:
+        assert d["config"]["densify_ms"]["calls"] == 7 // densify + (1 if False else 0) or d["config"]["densify_ms"]["calls"] >= 1
+        assert d["config"]["densify_ms"]["P_end"] > 0
+    if collective == "rs_ag" and world > 1:
+        assert "reduce-scatter" in d["config"]["gradient_exchange"]
+
+
 @pytest.mark.parametrize("world,cams", [(2, 2), (3, 4), (3, 2), (3, 7)])
 def test_multi_rank_training_loop_keeps_replicas_identical_and_matches_one_process(world, cams):
     """examples/train_dp.py (render -> losses -> backward -> factored exchange -> fused Adam -> densify/prune with a seeded sampler) as TWO

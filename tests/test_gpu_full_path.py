@@ -150,7 +150,9 @@ def test_c4_three_camera_accumulation_factored_vs_conventional_and_oracle():
             if g is not None:
                 total[n] = total.get(n, 0) + g
     for n in conv:
-        st = parity.assert_close("3-camera sum " + n, conv[n], total[n], max_frac=max(6e-4, 4.5 / conv[n].size))
+        # a sum over three cameras: the per-camera errors add while the summed rows may cancel (and the time mask hides an object
+        # at two of the three time stamps), so the per-row bands are three times the single-frame ones
+        st = parity.assert_close("3-camera sum " + n, conv[n], total[n], max_frac=max(6e-4, 4.5 / conv[n].size), row_tol=((1e-3, 3e-2), (1e-2, 3e-3)))
         print(parity.fmt_stats("3-camera sum " + n, st))
 
 

@@ -36,7 +36,8 @@ def test_hip_is_as_close_to_the_exact_result_as_the_float32_reference(config):
     o32 = run_oracle(sc, grads=g, precision="f32")
     o64 = run_oracle(sc, grads=g, precision="f64")
     np.testing.assert_array_equal(h["radii"].cpu().numpy(), o32["radii"])
-    np.testing.assert_array_equal(o32["radii"], o64["radii"])
+    # the float64 build rounds ceil(3 sqrt(lambda)) from a double: a handful of radii per million differ by one
+    assert float((o32["radii"] != o64["radii"]).mean()) <= 2e-5 and int(np.abs(o32["radii"].astype(np.int64) - o64["radii"]).max()) <= 1
     tensors = [(k, h[k].detach().cpu().numpy(), o32[k], o64[k]) for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic")]
     tensors += [("grad_" + hk, h["grads"][hk].cpu().numpy(), o32["grads"][ok], o64["grads"][ok]) for hk, ok in PAIRS]
     lines = []
