@@ -76,8 +76,18 @@ struct BinState {
 struct GeomStateV2 {
 	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects; uint4* dupinfo;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
-	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes) {
+	// bucket binning (binning.hip): ONE block of counters the host zeroes with a single memset -- pair counts / cursors per cell,
+	// the fine-tile total slots, the device-side (pairs, chunks, overflow) words -- then the cell starts and the chunk table
+	uint32_t* counters; uint32_t* cell_start; uint4* chunks; uint32_t* counts;      // counts[ceil(P / 256)][ncells]: pairs per (preprocess workgroup, cell)
+	static constexpr size_t COUNTER_WORDS = MAX_CELLS + 2 * SCAN_AUX_SLOTS + 8;
+	uint32_t* cell_count() const { return counters; }
+	unsigned long long* bucket_fine_total() const { return reinterpret_cast<unsigned long long*>(counters + MAX_CELLS); }
+	uint32_t* d_counts() const { return counters + MAX_CELLS + 2 * SCAN_AUX_SLOTS; }
+	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes, size_t ncells = 0) {
 		Carver c(chunk); GeomStateV2 g;
+		g.counters = c.take<uint32_t>(COUNTER_WORDS);
+		g.cell_start = c.take<uint32_t>(MAX_CELLS + 1);
+		g.chunks = c.take<uint4>(MAX_CHUNKS);
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
 		g.rects = c.take<FilterRec>(P);
@@ -89,6 +99,7 @@ struct GeomStateV2 {
 		g.sh0 = c.take<float>(P * 3);
 		g.fine_total = c.take<unsigned long long>(SCAN_AUX_SLOTS);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
+		g.counts = c.take<uint32_t>(((P + 255) / 256) * std::min<size_t>(ncells, (size_t)MAX_CELLS + 1));      // last: the backward carves without it
 		if (bytes) *bytes = c.size();
 		return g;
 	}
@@ -110,7 +121,21 @@ struct ImgStateV2 {
 struct BinStateV2 {
 	uint32_t* pool_cursor; uint32_t* pool;     // first, so that the backward finds them without knowing the sizes
 	uint64_t* keys_unsorted; uint64_t* keys; uint32_t* list_unsorted; uint32_t* list; char* sort_temp;
+	// bucket binning: unsorted (cell-grouped) 16-byte records, chunk-sorted (depth, id) keys + masks, final (id, mask) entries
+	uint4* rec_unsorted; uint2* key_stage; uint32_t* mask_stage; uint2* entries;
 	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + ntiles + 1; }
+	static BinStateV2 carve_buckets(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
+		Carver c(chunk); BinStateV2 b;
+		b.pool_cursor = c.take<uint32_t>(64);
+		b.pool = c.take<uint32_t>(pool_chunks(R_fine, ntiles) * CHUNK_WORDS);
+		b.entries = c.take<uint2>(R_cells);
+		b.rec_unsorted = c.take<uint4>(R_cells);
+		b.key_stage = c.take<uint2>(R_cells);
+		b.mask_stage = c.take<uint32_t>(R_cells);
+		b.keys = nullptr; b.keys_unsorted = nullptr; b.sort_temp = nullptr; b.list = nullptr; b.list_unsorted = nullptr;
+		if (bytes) *bytes = c.size();
+		return b;
+	}
 	static BinStateV2 carve(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
 		Carver c(chunk); BinStateV2 b;
 		b.pool_cursor = c.take<uint32_t>(64);
@@ -120,6 +145,7 @@ struct BinStateV2 {
 		b.keys = c.take<uint64_t>(R_cells);
 		b.keys_unsorted = c.take<uint64_t>(R_cells);
 		b.sort_temp = c.take<char>(sort_temp_bytes(R_cells));
+		b.rec_unsorted = nullptr; b.key_stage = nullptr; b.mask_stage = nullptr; b.entries = nullptr;
 		if (bytes) *bytes = c.size();
 		return b;
 	}
@@ -187,7 +213,6 @@ static uint32_t* pinned_word() {
 // middle of the frame, and a driver-level wait (hipEventSynchronize / hipStreamSynchronize) for them was measured to fall
 // back to a ~10 ms timeout per call in the first process on a freshly booted box (frames at 11 ms instead of 1.7 ms with
 // every kernel at its normal duration).  A volatile read of host memory has no such mode.
-struct Mailbox { volatile uint32_t seq; uint32_t pad; uint32_t r_cells; uint32_t pad2; unsigned long long r_fine; };
 struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; };
 static MailboxRef* mailbox() {
 	static thread_local MailboxRef m = { nullptr, nullptr, 0 };
@@ -205,7 +230,7 @@ __global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, 
 #pragma unroll
 	for (int off = WAVE / 2; off > 0; off >>= 1) f += __shfl_xor(f, off, WAVE);
 	if (threadIdx.x == 0) {
-		box->r_cells = *total_cells; box->r_fine = f;
+		box->r_cells = *total_cells; box->r_fine = f; box->oversize = 0u; box->n_groups = 0u;
 		__threadfence_system();
 		box->seq = seq;                       // published last: the host spins on it
 	}
@@ -297,7 +322,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
 		const size_t ncells = (size_t)cgx * cgy;
 		size_t gb = 0, ib = 0;
-		GeomStateV2::carve(nullptr, P, &gb);
+		GeomStateV2::carve(nullptr, P, &gb, ncells);
 		char* gch = geometryBuffer(geometryUser, gb);
 		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
 		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);                    // rows of wave tiles
@@ -305,7 +330,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ImgStateV2::carve(nullptr, npix, wtiles, ncells, &ib);
 		char* ich = imageBuffer(imageUser, ib);
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
-		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr);
+		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, ncells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
 
 		PreprocessArgs pa;
@@ -322,26 +347,50 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.rects = geom.rects; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
+		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs, 4 launches) unless the cell grid has more than
+		// MAX_CELLS cells or ADGS_BINNING=sort asks for the device-wide radix sort of (cell | depth) keys.
+		// (A cell of more than ~4 chunks -- tens of thousands of pairs per cell, C5's 3 M Gaussians on 70 cells -- pays k - 1 rank
+		// searches per entry in the merge; measured crossover against the device-wide sort at about 4 chunks per cell, so the
+		// previous frames' pair count picks the path unless ADGS_BINNING=bucket|sort forces one.)
+		const char* binning_env = getenv("ADGS_BINNING");
+		const std::string binning_mode = binning_env ? binning_env : "";
+		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
+			(binning_mode == "bucket" || g_hint_cells.load() <= (size_t)4 * GS_NMAX * ncells);
+		pa.bucket_count = nullptr;
+		if (buckets) {
+			ADGS_HIP_CHECK(hipMemsetAsync(geom.bucket_fine_total(), 0, (2 * SCAN_AUX_SLOTS + 8) * sizeof(uint32_t), stream));      // fine-tile slots + device words
+			pa.bucket_count = geom.counts; pa.fine_total = geom.bucket_fine_total();
+		}
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream) != 0) return -1; }
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
-		ADGS_LAUNCH_CHECK(debug, stream);
-		{
-			StageTimer t(ST_SCAN, stream);
-			// offsets of the (cell, Gaussian) pairs; the fine-tile bound of the chunk pool only needs its total
-			if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
-		}
 		ADGS_LAUNCH_CHECK(debug, stream);
 		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning
 		// buffer.  Instead of draining the stream for them (the reference's blocking cudaMemcpy,
 		// rasterizer_impl.cu:288), binning + sort + ranges are enqueued against a speculative capacity
 		// (previous frames' counts + 25%) with the exact count read on the device; the host then waits only
-		// for the scan to finish -- the GPU keeps working on the speculative launches meanwhile -- and
+		// for the totals to be published -- the GPU keeps working on the speculative launches meanwhile -- and
 		// re-runs them with exact sizes in the rare case the capacity was too small.
 		MailboxRef* mb = mailbox();
 		if (!mb) { set_error("hipHostMalloc (mapped) failed"); return -1; }
 		const uint32_t seq = mb->next_seq++;
-		hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(WAVE), 0, stream, (const uint32_t*)(geom.offsets + P), (const unsigned long long*)geom.fine_total, mb->dev, seq);
-		ADGS_HIP_CHECK(hipGetLastError());
+		if (buckets) {
+			StageTimer t(ST_SCAN, stream);
+			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
+			CellScanArgs sa;
+			sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
+			sa.chunks = geom.chunks; sa.max_chunks = (uint32_t)MAX_CHUNKS; sa.d_counts = geom.d_counts();
+			sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
+			if (launch_cell_scan(sa, stream) != 0) return -1;
+		} else {
+			{
+				StageTimer t(ST_SCAN, stream);
+				// offsets of the (cell, Gaussian) pairs; the fine-tile bound of the chunk pool only needs its total
+				if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
+			}
+			hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(WAVE), 0, stream, (const uint32_t*)(geom.offsets + P), (const unsigned long long*)geom.fine_total, mb->dev, seq);
+			ADGS_HIP_CHECK(hipGetLastError());
+		}
+		ADGS_LAUNCH_CHECK(debug, stream);
 		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
 		const bool speculate = env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99;
 		const int bit = (int)higher_msb((uint32_t)ncells);
@@ -352,6 +401,25 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const int mask_shift = (2 * cell_tiles + bit <= 32 && env_int("ADGS_KEY_MASKS", 1) != 0) ? 32 + bit : -1;
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
+			if (buckets) {
+				BinStateV2::carve_buckets(nullptr, cells, fine * sub, wtiles, &bb);
+				char* bch = binningBuffer(binningUser, bb);
+				if (!bch) { set_error("binning allocator returned NULL"); return -1; }
+				bin = BinStateV2::carve_buckets(bch, cells, fine * sub, wtiles, nullptr);
+				if (cells == 0) { ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream)); return 0; }     // cell_ranges: all (0, 0) from bucket_scan
+				const uint32_t cap = (uint32_t)std::min<size_t>(cells, 0xffffffffu);
+				{ StageTimer t(ST_DUPLICATE, stream);
+				  if (launch_cell_scatter(P, geom.dupinfo, geom.cell_start, geom.counts, bin.rec_unsorted, cap, cell_tiles, cgx, (int)ncells, bin.pool_cursor, stream) != 0) return -1; }
+				ADGS_LAUNCH_CHECK(debug, stream);
+				ChunkSortArgs ga;
+				ga.chunks = geom.chunks; ga.d_counts = geom.d_counts(); ga.rec_u = bin.rec_unsorted; ga.key_s = bin.key_stage; ga.mask_s = bin.mask_stage;
+				ga.ent_f = bin.entries; ga.cap = cap;
+				const size_t grid = std::min<size_t>((size_t)MAX_CHUNKS, ncells + cells / GS_NMAX + 1);      // every cell: full chunks + one partial
+				{ StageTimer t(ST_SORT, stream); if (launch_chunk_sort(ga, (uint32_t)grid, stream) != 0) return -1; }
+				{ StageTimer t(ST_RANGES, stream); if (launch_chunk_merge(ga, (uint32_t)grid, stream) != 0) return -1; }      // "tile_ranges" slot: the merge of multi-chunk cells
+				ADGS_LAUNCH_CHECK(debug, stream);
+				return 0;
+			}
 			BinStateV2::carve(nullptr, cells, fine * sub, wtiles, &bb);        // a Gaussian can enter both halves of a tile
 			char* bch = binningBuffer(binningUser, bb);
 			if (!bch) { set_error("binning allocator returned NULL"); return -1; }
@@ -373,13 +441,22 @@ static int raster_forward_impl(const ShSource* sh_src,
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
 		};
-		if (speculate && enqueue_binning(cap_cells, cap_fine, geom.offsets + P) != 0) return -1;
+		if (speculate && enqueue_binning(cap_cells, cap_fine, buckets ? nullptr : geom.offsets + P) != 0) return -1;
 		if (wait_mailbox(mb, seq, stream) != 0) return -1;
 		const size_t R_cells = mb->host->r_cells, R_fine = (size_t)mb->host->r_fine;
-		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu\n", P, ncells, R_cells, R_fine);
+		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu buckets=%d chunks=%u overflow=%u\n", P, ncells, R_cells, R_fine,
+			(int)buckets, mb->host->n_groups, mb->host->oversize);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
 		ADGS_DBG_STOP(0)
-		if (!speculate || R_cells > cap_cells || R_fine > cap_fine) {
+		if (buckets && mb->host->oversize) {
+			// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
+			// per-Gaussian pair offsets first
+			buckets = false;
+			ADGS_HIP_CHECK(hipMemsetAsync(geom.fine_total, 0, SCAN_AUX_SLOTS * sizeof(unsigned long long), stream));
+			{ StageTimer t(ST_SCAN, stream);
+			  if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1; }
+			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
+		} else if (!speculate || R_cells > cap_cells || R_fine > cap_fine) {
 			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
 		}
 		ADGS_DBG_STOP(3)
@@ -391,7 +468,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		}
 		RenderV2FwdArgs ra;
 		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
-		ra.cell_keys = bin.keys; ra.mask_shift = mask_shift;
+		ra.cell_keys = bin.keys; ra.mask_shift = mask_shift; ra.cell_entries = buckets ? bin.entries : nullptr;
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
 		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
@@ -402,8 +479,9 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
 		{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
-		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
-		g_stats.reserved = 0; g_stats.fine_pairs = (int64_t)R_fine;
+		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = buckets ? 32 : 32 + bit;
+		g_stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
+		g_stats.reserved = buckets ? 1 : 0; g_stats.fine_pairs = (int64_t)R_fine;       // reserved: 1 = bucket binning (the sort passes stay inside the CUs)
 		return (int)R_cells;
 	}
 
@@ -430,6 +508,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
 	pa.rects = nullptr; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
+	pa.bucket_count = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);

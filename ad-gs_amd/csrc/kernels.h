@@ -25,6 +25,10 @@ struct PreprocessArgs {
 	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
 	float* gacc;                     // v2: [P][GACC_STRIDE] accumulator lines, zeroed here for every visible Gaussian (nullptr: skip)
 	unsigned long long* fine_total;  // v2: reset here; the scan pass adds up fine_touched into it
+	// v2 bucket binning (binning.hip; bucket_count == nullptr: sort-based binning): every visible Gaussian is counted into the
+	// coarse cells it covers -- bucket_count[workgroup][cell], every entry written -- and fine_total is accumulated here (the host
+	// zeroed it)
+	uint32_t* bucket_count;
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
@@ -87,12 +91,42 @@ constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
 constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumulators per Gaussian
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
+// ---- bucket binning (binning.hip) ----
+constexpr int MAX_CELLS = 1024;         // coarse cells one cell_scan workgroup (and one LDS histogram) handles
+constexpr int GS_NMAX = 8192;           // entries one chunk_sort workgroup sorts inside its CU
+constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
+// pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, pad0, pad1; };
+struct CellScanArgs {
+	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
+	uint32_t* cell_start;               // [ncells + 1]
+	uint2* cell_ranges; int ncells;
+	uint4* chunks; uint32_t max_chunks; // sort chunks: (start, end, cell start, cell end) in list positions
+	uint32_t* d_counts;                 // [0] pairs, [1] chunks, [2] overflow flag (more chunks than the table holds)
+	const unsigned long long* fine_total;
+	Mailbox* box; uint32_t seq;
+};
+int launch_cell_scan(const CellScanArgs& a, hipStream_t stream);
+int launch_cell_colscan(uint32_t* counts, int nblocks, int ncells, uint32_t* cell_count, hipStream_t stream);
+int launch_cell_scatter(int P, const uint4* dupinfo, const uint32_t* cell_start, const uint32_t* counts, uint4* rec_u, uint32_t cap,
+	int cell_tiles, int cgx, int ncells, uint32_t* pool_cursor, hipStream_t stream);
+struct ChunkSortArgs {
+	const uint4* chunks; const uint32_t* d_counts;
+	const uint4* rec_u;                 // unsorted (cell-grouped) records (depth bits, id, mask, -)
+	uint2* key_s; uint32_t* mask_s;     // chunk-sorted (depth, id) keys + masks of the multi-chunk cells
+	uint2* ent_f;                       // final (id, mask) entries
+	uint32_t cap;
+};
+int launch_chunk_sort(const ChunkSortArgs& a, uint32_t grid, hipStream_t stream);
+int launch_chunk_merge(const ChunkSortArgs& a, uint32_t grid, hipStream_t stream);
+
 int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, int mask_shift, hipStream_t stream);
 
 struct RenderV2FwdArgs {
 	const uint2* cell_ranges; const uint32_t* cell_list; const FilterRec* rects; const Splat* splats;
 	const uint64_t* cell_keys; int mask_shift;   // sorted keys with the rectangle-coverage masks at bit mask_shift (-1: keys carry no masks)
+	const uint2* cell_entries;                   // bucket binning: (id, mask) per list entry (then cell_keys / cell_list == nullptr)
 	int W, H, gx, gy, cell_tiles, cgx;      // gy: rows of WAVE tiles (16 x 4*ppl pixels), not of 16x16 tiles
 	int ppl;                                // pixels per lane: 4 or 2 (v2_pixels_per_lane)
 	bool has_color, has_flow, has_sem;

@@ -87,10 +87,17 @@ __device__ __forceinline__ float sh_channel(int deg, float sh0c, const float* sh
 // stride: conflict-free per-thread reads) instead of 64 scattered 192-byte rows per wave access.
 constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
 
+struct PreOut { uint32_t nfine; uint32_t zbits; };     // per Gaussian: fine tiles covered, view-space depth bits (0: not visible)
+
+template <bool STAGED>
+__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell);
+
 template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	extern __shared__ float s_sh[];
+	__shared__ uint32_t s_cell[MAX_CELLS];     // bucket binning: this workgroup's (cell, Gaussian) pair count per coarse cell
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a.bucket_count) for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) s_cell[c] = 0u;
 	if (STAGED) {
 		const int tid = threadIdx.x, base = blockIdx.x * 256, nvalid = min(256, a.P - base);
 		if (a.sh_src.scene_dc) {
@@ -104,10 +111,34 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 			}
 		}
-		__syncthreads();
 	}
-	if (a.rects && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
-	if (idx >= a.P) return;
+	if (STAGED || a.bucket_count) __syncthreads();
+	if (a.rects && !a.bucket_count && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
+	PreOut o = { 0u, 0u };
+	if (idx < a.P) o = preprocess_one<STAGED>(a, idx, s_sh, s_cell);
+	if (a.bucket_count) {
+		// bucket binning (binning.hip): no scan pass runs.  The pair counts per coarse cell were summed in LDS (the Gaussians of an
+		// object are neighbours in index AND on the screen: global atomics serialise on a few hot cells) and go out as this
+		// workgroup's row of the counts matrix; the fine-tile total (capacity bound of the chunk pool) is one atomic per workgroup.
+		__shared__ uint32_t s_red[256 / WAVE];
+		uint32_t nf = o.nfine;
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) nf += __shfl_xor(nf, off, WAVE);
+		if ((threadIdx.x & (WAVE - 1)) == 0) s_red[threadIdx.x / WAVE] = nf;
+		__syncthreads();
+		for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) a.bucket_count[(size_t)blockIdx.x * (a.cgx * a.cgy) + c] = s_cell[c];
+		if (threadIdx.x == 0) {
+			uint32_t n = 0;
+#pragma unroll
+			for (int w = 0; w < 256 / WAVE; w++) n += s_red[w];
+			if (n) atomicAdd(a.fine_total + (blockIdx.x & (SCAN_AUX_SLOTS - 1)), (unsigned long long)n);
+		}
+	}
+}
+
+template <bool STAGED>
+__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell) {
+	const PreOut none = { 0u, 0u };
 	if (idx == 0) {       // sentinels: the exclusive scans over P + 1 entries leave the totals at [P]
 		a.tiles_touched[a.P] = 0;
 		if (a.rects) a.fine_touched[a.P] = 0;
@@ -120,7 +151,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	const float* V = a.view; const float* PJ = a.proj;
 	// near cull only (auxiliary.h:154)
 	const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
-	if (vz <= 0.2f) return;
+	if (vz <= 0.2f) return none;
 	const float vx = V[0] * px + V[4] * py + V[8] * pz + V[12];
 	const float vy = V[1] * px + V[5] * py + V[9] * pz + V[13];
 	const float hx = PJ[0] * px + PJ[4] * py + PJ[8] * pz + PJ[12];
@@ -157,7 +188,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	const float cxx = cov.v[0][0] + 0.3f, cxy = cov.v[0][1], cyy = cov.v[1][1] + 0.3f;
 
 	const float det = cxx * cyy - cxy * cxy;
-	if (det == 0.0f) return;
+	if (det == 0.0f) return none;
 	const float det_inv = 1.f / det;
 	const float conx = cyy * det_inv, cony = -cxy * det_inv, conz = cxx * det_inv;
 	const float mid = 0.5f * (cxx + cyy);
@@ -167,7 +198,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	const float pix = ndc2pix(projx, a.W), piy = ndc2pix(projy, a.H);
 	uint32_t minx, miny, maxx, maxy;
 	tile_rect(pix, piy, (int)my_radius, a.gx, a.gy, minx, miny, maxx, maxy);
-	if ((maxx - minx) * (maxy - miny) == 0) return;
+	if ((maxx - minx) * (maxy - miny) == 0) return none;
 
 	Splat s;
 	s.x = pix; s.y = piy; s.ca = conx; s.cb = cony; s.cc = conz; s.opacity = a.opacities[idx];
@@ -223,7 +254,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	}
 	if (!a.rects) {
 		a.tiles_touched[idx] = (maxy - miny) * (maxx - minx);
-		return;
+		return none;
 	}
 	// ---- v2: shrink the reference rectangle to the tiles on which alpha can reach 1/255.
 	// alpha = opacity * exp(-0.5 d^T Q d) >= 1/255  <=>  d^T Q d <= tau = 2 ln(255 opacity); the
@@ -255,11 +286,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	if (nfine) {
 		const uint32_t c0x = sminx / a.cell_tiles, c1x = (smaxx - 1) / a.cell_tiles, c0y = sminy / a.cell_tiles, c1y = (smaxy - 1) / a.cell_tiles;
 		ncell = (c1x - c0x + 1) * (c1y - c0y + 1);
+		if (a.bucket_count) {       // bucket binning: count this Gaussian into every coarse cell it covers
+			for (uint32_t y = c0y; y <= c1y; y++)
+				for (uint32_t x = c0x; x <= c1x; x++) atomicAdd(s_cell + y * a.cgx + x, 1u);
+		}
 	}
 	a.dupinfo[idx] = make_uint4(sminx | (sminy << 16), smaxx | (smaxy << 16), __float_as_uint(vz), 0u);   // all the binning kernel needs, 16 B
 	a.tiles_touched[idx] = ncell;
 	a.fine_touched[idx] = nfine;     // scanned on the host side of the pipeline: chunk-pool capacity bound
+	PreOut o; o.nfine = nfine; o.zbits = __float_as_uint(vz);
+	return o;
 }
+
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ V, uint8_t* __restrict__ present) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;

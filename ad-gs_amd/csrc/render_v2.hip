@@ -128,11 +128,17 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 	// stage-1 state: candidates whose rectangle holds this tile (ring buffer), the prefetched next batch of the key stream
 	uint32_t chead = 0, ccount = 0;
-	const bool masks = a.mask_shift >= 0;
-	const int row_bit = a.mask_shift + (int)(ty16 % a.cell_tiles), col_bit = a.mask_shift + a.cell_tiles + (int)(tx % a.cell_tiles);
-	unsigned long long pf_key = 0ull;
+	const bool masks = a.cell_entries != nullptr || a.mask_shift >= 0;
+	const int row_bit = (int)(ty16 % a.cell_tiles), col_bit = a.cell_tiles + (int)(tx % a.cell_tiles);
+	// a candidate = (Gaussian id, rectangle-coverage mask): one 8-byte entry (bucket binning) or the list id + the bits above
+	// (cell | depth) of its sort key
+	auto load_cand = [&](uint32_t e, uint32_t& id, uint32_t& mask) {
+		if (a.cell_entries) { const uint2 v = a.cell_entries[e]; id = v.x; mask = v.y; }
+		else { id = a.cell_list[e]; mask = a.mask_shift >= 0 ? (uint32_t)(a.cell_keys[e] >> a.mask_shift) : 0u; }
+	};
+	uint32_t pf_key = 0u;
 	uint32_t pf_id = 0;
-	if (pos + lane < range.y) { pf_key = a.cell_keys[pos + lane]; pf_id = a.cell_list[pos + lane]; }
+	if (pos + lane < range.y) load_cand(pos + lane, pf_id, pf_key);
 
 	while (true) {
 		bool mine_done = true;
@@ -147,14 +153,14 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		// holds the tile go on to stage 2, 64 at a time: gather of the 32-byte filter record + the exact ellipse test.
 		while (qcount < WAVE && (pos < range.y || ccount > 0)) {
 			while (ccount < WAVE && pos < range.y) {
-				const unsigned long long key = pf_key;
+				const uint32_t key = pf_key;
 				const uint32_t id = pf_id;
 				const bool have = pos + lane < range.y;
 				{
 					const uint32_t e2 = pos + WAVE + lane;
-					if (e2 < range.y) { pf_key = a.cell_keys[e2]; pf_id = a.cell_list[e2]; }
+					if (e2 < range.y) load_cand(e2, pf_id, pf_key);
 				}
-				const bool rp = have && (!masks || (((key >> row_bit) & (key >> col_bit)) & 1ull));
+				const bool rp = have && (!masks || (((key >> row_bit) & (key >> col_bit)) & 1u));
 				const uint64_t m = __ballot(rp);
 				if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
 				ccount += __popcll(m);

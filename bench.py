@@ -55,16 +55,18 @@ def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     }
 
 
-def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None):
+def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None, bucket=False):
     """Algorithmic bytes per launch of the default (v2, coarse-binned) pipeline -- DESIGN.md section 5.
-    Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries blended, E_pub = entries the backward replays."""
+    Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries blended, E_pub = entries the backward replays.
+    bucket: bucket binning (binning.hip) -- "scan" = the one-workgroup bucket scan (16384 counters in, starts + groups out),
+    "duplicate_keys" = the scatter (16 B per Gaussian in, 12 B per pair out), "radix_sort" = the in-CU group sort (12 B per pair
+    in, 8 B out: the radix passes never leave the CU), no range pass."""
     out = X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4)
+    binning = ({"scan": 16384 * 4 * 3, "duplicate_keys": P * 16 + Rc * 12, "radix_sort": Rc * 20, "tile_ranges": 0} if bucket else
+               {"scan": P * 12, "duplicate_keys": V * (8 + 4) + Rc * 12, "radix_sort": passes * Rc * 24 + Rc * 8, "tile_ranges": Rc * 8})
     return {
         "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 32 + 24 + 1 + 64),
-        "scan": P * 12,
-        "duplicate_keys": V * (8 + 4) + Rc * 12,
-        "radix_sort": passes * Rc * 24 + Rc * 8,
-        "tile_ranges": Rc * 8,
+        **binning,
         "render_fwd": E * (4 + 64 + 4) + out,
         "render_bwd": (E if E_pub is None else E_pub) * (4 + 64 + 56) + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),
         "preprocess_bwd": P * (12 + 12 + 16 + 4 + 12 * M) + V * (64 + 32 + 24 + 1) + V * 64 + P * (12 + 12 * M + 12 + 16 + 12 + 16 + 4 + 12 + 4 + 24),
@@ -566,9 +568,10 @@ def main():
                 e0.record()
                 dp.allreduce_densification_stats(model.xyz_gradient_accum, model.denom, model.max_radii2D)
                 dp.seed_all_ranks(1000 + it)
-                if densify_thr[0] is None:           # threshold: the 99th percentile of the accumulated screen-space gradient (about 1 % densify)
+                if densify_thr[0] is None:           # threshold: the 99.9th percentile of the accumulated screen-space gradient, so that
+                    # every densify step clones / splits about 0.1 % of the Gaussians and the scene keeps its size over the run
                     g = (model.xyz_gradient_accum / model.denom.clamp_min(1)).reshape(-1)
-                    thr = torch.quantile(g[g > 0][:2_000_000], 0.99) if bool((g > 0).any()) else torch.tensor(1.0, device=device)
+                    thr = torch.quantile(g[g > 0][:2_000_000], 0.999) if bool((g > 0).any()) else torch.tensor(1.0, device=device)
                     if world > 1:
                         dist.broadcast(thr, src=0)
                     densify_thr[0] = float(thr)
@@ -702,8 +705,9 @@ def main():
                     except Exception as exc:                 # statistics only
                         print("bench: scene statistics failed: %r" % (exc,), file=sys.stderr)
                         E, R_ref, E_pub, scanned = 0, 0, 0, 0
-                ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub)
-                config.update({"pipeline": "v2 (coarse cells + lazy per-tile filtering)", "P_visible": V, "tiles": T, "reference_pairs_R": R_ref,
+                ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub, bucket=bool(stats.get("bucket_binning")))
+                config.update({"pipeline": "v2 (coarse cells, %s, lazy per-tile filtering)" % ("bucket binning: per-cell depth buckets sorted inside one CU each"
+                                                                                                if stats.get("bucket_binning") else "device-wide radix sort of (cell | depth) keys"), "P_visible": V, "tiles": T, "reference_pairs_R": R_ref,
                                "R_over_P": round(R_ref / max(Pn, 1), 2), "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E,
                                "published_entries": E_pub, "E_over_R": round(E / max(R_ref, 1), 4), "mean_entries_per_tile": round(E / max(T, 1), 1),
                                "candidates_scanned_per_tile": round(scanned / max(T, 1), 1)})

@@ -61,7 +61,7 @@ def test_iteration_mode_cameras_per_iteration_densify_and_collective_forms(world
         ex = d["config"]["exchange_ms"]
         assert ex["calls"] == 7 and ex["total"] >= 0 and {"allgather_wait", "expansion", "dense_reduction_wait"} <= set(ex)
     if densify:
-        assert d["config"]["densify_ms"]["calls"] == 7 // densify + (1 if False else 0) or d["config"]["densify_ms"]["calls"] >= 1
+        assert d["config"]["densify_ms"]["calls"] >= 7 // densify
         assert d["config"]["densify_ms"]["P_end"] > 0
     if collective == "rs_ag" and world > 1:
         assert "reduce-scatter" in d["config"]["gradient_exchange"]

@@ -1,0 +1,104 @@
+"""Bucket binning (ad-gs_amd/csrc/binning.hip: per-cell lists, chunks of <= 8192 entries sorted inside one CU each, chunks of a
+cell merged by rank) against the oracle and against the device-wide radix-sort binning it replaces (ADGS_BINNING=sort), on the
+cases that stress it: exact depth ties (the reference orders equal depths by Gaussian index: stable sort of keys emitted in index
+order, rasterizer_impl.cu:70-111, 310-315) inside a chunk and across chunks, extreme depth ranges, cells of many chunks."""
+import numpy as np
+import pytest
+import torch
+
+from adgs import _lib, synthetic
+from tests.test_gpu_raster import compare, run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats():
+    return _lib.frame_stats()
+
+
+@pytest.fixture(autouse=True)
+def _force_bucket_binning(monkeypatch):
+    """The library picks bucket or sort binning from the previous frames' pair count (cells of many chunks favour the sort);
+    these tests exercise the bucket path on purpose, whatever ran before them."""
+    monkeypatch.setenv("ADGS_BINNING", "bucket")
+
+
+def test_default_is_bucket_binning_and_equals_sort_binning_bit_for_bit(monkeypatch):
+    """Both binnings hand the blend kernels the same per-cell (depth, index) order, so the forward images are bit-identical."""
+    sc = synthetic.make_scene(60000, 640, 400, 620.0, seed=41, n_objects=3)
+    g = synthetic.make_upstream_grads(sc, 41)
+    a = run_hip(sc, grads=g)
+    assert _stats()["bucket_binning"] == 1
+    monkeypatch.setenv("ADGS_BINNING", "sort")
+    b = run_hip(sc, grads=g)
+    assert _stats()["bucket_binning"] == 0
+    for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic", "radii"):
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("levels,P", [(8, 20000), (1, 6000), (3, 40000)])
+def test_exact_depth_ties_are_ordered_by_gaussian_index(levels, P):
+    """Only `levels` distinct depths: long runs of equal sort keys inside every bucket."""
+    sc = synthetic.make_scene(P, 320, 200, 300.0, seed=42, scale_mult=0.01)
+    z = sc["means3D"][:, 2]
+    vis = z > 0.5
+    q = torch.linspace(3.0, 40.0, levels)
+    znew = q[torch.randint(0, levels, (P,), generator=torch.Generator().manual_seed(1))]
+    sc["means3D"][vis, 0] *= (znew / z)[vis]
+    sc["means3D"][vis, 1] *= (znew / z)[vis]
+    sc["means3D"][vis, 2] = znew[vis]
+    sc["flow_points"] = sc["means3D"].clone()
+    sc["opacities"] = (sc["opacities"] * 0.5 + 0.3).contiguous()          # order matters: semi-opaque overlapping Gaussians
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 42))
+    assert _stats()["bucket_binning"] == 1
+
+
+def test_sort_binning_still_matches_the_oracle(monkeypatch):
+    monkeypatch.setenv("ADGS_BINNING", "sort")
+    sc = synthetic.make_scene(20000, 320, 200, 300.0, seed=49, n_objects=2)
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 49))
+    assert _stats()["bucket_binning"] == 0
+
+
+def test_one_depth_for_everything_ties_across_chunks():
+    """60 000 Gaussians at z = 5 exactly over a 2-cell image: every sort key of a cell is equal, the tie runs are as long as the
+    chunks (8192) and continue across the chunk boundaries, so the whole order comes from the index tie-break of the chunk sort
+    and of the merge."""
+    P = 60000
+    sc = synthetic.make_scene(P, 256, 128, 250.0, seed=43, scale_mult=0.004, near_frac=0.0)
+    z = sc["means3D"][:, 2].clone()
+    sc["means3D"][:, 0] *= 5.0 / z
+    sc["means3D"][:, 1] *= 5.0 / z
+    sc["means3D"][:, 2] = 5.0
+    sc["scales"] = (sc["scales"] * (5.0 / z)[:, None]).contiguous()
+    sc["flow_points"] = sc["means3D"].clone()
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 43))
+    st = _stats()
+    assert st["bucket_binning"] == 1 and st["num_rendered"] > 2 * 8192
+
+
+def test_extreme_depth_ranges():
+    """Depths 10^4 times larger than usual, then depths just behind the 0.2 near plane (the sort runs on the raw depth bits)."""
+    near = synthetic.make_scene(8000, 200, 136, 150.0, seed=45)
+    compare(near, grads=synthetic.make_upstream_grads(near, 45))
+    far = synthetic.make_scene(8000, 200, 136, 150.0, seed=46)
+    far["means3D"] = (far["means3D"] * 1.0e4).contiguous()
+    far["scales"] = (far["scales"] * 1.0e4).contiguous()
+    far["flow_points"] = far["means3D"].clone()
+    compare(far, grads=synthetic.make_upstream_grads(far, 46))
+    compare(near, grads=synthetic.make_upstream_grads(near, 45))
+    tiny = synthetic.make_scene(8000, 200, 136, 150.0, seed=47)
+    s = 0.3 / 2.0
+    tiny["means3D"] = (tiny["means3D"] * s).contiguous()                 # depths 0.3 ... 12: many just behind the 0.2 near plane
+    tiny["scales"] = (tiny["scales"] * s).contiguous()
+    tiny["flow_points"] = tiny["means3D"].clone()
+    compare(tiny, grads=synthetic.make_upstream_grads(tiny, 47))
+
+
+def test_cells_with_several_chunks():
+    """One coarse cell with ~40 000 entries: five or more chunks per cell, merged by rank."""
+    sc = synthetic.make_scene(45000, 128, 128, 120.0, seed=48, scale_mult=0.003, near_frac=0.0)
+    sc["opacities"] = (sc["opacities"] * 0.08 + 0.01).contiguous()       # translucent: the tiles walk the whole list
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 48))
+    st = _stats()
+    assert st["bucket_binning"] == 1 and st["num_rendered"] > 3 * 8192

