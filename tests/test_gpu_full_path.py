@@ -151,6 +151,9 @@ def test_c4_three_camera_accumulation_factored_vs_conventional_and_oracle():
             if g is not None:
                 total[n] = total.get(n, 0) + g
     for n in conv:
+        if n not in total:                       # a parameter the configuration does not use (obj_rotation under the quaternion spline)
+            assert not np.any(conv[n]), n
+            continue
         # a sum over three cameras: the per-camera errors add while the summed rows may cancel (and the time mask hides an object
         # at two of the three time stamps), so the per-row bands are three times the single-frame ones
         st = parity.assert_close("3-camera sum " + n, conv[n], total[n], max_frac=max(6e-4, 4.5 / conv[n].size), row_tol=((1e-3, 3e-2), (1e-2, 3e-3)))
