@@ -198,6 +198,7 @@ class _DeformPkgFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *tensors):
         t, order_args, use_time_mask, want, flow_t = meta[:5]
+        skip_scene = bool(meta[6]) if len(meta) > 6 else False
         ts = [None if x is None else x.contiguous() for x in tensors]
         named = dict(zip(_PTRS, ts))
         dev = named["scene_xyz"].device
@@ -207,7 +208,7 @@ class _DeformPkgFn(torch.autograd.Function):
         N = Ns + No
         M = 1 + named["scene_shs_rest"].shape[1]
         p = DeformParams()
-        p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)), float(t)
+        p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)) | (2 if skip_scene else 0), float(t)      # bit 1: ADGS_DEFORM_SKIP_SCENE
         for n in _PTRS:
             setattr(p, n, _dp(named[n]))
         # n_params is the parameter tensor's last dimension even when it has no rows (a model without object Gaussians)
@@ -244,13 +245,14 @@ class _DeformPkgFn(torch.autograd.Function):
     def backward(ctx, g_xyz, g_rot, g_shs, g_op, g_sc, g_flow):
         t, order_args, use_time_mask, want, flow_t = ctx.meta[:5]
         arena = ctx.meta[5] if len(ctx.meta) > 5 else None
+        skip_scene = bool(ctx.meta[6]) if len(ctx.meta) > 6 else False
         saved = list(ctx.saved_tensors)
         ts = [saved.pop(0) if pr else None for pr in ctx.present]
         named = dict(zip(_PTRS, ts))
         dev = named["scene_xyz"].device
         Ns, No, M = ctx.dims
         p = DeformParams()
-        p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)), float(t)
+        p.Ns, p.No, p.sh_coeffs, p.use_time_mask, p.t = Ns, No, M, int(bool(use_time_mask)) | (2 if skip_scene else 0), float(t)
         for n in _PTRS:
             setattr(p, n, _dp(named[n]))
         up = {}
@@ -278,6 +280,8 @@ class _DeformPkgFn(torch.autograd.Function):
             src = named[n]
             has_up = up[dep[n]] is not None or (dep[n] == "xyz" and up["flow"] is not None)
             need = (src is not None and src.numel() > 0 and ctx.needs_input_grad[1 + _PTRS.index(n)] and has_up)
+            if skip_scene and n in ("scene_xyz", "scene_rotation", "scene_opacity", "scene_scaling"):
+                need = False              # these gradients come from the rasterizer's backward (raw scene geometry)
             if not need or (xyz_factored and n == "xyz_deform_param"):
                 grads[n] = None
             elif n == "background_deform_param":          # accumulated with atomics
@@ -298,23 +302,37 @@ class _DeformPkgFn(torch.autograd.Function):
         return (None,) + tuple(grads.get(n) for n in _PTRS)
 
 
-def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales"), raw_sh=False, flow_time=None):
+def raw_scene_ok(model):
+    """The raw-scene path (the rasterizer's preprocess applies exp / normalize / sigmoid to the raw scene tensors itself) needs a
+    scene range that the deformation leaves alone: no background deformation (scene/gaussian_model.py:183), at least one scene
+    Gaussian."""
+    bg = model.order_args.get("background", [0] * 6)
+    return all(int(a) == 0 for a in bg) and model._scene_xyz.shape[0] > 0 and model._scene_xyz.is_cuda
+
+
+def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scales"), raw_sh=False, flow_time=None, raw_scene=False):
     """Fused scene/gaussian_model.py:216-231 (+ get_scaling :89-91) on the raw parameters of `model`
     (any object with the reference GaussianModel's attributes).  Returns the reference's dict
     {'xyz','rotation','shs','opacity'} plus 'scales'.  With raw_sh=True the [N,M,3] SH tensor is not
     materialised: 'shs' is a diff_gaussian_rasterization.RawSH for GaussianRasterizer.forward_rawsh.
     With flow_time the dict also holds 'flow_xyz' = get_deformed_xyz(flow_time) (reference
-    gaussian_renderer/__init__.py:57), evaluated in the same pass over the deformation rows."""
+    gaussian_renderer/__init__.py:57), evaluated in the same pass over the deformation rows.
+    raw_scene=True (with raw_sh, when raw_scene_ok(model)): the deformation pass covers the OBJECT range only -- rows [0, Ns) of
+    the returned tensors are uninitialised and must not be read -- and the RawSH carries the raw scene tensors, whose activations
+    the rasterizer's preprocess applies itself (gradients come back from the rasterizer's backward)."""
     if raw_sh and "shs" in want:
         from diff_gaussian_rasterization import RawSH
-        out = get_deformed_pkg(model, t, want=tuple(w for w in want if w != "shs"), flow_time=flow_time)
+        geo = bool(raw_scene) and raw_scene_ok(model)
+        out = get_deformed_pkg(model, t, want=tuple(w for w in want if w != "shs"), flow_time=flow_time, raw_scene="objects_only" if geo else False)
         sp = model.shs_deform_param_scene
         out["shs"] = RawSH(model._scene_shs_dc, model._obj_shs_dc, model._scene_shs_rest, model._obj_shs_rest, sp, model.shs_deform_param_obj,
-                           make_func_eval(float(t), model.order_args["shs"], sp.shape[-1]))
+                           make_func_eval(float(t), model.order_args["shs"], sp.shape[-1]),
+                           *((model._scene_xyz, model._scene_scaling, model._scene_rotation, model._scene_opacity, getattr(model, "grad_arena", None))
+                             if geo else ()))
         return out
     tensors = [getattr(model, _MODEL_ATTRS[n], None) for n in _PTRS]
     meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want),
-            None if flow_time is None else float(flow_time), getattr(model, "grad_arena", None))
+            None if flow_time is None else float(flow_time), getattr(model, "grad_arena", None), raw_scene == "objects_only")
     xyz, rot, shs, op, sc, flow = _DeformPkgFn.apply(meta, *tensors)
     out = {}
     if flow_time is not None:

@@ -99,13 +99,17 @@ class SyntheticGaussianModel:
         return deform.get_deformed_xyz(self, t)
 
     raw_sh = False     # True: get_deformed_pkg leaves the SH coefficients in raw layout (RawSH) for forward_rawsh
+    raw_scene = False  # True (with raw_sh): the scene range is not deformed/activated at all -- the rasterizer's preprocess reads the raw
+    #                    scene tensors (adgs.deform.get_deformed_pkg(raw_scene=True)); rows [0, Ns) of 'xyz' / 'rotation' / 'opacity' /
+    #                    'scales' / 'flow_xyz' are then uninitialised (gaussian_renderer.render() hides them behind lazy entries)
 
     supports_fused_flow = True     # get_deformed_pkg(t, flow_time=...) also returns 'flow_xyz'
 
-    def get_deformed_pkg(self, t, flow_time=None):
+    def get_deformed_pkg(self, t, flow_time=None, full_rows=False):
         """Reference keys 'xyz','rotation','shs','opacity' plus 'scales' (so that render() needs no
-        separate get_scaling pass) and, with flow_time, 'flow_xyz' = get_deformed_xyz(flow_time)."""
-        return deform.get_deformed_pkg(self, t, raw_sh=self.raw_sh, flow_time=flow_time)
+        separate get_scaling pass) and, with flow_time, 'flow_xyz' = get_deformed_xyz(flow_time).
+        full_rows=True: every row of every tensor is valid even when raw_scene is on (callers that read them, e.g. override_color)."""
+        return deform.get_deformed_pkg(self, t, raw_sh=self.raw_sh, flow_time=flow_time, raw_scene=self.raw_sh and self.raw_scene and not full_rows)
 
     def deform_bytes_per_frame(self):
         """Algorithmic bytes of the deformation stage per frame: deformation

@@ -214,16 +214,39 @@ static uint32_t* pinned_word() {
 // back to a ~10 ms timeout per call in the first process on a freshly booted box (frames at 11 ms instead of 1.7 ms with
 // every kernel at its normal duration).  A volatile read of host memory has no such mode.
 struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; };
+// one mailbox per (host thread, device): the device pointer of a mapped allocation belongs to the device that was current when
+// it was taken, so a thread that renders on several GPUs gets one per GPU (portable pinned memory)
 static MailboxRef* mailbox() {
-	static thread_local MailboxRef m = { nullptr, nullptr, 0 };
+	constexpr int MAX_DEV = 64;
+	static thread_local MailboxRef boxes[MAX_DEV] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+	MailboxRef& m = boxes[dev];
 	if (!m.host) {
 		void* h = nullptr; void* d = nullptr;
-		if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+		if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
 		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
 		memset(h, 0, 256);
 		m.host = (Mailbox*)h; m.dev = (Mailbox*)d; m.next_seq = 1;
 	}
 	return &m;
+}
+// What the forward decided from the environment (pipeline, cell size, pixels per lane), remembered per image-state buffer so that
+// the backward of THAT forward carves the saved buffers the same way even if the environment changed in between.  (The buffers are
+// opaque device memory; the host-side key is the pointer autograd hands back.)
+struct FrameCfg { int v2; int cell_tiles; int ppl; };
+static std::mutex g_cfg_mu;
+static std::vector<std::pair<const void*, FrameCfg>> g_cfg_table;
+static void remember_frame(const void* img_buffer, const FrameCfg& c) {
+	std::lock_guard<std::mutex> lk(g_cfg_mu);
+	for (auto& e : g_cfg_table) if (e.first == img_buffer) { e.second = c; return; }
+	if (g_cfg_table.size() >= 256) g_cfg_table.erase(g_cfg_table.begin());
+	g_cfg_table.emplace_back(img_buffer, c);
+}
+static bool lookup_frame(const void* img_buffer, FrameCfg* c) {
+	std::lock_guard<std::mutex> lk(g_cfg_mu);
+	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it) if (it->first == img_buffer) { *c = it->second; return true; }
+	return false;
 }
 __global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, const unsigned long long* __restrict__ fine_slots, Mailbox* box, uint32_t seq) {
 	unsigned long long f = threadIdx.x < SCAN_AUX_SLOTS ? fine_slots[threadIdx.x] : 0ull;
@@ -332,6 +355,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
 		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, ncells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
+		remember_frame(ich, FrameCfg{ 1, cell_tiles, ppl });
 
 		PreprocessArgs pa;
 		pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -493,6 +517,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (!gchunk || !ichunk) { set_error("buffer allocator returned NULL"); return -1; }
 	GeomState geom = GeomState::carve(gchunk, P, nullptr);
 	ImgState img = ImgState::carve(ichunk, npix, ntiles, nullptr);
+	remember_frame(ichunk, FrameCfg{ 0, 1, 4 });
 
 	PreprocessArgs pa;
 	pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -576,11 +601,13 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) { set_error("backward called without forward state buffers"); return -1; }
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	if (use_v2(D_S)) {
-		const int cell_tiles = v2_cell_tiles(ntiles);
+	FrameCfg cfg;
+	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = use_v2(D_S) ? 1 : 0; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }      // foreign buffers: today's environment
+	if (cfg.v2) {
+		const int cell_tiles = cfg.cell_tiles;
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr);
-		const int ppl = v2_pixels_per_lane(ntiles);
+		const int ppl = cfg.ppl;
 		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);
 		const size_t wtiles = (size_t)gx * wgy;
 		ImgStateV2 img = ImgStateV2::carve(img_buffer, npix, wtiles, ncells, nullptr);
@@ -709,12 +736,19 @@ static ShSource to_sh_source(const adgs_sh_source* s) {
 	ShSource r;
 	r.Ns = s->Ns; r.scene_dc = s->scene_dc; r.obj_dc = s->obj_dc; r.scene_rest = s->scene_rest; r.obj_rest = s->obj_rest;
 	r.scene_sp = s->scene_deform; r.obj_sp = s->obj_deform; r.f = s->f;
+	const bool raw_geo = s->Ns > 0 && s->scene_xyz && s->scene_scaling && s->scene_rotation && s->scene_opacity;
+	r.scene_xyz = raw_geo ? s->scene_xyz : nullptr; r.scene_scaling = raw_geo ? s->scene_scaling : nullptr;
+	r.scene_rotation = raw_geo ? s->scene_rotation : nullptr; r.scene_opacity = raw_geo ? s->scene_opacity : nullptr;
 	if (!r.scene_dc) { r.scene_dc = r.obj_dc; r.scene_rest = r.obj_rest; }
 	if (!r.obj_dc) { r.obj_dc = r.scene_dc; r.obj_rest = r.scene_rest; }
 	return r;
 }
 static int check_sh_source(const adgs_sh_source* sh, int P, int M, const char* who) {
 	const bool need_scene = sh && sh->Ns > 0, need_obj = sh && sh->Ns < P;
+	if (sh && (sh->scene_xyz || sh->scene_scaling || sh->scene_rotation || sh->scene_opacity) &&
+	    !(sh->scene_xyz && sh->scene_scaling && sh->scene_rotation && sh->scene_opacity)) {
+		set_error(std::string(who) + ": raw scene geometry needs all four tensors"); return -1;
+	}
 	if (!sh || sh->Ns < 0 || sh->Ns > P || (need_scene && (!sh->scene_dc || (M > 1 && !sh->scene_rest))) || (need_obj && (!sh->obj_dc || (M > 1 && !sh->obj_rest)))) {
 		set_error(std::string(who) + ": incomplete SH source"); return -1;
 	}
@@ -755,6 +789,10 @@ extern "C" int adgs_raster_backward_rawsh(
 	dst.scene_dc = dL_dsh->scene_dc; dst.obj_dc = dL_dsh->obj_dc; dst.scene_rest = dL_dsh->scene_rest; dst.obj_rest = dL_dsh->obj_rest;
 	dst.scene_sp = dL_dsh->scene_deform; dst.obj_sp = dL_dsh->obj_deform;
 	dst.rgb_factor = dL_dsh->rgb_factor;
+	dst.scene_xyz = dL_dsh->scene_xyz; dst.scene_scaling = dL_dsh->scene_scaling; dst.scene_rotation = dL_dsh->scene_rotation; dst.scene_opacity = dL_dsh->scene_opacity;
+	if (src.scene_xyz && !(dst.scene_xyz && dst.scene_scaling && dst.scene_rotation && dst.scene_opacity)) {
+		set_error("adgs_raster_backward_rawsh: the source carries raw scene geometry, its four gradient destinations are required"); return -1;
+	}
 	return raster_backward_impl(&src, &dst, P, D, M, R, D_S, background, width, height, means3D, nullptr, nullptr, flow_points, semantic,
 		scales, scale_modifier, rotations, nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
 		img_buffer, dL_dpix, dL_dpix_depth, dL_dpix_flow, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
@@ -782,7 +820,9 @@ extern "C" long long adgs_test_v2_published_entries(const char* img_buffer, int 
 	if (!img_buffer || width <= 0 || height <= 0) return -1;
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	const int cell_tiles = v2_cell_tiles(ntiles), ppl = v2_pixels_per_lane(ntiles);
+	FrameCfg cfg;
+	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
 	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
 	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
@@ -793,12 +833,31 @@ extern "C" long long adgs_test_v2_published_entries(const char* img_buffer, int 
 	for (uint32_t v : h) total += v;
 	return total;
 }
+// per-tile counters of the last forward: out_consumed / out_scanned receive one uint32 per wave tile (returns the tile count)
+extern "C" long long adgs_test_v2_tile_counters(const char* img_buffer, int width, int height, uint32_t* out_consumed, uint32_t* out_scanned, long long capacity, void* stream_) {
+	if (!img_buffer || width <= 0 || height <= 0) return -1;
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	FrameCfg cfg;
+	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
+	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
+	if ((long long)wtiles > capacity) return (long long)wtiles;
+	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
+	if (out_consumed && hipMemcpyAsync(out_consumed, img.tile_consumed, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (out_scanned && hipMemcpyAsync(out_scanned, img.tile_scanned, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	return (long long)wtiles;
+}
 // sum over the wave tiles of the candidates of the cell list each tile's walk went through before all its pixels were saturated
 extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream_) {
 	if (!img_buffer || width <= 0 || height <= 0) return -1;
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	const int cell_tiles = v2_cell_tiles(ntiles), ppl = v2_pixels_per_lane(ntiles);
+	FrameCfg cfg;
+	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
 	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
 	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);

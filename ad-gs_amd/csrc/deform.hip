@@ -364,7 +364,7 @@ __device__ __forceinline__ void deform_fwd_body(const DeformArgs& a, int blk, in
 	if (a.o.opacity) {
 		const float x = is_obj ? a.p.obj_opacity[m] : a.p.scene_opacity[m];
 		float o = 1.f / (1.f + expf(-x));
-		if (is_obj && a.p.use_time_mask) {
+		if (is_obj && (a.p.use_time_mask & ADGS_DEFORM_TIME_MASK)) {
 			const float dt = a.p.t - a.p.gs_time[m];
 			const float sig = expf(dt < 0.f ? a.p.gs_time_sigma[2 * (size_t)m] : a.p.gs_time_sigma[2 * (size_t)m + 1]);
 			const float r = dt / sig;
@@ -676,7 +676,7 @@ __device__ __forceinline__ void deform_bwd_body(const DeformBwdArgs& a, int blk,
 		const float x = is_obj ? a.p.obj_opacity[m] : a.p.scene_opacity[m];
 		const float sg = 1.f / (1.f + expf(-x));
 		float mask = 1.f;
-		if (is_obj && a.p.use_time_mask) {
+		if (is_obj && (a.p.use_time_mask & ADGS_DEFORM_TIME_MASK)) {
 			const float dt = a.p.t - a.p.gs_time[m];
 			const bool neg = dt < 0.f;
 			const float sig = expf(neg ? a.p.gs_time_sigma[2 * (size_t)m] : a.p.gs_time_sigma[2 * (size_t)m + 1]);
@@ -1029,7 +1029,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 			if (a.xyz_rows) lds = std::max(lds, (size_t)2 * np_x * sizeof(float));
 			if (lds > MAX_STAGING_LDS) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }
 			a.scene4 = scene4_ok({ p->scene_xyz, p->scene_rotation, p->scene_opacity, p->scene_scaling, a.o.xyz, a.flow_xyz, a.o.rotation, a.o.opacity, a.o.scales });
-			const int nb_o = (p->No + B - 1) / B, nb_scene = a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B;
+			const int nb_o = (p->No + B - 1) / B, nb_scene = (p->use_time_mask & ADGS_DEFORM_SKIP_SCENE) ? 0 : (a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B);
 			const int nb_rot = (a.o.rotation || a.o.opacity || a.o.scales) ? nb_o : 0;
 			const int nb_xyz = (a.o.xyz || a.flow_xyz) ? (a.xyz_rows ? (int)((3 * (size_t)p->No + B - 1) / B) : nb_o) : 0;
 			a.n_begin = 0; a.n_end = N;
@@ -1090,7 +1090,8 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 			const int nb_o = (p->No + B - 1) / B;
 			a.scene4 = scene4_ok({ p->scene_xyz, p->scene_rotation, p->scene_opacity, p->scene_scaling, dL_dxyz, dL_dflow_xyz, dL_drotation, dL_dopacity, dL_dscales,
 				grads->scene_xyz, grads->scene_rotation, grads->scene_opacity, grads->scene_scaling });
-			const int nb_rot = dL_drotation ? nb_o : 0, nb_xyz = want_rest ? nb_o : 0, nb_scene = a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B;
+			const int nb_rot = dL_drotation ? nb_o : 0, nb_xyz = want_rest ? nb_o : 0,
+				nb_scene = (p->use_time_mask & ADGS_DEFORM_SKIP_SCENE) ? 0 : (a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B);
 			a.n_begin = 0; a.n_end = N;
 #define ADGS_CALL(NQ) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_bwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 				hipLaunchKernelGGL((deform_bwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz); } while (0)

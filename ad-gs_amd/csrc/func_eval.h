@@ -111,10 +111,15 @@ struct ShSource {
 	int Ns;
 	const float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_sp, *obj_sp;
 	adgs_func_eval f;
+	// raw scene geometry (scene_xyz != nullptr): Gaussians idx < Ns take position / log-scale / raw rotation / opacity logit from
+	// these raw tensors and the preprocess applies exp / normalize / sigmoid itself; rows idx < Ns of the activated inputs are
+	// then never read (scene/gaussian_model.py:89-152: the reference materialises the activations with torch ops)
+	const float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;
 };
 struct ShGradDst {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_sp, *obj_sp;
 	float *rgb_factor;   // [P,3] clamp-masked colour gradient: the per-camera factor every SH gradient row is a multiple of
+	float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;   // raw scene geometry gradients ([Ns,3] [Ns,3] [Ns,4] [Ns,1])
 };
 
 } // namespace adgs

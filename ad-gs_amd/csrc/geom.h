@@ -8,10 +8,9 @@ namespace adgs {
 // upper triangle out.  Evaluated in glm's column-major order.  Contraction is pinned off inside this function (it is
 // self-contained for that reason) so that the forward preprocess and the v2 backward -- which recomputes Sigma instead of
 // reading it back -- produce the same bits whatever the flags of their translation units.
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q, float* out) {
+__device__ __forceinline__ void cov3d_from_values(float s0, float s1, float s2, float mod, float r, float x, float y, float z, float* out) {
 #pragma clang fp contract(off)
-	const float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
-	const float r = q[0], x = q[1], y = q[2], z = q[3];
+	const float sx = mod * s0, sy = mod * s1, sz = mod * s2;
 	// R.v[col][row] (column-major, as glm stores mat3(...) given row by row in forward.cu:133-137)
 	const float Rm[3][3] = { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
 	                         { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
@@ -36,6 +35,24 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod,
 			Sg[c][rr] = M[rr][0] * M[c][0] + M[rr][1] * M[c][1] + M[rr][2] * M[c][2];
 	out[0] = Sg[0][0]; out[1] = Sg[0][1]; out[2] = Sg[0][2];
 	out[3] = Sg[1][1]; out[4] = Sg[1][2]; out[5] = Sg[2][2];
+}
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q, float* out) {
+	cov3d_from_values(s3[0], s3[1], s3[2], mod, q[0], q[1], q[2], q[3], out);
+}
+
+// Activations of the raw scene geometry (scene/gaussian_model.py:36-44: exp, F.normalize with eps 1e-12, sigmoid), evaluated
+// by the forward preprocess AND re-evaluated by its backward: one rounding per operation so that both see the same bits.
+struct SceneAct { float s[3]; float q[4]; float inv_norm; float op; };
+__device__ __forceinline__ SceneAct scene_activations(const float* __restrict__ raw_scaling, const float* __restrict__ raw_rotation,
+	const float* __restrict__ raw_opacity, size_t idx) {
+#pragma clang fp contract(off)
+	SceneAct a;
+	a.s[0] = expf(raw_scaling[3 * idx]); a.s[1] = expf(raw_scaling[3 * idx + 1]); a.s[2] = expf(raw_scaling[3 * idx + 2]);
+	const float4 r = *reinterpret_cast<const float4*>(raw_rotation + 4 * idx);
+	a.inv_norm = 1.f / fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);
+	a.q[0] = r.x * a.inv_norm; a.q[1] = r.y * a.inv_norm; a.q[2] = r.z * a.inv_norm; a.q[3] = r.w * a.inv_norm;
+	a.op = 1.f / (1.f + expf(-raw_opacity[idx]));
+	return a;
 }
 
 // d colour / d SH coefficient k for the unit view direction (x, y, z): the per-coefficient factors of

@@ -147,7 +147,10 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	a.tiles_touched[idx] = 0;
 	if (a.rects) { a.dupinfo[idx] = make_uint4(0u, 0u, 0u, 0u); a.fine_touched[idx] = 0; }      // culled: no cells
 
-	const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
+	// raw scene geometry: Gaussians idx < Ns read position / log-scale / raw rotation / opacity logit from the raw tensors
+	const bool rs = a.sh_src.scene_xyz != nullptr && idx < a.sh_src.Ns;
+	const float* pos = rs ? a.sh_src.scene_xyz : a.means3D;
+	const float px = pos[3 * (size_t)idx], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
 	const float* V = a.view; const float* PJ = a.proj;
 	// near cull only (auxiliary.h:154)
 	const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
@@ -161,11 +164,18 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	const float projx = hx * p_w, projy = hy * p_w;
 
 	float c3[6];
+	float opacity_in = 0.f;            // raw scene row: sigmoid of the logit (below); else read where the reference reads it
 	if (a.cov3D_precomp) {
 #pragma unroll
 		for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
 	} else {
-		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
+		if (rs) {
+			const SceneAct act = scene_activations(a.sh_src.scene_scaling, a.sh_src.scene_rotation, a.sh_src.scene_opacity, (size_t)idx);
+			cov3d_from_values(act.s[0], act.s[1], act.s[2], a.scale_modifier, act.q[0], act.q[1], act.q[2], act.q[3], c3);
+			opacity_in = act.op;
+		} else {
+			cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
+		}
 		if (a.cov3D) {        // classic pipeline keeps it for the backward; v2 recomputes it there (same function, same rounding)
 #pragma unroll
 			for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = c3[k];
@@ -201,7 +211,7 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	if ((maxx - minx) * (maxy - miny) == 0) return none;
 
 	Splat s;
-	s.x = pix; s.y = piy; s.ca = conx; s.cb = cony; s.cc = conz; s.opacity = a.opacities[idx];
+	s.x = pix; s.y = piy; s.ca = conx; s.cb = cony; s.cc = conz; s.opacity = rs ? opacity_in : a.opacities[idx];
 	uint8_t clamp_bits = 0;
 	if (a.colors_precomp) {
 		s.r = a.colors_precomp[3 * (size_t)idx]; s.g = a.colors_precomp[3 * (size_t)idx + 1]; s.b = a.colors_precomp[3 * (size_t)idx + 2];
@@ -234,7 +244,8 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 		s.r = 0.f; s.g = 0.f; s.b = 0.f;
 	}
 	s.dval = a.inv_depth ? (1.0f / (vz + 0.0000001f)) : vz;
-	if (a.flow_points) { s.fx = a.flow_points[3 * (size_t)idx]; s.fy = a.flow_points[3 * (size_t)idx + 1]; s.fz = a.flow_points[3 * (size_t)idx + 2]; }
+	if (a.flow_points && rs) { s.fx = px; s.fy = py; s.fz = pz; }       // a scene Gaussian does not move: its flow point is its position
+	else if (a.flow_points) { s.fx = a.flow_points[3 * (size_t)idx]; s.fy = a.flow_points[3 * (size_t)idx + 1]; s.fz = a.flow_points[3 * (size_t)idx + 2]; }
 	else { s.fx = 0.f; s.fy = 0.f; s.fz = 0.f; }
 	s.sem0 = (a.semantic && a.D_S > 0) ? a.semantic[(size_t)idx * a.D_S] : 0.f;
 	s.zview = vz;

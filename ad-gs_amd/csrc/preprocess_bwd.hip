@@ -68,17 +68,28 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	}
 	const bool valid = idx < a.P;
 	const bool vis = valid && (a.radii[idx] > 0);
+	// raw scene geometry (preprocess.hip): position / log-scale / raw rotation / opacity logit of Gaussians idx < Ns come from the raw
+	// tensors, and their gradients -- chain rule through exp / normalize / sigmoid included -- go to the raw tensors' gradients
+	const bool rs = a.sh_src.scene_xyz != nullptr && idx < a.sh_src.Ns;
 	if (valid && !vis) {
 		// v2: every output row is written here, so the caller does not have to zero-fill them
 		if (a.gacc) {
 			a.out_mean2D[3 * (size_t)idx] = 0.f; a.out_mean2D[3 * (size_t)idx + 1] = 0.f; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
 			// out_conic / out_color / out_depth / dL_dcov3D are intermediates of the reference's ABI: NULL = not wanted
 			if (a.out_conic) *reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
-			a.out_opacity[idx] = 0.f; if (a.out_depth) a.out_depth[idx] = 0.f;
+			if (!rs) a.out_opacity[idx] = 0.f;
+			if (a.out_depth) a.out_depth[idx] = 0.f;
 			if (a.out_color) { a.out_color[3 * (size_t)idx] = 0.f; a.out_color[3 * (size_t)idx + 1] = 0.f; a.out_color[3 * (size_t)idx + 2] = 0.f; }
-			if (a.out_flow) { a.out_flow[3 * (size_t)idx] = 0.f; a.out_flow[3 * (size_t)idx + 1] = 0.f; a.out_flow[3 * (size_t)idx + 2] = 0.f; }
+			if (a.out_flow && !rs) { a.out_flow[3 * (size_t)idx] = 0.f; a.out_flow[3 * (size_t)idx + 1] = 0.f; a.out_flow[3 * (size_t)idx + 2] = 0.f; }
 			if (a.out_sem && a.D_S == 1) a.out_sem[idx] = 0.f;
-			a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f;
+			if (rs) {      // raw scene row: the gradients of the raw tensors are what the caller reads
+				float* gx = a.sh_dst.scene_xyz + 3 * (size_t)idx; gx[0] = 0.f; gx[1] = 0.f; gx[2] = 0.f;
+				float* gs = a.sh_dst.scene_scaling + 3 * (size_t)idx; gs[0] = 0.f; gs[1] = 0.f; gs[2] = 0.f;
+				*reinterpret_cast<float4*>(a.sh_dst.scene_rotation + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+				a.sh_dst.scene_opacity[idx] = 0.f;
+			} else {
+				a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f;
+			}
 			if (a.dL_dcov3D) for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
 			if (raw) {
 				const bool is_obj = idx >= a.sh_src.Ns;
@@ -93,7 +104,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 				if (STAGED) { for (int i = 0; i < SH_ROW_FULL; i++) s_sh[tid * SH_ROW_FULL_LDS + i] = 0.f; }
 				else { float* dsh = a.dL_dsh + (size_t)idx * a.M * 3; for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f; }
 			}
-			if (a.scales) {
+			if (a.scales && !rs) {
 				a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f;
 				*reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
 			}
@@ -101,7 +112,11 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	}
 	if (vis) {
 	const float* V = a.view; const float* PJ = a.proj;
-	const float mx = a.means3D[3 * (size_t)idx], my = a.means3D[3 * (size_t)idx + 1], mz = a.means3D[3 * (size_t)idx + 2];
+	const float* pos = rs ? a.sh_src.scene_xyz : a.means3D;
+	const float mx = pos[3 * (size_t)idx], my = pos[3 * (size_t)idx + 1], mz = pos[3 * (size_t)idx + 2];
+	SceneAct act;
+	if (rs) act = scene_activations(a.sh_src.scene_scaling, a.sh_src.scene_rotation, a.sh_src.scene_opacity, (size_t)idx);
+	float gflow[3] = { 0.f, 0.f, 0.f };      // raw scene row: the flow point IS the position, its gradient joins the position's
 
 	// per-Gaussian sums of the blend backward: classic = separate ABI arrays filled by atomics,
 	// v2 = one packed 64-byte line per Gaussian, unpacked here into the ABI outputs
@@ -124,10 +139,12 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		gcol[0] = u1.z; gcol[1] = u1.w; gcol[2] = u2.x; gd = u2.y;
 		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
 		if (a.out_conic) *reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
-		a.out_opacity[idx] = u0.x;
+		if (rs) a.sh_dst.scene_opacity[idx] = u0.x * act.op * (1.f - act.op);      // d sigmoid
+		else a.out_opacity[idx] = u0.x;
 		if (a.out_color) { a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2]; }
 		if (a.out_depth) a.out_depth[idx] = gd;
-		if (a.out_flow) { a.out_flow[3 * (size_t)idx] = u2.z; a.out_flow[3 * (size_t)idx + 1] = u2.w; a.out_flow[3 * (size_t)idx + 2] = u3.x; }
+		if (a.out_flow && rs) { gflow[0] = u2.z; gflow[1] = u2.w; gflow[2] = u3.x; }
+		else if (a.out_flow) { a.out_flow[3 * (size_t)idx] = u2.z; a.out_flow[3 * (size_t)idx + 1] = u2.w; a.out_flow[3 * (size_t)idx + 2] = u3.x; }
 		if (a.out_sem && a.D_S == 1) a.out_sem[idx] = u3.y;
 	} else {
 		dcon_x = a.dL_dconic[4 * (size_t)idx]; dcon_y = a.dL_dconic[4 * (size_t)idx + 1]; dcon_z = a.dL_dconic[4 * (size_t)idx + 3];
@@ -141,6 +158,8 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	if (a.cov3D) {
 #pragma unroll
 		for (int i = 0; i < 6; i++) c3[i] = a.cov3D[6 * (size_t)idx + i];
+	} else if (rs) {
+		cov3d_from_values(act.s[0], act.s[1], act.s[2], a.scale_modifier, act.q[0], act.q[1], act.q[2], act.q[3], c3);
 	} else {                  // v2 without cov3D_precomp: recomputed instead of stored by the forward (24 B written + read per Gaussian)
 		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
 	}
@@ -313,16 +332,19 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
 		gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
 	}
-	a.dL_dmean3D[3 * (size_t)idx] = gmx; a.dL_dmean3D[3 * (size_t)idx + 1] = gmy; a.dL_dmean3D[3 * (size_t)idx + 2] = gmz;
+	if (rs) { float* gx = a.sh_dst.scene_xyz + 3 * (size_t)idx; gx[0] = gmx + gflow[0]; gx[1] = gmy + gflow[1]; gx[2] = gmz + gflow[2]; }
+	else { a.dL_dmean3D[3 * (size_t)idx] = gmx; a.dL_dmean3D[3 * (size_t)idx + 1] = gmy; a.dL_dmean3D[3 * (size_t)idx + 2] = gmz; }
 
 	// ---------------- cov3D -> scale / rotation (backward.cu:278-341)
 	if (a.scales) {
-		const float* q = a.rotations + 4 * (size_t)idx;
-		const float r = q[0], x = q[1], y = q[2], z = q[3];
+		float r, x, y, z;
+		if (rs) { r = act.q[0]; x = act.q[1]; y = act.q[2]; z = act.q[3]; }
+		else { const float* q = a.rotations + 4 * (size_t)idx; r = q[0]; x = q[1]; y = q[2]; z = q[3]; }
+		const float sc0 = rs ? act.s[0] : a.scales[3 * (size_t)idx], sc1 = rs ? act.s[1] : a.scales[3 * (size_t)idx + 1], sc2 = rs ? act.s[2] : a.scales[3 * (size_t)idx + 2];
 		M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
 		           { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
 		           { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } } };
-		const float s0 = a.scale_modifier * a.scales[3 * (size_t)idx], s1 = a.scale_modifier * a.scales[3 * (size_t)idx + 1], s2 = a.scale_modifier * a.scales[3 * (size_t)idx + 2];
+		const float s0 = a.scale_modifier * sc0, s1 = a.scale_modifier * sc1, s2 = a.scale_modifier * sc2;
 		M3 S = { { { s0, 0.f, 0.f }, { 0.f, s1, 0.f }, { 0.f, 0.f, s2 } } };
 		M3 Mm = m3mul(S, R);
 		M3 dSig = { { { dcov[0], 0.5f * dcov[1], 0.5f * dcov[2] }, { 0.5f * dcov[1], dcov[3], 0.5f * dcov[4] }, { 0.5f * dcov[2], 0.5f * dcov[4], dcov[5] } } };
@@ -334,9 +356,11 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		M3 dL_dM = m3mul(twoM, dSig);
 		M3 Rt = m3t(R);
 		M3 dMt = m3t(dL_dM);
-		a.dL_dscale[3 * (size_t)idx + 0] = Rt.v[0][0] * dMt.v[0][0] + Rt.v[0][1] * dMt.v[0][1] + Rt.v[0][2] * dMt.v[0][2];
-		a.dL_dscale[3 * (size_t)idx + 1] = Rt.v[1][0] * dMt.v[1][0] + Rt.v[1][1] * dMt.v[1][1] + Rt.v[1][2] * dMt.v[1][2];
-		a.dL_dscale[3 * (size_t)idx + 2] = Rt.v[2][0] * dMt.v[2][0] + Rt.v[2][1] * dMt.v[2][1] + Rt.v[2][2] * dMt.v[2][2];
+		const float ds0 = Rt.v[0][0] * dMt.v[0][0] + Rt.v[0][1] * dMt.v[0][1] + Rt.v[0][2] * dMt.v[0][2];
+		const float ds1 = Rt.v[1][0] * dMt.v[1][0] + Rt.v[1][1] * dMt.v[1][1] + Rt.v[1][2] * dMt.v[1][2];
+		const float ds2 = Rt.v[2][0] * dMt.v[2][0] + Rt.v[2][1] * dMt.v[2][1] + Rt.v[2][2] * dMt.v[2][2];
+		if (rs) { float* gs = a.sh_dst.scene_scaling + 3 * (size_t)idx; gs[0] = ds0 * sc0; gs[1] = ds1 * sc1; gs[2] = ds2 * sc2; }      // d exp
+		else { a.dL_dscale[3 * (size_t)idx + 0] = ds0; a.dL_dscale[3 * (size_t)idx + 1] = ds1; a.dL_dscale[3 * (size_t)idx + 2] = ds2; }
 #pragma unroll
 		for (int k = 0; k < 3; k++) { dMt.v[0][k] *= s0; dMt.v[1][k] *= s1; dMt.v[2][k] *= s2; }
 #define MT(i, j) dMt.v[i][j]
@@ -346,7 +370,11 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		dq.z = 2 * x * (MT(1, 0) + MT(0, 1)) + 2 * r * (MT(2, 0) - MT(0, 2)) + 2 * z * (MT(1, 2) + MT(2, 1)) - 4 * y * (MT(2, 2) + MT(0, 0));
 		dq.w = 2 * r * (MT(0, 1) - MT(1, 0)) + 2 * x * (MT(2, 0) + MT(0, 2)) + 2 * y * (MT(1, 2) + MT(2, 1)) - 4 * z * (MT(1, 1) + MT(0, 0));
 #undef MT
-		*reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;     // no normalisation Jacobian (backward.cu:340)
+		if (rs) {      // the Python-side F.normalize of the reference (scene/gaussian_model.py:44): (g - q (q . g)) / |raw|
+			const float qg = r * dq.x + x * dq.y + y * dq.z + z * dq.w;
+			*reinterpret_cast<float4*>(a.sh_dst.scene_rotation + 4 * (size_t)idx) =
+				make_float4((dq.x - r * qg) * act.inv_norm, (dq.y - x * qg) * act.inv_norm, (dq.z - y * qg) * act.inv_norm, (dq.w - z * qg) * act.inv_norm);
+		} else *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;     // no normalisation Jacobian (backward.cu:340)
 	}
 	}   // if (vis)
 	if (STAGED) {

@@ -36,6 +36,9 @@ constexpr float PIXEL_DONE = 3.0e38f;      // row coordinate of a pixel that tak
 // half tile: twice the waves, a shorter dependent chain per wave); PPL is a template parameter of both blend kernels
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
 
+#ifndef ADGS_FWD_PREFETCH
+#define ADGS_FWD_PREFETCH 0
+#endif
 #ifndef ADGS_PRECISE_EXP
 #define ADGS_EXP(x) __expf(x)      // v_exp_f32(x * log2 e): ~3e-7 relative, far inside the 1e-4 budget
 #else
@@ -206,9 +209,27 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		// the backward replay (at C3 22 % of the entries that pass the tile test are blended by no pixel -- the test is a bound
 		// over the tile rectangle, and pixels saturate), and positions (n_contrib) count live entries only.
 		uint64_t live = 0ull;
+#if ADGS_FWD_PREFETCH >= 1
+		// software pipeline: the LDS reads of entry j + 1 are issued before entry j is evaluated (hipcc emits `ds_read; s_waitcnt`
+		// back to back at the top of every iteration otherwise: two exposed LDS round trips per entry; PMC: 61 % of the wave
+		// cycles of this kernel were spent parked at s_waitcnt).  Row n of s_splat exists (WAVE + 1 rows) and is never used.
+		float4 nq0 = s_splat[0], nq1 = s_splat[1];
+#if ADGS_FWD_PREFETCH >= 2
+		float4 nq2 = s_splat[2], nq3 = s_splat[3];
+#endif
+#endif
 		for (uint32_t j = 0; j < n; j++) {
+#if ADGS_FWD_PREFETCH >= 1
+			const float4 q0 = nq0, q1 = nq1;
+			nq0 = s_splat[(j + 1) * 4 + 0]; nq1 = s_splat[(j + 1) * 4 + 1];
+#if ADGS_FWD_PREFETCH >= 2
+			const float4 pq2 = nq2, pq3 = nq3;
+			nq2 = s_splat[(j + 1) * 4 + 2]; nq3 = s_splat[(j + 1) * 4 + 3];
+#endif
+#else
 			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
 			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
+#endif
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
 			float alpha[PPL]; bool act[PPL]; bool any_act = false;
 #pragma unroll
@@ -222,8 +243,12 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			if (!__any(any_act)) continue;
 			const uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
 			live |= 1ull << j;
+#if ADGS_FWD_PREFETCH >= 2
+			const float4 q2 = pq2, q3 = pq3;
+#else
 			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
 			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview pad
+#endif
 #pragma unroll
 			for (int k = 0; k < PPL; k++) {
 				if (!__any(act[k])) continue;           // wave-uniform: a 16x4 pixel strip the entry does not reach costs nothing

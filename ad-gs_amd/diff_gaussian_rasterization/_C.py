@@ -163,16 +163,19 @@ class ShSource(ctypes.Structure):
     """adgs_sh_source (include/adgs_rasterizer.h)."""
     from adgs.deform import FuncEval as _FE
     _fields_ = [("Ns", ctypes.c_int32)] + [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform",
-                                                                              "obj_deform")] + [("f", _FE)]
+                                                                              "obj_deform")] + [("f", _FE)] + \
+               [(n, ctypes.c_void_p) for n in ("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")]
 
 
 class ShGrads(ctypes.Structure):
     """adgs_sh_grads (include/adgs_rasterizer.h)."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor",
+                                               "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")]
 
 
 def _sh_source(raw, dev):
-    """raw: (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval)."""
+    """raw: (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval[, (scene_xyz, scene_scaling, scene_rotation,
+    scene_opacity) -- the RAW scene geometry, activations applied by the preprocess])."""
     src = ShSource()
     ts = [_prep(t, dev, n) for t, n in zip(raw[:6], ("scene_shs_dc", "obj_shs_dc", "scene_shs_rest", "obj_shs_rest",
                                                       "shs_deform_param_scene", "shs_deform_param_obj"))]
@@ -180,6 +183,17 @@ def _sh_source(raw, dev):
     for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), ts):
         setattr(src, name, _ptr(t))
     src.f = raw[6]
+    geo = raw[7] if len(raw) > 7 else None
+    if geo is not None:
+        if src.Ns == 0:
+            geo = None
+        else:
+            gs = [_prep(t, dev, n) for t, n in zip(geo, ("_scene_xyz", "_scene_scaling", "_scene_rotation", "_scene_opacity"))]
+            if any(g is None for g in gs) or [g.shape[0] for g in gs] != [src.Ns] * 4:
+                raise RuntimeError("raw scene geometry: four tensors of Ns rows (xyz, scaling, rotation, opacity) are required")
+            for name, t in zip(("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity"), gs):
+                setattr(src, name, _ptr(t))
+            ts = ts + gs
     return src, ts
 
 
@@ -221,7 +235,7 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
 def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_semantic, semantic, flow_points, sh_raw,
                                        sh_needs_grad, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, img_opacity, grad_img_opacity,
-                                       inv_depth, debug, want_rgb_factor=False):
+                                       inv_depth, debug, want_rgb_factor=False, geo_grad_alloc=None):
     """With want_rgb_factor the result carries one more entry: the [P,3] clamp-masked colour gradient every SH gradient row is a
     multiple of (include/adgs_exchange.h); combined with sh_needs_grad all False the SH rows are not materialised at all."""
     lib = _lib.lib()
@@ -248,12 +262,20 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
             raise RuntimeError("rgb_factor destination must be a contiguous float32 [P,3] tensor on the rasterizer's device")
     else:
         rgb_factor = (e(P, 3) if P != 0 else torch.zeros((0, 3), dtype=torch.float32, device=dev)) if want_rgb_factor else None
+    geo_grads = None
     if P != 0:
         src, keep_sh = _sh_source(sh_raw, dev)
         gs = ShGrads()
         for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
             setattr(gs, name, _ptr(t))
         gs.rgb_factor = _ptr(rgb_factor)
+        geo = sh_raw[7] if len(sh_raw) > 7 and src.scene_xyz else None
+        if geo is not None:          # raw scene geometry: the gradients of the four raw tensors (every row written by the kernel)
+            names = ("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")
+            geo_grads = [(geo_grad_alloc(n, t) if geo_grad_alloc is not None else None) for n, t in zip(names, geo)]
+            geo_grads = [g if g is not None else torch.empty_like(t) for g, t in zip(geo_grads, geo)]
+            for n, g in zip(names, geo_grads):
+                setattr(gs, n, _ptr(g))
         keep = [_prep(t, dev, n) for t, n in (
             (background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"), (scales, "scales"),
             (rotations, "rotations"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"),
@@ -270,6 +292,7 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
                 ctypes.byref(gs), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dflow_points), _ptr(dL_dsemantic), _ptr(go_), _ptr(io_),
                 int(bool(inv_depth)), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_backward_rawsh")
     sh_grads = [g if nd else None for g, nd in zip(sh_grads, sh_needs_grad)]
-    if rgb_factor is not None:
-        return dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic, rgb_factor
-    return dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic
+    if P == 0 or not (len(sh_raw) > 7 and sh_raw[7] is not None and sh_raw[0].size(0) > 0):
+        geo_grads = None
+    res = (dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic)
+    return res + ((rgb_factor,) if rgb_factor is not None else (None,)) + (geo_grads,)

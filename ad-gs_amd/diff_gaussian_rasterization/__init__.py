@@ -101,6 +101,14 @@ class RawSH(NamedTuple):
     scene_deform: torch.Tensor
     obj_deform: torch.Tensor
     func_eval: object          # adgs.deform.FuncEval of f_shs at the camera time
+    # RAW scene geometry (all four or None): _scene_xyz, _scene_scaling (log), _scene_rotation (unnormalised), _scene_opacity (logit).
+    # The preprocess applies exp / normalize / sigmoid itself for the Gaussians idx < Ns and never reads rows idx < Ns of means3D /
+    # scales / rotations / opacities / flow_points; the backward writes the gradients of these raw tensors directly.
+    scene_xyz: object = None
+    scene_scaling: object = None
+    scene_rotation: object = None
+    scene_opacity: object = None
+    grad_arena: object = None  # adgs.dp.GradArena: where the raw scene geometry gradients are written (one flat all-reduce buffer)
 
 
 class _RasterizeGaussiansRawSH(torch.autograd.Function):
@@ -112,37 +120,45 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, scales, rotations, flow_points, semantic, scene_dc, obj_dc, scene_rest, obj_rest,
-                scene_deform, obj_deform, func_eval, raster_settings, factor_sink=None):
+                scene_deform, obj_deform, func_eval, raster_settings, factor_sink=None, scene_xyz=None, scene_scaling=None, scene_rotation=None,
+                scene_opacity=None, grad_arena=None):
         s = raster_settings
-        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval)
+        geo = (scene_xyz, scene_scaling, scene_rotation, scene_opacity) if scene_xyz is not None else None
+        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval, geo)
         (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow, img_semantic) = _C.rasterize_gaussians_rawsh(
             s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
             s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
         ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink = s, num_rendered, func_eval, factor_sink
+        ctx.has_geo, ctx.grad_arena = geo is not None, grad_arena
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
-                              scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform)
+                              scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, *(geo or ()))
         return color, radii, depth, img_opacity, img_flow, img_semantic
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_img_opacity, grad_img_flow, grad_img_semantic):
         s = ctx.raster_settings
+        saved = ctx.saved_tensors
         (means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
-         scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform) = ctx.saved_tensors
-        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval)
+         scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform) = saved[:16]
+        geo = tuple(saved[16:20]) if ctx.has_geo else None
+        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval, geo)
         if grad_out_color is None:
             grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
         factored = ctx.factor_sink is not None
         need = (False,) * 6 if factored else ctx.needs_input_grad[7:13]
+        arena = ctx.grad_arena
         res = _C.rasterize_gaussians_backward_rawsh(
             s.bg, means3D, radii, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
             grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, need, s.sh_degree, s.campos,
             geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
-            want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False)
-        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem) = res[:8]
+            want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False,
+            geo_grad_alloc=(arena.take if arena is not None else None))
+        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem, g_factor, g_geo) = res
         if factored:
-            ctx.factor_sink.append(res[8])
-        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None)
+            ctx.factor_sink.append(g_factor)
+        g_geo = tuple(g_geo) if g_geo is not None else (None,) * 4
+        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None) + g_geo + (None,)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
@@ -168,7 +184,10 @@ class GaussianRasterizer(nn.Module):
         empty = lambda t: torch.Tensor([]) if t is None else t
         return _RasterizeGaussiansRawSH.apply(means3D, means2D, opacities, scales, rotations, empty(flow_points), empty(semantic),
                                               sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest, sh_raw.obj_rest, sh_raw.scene_deform,
-                                              sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings, factor_sink)
+                                              sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings, factor_sink,
+                                              getattr(sh_raw, "scene_xyz", None), getattr(sh_raw, "scene_scaling", None),
+                                              getattr(sh_raw, "scene_rotation", None), getattr(sh_raw, "scene_opacity", None),
+                                              getattr(sh_raw, "grad_arena", None))
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, flow_points=None, semantic=None):

@@ -25,15 +25,18 @@ def _camera_settings(cam, pc, pipe, scale_modifier, device):
         pc.active_sh_degree, on(cam.camera_center), False, pipe.inv_depth, pipe.debug)
 
 
-def _deformed_state(pc, t, flow_pkg):
-    """(deform_pkg, flow_points): the Gaussians at the camera time and, for a flow target, their positions at its time stamp."""
+def _deformed_state(pc, t, flow_pkg, full_rows=False):
+    """(deform_pkg, flow_points): the Gaussians at the camera time and, for a flow target, their positions at its time stamp.
+    full_rows: the caller reads the scene rows of the deformed tensors (override_color goes through the plain rasterizer entry), so a
+    model on the raw-scene path must materialise them."""
+    kw = dict(full_rows=True) if (full_rows and getattr(pc, "raw_scene", False)) else {}
     if flow_pkg is None:
-        return pc.get_deformed_pkg(t), None
+        return pc.get_deformed_pkg(t, **kw), None
     flow_t = flow_pkg[0]
     if getattr(pc, "supports_fused_flow", False):          # adgs.model: both time stamps in one pass over the deformation rows
-        pkg = pc.get_deformed_pkg(t, flow_time=flow_t)
+        pkg = pc.get_deformed_pkg(t, flow_time=flow_t, **kw)
         return pkg, pkg["flow_xyz"]
-    return pc.get_deformed_pkg(t), pc.get_deformed_xyz(flow_t)
+    return pc.get_deformed_pkg(t, **kw), pc.get_deformed_xyz(flow_t)
 
 
 def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic, sh_factor_sink=None):
@@ -47,6 +50,32 @@ def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semant
         raise RuntimeError("sh_factor_sink needs the raw-SH path (a model whose get_deformed_pkg hands out a RawSH)")
     return rasterizer(means3D=pkg["xyz"], means2D=means2D, opacities=pkg["opacity"], shs=shs, colors_precomp=override_color, scales=scales,
                       rotations=pkg["rotation"], flow_points=flow_points, semantic=semantic)
+
+
+class _LazyResult(dict):
+    """render()'s result dictionary when the scene range never went through the deformation pass (model.raw_scene: the rasterizer
+    read the raw scene tensors): the reference's 'xyz' / 'rotation' / 'opacity' (/ 'scales', 'flow_xyz') entries
+    (gaussian_renderer/__init__.py:99-115) are produced on first access by a full deformation pass instead of being stored --
+    train.py / render.py never read them."""
+
+    def __init__(self, thunks):
+        super().__init__()
+        self._thunks = dict(thunks)
+
+    def __missing__(self, key):
+        if key in self._thunks:
+            self[key] = self._thunks.pop(key)()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._thunks
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._thunks)
 
 
 _ZEROS = {}
@@ -75,15 +104,29 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
     means2D = screenspace_points(n_pts, device)
 
     rasterizer = GaussianRasterizer(raster_settings=_camera_settings(viewpoint_camera, pc, pipe, scaling_modifier, device))
-    pkg, flow_points = _deformed_state(pc, viewpoint_camera.time, flow_pkg)
+    pkg, flow_points = _deformed_state(pc, viewpoint_camera.time, flow_pkg, full_rows=override_color is not None)
     semantic = pc.get_obj_mask.float()[..., None] if render_objmask else None
     foreground, radii, depth, img_opacity, img_flow, img_semantic = _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic,
                                                                                 sh_factor_sink)
 
     background = env_map.get_image_background(viewpoint_camera) if env_map is not None else torch.zeros_like(foreground)
-    out = dict(pkg)                                             # the reference also hands back xyz / rotation / shs / opacity
+    shs = pkg.get("shs")
+    if shs is not None and not torch.is_tensor(shs) and getattr(shs, "scene_xyz", None) is not None:
+        # raw-scene path: rows [0, Ns) of the deformed tensors were never written; hand them out lazily (a full deformation pass)
+        from adgs import deform as _deform
+        t_cam, flow_t = viewpoint_camera.time, (None if flow_pkg is None else flow_pkg[0])
+        full = lambda key: (lambda: _deform.get_deformed_pkg(pc, t_cam, want=(key,))[key])
+        out = _LazyResult({k: full(k) for k in ("xyz", "rotation", "opacity", "scales")})
+        if flow_t is not None:
+            out._thunks["flow_xyz"] = lambda: _deform.get_deformed_xyz(pc, flow_t)
+        out["shs"] = shs
+        opacity_entry = {}
+    else:
+        out = dict(pkg)                                         # the reference also hands back xyz / rotation / shs / opacity
+        opacity_entry = dict(opacity=pkg["opacity"])
+    out.update(opacity_entry)
     out.update(render=foreground + (1.0 - img_opacity) * background, viewspace_points=means2D, visibility_filter=radii > 0, radii=radii,
-               depth=depth.squeeze(0), opacity=pkg["opacity"], img_opacity=img_opacity.squeeze(0), foreground=foreground,
+               depth=depth.squeeze(0), img_opacity=img_opacity.squeeze(0), foreground=foreground,
                background=background, img_flow=img_flow if flow_points is not None else None,
                img_semantic=img_semantic if semantic is not None else None)
     return out

@@ -141,6 +141,7 @@ class DeformFrame:
         self.rast, self.t, self.use_fs = rasterizer, t, use_flow_sem
         self.model = model if model is not None else SyntheticGaussianModel.from_scene(sc, device, seed=0)
         self.model.raw_sh = os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0"     # SH read straight from the raw parameters
+        self.model.raw_scene = os.environ.get("ADGS_BENCH_RAW_SCENE", "1") != "0"   # scene geometry too: activations inside the preprocess
         self.fused_flow = os.environ.get("ADGS_BENCH_FUSED_FLOW", "1") != "0"      # flow-time xyz in the same deformation pass
         self._sem = None
         self.last_radii = None
@@ -148,7 +149,8 @@ class DeformFrame:
         self.deform_bytes = self.model.deform_bytes_per_frame()
         oa = self.model.order_args
         self.deform_desc = "fused HIP: xyz %s, rotation %s (quaternion spline), shs %s%s, time-masked opacity; %d object Gaussians" % (
-            oa["xyz"], oa["rotation"], oa["shs"], " (read in place by the preprocess: raw-SH path)" if self.model.raw_sh else "",
+            oa["xyz"], oa["rotation"], oa["shs"], (" (read in place by the preprocess: raw-SH path%s)" % (
+                "; scene-range exp / normalize / sigmoid inside the preprocess: raw-scene path" if self.model.raw_scene else "")) if self.model.raw_sh else "",
             self.model.get_obj_pts_num)
 
     @property
@@ -509,6 +511,7 @@ def main():
         from adgs.model import SyntheticGaussianModel
         model = SyntheticGaussianModel.from_scene(sc, device, seed=0)
         model.raw_sh = os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0"
+        model.raw_scene = os.environ.get("ADGS_BENCH_RAW_SCENE", "1") != "0"
     frame = frames[0] if frames else None
     dynamic = cfg["n_objects"] > 0
     params = (lambda: model.parameters()) if dynamic else (lambda: frame.parameters())

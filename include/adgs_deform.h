@@ -41,10 +41,15 @@ int adgs_func_eval_forward(int N, int D, const float* param, const adgs_func_eva
 int adgs_func_eval_backward(int N, int D, const float* param, const adgs_func_eval* f, const float* dL_dout, float* dL_dparam, void* stream);
 
 /* Raw parameters of the reference GaussianModel (scene || object split, scene first). */
+#define ADGS_DEFORM_TIME_MASK 1
+#define ADGS_DEFORM_SKIP_SCENE 2
 typedef struct adgs_deform_params {
 	int32_t Ns, No;                         /* number of scene / object Gaussians */
 	int32_t sh_coeffs;                      /* (max_sh_degree+1)^2 */
-	int32_t use_time_mask;
+	int32_t use_time_mask;                  /* bit 0: time-masked object opacity (scene/gaussian_model.py:207-214); bit 1
+	                                           (ADGS_DEFORM_SKIP_SCENE): the scene range [0, Ns) is not processed -- no output row
+	                                           written, no scene gradient produced (its activations are applied by the rasterizer's
+	                                           preprocess from the raw tensors, adgs_sh_source.scene_xyz ...) */
 	float t;                                /* camera time in [0,1] */
 	const float *scene_xyz, *obj_xyz;                   /* [Ns,3] [No,3] */
 	const float *scene_rotation, *obj_rotation;         /* [Ns,4] [No,4] */

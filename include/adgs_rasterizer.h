@@ -132,12 +132,21 @@ typedef struct adgs_sh_source {
 	const float *scene_rest, *obj_rest;       /* [Ns,M-1,3] [No,M-1,3] */
 	const float *scene_deform, *obj_deform;   /* shs_deform_param_{scene,obj} [.,3,C] or NULL */
 	adgs_func_eval f;                         /* f_shs evaluated at the camera time (n_params = C) */
+	/* Raw scene geometry (all four or none; NULL = off): the Gaussians idx < Ns take their position, log-scale, raw rotation and
+	 * opacity logit from these RAW tensors (_scene_xyz [Ns,3], _scene_scaling [Ns,3], _scene_rotation [Ns,4], _scene_opacity
+	 * [Ns,1]) and the preprocess applies exp / normalize / sigmoid itself (scene/gaussian_model.py:89-152); rows idx < Ns of
+	 * means3D / scales / rotations / opacities / flow_points are then never read (their flow point is the position itself), and
+	 * the backward writes the gradients of the raw tensors (adgs_sh_grads) instead of rows idx < Ns of dL_dmean3D / dL_dscale /
+	 * dL_drot / dL_dopacity / dL_dflow. */
+	const float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;
 } adgs_sh_source;
 typedef struct adgs_sh_grads {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_deform, *obj_deform;   /* NULL = not wanted */
 	float *rgb_factor;   /* [P,3] or NULL: the clamp-masked colour gradient dL/dRGB * (1 - clamped) (backward.cu:20-139), 0 for
 	                        Gaussians with radii == 0 -- the one per-camera vector every SH gradient row above is a multiple of
 	                        (adgs_exchange.h: data-parallel ranks exchange this instead of the expanded rows) */
+	float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;   /* raw scene geometry gradients (required when the
+	                        source carries raw scene geometry): every row written */
 } adgs_sh_grads;
 
 int adgs_raster_forward_rawsh(

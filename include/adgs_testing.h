@@ -23,6 +23,8 @@ long long adgs_test_v2_published_entries(const char* img_buffer, int width, int 
 /* Sum over the tiles of the candidates of the coarse cell's depth-sorted list each tile's walk went through before all of
  * its pixels were saturated (same buffer, same conditions). */
 long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream);
+/* The two per-tile counters themselves (host arrays of `capacity` uint32 each, either may be NULL); returns the number of tiles. */
+long long adgs_test_v2_tile_counters(const char* img_buffer, int width, int height, uint32_t* out_consumed, uint32_t* out_scanned, long long capacity, void* stream);
 
 #ifdef __cplusplus
 }

@@ -394,3 +394,57 @@ def test_render_entry_fuzz(seed):
             close(name, gb.cpu().numpy(), ga.cpu().numpy(), tol=1e-4)
     if use_env:
         close("grid_map", e1.grid_map.grad.cpu().numpy(), e0.grid_map.grad.cpu().numpy(), tol=1e-4)
+
+
+@pytest.mark.parametrize("seed,n_objects,flow,use_arena", [(0, 2, True, False), (1, 3, False, False), (2, 2, True, True)])
+def test_raw_scene_path_matches_materialised_path(seed, n_objects, flow, use_arena):
+    """model.raw_scene (the deformation pass covers the object range only; the rasterizer's preprocess applies exp / normalize /
+    sigmoid to the RAW scene tensors and its backward writes their gradients, scene/gaussian_model.py:89-152) == the fully
+    materialised path: images, radii and every raw-parameter gradient; render() hides the unwritten scene rows behind lazy entries."""
+    from adgs import synthetic, dp
+    from adgs.model import SyntheticGaussianModel
+    from gaussian_renderer import render
+    sc = synthetic.make_scene(9000, 240, 152, 180.0, sh_degree=3, seed=40 + seed, n_objects=n_objects)
+    cam = synthetic.camera_object(synthetic.make_camera(240, 152, 180.0, cam_seed=seed), time=0.43)
+    g = synthetic.make_upstream_grads(sc, seed)
+    d = lambda x: x.cuda()
+
+    class Pipe:
+        inv_depth, debug = True, False
+    res = []
+    for raw_scene in (False, True):
+        m = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=5)
+        m.raw_sh, m.raw_scene = True, raw_scene
+        ex = dp.FactoredSHExchange(m, factor_xyz=False) if (use_arena and raw_scene) else None      # installs the gradient arena
+        out = render(cam, m, None, Pipe(), flow_pkg=(0.5,) + (None,) * 5 if flow else None, render_objmask=True,
+                     sh_factor_sink=ex.sink_for if ex is not None else None)
+        outs = [out["render"], out["depth"], out["img_opacity"], out["img_semantic"]] + ([out["img_flow"]] if flow else [])
+        ups = [d(g["color"]), d(g["depth"])[0], d(g["img_opacity"])[0], d(g["semantic"])] + ([d(g["flow"])] if flow else [])
+        torch.autograd.backward(outs, ups)
+        if ex is not None:
+            assert ex.arena.holds("scene_xyz", m._scene_xyz.grad) and ex.arena.holds("scene_opacity", m._scene_opacity.grad)
+            ex.reduce([cam.time], [cam.camera_center.tolist()], flow_times=[0.5 if flow else None])
+        torch.cuda.synchronize()
+        res.append((out, m))
+    (o0, m0), (o1, m1) = res
+    assert torch.equal(o0["radii"], o1["radii"])
+    for k in ("render", "depth", "img_opacity", "img_semantic") + (("img_flow",) if flow else ()):
+        close(k, o1[k].detach().cpu().numpy(), o0[k].detach().cpu().numpy(), tol=2e-5)
+    close("viewspace", o1["viewspace_points"].grad.cpu().numpy(), o0["viewspace_points"].grad.cpu().numpy(), tol=1e-4)
+    from adgs.model import _RAW
+    for name in _RAW:
+        p0, p1 = getattr(m0, name), getattr(m1, name)
+        if p0.numel() == 0:
+            continue
+        assert (p0.grad is None) == (p1.grad is None), name
+        if p0.grad is not None:
+            close(name, p1.grad.cpu().numpy(), p0.grad.cpu().numpy(), tol=1e-4)
+    # the reference's result entries are still there, produced on demand
+    assert "xyz" in o1 and "rotation" in o1
+    close("lazy xyz", o1["xyz"].detach().cpu().numpy(), o0["xyz"].detach().cpu().numpy(), tol=1e-6)
+    close("lazy opacity", o1["opacity"].detach().cpu().numpy(), o0["opacity"].detach().cpu().numpy(), tol=1e-6)
+    # override_color goes through the plain entry: the raw-scene model materialises full rows for it
+    col = torch.rand(sc["P"], 3, device="cuda")
+    a = render(cam, m0, None, Pipe(), override_color=col)["render"]
+    b = render(cam, m1, None, Pipe(), override_color=col)["render"]
+    close("override_color", b.detach().cpu().numpy(), a.detach().cpu().numpy(), tol=2e-5)

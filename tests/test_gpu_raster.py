@@ -344,3 +344,25 @@ def test_c3_full_size_vs_oracle():
     sc = synthetic.make_config_scene("C3")
     h, o = compare(sc, grads=synthetic.make_upstream_grads(sc, 2))
     assert o["num_rendered"] > 40_000_000                       # the reference's (tile, Gaussian) pair count of this frame
+
+
+def test_backward_uses_the_forwards_configuration_not_the_environment(monkeypatch):
+    """Pipeline, cell size and pixels per lane are read from the environment by the FORWARD and remembered with its state buffers:
+    changing the environment between forward and backward must not change how the backward carves them."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = synthetic.make_scene(6000, 320, 200, 300.0, seed=23, n_objects=2)
+    g = synthetic.make_upstream_grads(sc, 23)
+    ref = run_hip(sc, grads=g)
+    s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], dev(sc["bg"]), 1.0, dev(sc["viewmatrix"]), dev(sc["projmatrix"]), 3,
+                                      dev(sc["campos"]), False, True, False)
+    L = {k: sc[k].cuda().clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    m2 = torch.zeros(sc["P"], 3, device="cuda", requires_grad=True)
+    out = GaussianRasterizer(s)(means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"], rotations=L["rotations"],
+                                flow_points=dev(sc["flow_points"]), semantic=dev(sc["semantic"]))
+    monkeypatch.setenv("ADGS_CELL_TILES", "3")
+    monkeypatch.setenv("ADGS_V2_PPL", "4")
+    monkeypatch.setenv("ADGS_RASTER_MODE", "classic")
+    torch.autograd.backward([out[0], out[2], out[3], out[4], out[5]], [dev(g["color"]), dev(g["depth"]), dev(g["img_opacity"]), dev(g["flow"]), dev(g["semantic"])])
+    torch.cuda.synchronize()
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert_close("grad_" + k, L[k].grad.cpu().numpy(), ref["grads"][k].cpu().numpy(), tol=2e-5, max_frac=1e-5, rel_l2=2e-5)
