@@ -96,8 +96,14 @@ __device__ __forceinline__ void eval_pixel(const EntryGeom& g, float py, float& 
 	al = fminf(ALPHA_MAX, g.op * G);
 }
 
+#ifndef ADGS_FWD_WAVES
+#define ADGS_FWD_WAVES 1
+#endif
+#ifndef ADGS_BWD_WAVES
+#define ADGS_BWD_WAVES 1
+#endif
 template <int PPL>
-__global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
+__global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(RenderV2FwdArgs a) {
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
@@ -384,7 +390,7 @@ __device__ __forceinline__ float wave_sum14_transposed(float x0, float x1, float
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
 // the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
 template <int PPL, bool FULL>
-__global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) {
+__global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(RenderV2BwdArgs a) {
 	constexpr int ROWS = 4 * PPL;
 	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
 	__shared__ float4 s_splat[(WAVE + 1) * 4];      // entry j lives in row j+1 (row 0: prefetch padding)
