@@ -385,8 +385,11 @@ def quick_measure(config, steps, device, use_fs, variant="default", mode=None, w
     sc = build_scene(config, variant)
     cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
     old = os.environ.get("ADGS_RASTER_MODE")
+    old_raw = os.environ.get("ADGS_BENCH_RAW_SH")
     if mode:
         os.environ["ADGS_RASTER_MODE"] = mode
+        if mode == "classic":
+            os.environ["ADGS_BENCH_RAW_SH"] = "0"          # the raw-SH / raw-scene entries exist in the default pipeline only
     try:
         frame = make_frame(sc, cfg, cam, device, use_fs)
         up = synthetic.make_upstream_grads(sc, 0)
@@ -418,6 +421,10 @@ def quick_measure(config, steps, device, use_fs, variant="default", mode=None, w
                 os.environ.pop("ADGS_RASTER_MODE", None)
             else:
                 os.environ["ADGS_RASTER_MODE"] = old
+            if old_raw is None:
+                os.environ.pop("ADGS_BENCH_RAW_SH", None)
+            else:
+                os.environ["ADGS_BENCH_RAW_SH"] = old_raw
 
 
 def self_launch(n):
