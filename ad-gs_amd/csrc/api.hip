@@ -402,7 +402,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
 			CellScanArgs sa;
 			sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
-			sa.chunks = geom.chunks; sa.max_chunks = (uint32_t)MAX_CHUNKS; sa.d_counts = geom.d_counts();
+			sa.chunks = geom.chunks; sa.max_chunks = (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))); sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
 			sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
 			if (launch_cell_scan(sa, stream) != 0) return -1;
 		} else {

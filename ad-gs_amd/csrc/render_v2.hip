@@ -113,7 +113,20 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
 	// objects of the synthetic configs) the lower image rows carry the long lists, and tiles dispatched last run on a draining
 	// machine.  Measured at C3: 0.409 -> 0.400 ms; a strided permutation of the tiles: 0.412 ms.  ADGS_FWD_ORDER=0: top-down.
-	const uint32_t tile = a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	uint32_t tile = a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	if (a.order_mode == 2) {
+		// XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; only speed depends on it).  Neighbouring tiles gather
+		// the same 64-byte Splat lines and walk the same cell lists, and every XCD has its own L2: with the linear order each line is
+		// fetched by all eight.  Here XCD k sweeps whole bands of `band` tile rows (bands k, k + 8, ... from the bottom up), so a line
+		// is fetched by one or two XCDs; the rows that do not fill a group of 8 bands keep the linear order.
+		const uint32_t band = 2u * (uint32_t)(TILE_Y / (4 * PPL)), per_band = band * a.gx, group = 8u * per_band;
+		const uint32_t b = blockIdx.x, full = (gridDim.x / group) * group;
+		if (b < full) {
+			const uint32_t g = b / group, r = b % group, xcd = r % 8u, j = r / 8u;      // j-th workgroup of this XCD inside the group
+			tile = g * group + xcd * per_band + j;
+		}
+		tile = gridDim.x - 1u - tile;
+	}
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	const uint32_t ty16 = ty / SUB;                           // row of the 16x16 tile grid the binning works on
 	const uint32_t cell = (ty16 / a.cell_tiles) * a.cgx + (tx / a.cell_tiles);

@@ -102,3 +102,15 @@ def test_cells_with_several_chunks():
     compare(sc, grads=synthetic.make_upstream_grads(sc, 48))
     st = _stats()
     assert st["bucket_binning"] == 1 and st["num_rendered"] > 3 * 8192
+
+
+def test_chunk_table_overflow_falls_back_to_the_device_wide_sort(monkeypatch):
+    """More chunks than the chunk table holds (134 M pairs in production; forced here with a 3-entry table): cell_scan flags the
+    overflow, the host re-bins the frame with the device-wide radix sort, and the result still matches the oracle."""
+    monkeypatch.setenv("ADGS_MAX_CHUNKS", "3")
+    sc = synthetic.make_scene(30000, 400, 300, 300.0, seed=50, n_objects=2)
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 50))
+    assert _stats()["bucket_binning"] == 0
+    monkeypatch.delenv("ADGS_MAX_CHUNKS")
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 50))
+    assert _stats()["bucket_binning"] == 1
