@@ -496,7 +496,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
 		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
-		ra.bg = background;
+		ra.bg = background; ra.bg_image = sh_src ? sh_src->bg_image : nullptr;
 		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned;
 		ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 		ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
@@ -617,13 +617,14 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		ra.splats = geom.splats; ra.pool = bin.pool; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed;
 		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl;
 		ra.bg = background; ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
+		ra.bg_image = sh_src ? sh_src->bg_image : nullptr; ra.dL_dbg_image = (sh_src && sh_dst && ra.bg_image && dL_dpix) ? sh_dst->bg_image : nullptr;
 		ra.dL_dpix = dL_dpix; ra.dL_dpix_depth = dL_dpix_depth; ra.dL_dpix_flow = dL_dpix_flow; ra.dL_dpix_sem = dL_dpix_semantic;
 		ra.dL_dpix_opacity = grad_img_opacity;
 		ra.do_color = dL_dpix && has_color;
 		ra.do_flow = dL_dpix_flow && flow_points;
 		ra.do_sem = dL_dpix_semantic && semantic && D_S > 0;
 		ra.do_depth = dL_dpix_depth != nullptr;
-		ra.do_opacity = grad_img_opacity != nullptr;
+		ra.do_opacity = grad_img_opacity != nullptr || (ra.bg_image != nullptr && ra.do_color);      // the per-pixel background's term rides on the opacity path
 		ra.gacc = geom.gacc;
 		ra.tile_order = nullptr;
 		{
@@ -739,6 +740,7 @@ static ShSource to_sh_source(const adgs_sh_source* s) {
 	const bool raw_geo = s->Ns > 0 && s->scene_xyz && s->scene_scaling && s->scene_rotation && s->scene_opacity;
 	r.scene_xyz = raw_geo ? s->scene_xyz : nullptr; r.scene_scaling = raw_geo ? s->scene_scaling : nullptr;
 	r.scene_rotation = raw_geo ? s->scene_rotation : nullptr; r.scene_opacity = raw_geo ? s->scene_opacity : nullptr;
+	r.bg_image = s->bg_image;
 	if (!r.scene_dc) { r.scene_dc = r.obj_dc; r.scene_rest = r.obj_rest; }
 	if (!r.obj_dc) { r.obj_dc = r.scene_dc; r.obj_rest = r.scene_rest; }
 	return r;
@@ -789,6 +791,7 @@ extern "C" int adgs_raster_backward_rawsh(
 	dst.scene_dc = dL_dsh->scene_dc; dst.obj_dc = dL_dsh->obj_dc; dst.scene_rest = dL_dsh->scene_rest; dst.obj_rest = dL_dsh->obj_rest;
 	dst.scene_sp = dL_dsh->scene_deform; dst.obj_sp = dL_dsh->obj_deform;
 	dst.rgb_factor = dL_dsh->rgb_factor;
+	dst.bg_image = dL_dsh->bg_image;
 	dst.scene_xyz = dL_dsh->scene_xyz; dst.scene_scaling = dL_dsh->scene_scaling; dst.scene_rotation = dL_dsh->scene_rotation; dst.scene_opacity = dL_dsh->scene_opacity;
 	if (src.scene_xyz && !(dst.scene_xyz && dst.scene_scaling && dst.scene_rotation && dst.scene_opacity)) {
 		set_error("adgs_raster_backward_rawsh: the source carries raw scene geometry, its four gradient destinations are required"); return -1;

@@ -115,11 +115,13 @@ struct ShSource {
 	// these raw tensors and the preprocess applies exp / normalize / sigmoid itself; rows idx < Ns of the activated inputs are
 	// then never read (scene/gaussian_model.py:89-152: the reference materialises the activations with torch ops)
 	const float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;
+	const float *bg_image;    // [3,H,W] per-pixel background composited in the blend epilogue (nullptr: the constant background colour)
 };
 struct ShGradDst {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_sp, *obj_sp;
 	float *rgb_factor;   // [P,3] clamp-masked colour gradient: the per-camera factor every SH gradient row is a multiple of
 	float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;   // raw scene geometry gradients ([Ns,3] [Ns,3] [Ns,4] [Ns,1])
+	float *bg_image;          // [3,H,W] gradient of the per-pixel background (every pixel written) or nullptr
 };
 
 } // namespace adgs

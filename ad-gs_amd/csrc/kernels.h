@@ -131,6 +131,7 @@ struct RenderV2FwdArgs {
 	int ppl;                                // pixels per lane: 4 or 2 (v2_pixels_per_lane)
 	bool has_color, has_flow, has_sem;
 	const float* bg;
+	const float* bg_image;                  // [3,H,W] per-pixel background (environment map) or nullptr: color = C + T * bg_image instead of + T * bg
 	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_scanned;
 	float* final_T; uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
@@ -142,6 +143,7 @@ struct RenderV2BwdArgs {
 	const Splat* splats; const uint32_t* pool; const uint32_t* tile_last_chunk; const uint32_t* tile_consumed;
 	int W, H, gx, gy, ppl;                  // gy: rows of WAVE tiles, as in the forward
 	const float* bg; const float* final_T; const uint32_t* n_contrib;
+	const float* bg_image; float* dL_dbg_image;      // per-pixel background of the forward and its gradient T_final * dL/dC ([3,H,W], every pixel written)
 	const float* dL_dpix; const float* dL_dpix_depth; const float* dL_dpix_flow; const float* dL_dpix_sem; const float* dL_dpix_opacity;
 	bool do_color, do_flow, do_sem, do_depth, do_opacity;
 	float* gacc;                     // [P][GACC_STRIDE], zero-initialised

@@ -303,9 +303,13 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			a.final_T[pix_id] = (float)(1.0 - (double)T[k]);
 			a.n_contrib[pix_id] = last_contrib[k];
 			if (a.has_color) {
-				a.out_color[0 * HW + pix_id] = C0[k] + T[k] * a.bg[0];
-				a.out_color[1 * HW + pix_id] = C1[k] + T[k] * a.bg[1];
-				a.out_color[2 * HW + pix_id] = C2[k] + T[k] * a.bg[2];
+				// background composite in the epilogue: constant colour (forward.cu:392-394) or, with an environment map, the per-pixel
+				// background of gaussian_renderer/__init__.py:93-94 (render = foreground + (1 - O) * background, T = 1 - O)
+				const float b0 = a.bg[0] + (a.bg_image ? a.bg_image[0 * HW + pix_id] : 0.f), b1 = a.bg[1] + (a.bg_image ? a.bg_image[1 * HW + pix_id] : 0.f),
+					b2 = a.bg[2] + (a.bg_image ? a.bg_image[2 * HW + pix_id] : 0.f);
+				a.out_color[0 * HW + pix_id] = C0[k] + T[k] * b0;
+				a.out_color[1 * HW + pix_id] = C1[k] + T[k] * b1;
+				a.out_color[2 * HW + pix_id] = C2[k] + T[k] * b2;
 			}
 			if (a.has_flow) { a.out_flow[0 * HW + pix_id] = F0[k]; a.out_flow[1 * HW + pix_id] = F1[k]; a.out_flow[2 * HW + pix_id] = F2[k]; }
 			if (a.has_sem) a.out_semantic[pix_id] = S0[k];
@@ -441,10 +445,19 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 			if (do_flow) { gF0[k] = a.dL_dpix_flow[0 * HW + pix_id]; gF1[k] = a.dL_dpix_flow[1 * HW + pix_id]; gF2[k] = a.dL_dpix_flow[2 * HW + pix_id]; }
 			if (do_sem) gS[k] = a.dL_dpix_sem[pix_id];
 			if (do_depth) gD[k] = a.dL_dpix_depth[pix_id];
-			if (do_opacity) gO = a.dL_dpix_opacity[pix_id];
+			if (do_opacity && a.dL_dpix_opacity) gO = a.dL_dpix_opacity[pix_id];
 		}
 		float b = 0.f;
 		b += a.bg[0] * gC0[k]; b += a.bg[1] * gC1[k]; b += a.bg[2] * gC2[k];
+		if (a.bg_image && inside[k]) {
+			// The reference composites the environment map in Python: render = fg + (1 - O) * bg_image, so -sum_c bg_c dL/dC_c reaches the
+			// rasterizer as part of grad_img_opacity and takes the opacity path WITH its extra factor T (backward.cu:612-614, the
+			// "opacity-T quirk") -- unlike the constant background above, which the rasterizer differentiates itself.
+			gO -= a.bg_image[0 * HW + pix_id] * gC0[k] + a.bg_image[1 * HW + pix_id] * gC1[k] + a.bg_image[2 * HW + pix_id] * gC2[k];
+			if (a.dL_dbg_image) {      // d render / d background = T_final
+				a.dL_dbg_image[0 * HW + pix_id] = T_final * gC0[k]; a.dL_dbg_image[1 * HW + pix_id] = T_final * gC1[k]; a.dL_dbg_image[2 * HW + pix_id] = T_final * gC2[k];
+			}
+		}
 		tfo[k] = gO * T_final; tfb[k] = T_final * b;
 	}
 #pragma unroll
@@ -603,7 +616,7 @@ int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order
 
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;
-	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity;
+	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity && a.dL_dpix_opacity != nullptr;
 	if (a.ppl == 2) {
 		if (full) hipLaunchKernelGGL((render_bwd_v2_kernel<2, true>), dim3(T), dim3(WAVE), 0, stream, a);
 		else hipLaunchKernelGGL((render_bwd_v2_kernel<2, false>), dim3(T), dim3(WAVE), 0, stream, a);

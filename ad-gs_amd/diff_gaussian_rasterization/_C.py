@@ -164,13 +164,13 @@ class ShSource(ctypes.Structure):
     from adgs.deform import FuncEval as _FE
     _fields_ = [("Ns", ctypes.c_int32)] + [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform",
                                                                               "obj_deform")] + [("f", _FE)] + \
-               [(n, ctypes.c_void_p) for n in ("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")]
+               [(n, ctypes.c_void_p) for n in ("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity", "bg_image")]
 
 
 class ShGrads(ctypes.Structure):
     """adgs_sh_grads (include/adgs_rasterizer.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor",
-                                               "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")]
+                                               "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity", "bg_image")]
 
 
 def _sh_source(raw, dev):
@@ -194,6 +194,11 @@ def _sh_source(raw, dev):
             for name, t in zip(("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity"), gs):
                 setattr(src, name, _ptr(t))
             ts = ts + gs
+    bg_image = raw[8] if len(raw) > 8 else None
+    if bg_image is not None:
+        b = _prep(bg_image, dev, "bg_image")
+        src.bg_image = _ptr(b)
+        ts = ts + [b]
     return src, ts
 
 
@@ -217,6 +222,11 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
     radii = (torch.empty if P != 0 else torch.zeros)((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Buffer(dev), _Buffer(dev), _Buffer(dev)
     rendered = 0
+    bg_image = sh_raw[8] if len(sh_raw) > 8 else None
+    if bg_image is not None and tuple(bg_image.shape) != (NUM_CHANNELS, H, W):
+        raise RuntimeError("bg_image must be [3, H, W]")
+    if P == 0 and bg_image is not None:
+        out_color = bg_image.detach().clone()          # nothing to blend: T = 1 everywhere
     if P != 0:
         src, keep_sh = _sh_source(sh_raw, dev)
         keep = [_prep(t, dev, n) for t, n in ((background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"),
@@ -263,12 +273,19 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     else:
         rgb_factor = (e(P, 3) if P != 0 else torch.zeros((0, 3), dtype=torch.float32, device=dev)) if want_rgb_factor else None
     geo_grads = None
+    bg_grad = None
+    if P == 0 and len(sh_raw) > 8 and sh_raw[8] is not None:
+        bg_grad = dL_dout_color.clone()                # T = 1 everywhere
     if P != 0:
         src, keep_sh = _sh_source(sh_raw, dev)
         gs = ShGrads()
         for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
             setattr(gs, name, _ptr(t))
         gs.rgb_factor = _ptr(rgb_factor)
+        bg_image = sh_raw[8] if len(sh_raw) > 8 else None
+        if bg_image is not None:
+            bg_grad = torch.empty_like(bg_image, memory_format=torch.contiguous_format)
+            gs.bg_image = _ptr(bg_grad)
         geo = sh_raw[7] if len(sh_raw) > 7 and src.scene_xyz else None
         if geo is not None:          # raw scene geometry: the gradients of the four raw tensors (every row written by the kernel)
             names = ("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")
@@ -295,4 +312,4 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     if P == 0 or not (len(sh_raw) > 7 and sh_raw[7] is not None and sh_raw[0].size(0) > 0):
         geo_grads = None
     res = (dL_dmeans2D, dL_dopacity, dL_dmeans3D, sh_grads, dL_dscales, dL_drotations, dL_dflow_points, dL_dsemantic)
-    return res + ((rgb_factor,) if rgb_factor is not None else (None,)) + (geo_grads,)
+    return res + ((rgb_factor,) if rgb_factor is not None else (None,)) + (geo_grads, bg_grad)

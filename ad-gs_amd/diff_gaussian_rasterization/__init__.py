@@ -121,18 +121,18 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, scales, rotations, flow_points, semantic, scene_dc, obj_dc, scene_rest, obj_rest,
                 scene_deform, obj_deform, func_eval, raster_settings, factor_sink=None, scene_xyz=None, scene_scaling=None, scene_rotation=None,
-                scene_opacity=None, grad_arena=None):
+                scene_opacity=None, grad_arena=None, bg_image=None):
         s = raster_settings
         geo = (scene_xyz, scene_scaling, scene_rotation, scene_opacity) if scene_xyz is not None else None
-        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval, geo)
+        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval, geo, bg_image)
         (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow, img_semantic) = _C.rasterize_gaussians_rawsh(
             s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
             s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
         ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink = s, num_rendered, func_eval, factor_sink
-        ctx.has_geo, ctx.grad_arena = geo is not None, grad_arena
+        ctx.has_geo, ctx.grad_arena, ctx.has_bg = geo is not None, grad_arena, bg_image is not None
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
-                              scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, *(geo or ()))
+                              scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, *(geo or ()), *((bg_image,) if bg_image is not None else ()))
         return color, radii, depth, img_opacity, img_flow, img_semantic
 
     @staticmethod
@@ -142,7 +142,8 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         (means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
          scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform) = saved[:16]
         geo = tuple(saved[16:20]) if ctx.has_geo else None
-        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval, geo)
+        bg_image = saved[-1] if ctx.has_bg else None
+        raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, ctx.func_eval, geo, bg_image)
         if grad_out_color is None:
             grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
         factored = ctx.factor_sink is not None
@@ -154,11 +155,11 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
             geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
             want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False,
             geo_grad_alloc=(arena.take if arena is not None else None))
-        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem, g_factor, g_geo) = res
+        (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem, g_factor, g_geo, g_bg) = res
         if factored:
             ctx.factor_sink.append(g_factor)
         g_geo = tuple(g_geo) if g_geo is not None else (None,) * 4
-        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None) + g_geo + (None,)
+        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None) + g_geo + (None, g_bg)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
@@ -178,16 +179,18 @@ class GaussianRasterizer(nn.Module):
             s = self.raster_settings
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
-    def forward_rawsh(self, means3D, means2D, opacities, sh_raw, scales, rotations, flow_points=None, semantic=None, factor_sink=None):
+    def forward_rawsh(self, means3D, means2D, opacities, sh_raw, scales, rotations, flow_points=None, semantic=None, factor_sink=None, bg_image=None):
         """Extension (no reference counterpart): like forward(), with the SH coefficients given as a RawSH.
-        factor_sink: see _RasterizeGaussiansRawSH (factored SH gradients for data-parallel training)."""
+        factor_sink: see _RasterizeGaussiansRawSH (factored SH gradients for data-parallel training).
+        bg_image [3,H,W]: per-pixel background composited in the blend epilogue -- the first output is then
+        `foreground + (1 - img_opacity) * bg_image` (gaussian_renderer/__init__.py:93-94) and bg_image receives a gradient."""
         empty = lambda t: torch.Tensor([]) if t is None else t
         return _RasterizeGaussiansRawSH.apply(means3D, means2D, opacities, scales, rotations, empty(flow_points), empty(semantic),
                                               sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest, sh_raw.obj_rest, sh_raw.scene_deform,
                                               sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings, factor_sink,
                                               getattr(sh_raw, "scene_xyz", None), getattr(sh_raw, "scene_scaling", None),
                                               getattr(sh_raw, "scene_rotation", None), getattr(sh_raw, "scene_opacity", None),
-                                              getattr(sh_raw, "grad_arena", None))
+                                              getattr(sh_raw, "grad_arena", None), bg_image)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, flow_points=None, semantic=None):

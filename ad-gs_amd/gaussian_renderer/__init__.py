@@ -39,17 +39,20 @@ def _deformed_state(pc, t, flow_pkg, full_rows=False):
     return pc.get_deformed_pkg(t, **kw), pc.get_deformed_xyz(flow_t)
 
 
-def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic, sh_factor_sink=None):
+def _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic, sh_factor_sink=None, bg_image=None):
+    """bg_image: the environment-map background; on the raw-SH path it is composited in the blend epilogue (the first output is then the
+    final `render`), otherwise the caller composites."""
     scales = pkg["scales"] if "scales" in pkg else pc.get_scaling
     shs = None if override_color is not None else pkg["shs"]
     if shs is not None and not torch.is_tensor(shs):
         # a RawSH: the rasterizer reads dc / rest / deformation rows in place, the [N,16,3] tensor is never built
         return rasterizer.forward_rawsh(pkg["xyz"], means2D, pkg["opacity"], shs, scales, pkg["rotation"], flow_points=flow_points,
-                                        semantic=semantic, factor_sink=None if sh_factor_sink is None else sh_factor_sink(pkg["xyz"]))
+                                        semantic=semantic, factor_sink=None if sh_factor_sink is None else sh_factor_sink(pkg["xyz"]),
+                                        bg_image=bg_image), bg_image is not None
     if sh_factor_sink is not None:
         raise RuntimeError("sh_factor_sink needs the raw-SH path (a model whose get_deformed_pkg hands out a RawSH)")
     return rasterizer(means3D=pkg["xyz"], means2D=means2D, opacities=pkg["opacity"], shs=shs, colors_precomp=override_color, scales=scales,
-                      rotations=pkg["rotation"], flow_points=flow_points, semantic=semantic)
+                      rotations=pkg["rotation"], flow_points=flow_points, semantic=semantic), False
 
 
 class _LazyResult(dict):
@@ -106,10 +109,18 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
     rasterizer = GaussianRasterizer(raster_settings=_camera_settings(viewpoint_camera, pc, pipe, scaling_modifier, device))
     pkg, flow_points = _deformed_state(pc, viewpoint_camera.time, flow_pkg, full_rows=override_color is not None)
     semantic = pc.get_obj_mask.float()[..., None] if render_objmask else None
-    foreground, radii, depth, img_opacity, img_flow, img_semantic = _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points, semantic,
-                                                                                sh_factor_sink)
-
-    background = env_map.get_image_background(viewpoint_camera) if env_map is not None else torch.zeros_like(foreground)
+    # the environment-map background first: on the raw-SH path the blend epilogue composites it (`render = C + T * background`,
+    # gaussian_renderer/__init__.py:93-94) and the blend backward returns dL/dbackground = T * dL/drender -- no element-wise pass
+    background = env_map.get_image_background(viewpoint_camera) if env_map is not None else None
+    (first, radii, depth, img_opacity, img_flow, img_semantic), composited = _rasterize(rasterizer, pc, pkg, means2D, override_color, flow_points,
+                                                                                         semantic, sh_factor_sink, bg_image=background)
+    if composited:
+        rendered, foreground = first, None                      # 'foreground' on demand: render - (1 - O) * background
+    else:
+        foreground = first
+        if background is None:
+            background = torch.zeros_like(foreground)
+        rendered = foreground + (1.0 - img_opacity) * background
     shs = pkg.get("shs")
     if shs is not None and not torch.is_tensor(shs) and getattr(shs, "scene_xyz", None) is not None:
         # raw-scene path: rows [0, Ns) of the deformed tensors were never written; hand them out lazily (a full deformation pass)
@@ -125,8 +136,16 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
         out = dict(pkg)                                         # the reference also hands back xyz / rotation / shs / opacity
         opacity_entry = dict(opacity=pkg["opacity"])
     out.update(opacity_entry)
-    out.update(render=foreground + (1.0 - img_opacity) * background, viewspace_points=means2D, visibility_filter=radii > 0, radii=radii,
-               depth=depth.squeeze(0), img_opacity=img_opacity.squeeze(0), foreground=foreground,
+    out.update(render=rendered, viewspace_points=means2D, visibility_filter=radii > 0, radii=radii,
+               depth=depth.squeeze(0), img_opacity=img_opacity.squeeze(0),
                background=background, img_flow=img_flow if flow_points is not None else None,
                img_semantic=img_semantic if semantic is not None else None)
+    if foreground is not None:
+        out["foreground"] = foreground
+    else:                                                       # composited in the epilogue: the reference's 'foreground' entry on first access
+        if not isinstance(out, _LazyResult):
+            lazy = _LazyResult({})
+            lazy.update(out)
+            out = lazy
+        out._thunks["foreground"] = lambda: rendered - (1.0 - img_opacity) * background
     return out

@@ -92,6 +92,7 @@ def main():
     sc = synthetic.make_config_scene(args.config)
     model = SyntheticGaussianModel.from_scene(sc, dev, seed=0)            # same seed on every rank: identical replicas
     model.raw_sh = True
+    model.raw_scene = True          # scene-range activations inside the rasterizer's preprocess
     model.training_setup(lrs={"scene_xyz": 1.6e-4, "obj_xyz": 1.6e-4, "scene_shs_dc": 2.5e-3, "obj_shs_dc": 2.5e-3, "scene_opacity": 0.05,
                               "obj_opacity": 0.05, "scene_scaling": 5e-3, "obj_scaling": 5e-3}, scene_extent=20.0, object_extent=4.0)
     cameras = make_cameras(cfg, args.cams or world)

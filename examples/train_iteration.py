@@ -28,6 +28,7 @@ def build(config, env_res, device):
     sc = synthetic.make_config_scene(config)
     model = SyntheticGaussianModel.from_scene(sc, device=device, seed=0)
     model.raw_sh = True
+    model.raw_scene = True          # scene-range activations inside the rasterizer's preprocess
     cam = synthetic.camera_object(sc, time=0.37)
     cam.cam_id = 0
     env_map = env.EnvironmentMap(env_res, 3, device=device)

@@ -139,6 +139,11 @@ typedef struct adgs_sh_source {
 	 * the backward writes the gradients of the raw tensors (adgs_sh_grads) instead of rows idx < Ns of dL_dmean3D / dL_dscale /
 	 * dL_drot / dL_dopacity / dL_dflow. */
 	const float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;
+	/* Per-pixel background [3,H,W] (NULL = the constant `background` colour): the blend epilogue writes out_color = C + T * bg_image,
+	 * i.e. the reference's composite `render = foreground + (1 - img_opacity) * background` of the environment map
+	 * (gaussian_renderer/__init__.py:93-94, scene/env.py:43-76) without a pass of its own; the backward then uses the per-pixel
+	 * background in its `bg . dL/dC` term and writes dL/dbg_image = T_final * dL/dC (adgs_sh_grads.bg_image). */
+	const float *bg_image;
 } adgs_sh_source;
 typedef struct adgs_sh_grads {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_deform, *obj_deform;   /* NULL = not wanted */
@@ -147,6 +152,7 @@ typedef struct adgs_sh_grads {
 	                        (adgs_exchange.h: data-parallel ranks exchange this instead of the expanded rows) */
 	float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;   /* raw scene geometry gradients (required when the
 	                        source carries raw scene geometry): every row written */
+	float *bg_image;     /* [3,H,W] gradient of the per-pixel background or NULL (not wanted) */
 } adgs_sh_grads;
 
 int adgs_raster_forward_rawsh(

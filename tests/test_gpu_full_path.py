@@ -167,7 +167,8 @@ class _Pipe:
 @pytest.mark.parametrize("P,W,H,focal,n_objects,res,cam_seed", [(60000, 640, 400, 620.0, 4, 256, 5), (300000, 1242, 375, 721.5, 6, 1024, None)])
 def test_render_entry_with_env_map_vs_oracle_chain(P, W, H, focal, n_objects, res, cam_seed):
     """The whole `render()` result -- deformation -> rasterizer -> environment-map composite `fg + (1 - O) bg`
-    (gaussian_renderer/__init__.py:93-94, scene/env.py:43-76) -- and the gradients of a loss on every returned image, into the
+    (gaussian_renderer/__init__.py:93-94, scene/env.py:43-76; composited in the blend epilogue on this path, 'foreground' handed out
+    on demand) -- and the gradients of a loss on every returned image, into the
     raw parameters, the screen-space means (viewspace_points.grad, what add_densification_stats reads) and the environment map."""
     from adgs import synthetic
     from adgs.env import EnvironmentMap, fov2focal
@@ -177,6 +178,7 @@ def test_render_entry_with_env_map_vs_oracle_chain(P, W, H, focal, n_objects, re
     camd = synthetic.make_camera(W, H, focal, cam_seed=cam_seed)
     model = SyntheticGaussianModel.from_scene(sc, device="cuda", seed=2)
     model.raw_sh = True
+    model.raw_scene = cam_seed is None             # the second case also takes the raw-scene path (activations inside the preprocess)
     cam = synthetic.camera_object(camd, time=0.61)
     env = EnvironmentMap(res, device="cuda")
     with torch.no_grad():
