@@ -114,3 +114,27 @@ def test_chunk_table_overflow_falls_back_to_the_device_wide_sort(monkeypatch):
     monkeypatch.delenv("ADGS_MAX_CHUNKS")
     compare(sc, grads=synthetic.make_upstream_grads(sc, 50))
     assert _stats()["bucket_binning"] == 1
+
+
+def test_c5_size_bucket_binning_equals_sort_binning_bit_for_bit(monkeypatch):
+    """3 M Gaussians, 68 k pairs per cell (9 chunks per cell, 11 719 preprocess workgroups in the counts matrix): the library would pick
+    the device-wide sort for this frame by itself; forced onto the bucket path, every forward output must still be bit-identical."""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    cfg = synthetic.CONFIGS["C5"]
+    sc = synthetic.make_config_scene("C5")
+    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
+    frame = bench.make_frame(sc, cfg, cam, torch.device("cuda", 0), True)
+    outs = {}
+    for mode in ("bucket", "sort"):
+        monkeypatch.setenv("ADGS_BINNING", mode)
+        with torch.no_grad():
+            outs[mode] = [o.clone() for o in frame.forward()] + [frame.last_radii.clone()]
+        assert _stats()["bucket_binning"] == (1 if mode == "bucket" else 0)
+        assert _stats()["num_rendered"] > 4_000_000
+    for a, b in zip(outs["bucket"], outs["sort"]):
+        assert torch.equal(a, b)
