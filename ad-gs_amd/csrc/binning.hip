@@ -277,11 +277,16 @@ __global__ void __launch_bounds__(MG_THREADS) chunk_merge_kernel(ChunkSortArgs a
 		if (q == chunk_x) continue;                                     // block-uniform
 		const uint32_t nb = min((uint32_t)GS_NMAX, ch.w - q);
 		__syncthreads();
+		{	// all loads of the chunk in flight at once, then the LDS stores (one load -> wait -> store per step serialises 16 L2 round
+			// trips: the staging, not the search, was what this kernel's time went into)
+			unsigned long long v[GS_NMAX / MG_THREADS];
 #pragma unroll
-		for (int k = 0; k < GS_NMAX / MG_THREADS; k++) {
-			const uint32_t i = k * MG_THREADS + tid;
-			const unsigned long long v = keys[q + min(i, nb - 1)];
-			if (i < nb) s_key[i + (i >> 5)] = v;
+			for (int k = 0; k < GS_NMAX / MG_THREADS; k++) v[k] = keys[q + min((uint32_t)(k * MG_THREADS + tid), nb - 1)];
+#pragma unroll
+			for (int k = 0; k < GS_NMAX / MG_THREADS; k++) {
+				const uint32_t i = k * MG_THREADS + tid;
+				if (i < nb) s_key[i + (i >> 5)] = v[k];
+			}
 		}
 		__syncthreads();
 		// Branch-free lower bound, the GS_ITEMS searches of a thread interleaved (a first version with `if (lo < hi)` and a
