@@ -853,6 +853,22 @@ extern "C" long long adgs_test_v2_tile_counters(const char* img_buffer, int widt
 	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
 	return (long long)wtiles;
 }
+// per-cell (start, end) ranges of the depth-sorted candidate lists of the last forward (returns the cell count)
+extern "C" long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height, uint32_t* out_ranges, long long capacity, void* stream_) {
+	if (!img_buffer || width <= 0 || height <= 0) return -1;
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	FrameCfg cfg;
+	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
+	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
+	if ((long long)ncells > capacity) return (long long)ncells;
+	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
+	if (out_ranges && hipMemcpyAsync(out_ranges, img.cell_ranges, ncells * sizeof(uint2), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	return (long long)ncells;
+}
 // sum over the wave tiles of the candidates of the cell list each tile's walk went through before all its pixels were saturated
 extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream_) {
 	if (!img_buffer || width <= 0 || height <= 0) return -1;

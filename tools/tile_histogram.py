@@ -41,6 +41,14 @@ for name in sys.argv[1:] or ["C3"]:
     cons, scan = cons[:nt], scan[:nt]
     st = lambda a: dict(mean=float(a.mean()), p50=float(np.percentile(a, 50)), p90=float(np.percentile(a, 90)), p99=float(np.percentile(a, 99)), max=int(a.max()),
                         share_of_top_1pct=float(np.sort(a)[-max(nt // 100, 1):].sum() / max(a.sum(), 1)))
-    out[name] = dict(tiles=int(nt), blended_entries_per_tile=st(cons), scanned_candidates_per_tile=st(scan))
+    cr = np.zeros(2 * 4096, np.uint32)
+    nc = _lib.lib().adgs_test_v2_cell_ranges(r[7].data_ptr(), cfg["W"], cfg["H"], cr.ctypes.data, 4096, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    cr = cr[:2 * nc].reshape(-1, 2).astype(np.int64)
+    csz = cr[:, 1] - cr[:, 0]
+    chunks = (csz + 8191) // 8192
+    out[name] = dict(tiles=int(nt), blended_entries_per_tile=st(cons), scanned_candidates_per_tile=st(scan),
+                     cells=int(nc), candidates_per_cell=dict(mean=float(csz.mean()), p50=float(np.percentile(csz, 50)), p90=float(np.percentile(csz, 90)),
+                                                            p99=float(np.percentile(csz, 99)), max=int(csz.max())),
+                     chunks_per_cell={str(k): int((chunks == k).sum()) for k in np.unique(chunks)})
     print(name, json.dumps(out[name]))
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "tile_histogram.json"), "w"), indent=1)
