@@ -105,7 +105,7 @@ struct GeomStateV2 {
 	}
 };
 struct ImgStateV2 {
-	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order; uint32_t* tile_scanned;
+	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order; uint32_t* tile_scanned; uint32_t* tile_batches;
 	static ImgStateV2 carve(char* chunk, size_t npix, size_t ntiles, size_t ncells, size_t* bytes) {
 		Carver c(chunk); ImgStateV2 s;
 		s.n_contrib = c.take<uint32_t>(npix);
@@ -114,6 +114,7 @@ struct ImgStateV2 {
 		s.tile_consumed = c.take<uint32_t>(ntiles);
 		s.tile_order = c.take<uint32_t>(ntiles);
 		s.tile_scanned = c.take<uint32_t>(ntiles);          // candidates of the cell list the tile's walk went through (statistics)
+		s.tile_batches = c.take<uint32_t>(ntiles);          // batches of <= 64 entries handed to the blend loop (statistics)
 		if (bytes) *bytes = c.size();
 		return s;
 	}
@@ -123,7 +124,8 @@ struct BinStateV2 {
 	uint64_t* keys_unsorted; uint64_t* keys; uint32_t* list_unsorted; uint32_t* list; char* sort_temp;
 	// bucket binning: unsorted (cell-grouped) 16-byte records, chunk-sorted (depth, id) keys + masks, final (id, mask) entries
 	uint4* rec_unsorted; uint2* key_stage; uint32_t* mask_stage; uint2* entries;
-	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + ntiles + 1; }
+	// every tile's own block + blocks drawn from the cursor, each of which may end partly used
+	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + (2 * (size_t)POOL_BLOCK + 1) * ntiles + 1; }
 	static BinStateV2 carve_buckets(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
 		Carver c(chunk); BinStateV2 b;
 		b.pool_cursor = c.take<uint32_t>(64);
@@ -497,7 +499,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
 		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
 		ra.bg = background; ra.bg_image = sh_src ? sh_src->bg_image : nullptr;
-		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned;
+		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned; ra.tile_batches = img.tile_batches;
 		ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 		ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
 		ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
@@ -852,6 +854,24 @@ extern "C" long long adgs_test_v2_tile_counters(const char* img_buffer, int widt
 	if (out_scanned && hipMemcpyAsync(out_scanned, img.tile_scanned, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
 	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
 	return (long long)wtiles;
+}
+// number of batches (of <= 64 entries that passed the tile test) the forward handed to its blend loop, summed over the tiles
+extern "C" long long adgs_test_v2_blend_batches(const char* img_buffer, int width, int height, void* stream_) {
+	if (!img_buffer || width <= 0 || height <= 0) return -1;
+	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
+	FrameCfg cfg;
+	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
+	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
+	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
+	std::vector<uint32_t> h(wtiles);
+	if (hipMemcpyAsync(h.data(), img.tile_batches, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	long long total = 0;
+	for (uint32_t v : h) total += v;
+	return total;
 }
 // per-cell (start, end) ranges of the depth-sorted candidate lists of the last forward (returns the cell count)
 extern "C" long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height, uint32_t* out_ranges, long long capacity, void* stream_) {

@@ -487,7 +487,9 @@ struct ParamGradArgs {
 	// optional second segment in the same launch (blocks >= nb0): the object side after the scene side
 	int nb0, n0_b, count_b; const float* g_b; float* out_b;
 };
-constexpr int PG_ITEMS = 8;                          // consecutive outputs per thread (two 16-byte stores)
+constexpr int PG_ITEMS = 8;                          // outputs per thread: two 16-byte stores, 256 float4 apart
+// Every store instruction of a wave covers 1 KiB of consecutive bytes (lane i writes float4 number base + i; the thread's second
+// float4 lies one block width further): 16 full 64-byte lines per instruction instead of 64 half-covered 32-byte pieces.
 __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
 	extern __shared__ float s_w[];
 	const int np = a.f.n_params;
@@ -502,29 +504,29 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 	const float* __restrict__ seg_g = second ? a.g_b : a.g;
 	float* __restrict__ seg_out = second ? a.out_b : a.out;
 	const size_t tot = (size_t)seg_count * a.D * np;
-	const size_t e0 = ((size_t)(blockIdx.x - (second ? a.nb0 : 0)) * 256 + threadIdx.x) * PG_ITEMS;
-	if (e0 >= tot) return;
-	// (Gaussian m, channel d, column k) of the first output; then advanced incrementally
-	size_t row; int k;
-	if (tot <= 0xffffffffull) { const uint32_t r32 = (uint32_t)e0 / (uint32_t)np; row = r32; k = (int)((uint32_t)e0 - r32 * (uint32_t)np); }
-	else { row = e0 / np; k = (int)(e0 - row * np); }
-	size_t m = row / a.D; int d = (int)(row - m * a.D);
-	float gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
-	float v[PG_ITEMS];
+	const size_t blk0 = (size_t)(blockIdx.x - (second ? a.nb0 : 0)) * 256 * PG_ITEMS;
 #pragma unroll
-	for (int it = 0; it < PG_ITEMS; it++) {
-		v[it] = s_w[k] * gv;
-		if (++k == np) {
-			k = 0;
-			if (++d == a.D) { d = 0; m++; }
-			if (e0 + it + 1 < tot) gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
+	for (int half = 0; half < PG_ITEMS / 4; half++) {
+		const size_t e0 = blk0 + ((size_t)half * 256 + threadIdx.x) * 4;
+		if (e0 >= tot) return;
+		// (Gaussian m, channel d, column k) of the first output; then advanced incrementally
+		size_t row; int k;
+		if (tot <= 0xffffffffull) { const uint32_t r32 = (uint32_t)e0 / (uint32_t)np; row = r32; k = (int)((uint32_t)e0 - r32 * (uint32_t)np); }
+		else { row = e0 / np; k = (int)(e0 - row * np); }
+		size_t m = row / a.D; int d = (int)(row - m * a.D);
+		float gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
+		float v[4];
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			v[it] = s_w[k] * gv;
+			if (++k == np) {
+				k = 0;
+				if (++d == a.D) { d = 0; m++; }
+				if (e0 + it + 1 < tot) gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
+			}
 		}
-	}
-	if (e0 + PG_ITEMS <= tot) {
-		float4* o = reinterpret_cast<float4*>(seg_out + e0);
-		o[0] = make_float4(v[0], v[1], v[2], v[3]); o[1] = make_float4(v[4], v[5], v[6], v[7]);
-	} else {
-		for (int it = 0; it < PG_ITEMS && e0 + it < tot; it++) seg_out[e0 + it] = v[it];
+		if (e0 + 4 <= tot) *reinterpret_cast<float4*>(seg_out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+		else for (int it = 0; it < 4 && e0 + it < tot; it++) seg_out[e0 + it] = v[it];
 	}
 }
 
@@ -615,7 +617,7 @@ __device__ __forceinline__ void deform_bwd_body(const DeformBwdArgs& a, int blk,
 		const int np = a.fr.n_params;
 		const bool haver = a.p.rotation_deform_param != nullptr;
 		const bool staged = blk_obj && haver;
-		float* s_out = s_rows + B * a.stride_r;           // gradient rows
+		float* s_out = s_rows;           // gradient rows, in place: a thread is done with its parameter row (spline state saved in registers) before it writes its gradient row, and two sets of rows halved the waves a CU can hold
 		if (staged) {
 			stage_rows<true>(s_rows, a.stride_r, 4 * np, base, count, Ns, (const float*)nullptr, a.p.rotation_deform_param, tid, B);
 			__syncthreads();
@@ -844,20 +846,53 @@ namespace {
 template <int NV4>
 __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out) {
 	__shared__ float s_w[NV4 * 4];
+	__shared__ float s_part[256 * NV4 + 4];
 	for (int k = threadIdx.x; k < NV4 * 4; k += 256) s_w[k] = 0.f;
 	__syncthreads();
 	const int total = s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2];
 	for (int i = threadIdx.x; i < total; i += 256) s_w[s.f.index[i]] = s.f.weight[i];
 	__syncthreads();
-	const int e = blockIdx.x * 256 + threadIdx.x;          // row = n * 3 + c
+	// The block owns 256 consecutive rows = 256 * NV4 consecutive 16-byte words of one segment (scene or object side).  Lane i of a
+	// load instruction reads word base + i -- 1 KiB of consecutive bytes per wave and instruction instead of 64 words 16 * NV4 bytes
+	// apart --, dots it with its quarter of the basis vector, and the NV4 partial sums of a row meet in LDS.  A block that straddles
+	// the scene / object boundary takes the row-per-thread path.
+	const int e0 = blockIdx.x * 256;                       // first row (row = n * 3 + c)
+	const int rows = min(256, N * 3 - e0);
+	if (rows <= 0) return;
+	const int split = 3 * s.Ns;                            // rows [0, split): scene side
+	const bool one_side = (e0 >= split) || (e0 + rows <= split);
+	const bool ob = e0 >= split;
+	const float* sp = ob ? s.obj_sp : s.scene_sp;
+	if (one_side && sp) {
+		const size_t r0 = ob ? (size_t)e0 - split : (size_t)e0;
+		const float4* src = reinterpret_cast<const float4*>(sp + r0 * (NV4 * 4));
+		const int words = rows * NV4;
+		float4 q[NV4];
+#pragma unroll
+		for (int k = 0; k < NV4; k++) { const int wd = k * 256 + threadIdx.x; q[k] = src[min(wd, words - 1)]; }
+#pragma unroll
+		for (int k = 0; k < NV4; k++) {
+			const int wd = k * 256 + threadIdx.x, part = wd % NV4;
+			s_part[wd] = q[k].x * s_w[4 * part] + q[k].y * s_w[4 * part + 1] + q[k].z * s_w[4 * part + 2] + q[k].w * s_w[4 * part + 3];
+		}
+		__syncthreads();
+		if ((int)threadIdx.x < rows) {
+			float acc = 0.f;
+#pragma unroll
+			for (int k = 0; k < NV4; k++) acc += s_part[threadIdx.x * NV4 + k];
+			out[e0 + threadIdx.x] = (ob ? s.obj_dc : s.scene_dc)[r0 + threadIdx.x] + acc;
+		}
+		return;
+	}
+	const int e = e0 + threadIdx.x;
 	if (e >= N * 3) return;
 	const int n = e / 3;
-	const bool ob = n >= s.Ns;
-	const size_t r = ob ? (size_t)e - 3 * (size_t)s.Ns : (size_t)e;
-	float v = (ob ? s.obj_dc : s.scene_dc)[r];
-	const float* sp = ob ? s.obj_sp : s.scene_sp;
-	if (sp) {
-		const float4* row = reinterpret_cast<const float4*>(sp + r * (NV4 * 4));
+	const bool tob = n >= s.Ns;
+	const size_t r = tob ? (size_t)e - 3 * (size_t)s.Ns : (size_t)e;
+	float v = (tob ? s.obj_dc : s.scene_dc)[r];
+	const float* tsp = tob ? s.obj_sp : s.scene_sp;
+	if (tsp) {
+		const float4* row = reinterpret_cast<const float4*>(tsp + r * (NV4 * 4));
 		float4 q[NV4];
 #pragma unroll
 		for (int k = 0; k < NV4; k++) q[k] = row[k];
@@ -1083,7 +1118,7 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 			size_t lds = 0;
 			int B = 256;
 			if (p->No > 0) {
-				B = pick_block(std::max(a.stride_x, 2 * a.stride_r), &lds);
+				B = pick_block(std::max(a.stride_x, a.stride_r), &lds);
 				lds = std::max(lds, (size_t)B * a.stride_x * sizeof(float) + 2 * (size_t)np_x * sizeof(float));     // + dense basis rows of the two time stamps
 			}
 			if (lds > MAX_STAGING_LDS) { set_error("adgs_deform_backward: deformation rows too large for the LDS staging buffer"); return -1; }

@@ -88,6 +88,11 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
 
 // ---- v2 pipeline (render_v2.hip) ----
 constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
+// Chunk slots are handed out in blocks of POOL_BLOCK: tile t owns slots [t * POOL_BLOCK, (t + 1) * POOL_BLOCK) outright and draws further
+// blocks from the shared cursor (which counts from #tiles * POOL_BLOCK).  One returning atomic per BATCH on one address -- 28 800 per
+// C3 frame -- was what the forward blend kernel's time consisted of: the serialised atomics back up the CUs' memory pipelines, and
+// every load of every wave queues behind them (the kernel took 375 us whatever its arithmetic, occupancy or locality were changed to).
+constexpr int POOL_BLOCK = 4;
 constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumulators per Gaussian
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
@@ -132,7 +137,7 @@ struct RenderV2FwdArgs {
 	bool has_color, has_flow, has_sem;
 	const float* bg;
 	const float* bg_image;                  // [3,H,W] per-pixel background (environment map) or nullptr: color = C + T * bg_image instead of + T * bg
-	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_scanned;
+	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_scanned; uint32_t* tile_batches;
 	float* final_T; uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
 	int order_mode;                         // 1: workgroups walk the tiles bottom-up (default), 0: top-down

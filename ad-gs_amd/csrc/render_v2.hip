@@ -84,6 +84,22 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 // Forward and backward evaluate alpha through this one function, so both take identical
 // per-pixel decisions (power > 0, alpha < 1/255) on identical bits.
 struct EntryGeom { float y, a0, b0, c0, op; };
+// wave-uniform "does any lane ...": the ballot compared on the scalar unit (hipcc turns __any() of a value that already lives in
+// an SGPR mask into v_cndmask + v_cmp_ne + s_cbranch_vccz: two vector instructions, ~7 cycles of the SIMD, per test)
+#ifndef ADGS_PROBE
+#define ADGS_PROBE 0
+#endif
+#ifdef ADGS_FWD_TIMING
+// experiment build (make variant TAG=timing DEFS=-DADGS_FWD_TIMING): shader-clock cycles every wave spends in the phases of the forward,
+// summed over the launch: [0] key-stream scan, [1] filter-record test, [2] Splat gather + staging, [3] blend loop, [4] whole wave, [5] waves
+__device__ unsigned long long g_fwd_timing[16];
+#define ADGS_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define ADGS_TACC(slot, a, b) t_acc[slot] += (b) - (a)
+#else
+#define ADGS_T(var)
+#define ADGS_TACC(slot, a, b)
+#endif
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ EntryGeom entry_geom(const float4 q0, const float4 q1, float dx) {
 	EntryGeom g;
 	g.y = q0.y; g.a0 = (-0.5f * q0.z * dx) * dx; g.b0 = -q0.w * dx; g.c0 = -0.5f * q1.x; g.op = q1.y;
@@ -107,7 +123,12 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
-	__shared__ uint32_t s_cand[2 * WAVE];
+#ifdef ADGS_FWD_LDS_PAD      // occupancy probe: extra LDS per one-wave workgroup limits the waves a CU holds
+	__shared__ uint32_t s_pad[ADGS_FWD_LDS_PAD / 4];
+	if (a.W < 0) s_pad[threadIdx.x] = 1u;
+#endif
+	constexpr int SCAN_ROUNDS = 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;      // ring: < 64 waiting + one super-round of 256, power of two
+	__shared__ uint32_t s_cand[CAND_RING];
 	const int lane = threadIdx.x;
 	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
 	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
@@ -147,6 +168,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		C0[k] = C1[k] = C2[k] = Dp[k] = F0[k] = F1[k] = F2[k] = S0[k] = 0.f;
 	}
 	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
+	uint32_t blk_next = tile * POOL_BLOCK, blk_left = POOL_BLOCK, batches = 0;      // chunk slots: the tile's own block first (kernels.h)
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 	// stage-1 state: candidates whose rectangle holds this tile (ring buffer), the prefetched next batch of the key stream
 	uint32_t chead = 0, ccount = 0;
@@ -154,19 +176,16 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	const int row_bit = (int)(ty16 % a.cell_tiles), col_bit = a.cell_tiles + (int)(tx % a.cell_tiles);
 	// a candidate = (Gaussian id, rectangle-coverage mask): one 8-byte entry (bucket binning) or the list id + the bits above
 	// (cell | depth) of its sort key
-	auto load_cand = [&](uint32_t e, uint32_t& id, uint32_t& mask) {
-		if (a.cell_entries) { const uint2 v = a.cell_entries[e]; id = v.x; mask = v.y; }
-		else { id = a.cell_list[e]; mask = a.mask_shift >= 0 ? (uint32_t)(a.cell_keys[e] >> a.mask_shift) : 0u; }
-	};
-	uint32_t pf_key = 0u;
-	uint32_t pf_id = 0;
-	if (pos + lane < range.y) load_cand(pos + lane, pf_id, pf_key);
+#ifdef ADGS_FWD_TIMING
+	unsigned long long t_acc[4] = { 0ull, 0ull, 0ull, 0ull }, t_load = 0ull, n_rounds = 0ull, t_frec = 0ull, n_frec = 0ull;
+#endif
+	ADGS_T(t_wave0);
 
 	while (true) {
 		bool mine_done = true;
 #pragma unroll
 		for (int k = 0; k < PPL; k++) mine_done = mine_done && (pyf[k] == PIXEL_DONE);
-		const bool all_done = __all(mine_done);
+		const bool all_done = !wave_any(!mine_done);
 		if (all_done) break;
 		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction), in two stages.
 		// Stage 1 scans the sorted KEY stream: the key bits above (cell | depth) say which tile rows and columns of the cell the
@@ -174,40 +193,84 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		// shifts per candidate -- at C3 a tile scans ~2100 candidates to blend ~180 entries.  Only candidates whose rectangle
 		// holds the tile go on to stage 2, 64 at a time: gather of the 32-byte filter record + the exact ellipse test.
 		while (qcount < WAVE && (pos < range.y || ccount > 0)) {
+			ADGS_T(t_s1a);
+			// A super-round = SCAN_ROUNDS x 64 candidates with all their loads in flight before the first is looked at: one exposed
+			// memory round trip per 256 candidates.  (One round of 64 with the next round prefetched still waited ~a full round
+			// trip per round -- a round is ~30 instructions --, and the key-stream scan was 52 % of a wave's life at C3:
+			// tools/fwd_phase_timing.py.)  The ring holds a whole super-round on top of a stage-2 batch.
 			while (ccount < WAVE && pos < range.y) {
-				const uint32_t key = pf_key;
-				const uint32_t id = pf_id;
-				const bool have = pos + lane < range.y;
-				{
-					const uint32_t e2 = pos + WAVE + lane;
-					if (e2 < range.y) load_cand(e2, pf_id, pf_key);
+				uint32_t key[SCAN_ROUNDS], id[SCAN_ROUNDS];
+				// UNCONDITIONAL loads at clamped indices, the bucket / sort distinction outside the unrolled loop: a load inside a
+				// divergent `if (e < end)` is followed by s_waitcnt vmcnt(0) at the end of its block (its value is copied into the
+				// merged register there), which serialises the round trips again -- the one-round prefetch this replaces never
+				// overlapped anything for that reason.
+				const uint32_t last = range.y - 1u;
+				if (a.cell_entries) {
+					uint2 v[SCAN_ROUNDS];
+#pragma unroll
+					for (int r = 0; r < SCAN_ROUNDS; r++) v[r] = a.cell_entries[min(pos + r * WAVE + lane, last)];
+#pragma unroll
+					for (int r = 0; r < SCAN_ROUNDS; r++) { id[r] = v[r].x; key[r] = v[r].y; }
+				} else {
+					unsigned long long kk[SCAN_ROUNDS];
+#pragma unroll
+					for (int r = 0; r < SCAN_ROUNDS; r++) {
+						const uint32_t e = min(pos + r * WAVE + lane, last);
+						id[r] = a.cell_list[e];
+						kk[r] = a.mask_shift >= 0 ? a.cell_keys[e] : 0ull;
+					}
+#pragma unroll
+					for (int r = 0; r < SCAN_ROUNDS; r++) key[r] = a.mask_shift >= 0 ? (uint32_t)(kk[r] >> a.mask_shift) : 0u;
 				}
-				const bool rp = have && (!masks || (((key >> row_bit) & (key >> col_bit)) & 1u));
-				const uint64_t m = __ballot(rp);
-				if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
-				ccount += __popcll(m);
-				pos += WAVE;
+#ifdef ADGS_FWD_TIMING
+				{
+					ADGS_T(t_l0);
+					asm volatile("s_waitcnt vmcnt(0)" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]) :: "memory");
+					ADGS_T(t_l1);
+					t_load += t_l1 - t_l0; n_rounds += 1ull;
+				}
+#endif
+#pragma unroll
+				for (int r = 0; r < SCAN_ROUNDS; r++) {
+					const bool have = pos + r * WAVE + lane < range.y;
+					const bool rp = have && (!masks || (((key[r] >> row_bit) & (key[r] >> col_bit)) & 1u));
+					const uint64_t m = __ballot(rp);
+					if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (CAND_RING - 1)] = id[r];
+					ccount += __popcll(m);
+				}
+				pos += SCAN_ROUNDS * WAVE;
 			}
+			ADGS_T(t_s1b); ADGS_TACC(0, t_s1a, t_s1b);
 			const uint32_t nc = min(ccount, (uint32_t)WAVE);
 			if (nc == 0) break;
 			__syncthreads();
 			bool pass = false; uint32_t id = 0;
 			if ((uint32_t)lane < nc) {
-				id = s_cand[(chead + lane) & (2 * WAVE - 1)];
+				id = s_cand[(chead + lane) & (CAND_RING - 1)];
 				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
 				float4 f0 = fr[0], f1 = fr[1];
+#ifdef ADGS_FWD_TIMING
+				{
+					ADGS_T(t_f0);
+					asm volatile("s_waitcnt vmcnt(0)" : "+v"(f0.x), "+v"(f0.y), "+v"(f0.z), "+v"(f0.w), "+v"(f1.x), "+v"(f1.y), "+v"(f1.z), "+v"(f1.w) :: "memory");
+					ADGS_T(t_f1);
+					t_frec += t_f1 - t_f0; n_frec += 1ull;
+				}
+#endif
 				// both halves of the record are requested together (otherwise the compiler sinks the first
 				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
 				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
 				pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
 			}
-			chead = (chead + nc) & (2 * WAVE - 1); ccount -= nc;
+			chead = (chead + nc) & (CAND_RING - 1); ccount -= nc;
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
 			qcount += __popcll(m);
+			ADGS_T(t_s2b); ADGS_TACC(1, t_s1b, t_s2b);
 		}
 		const uint32_t n = min(qcount, (uint32_t)WAVE);
 		if (n == 0) break;
+		ADGS_T(t_g0);
 		__syncthreads();
 		uint32_t myid = 0;
 		if ((uint32_t)lane < n) {
@@ -219,15 +282,19 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			s_splat[lane * 4 + 3] = src[3];
 		}
 		qhead = (qhead + n) & (2 * WAVE - 1); qcount -= n;
-		// the chunk slot is drawn now, so that the atomic's round trip hides behind the blend loop (a batch without a live
-		// entry leaves its slot unused)
-		uint32_t chunk = 0;
-		if (lane == 0) chunk = atomicAdd(a.pool_cursor, 1u);
+		// the chunk slot of this batch: the next one of the tile's current block; a new block of POOL_BLOCK slots is drawn from the
+		// shared cursor only when the block is used up -- now, so that the atomic's round trip hides behind the blend loop (a
+		// batch without a live entry gives its slot back)
+		batches++;
+		uint32_t new_block = 0;
+		const bool draw = blk_left == 0;                 // wave-uniform
+		if (draw && lane == 0) new_block = atomicAdd(a.pool_cursor, (uint32_t)POOL_BLOCK);
 		__syncthreads();
 		// ---- blend.  `live` collects the entries at least one pixel evaluates as contributing: only those are published for
 		// the backward replay (at C3 22 % of the entries that pass the tile test are blended by no pixel -- the test is a bound
 		// over the tile rectangle, and pixels saturate), and positions (n_contrib) count live entries only.
 		uint64_t live = 0ull;
+		ADGS_T(t_b0); ADGS_TACC(2, t_g0, t_b0);
 #if ADGS_FWD_PREFETCH >= 1
 		// software pipeline: the LDS reads of entry j + 1 are issued before entry j is evaluated (hipcc emits `ds_read; s_waitcnt`
 		// back to back at the top of every iteration otherwise: two exposed LDS round trips per entry; PMC: 61 % of the wave
@@ -250,17 +317,21 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
 #endif
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
-			float alpha[PPL]; bool act[PPL]; bool any_act = false;
+			// "which pixels does the entry reach" as 64-bit lane masks on the scalar unit: the ballot of one comparison IS the
+			// comparison's result register, the two are combined by s_and and tested by s_cmp (a ballot of `a && b` would be
+			// rebuilt from a per-lane 0 / 1 value: two vector instructions per strip and entry)
+			float alpha[PPL]; uint64_t actm[PPL]; uint64_t any_m = 0ull;
 #pragma unroll
 			for (int k = 0; k < PPL; k++) {
 				float dy, pw, G;
 				// a finished (or out-of-image) pixel sits at row 3e38: its exponent is -inf, alpha 0, so it needs no flag here
 				eval_pixel(eg, pyf[k], dy, pw, G, alpha[k]);
-				act[k] = !(pw > 0.0f) && !(alpha[k] < ALPHA_MIN);
-				any_act = any_act || act[k];
+				actm[k] = __builtin_amdgcn_ballot_w64(!(pw > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN));
+				any_m |= actm[k];
 			}
-			if (!__any(any_act)) continue;
-			const uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
+			if (any_m == 0ull) continue;
+			uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
+			asm volatile("" : "+v"(position));        // one copy into a vector register per entry (else: one v_mov per strip)
 			live |= 1ull << j;
 #if ADGS_FWD_PREFETCH >= 2
 			const float4 q2 = pq2, q3 = pq3;
@@ -270,23 +341,31 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 #endif
 #pragma unroll
 			for (int k = 0; k < PPL; k++) {
-				if (!__any(act[k])) continue;           // wave-uniform: a 16x4 pixel strip the entry does not reach costs nothing
+				if (actm[k] == 0ull) continue;           // wave-uniform: a 16x4 pixel strip the entry does not reach costs nothing
 				const float test_T = T[k] * (1.f - alpha[k]);
-				const bool stop = act[k] && test_T < T_STOP;
-				const bool up = act[k] && !stop;
+				const uint64_t stopm = actm[k] & __builtin_amdgcn_ballot_w64(test_T < T_STOP);
+				const bool stop = __builtin_amdgcn_inverse_ballot_w64(stopm);
+				const bool up = __builtin_amdgcn_inverse_ballot_w64(actm[k] & ~stopm);
 				pyf[k] = stop ? PIXEL_DONE : pyf[k];
 				const float w = up ? alpha[k] * T[k] : 0.f;   // pixels that do not blend this entry add exactly 0
+#if ADGS_PROBE == 1      // timing probe (wrong images): one accumulation instead of eight
+				C0[k] = fmaf(q1.z, w, C0[k]);
+#else
 				C0[k] = fmaf(q1.z, w, C0[k]); C1[k] = fmaf(q1.w, w, C1[k]); C2[k] = fmaf(q2.x, w, C2[k]);
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
 				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
+#endif
 				T[k] = up ? test_T : T[k];
 				last_contrib[k] = up ? position : last_contrib[k];
 			}
 		}
+		ADGS_T(t_b1); ADGS_TACC(3, t_b0, t_b1);
 		// ---- publish the live entries of this batch, in order, as one chunk of the backward's replay list
 		const uint32_t nlive = (uint32_t)__popcll(live);
+		if (draw) { blk_next = gridDim.x * (uint32_t)POOL_BLOCK + __shfl(new_block, 0, WAVE); blk_left = POOL_BLOCK; }
 		if (nlive > 0) {
-			chunk = __shfl(chunk, 0, WAVE);
+			const uint32_t chunk = blk_next;
+			blk_next++; blk_left--;
 			uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
 			if (lane == 0) { c[0] = prev_chunk; c[1] = nlive; }
 			if ((live >> lane) & 1ull) c[2 + __popcll(live & lt_mask)] = myid;
@@ -294,7 +373,18 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			consumed += nlive;
 		}
 	}
-	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; }
+	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = batches; }
+#ifdef ADGS_FWD_TIMING
+	{
+		ADGS_T(t_wave1);
+		if (lane == 0) {
+			for (int i = 0; i < 4; i++) atomicAdd(&g_fwd_timing[i], t_acc[i]);
+			atomicAdd(&g_fwd_timing[4], t_wave1 - t_wave0); atomicAdd(&g_fwd_timing[5], 1ull);
+			atomicAdd(&g_fwd_timing[6], t_load); atomicAdd(&g_fwd_timing[7], n_rounds);
+			atomicAdd(&g_fwd_timing[8], t_frec); atomicAdd(&g_fwd_timing[9], n_frec);
+		}
+	}
+#endif
 	const size_t HW = (size_t)a.H * a.W;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
@@ -487,15 +577,16 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				const float4 q0 = s_splat[(j + 1) * 4 + 0], q1 = s_splat[(j + 1) * 4 + 1];
 				const float dx = q0.x - pxf;
 				const EntryGeom eg = entry_geom(q0, q1, dx);
-				float alpha[PPL], G[PPL], dy[PPL]; bool act[PPL]; bool any_act = false;
+				float alpha[PPL], G[PPL], dy[PPL]; uint64_t actm[PPL]; uint64_t any_m = 0ull;      // lane masks on the scalar unit, as in the forward
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
 					float power;
 					eval_pixel(eg, pyf0 + (float)(4 * k), dy[k], power, G[k], alpha[k]);
-					act[k] = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha[k] < ALPHA_MIN);
-					any_act = any_act || act[k];
+					actm[k] = __builtin_amdgcn_ballot_w64(contributor < last_contributor[k]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+						__builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN));
+					any_m |= actm[k];
 				}
-				if (!__any(any_act)) continue;
+				if (any_m == 0ull) continue;
 				const float4 q2 = s_splat[(j + 1) * 4 + 2];
 				const float4 q3 = s_splat[(j + 1) * 4 + 3];
 				float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_s = 0.f, v_d = 0.f;
@@ -506,7 +597,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
-					if (act[k]) {
+					if (__builtin_amdgcn_inverse_ballot_w64(actm[k])) {
 						const float al = alpha[k];
 						const float rinv = __builtin_amdgcn_rcpf(1.f - al);
 						T[k] = T[k] * rinv;
@@ -629,3 +720,13 @@ int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 }
 
 } // namespace adgs
+
+#ifdef ADGS_FWD_TIMING
+// experiment build only: read and reset the phase counters of render_fwd_v2_kernel
+extern "C" int adgs_test_fwd_timing(unsigned long long* out16) {
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(adgs::g_fwd_timing), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+	unsigned long long z[16] = { 0 };
+	if (hipMemcpyToSymbol(HIP_SYMBOL(adgs::g_fwd_timing), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+#endif

@@ -95,6 +95,23 @@ def build_scene(config, variant="default"):
         sc["flow_points"] = (xyz + 0.05 * torch.randn(xyz.shape, generator=g)).float().contiguous()
     elif variant != "default":
         raise ValueError(variant)
+    if os.environ.get("ADGS_BENCH_SCENE_ORDER") == "morton":
+        # locality experiment (never the headline): the same Gaussians, stored in Morton order of their image position inside the
+        # scene range and inside the object range (the generator -- like SfM points and densification -- leaves them in random order)
+        xyz = sc["means3D"]
+        z = xyz[:, 2].clamp_min(0.3)
+        u = ((xyz[:, 0] / z / sc["tanfovx"]) * 0.5 + 0.5).clamp(0, 1)
+        v = ((xyz[:, 1] / z / sc["tanfovy"]) * 0.5 + 0.5).clamp(0, 1)
+        ui, vi = (u * 1023).long(), (v * 1023).long()
+        code = torch.zeros_like(ui)
+        for b in range(10):
+            code |= ((ui >> b) & 1) << (2 * b)
+            code |= ((vi >> b) & 1) << (2 * b + 1)
+        code = code + (sc["obj_mask"].long() << 40)              # objects stay behind the scene Gaussians
+        perm = torch.argsort(code, stable=True)
+        for k in ("means3D", "scales", "rotations", "opacities", "shs", "semantic", "flow_points", "obj_mask"):
+            if k in sc:
+                sc[k] = sc[k][perm].contiguous()
     return sc
 
 
@@ -240,8 +257,8 @@ def frame_work_figures(frame, settings, use_fs, device):
                                               s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, t["shs"], flow, sem, s.sh_degree,
                                               s.campos, s.prefiltered, s.inv_depth, False)
         out = call()
-        chunks = int(out[6][:4].view(torch.int32)[0].item())      # BinStateV2 starts with the chunk-pool cursor
         st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        chunks = int(_lib.lib().adgs_test_v2_blend_batches(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
         published = int(_lib.lib().adgs_test_v2_published_entries(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
         scanned = int(_lib.lib().adgs_test_v2_scanned_candidates(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
         old = os.environ.get("ADGS_RASTER_MODE")

@@ -25,6 +25,8 @@ long long adgs_test_v2_published_entries(const char* img_buffer, int width, int 
 long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream);
 /* The two per-tile counters themselves (host arrays of `capacity` uint32 each, either may be NULL); returns the number of tiles. */
 long long adgs_test_v2_tile_counters(const char* img_buffer, int width, int height, uint32_t* out_consumed, uint32_t* out_scanned, long long capacity, void* stream);
+/* Batches of <= 64 tile-test survivors the forward handed to its blend loop, summed over the tiles (same buffer, same conditions). */
+long long adgs_test_v2_blend_batches(const char* img_buffer, int width, int height, void* stream);
 /* (start, end) of every coarse cell's depth-sorted candidate list (host array of 2 x `capacity` uint32); returns the number of cells. */
 long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height, uint32_t* out_ranges, long long capacity, void* stream);
 

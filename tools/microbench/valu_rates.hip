@@ -1,0 +1,123 @@
+// VALU issue rates on gfx950, measured: wave64 instructions per SIMD and cycle for the instruction kinds the blend kernels are made
+// of (plain / packed fp32 FMA, mul, min, compare + select, exp2, rcp, DPP moves), at 1 / 2 / 4 / 8 waves per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates
+// Every kernel runs ITER iterations of 32 independent instructions of one kind (8 accumulator chains x 4), so neither dependent-issue
+// latency nor the loop overhead (2 scalar instructions per 32) limits it.  Cycles: s_memrealtime is a constant 100 MHz clock, so the
+// shader clock is taken from wall time x the clock rate reported by the runtime, and printed.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+constexpr int ITER = 4096;
+
+#define BODY8(INS) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)
+#define REP4(X) X X X X
+
+template <int KIND>
+__global__ void __launch_bounds__(64) rate_kernel(float* out, float seed) {
+	float a[8], b = seed + threadIdx.x * 1e-7f, c = 1.0f - seed;
+	typedef float f2 __attribute__((ext_vector_type(2)));
+	f2 p[8], pb = { b, b }, pc = { c, c };
+#pragma unroll
+	for (int i = 0; i < 8; i++) { a[i] = seed * (i + 1); p[i] = f2{ a[i], a[i] + 1.f }; }
+	for (int it = 0; it < ITER; it++) {
+		if (KIND == 0) {        // v_fma_f32
+#define I(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 1) { // v_pk_fma_f32
+#define I(k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pb), "v"(pc));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 2) { // v_mul_f32
+#define I(k) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 3) { // v_min_f32
+#define I(k) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 4) { // v_exp_f32
+#define I(k) asm volatile("v_exp_f32 %0, %0" : "+v"(a[k]));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 5) { // v_rcp_f32
+#define I(k) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k]));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 6) { // v_cmp + v_cndmask (counted as two instructions)
+#define I(k) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[k]) : "v"(b), "v"(c) : "vcc");
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 7) { // v_add_f32 with a DPP row shift
+#define I(k) asm volatile("v_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(b));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 8) { // v_pk_mul_f32
+#define I(k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pb));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 9) { // v_pk_add_f32
+#define I(k) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pb));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 10) { // v_fmac_f32 (VOP2 form)
+#define I(k) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 11) { // v_sub_f32
+#define I(k) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+			REP4(BODY8(I))
+#undef I
+		} else if (KIND == 12) { // v_pk_fma_f32 with the scalar operand broadcast by op_sel (both halves take the low dword of src1)
+#define I(k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(p[k]) : "v"(pb), "v"(pc));
+			REP4(BODY8(I))
+#undef I
+		}
+	}
+	float s = 0.f;
+#pragma unroll
+	for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+	if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+template <int KIND>
+static void run(const char* name, int per_pair, float* d_out, int n_simd, double ghz) {
+	for (int waves : { 1, 2, 4, 8 }) {
+		hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+		const int blocks = n_simd * waves;
+		hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(64), 0, 0, d_out, 0.5f);
+		CHECK(hipDeviceSynchronize());
+		CHECK(hipEventRecord(e0));
+		hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(64), 0, 0, d_out, 0.5f);
+		CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+		float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		const double insts_per_simd = (double)ITER * 32 * per_pair * waves;
+		const double cycles = ms * 1e-3 * ghz * 1e9;
+		printf("%-34s waves/SIMD %d: %7.3f ms  %6.3f inst/SIMD/cycle  (%.2f cycles per wave64 instruction)\n", name, waves, ms, insts_per_simd / cycles, cycles / insts_per_simd);
+	}
+}
+
+int main() {
+	hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+	const int n_simd = prop.multiProcessorCount * 4;
+	const double ghz = prop.clockRate * 1e-6;
+	printf("%s: %d CUs, %d SIMDs, clock %.3f GHz (runtime-reported peak; sustained clocks are lower under load)\n", prop.gcnArchName, prop.multiProcessorCount, n_simd, ghz);
+	float* d_out; CHECK(hipMalloc(&d_out, 4096));
+	run<0>("v_fma_f32", 1, d_out, n_simd, ghz);
+	run<10>("v_fmac_f32 (VOP2)", 1, d_out, n_simd, ghz);
+	run<1>("v_pk_fma_f32", 1, d_out, n_simd, ghz);
+	run<12>("v_pk_fma_f32 op_sel broadcast", 1, d_out, n_simd, ghz);
+	run<2>("v_mul_f32", 1, d_out, n_simd, ghz);
+	run<8>("v_pk_mul_f32", 1, d_out, n_simd, ghz);
+	run<9>("v_pk_add_f32", 1, d_out, n_simd, ghz);
+	run<11>("v_sub_f32", 1, d_out, n_simd, ghz);
+	run<3>("v_min_f32", 1, d_out, n_simd, ghz);
+	run<6>("v_cmp_lt_f32 + v_cndmask_b32", 2, d_out, n_simd, ghz);
+	run<7>("v_add_f32 dpp row_shr", 1, d_out, n_simd, ghz);
+	run<4>("v_exp_f32", 1, d_out, n_simd, ghz);
+	run<5>("v_rcp_f32", 1, d_out, n_simd, ghz);
+	return 0;
+}
