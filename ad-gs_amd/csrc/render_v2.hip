@@ -86,9 +86,6 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 struct EntryGeom { float y, a0, b0, c0, op; };
 // wave-uniform "does any lane ...": the ballot compared on the scalar unit (hipcc turns __any() of a value that already lives in
 // an SGPR mask into v_cndmask + v_cmp_ne + s_cbranch_vccz: two vector instructions, ~7 cycles of the SIMD, per test)
-#ifndef ADGS_PROBE
-#define ADGS_PROBE 0
-#endif
 #ifdef ADGS_FWD_TIMING
 // experiment build (make variant TAG=timing DEFS=-DADGS_FWD_TIMING): shader-clock cycles every wave spends in the phases of the forward,
 // summed over the launch: [0] key-stream scan, [1] filter-record test, [2] Splat gather + staging, [3] blend loop, [4] whole wave, [5] waves
@@ -123,10 +120,6 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	__shared__ float4 s_splat[(WAVE + 1) * 4];
 	__shared__ uint32_t s_queue[2 * WAVE];
-#ifdef ADGS_FWD_LDS_PAD      // occupancy probe: extra LDS per one-wave workgroup limits the waves a CU holds
-	__shared__ uint32_t s_pad[ADGS_FWD_LDS_PAD / 4];
-	if (a.W < 0) s_pad[threadIdx.x] = 1u;
-#endif
 	constexpr int SCAN_ROUNDS = 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;      // ring: < 64 waiting + one super-round of 256, power of two
 	__shared__ uint32_t s_cand[CAND_RING];
 	const int lane = threadIdx.x;
@@ -348,13 +341,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				const bool up = __builtin_amdgcn_inverse_ballot_w64(actm[k] & ~stopm);
 				pyf[k] = stop ? PIXEL_DONE : pyf[k];
 				const float w = up ? alpha[k] * T[k] : 0.f;   // pixels that do not blend this entry add exactly 0
-#if ADGS_PROBE == 1      // timing probe (wrong images): one accumulation instead of eight
-				C0[k] = fmaf(q1.z, w, C0[k]);
-#else
 				C0[k] = fmaf(q1.z, w, C0[k]); C1[k] = fmaf(q1.w, w, C1[k]); C2[k] = fmaf(q2.x, w, C2[k]);
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
 				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
-#endif
 				T[k] = up ? test_T : T[k];
 				last_contrib[k] = up ? position : last_contrib[k];
 			}
