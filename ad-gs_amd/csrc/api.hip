@@ -236,7 +236,7 @@ static MailboxRef* mailbox() {
 // What the forward decided from the environment (pipeline, cell size, pixels per lane), remembered per image-state buffer so that
 // the backward of THAT forward carves the saved buffers the same way even if the environment changed in between.  (The buffers are
 // opaque device memory; the host-side key is the pointer autograd hands back.)
-struct FrameCfg { int v2; int cell_tiles; int ppl; };
+struct FrameCfg { int v2; int cell_tiles; int ppl; int backwards = 0; };      // backwards: how many backward passes have consumed this forward's accumulator lines
 static std::mutex g_cfg_mu;
 static std::vector<std::pair<const void*, FrameCfg>> g_cfg_table;
 static void remember_frame(const void* img_buffer, const FrameCfg& c) {
@@ -244,6 +244,12 @@ static void remember_frame(const void* img_buffer, const FrameCfg& c) {
 	for (auto& e : g_cfg_table) if (e.first == img_buffer) { e.second = c; return; }
 	if (g_cfg_table.size() >= 256) g_cfg_table.erase(g_cfg_table.begin());
 	g_cfg_table.emplace_back(img_buffer, c);
+}
+// counts a backward over this forward state; returns how many ran before it, or -1 if the forward is not in the table any more
+static int note_backward(const void* img_buffer) {
+	std::lock_guard<std::mutex> lk(g_cfg_mu);
+	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it) if (it->first == img_buffer) return it->second.backwards++;
+	return -1;
 }
 static bool lookup_frame(const void* img_buffer, FrameCfg* c) {
 	std::lock_guard<std::mutex> lk(g_cfg_mu);
@@ -635,8 +641,11 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream) != 0) return -1;
 				ra.tile_order = img.tile_order;
 			}
-			// geom.gacc lines of the visible Gaussians were zeroed by the forward preprocess (and are re-zeroed
-			// by the preprocess backward after it consumed them)
+			// geom.gacc lines of the visible Gaussians were zeroed by the forward preprocess: the FIRST backward over a forward
+			// accumulates into them as they are.  A second backward over the same forward state (retain_graph) -- or one whose
+			// forward has dropped out of the frame table -- gets them zeroed again here (64 B per Gaussian: the preprocess
+			// backward used to re-zero every line after reading it, 64 MB of writes per frame at C3 for a case that is rare).
+			if (note_backward(img_buffer) != 0) ADGS_HIP_CHECK(hipMemsetAsync(geom.gacc, 0, (size_t)P * GACC_STRIDE * sizeof(float), stream));
 			if (binning_buffer && launch_render_bwd_v2(ra, stream) != 0) return -1;
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);

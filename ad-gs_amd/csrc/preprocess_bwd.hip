@@ -122,12 +122,9 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	// v2 = one packed 64-byte line per Gaussian, unpacked here into the ABI outputs
 	float dcon_x, dcon_y, dcon_z, g2x, g2y, gd, gcol[3];
 	if (a.gacc) {
-		float4* ga = reinterpret_cast<float4*>(a.gacc + (size_t)idx * GACC_STRIDE);
+		const float4* ga = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GACC_STRIDE);
 		const float4 u0 = ga[0], u1 = ga[1], u2 = ga[2], u3 = ga[3];
-		{	// leave the line clean: a second backward over the same forward state accumulates from zero again
-			const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-			ga[0] = z; ga[1] = z; ga[2] = z; ga[3] = z;
-		}
+		// (the line stays as it is: api.hip zeroes the accumulator again before a second backward over the same forward)
 		// u0 = (S0, Sx, Sy, Sxx), u1 = (Sxy, Syy, c0, c1): raw moment sums of L = G*dL/dalpha (render_v2.hip);
 		// the per-Gaussian factors of backward.cu:626-643 are applied here, once per Gaussian
 		const float4* sp = reinterpret_cast<const float4*>(a.splats + idx);

@@ -366,3 +366,40 @@ def test_backward_uses_the_forwards_configuration_not_the_environment(monkeypatc
     torch.cuda.synchronize()
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         assert_close("grad_" + k, L[k].grad.cpu().numpy(), ref["grads"][k].cpu().numpy(), tol=2e-5, max_frac=1e-5, rel_l2=2e-5)
+
+
+def test_repeated_backward_over_one_forward_state():
+    """retain_graph: the per-Gaussian accumulator lines of a forward are consumed by its first backward and zeroed again (by the
+    library, api.hip: note_backward) before every further one -- three backward passes over one forward give the same gradients
+    (up to the summation order of the atomics), and so does a backward whose forward has dropped out of the library's frame table."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = synthetic.make_scene(30000, 320, 208, 300.0, seed=61, n_objects=2)
+    g = synthetic.make_upstream_grads(sc, 61)
+    settings = GaussianRasterizationSettings(
+        image_height=sc["H"], image_width=sc["W"], tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=dev(sc["bg"]), scale_modifier=1.0,
+        viewmatrix=dev(sc["viewmatrix"]), projmatrix=dev(sc["projmatrix"]), sh_degree=sc["sh_degree"], campos=dev(sc["campos"]),
+        prefiltered=False, inv_depth=True, debug=False)
+    rast = GaussianRasterizer(settings)
+    leaf = lambda t: t.cuda().clone().requires_grad_(True)
+    L = [leaf(sc["means3D"]), torch.zeros(sc["P"], 3, device="cuda", requires_grad=True), leaf(sc["opacities"]), leaf(sc["shs"]),
+         leaf(sc["scales"]), leaf(sc["rotations"]), leaf(sc["flow_points"]), leaf(sc["semantic"])]
+
+    def forward():
+        color, radii, depth, op, fl, sem = rast(means3D=L[0], means2D=L[1], opacities=L[2], shs=L[3], scales=L[4], rotations=L[5],
+                                               flow_points=L[6], semantic=L[7])
+        return ((color * dev(g["color"])).sum() + (depth * dev(g["depth"])).sum() + (op * dev(g["img_opacity"])).sum() +
+                (fl * dev(g["flow"])).sum() + (sem * dev(g["semantic"])).sum())
+    loss = forward()
+    runs = [torch.autograd.grad(loss, L, retain_graph=True) for _ in range(3)]
+    for later in runs[1:]:
+        for a, b in zip(runs[0], later):
+            assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), float((a - b).abs().max())
+    assert float(runs[0][0].abs().sum()) > 0
+    # more forwards than the frame table holds in between: the backward of the first one no longer finds its entry
+    loss0 = forward()
+    with torch.no_grad():
+        for _ in range(260):
+            forward()
+    late = torch.autograd.grad(loss0, L)
+    for a, b in zip(runs[0], late):
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), float((a - b).abs().max())
