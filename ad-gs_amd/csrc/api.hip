@@ -389,11 +389,15 @@ static int raster_forward_impl(const ShSource* sh_src,
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
 			(binning_mode == "bucket" || g_hint_cells.load() <= (size_t)4 * GS_NMAX * ncells);
 		pa.bucket_count = nullptr;
+		// bucket binning accumulates the fine-tile total and a few device words: zeroed by the sh0 kernel on the raw-SH path (one
+		// launch less), by a memset otherwise
+		uint32_t* zero_words = nullptr; const int n_zero = 2 * SCAN_AUX_SLOTS + 8;
 		if (buckets) {
-			ADGS_HIP_CHECK(hipMemsetAsync(geom.bucket_fine_total(), 0, (2 * SCAN_AUX_SLOTS + 8) * sizeof(uint32_t), stream));      // fine-tile slots + device words
+			zero_words = reinterpret_cast<uint32_t*>(geom.bucket_fine_total());
+			if (!sh_src) ADGS_HIP_CHECK(hipMemsetAsync(zero_words, 0, n_zero * sizeof(uint32_t), stream));
 			pa.bucket_count = geom.counts; pa.fine_total = geom.bucket_fine_total();
 		}
-		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream) != 0) return -1; }
+		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream, zero_words, zero_words ? n_zero : 0) != 0) return -1; }
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning

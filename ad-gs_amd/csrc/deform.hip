@@ -493,11 +493,6 @@ constexpr int PG_ITEMS = 8;                          // outputs per thread: two 
 __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
 	extern __shared__ float s_w[];
 	const int np = a.f.n_params;
-	for (int k = threadIdx.x; k < np; k += blockDim.x) s_w[k] = 0.f;
-	__syncthreads();
-	const int total = a.f.n_terms[0] + a.f.n_terms[1] + a.f.n_terms[2];
-	for (int i = threadIdx.x; i < total; i += blockDim.x) s_w[a.f.index[i]] = a.f.weight[i];
-	__syncthreads();
 	// the segment's fields go into locals: writing to the by-value argument struct would move all of it into scratch memory
 	const bool second = a.nb0 > 0 && (int)blockIdx.x >= a.nb0;
 	const int seg_n0 = second ? a.n0_b : a.n0, seg_count = second ? a.count_b : a.count;
@@ -505,16 +500,30 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 	float* __restrict__ seg_out = second ? a.out_b : a.out;
 	const size_t tot = (size_t)seg_count * a.D * np;
 	const size_t blk0 = (size_t)(blockIdx.x - (second ? a.nb0 : 0)) * 256 * PG_ITEMS;
+	// (Gaussian m, channel d, column k) of each half's first output and its upstream value: requested before the basis vector is
+	// assembled in LDS, so that the load's round trip runs under the two barriers
+	constexpr int HALVES = PG_ITEMS / 4;
+	size_t e0[HALVES], m0[HALVES]; int k0[HALVES], d0[HALVES]; float gv0[HALVES];
 #pragma unroll
-	for (int half = 0; half < PG_ITEMS / 4; half++) {
-		const size_t e0 = blk0 + ((size_t)half * 256 + threadIdx.x) * 4;
-		if (e0 >= tot) return;
-		// (Gaussian m, channel d, column k) of the first output; then advanced incrementally
-		size_t row; int k;
-		if (tot <= 0xffffffffull) { const uint32_t r32 = (uint32_t)e0 / (uint32_t)np; row = r32; k = (int)((uint32_t)e0 - r32 * (uint32_t)np); }
-		else { row = e0 / np; k = (int)(e0 - row * np); }
-		size_t m = row / a.D; int d = (int)(row - m * a.D);
-		float gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
+	for (int half = 0; half < HALVES; half++) {
+		e0[half] = blk0 + ((size_t)half * 256 + threadIdx.x) * 4;
+		const size_t e = min(e0[half], tot - 1);
+		size_t row;
+		if (tot <= 0xffffffffull) { const uint32_t r32 = (uint32_t)e / (uint32_t)np; row = r32; k0[half] = (int)((uint32_t)e - r32 * (uint32_t)np); }
+		else { row = e / np; k0[half] = (int)(e - row * np); }
+		m0[half] = row / a.D; d0[half] = (int)(row - m0[half] * a.D);
+		gv0[half] = seg_g[(seg_n0 + m0[half]) * (size_t)a.gstride + d0[half]];
+	}
+	for (int k = threadIdx.x; k < np; k += blockDim.x) s_w[k] = 0.f;
+	__syncthreads();
+	const int total = a.f.n_terms[0] + a.f.n_terms[1] + a.f.n_terms[2];
+	for (int i = threadIdx.x; i < total; i += blockDim.x) s_w[a.f.index[i]] = a.f.weight[i];
+	__syncthreads();
+#pragma unroll
+	for (int half = 0; half < HALVES; half++) {
+		if (e0[half] >= tot) return;
+		size_t m = m0[half]; int k = k0[half], d = d0[half];
+		float gv = gv0[half];
 		float v[4];
 #pragma unroll
 		for (int it = 0; it < 4; it++) {
@@ -522,11 +531,11 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 			if (++k == np) {
 				k = 0;
 				if (++d == a.D) { d = 0; m++; }
-				if (e0 + it + 1 < tot) gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
+				if (e0[half] + it + 1 < tot) gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
 			}
 		}
-		if (e0 + 4 <= tot) *reinterpret_cast<float4*>(seg_out + e0) = make_float4(v[0], v[1], v[2], v[3]);
-		else for (int it = 0; it < 4 && e0 + it < tot; it++) seg_out[e0 + it] = v[it];
+		if (e0[half] + 4 <= tot) *reinterpret_cast<float4*>(seg_out + e0[half]) = make_float4(v[0], v[1], v[2], v[3]);
+		else for (int it = 0; it < 4 && e0[half] + it < tot; it++) seg_out[e0[half] + it] = v[it];
 	}
 }
 
@@ -844,32 +853,39 @@ namespace {
 // words -- consecutive threads own consecutive rows, so the loads are perfectly coalesced without any staging -- and dots
 // with the dense basis vector (zero where the family has no term).  General kernel: rows staged through LDS.
 template <int NV4>
-__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero) {
 	__shared__ float s_w[NV4 * 4];
+	if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;      // counters the next kernel accumulates into (saves a memset launch)
 	__shared__ float s_part[256 * NV4 + 4];
+	// The block owns 256 consecutive rows = 256 * NV4 consecutive 16-byte words of one segment (scene or object side).  Lane i of a
+	// load instruction reads word base + i -- 1 KiB of consecutive bytes per wave and instruction instead of 64 words 16 * NV4 bytes
+	// apart --, dots it with its quarter of the basis vector, and the NV4 partial sums of a row meet in LDS.  A block that straddles
+	// the scene / object boundary takes the row-per-thread path.  The loads are issued BEFORE the basis vector is assembled in LDS
+	// (two barriers): their round trip runs under that prologue.
+	const int e0 = blockIdx.x * 256;                       // first row (row = n * 3 + c)
+	const int rows = min(256, N * 3 - e0);
+	const int split = 3 * s.Ns;                            // rows [0, split): scene side
+	const bool one_side = (e0 >= split) || (e0 + rows <= split);
+	const bool ob = e0 >= split;
+	const float* sp = ob ? s.obj_sp : s.scene_sp;
+	const bool fast = rows > 0 && one_side && sp != nullptr;            // block-uniform
+	const size_t r0 = ob ? (size_t)e0 - split : (size_t)e0;
+	float4 q[NV4];
+	float dc = 0.f;
+	if (fast) {
+		const float4* src = reinterpret_cast<const float4*>(sp + r0 * (NV4 * 4));
+		const int words = rows * NV4;
+#pragma unroll
+		for (int k = 0; k < NV4; k++) { const int wd = k * 256 + threadIdx.x; q[k] = src[min(wd, words - 1)]; }
+		dc = (ob ? s.obj_dc : s.scene_dc)[r0 + min((int)threadIdx.x, rows - 1)];
+	}
 	for (int k = threadIdx.x; k < NV4 * 4; k += 256) s_w[k] = 0.f;
 	__syncthreads();
 	const int total = s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2];
 	for (int i = threadIdx.x; i < total; i += 256) s_w[s.f.index[i]] = s.f.weight[i];
 	__syncthreads();
-	// The block owns 256 consecutive rows = 256 * NV4 consecutive 16-byte words of one segment (scene or object side).  Lane i of a
-	// load instruction reads word base + i -- 1 KiB of consecutive bytes per wave and instruction instead of 64 words 16 * NV4 bytes
-	// apart --, dots it with its quarter of the basis vector, and the NV4 partial sums of a row meet in LDS.  A block that straddles
-	// the scene / object boundary takes the row-per-thread path.
-	const int e0 = blockIdx.x * 256;                       // first row (row = n * 3 + c)
-	const int rows = min(256, N * 3 - e0);
 	if (rows <= 0) return;
-	const int split = 3 * s.Ns;                            // rows [0, split): scene side
-	const bool one_side = (e0 >= split) || (e0 + rows <= split);
-	const bool ob = e0 >= split;
-	const float* sp = ob ? s.obj_sp : s.scene_sp;
-	if (one_side && sp) {
-		const size_t r0 = ob ? (size_t)e0 - split : (size_t)e0;
-		const float4* src = reinterpret_cast<const float4*>(sp + r0 * (NV4 * 4));
-		const int words = rows * NV4;
-		float4 q[NV4];
-#pragma unroll
-		for (int k = 0; k < NV4; k++) { const int wd = k * 256 + threadIdx.x; q[k] = src[min(wd, words - 1)]; }
+	if (fast) {
 #pragma unroll
 		for (int k = 0; k < NV4; k++) {
 			const int wd = k * 256 + threadIdx.x, part = wd % NV4;
@@ -880,7 +896,7 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 			float acc = 0.f;
 #pragma unroll
 			for (int k = 0; k < NV4; k++) acc += s_part[threadIdx.x * NV4 + k];
-			out[e0 + threadIdx.x] = (ob ? s.obj_dc : s.scene_dc)[r0 + threadIdx.x] + acc;
+			out[e0 + threadIdx.x] = dc + acc;
 		}
 		return;
 	}
@@ -903,8 +919,9 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 	}
 	out[e] = v;
 }
-__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero) {
 	extern __shared__ float s_rows[];
+	if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
 	const int tid = threadIdx.x, B = blockDim.x, base = blockIdx.x * B, count = min(B, N - base);
 	const int np = s.f.n_params, L = 3 * np, stride = L | 1;
 	const bool lin = (s.scene_sp || s.obj_sp) && has_lin(s.f);
@@ -937,7 +954,7 @@ static int pick_block(int row_floats, size_t* lds) {
 	return 64;
 }
 
-int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words, int n_zero) {
 	if (N <= 0) return 0;
 	const int np = s.f.n_params;
 	const bool lin = (s.scene_sp || s.obj_sp) && (s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2]) > 0 && np > 0;
@@ -945,14 +962,14 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 	if (lin && np % 4 == 0 && np <= 32 && aligned) {
 		const unsigned blocks = (unsigned)(((size_t)N * 3 + 255) / 256);
 		switch (np / 4) {
-			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
-			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out); break;
+			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
 		}
 		ADGS_HIP_CHECK(hipGetLastError());
 		return 0;
@@ -961,7 +978,7 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream) {
 	const int B = pick_block((3 * np) | 1, &lds);
 	if (lds > MAX_STAGING_LDS) { set_error("launch_sh0: SH deformation rows too large for the LDS staging buffer (more than 207 parameters per channel)"); return -1; }
 	if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out);
+	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out, zero_words, n_zero);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
