@@ -40,6 +40,9 @@ PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, densify_every=10)}
 
 
+VALU_FMA_RATE = 0.36      # wave64 v_fma_f32 per SIMD and cycle, measured on MI355X (profiles/r02/valu_rates.txt)
+
+
 def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     """Algorithmic bytes per launch of every stage of the reference-order ("classic") pipeline."""
     pay = 12 + 4 + 12 * F + 4 * D_S
@@ -292,9 +295,11 @@ def committed_pmc(stage, config, measured_case):
         pm = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))["kernels"].get(kname)
         if pm:
             out["valu_insts_per_simd_cycle"] = pm.get("valu_insts_per_simd_cycle")
-            out["valu_issue_frac_of_peak"] = None if pm.get("valu_insts_per_simd_cycle") is None else round(pm["valu_insts_per_simd_cycle"] / 0.5, 3)
+            out["valu_issue_frac_of_peak"] = None if pm.get("valu_insts_per_simd_cycle") is None else round(pm["valu_insts_per_simd_cycle"] / VALU_FMA_RATE, 3)
             out["valu_note"] = ("the blend kernels are fp32-VALU-issue bound, not HBM bound (SURVEY.md 8(d)): wave64 VALU instructions per SIMD and "
-                                "cycle against the full-rate peak of 0.5; profiles/r02/pmc_blend_kernels.json")
+                                "cycle (profiles/r02/pmc_blend_kernels.json) against the MEASURED v_fma_f32 rate of gfx950, %.2f at 2+ waves per "
+                                "SIMD (tools/microbench/valu_rates.hip, profiles/r02/valu_rates.txt; v_mul 0.40, v_min / DPP 0.24, compare + "
+                                "select 0.30, v_exp 0.12)" % VALU_FMA_RATE)
     except (OSError, ValueError, KeyError):
         pass
     return out
