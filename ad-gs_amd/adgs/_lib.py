@@ -108,6 +108,11 @@ def lib():
             raise RuntimeError(
                 "libadgs_hip.so not found at %s: build it with `make -C ad-gs_amd/csrc` "
                 "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        # torch first: this library and torch must share ONE HIP runtime, and it has to be the one torch ships -- with the
+        # system's libamdhip64 loaded first (this library's own dependency), torch.cuda.is_available() turns False and the two
+        # sides stop seeing each other's devices and streams (observed on the MI355X boxes: "no HIP device" from adgs_device_check
+        # in a process that had built and loaded the library before importing torch)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if a declared symbol is not exported
