@@ -705,6 +705,8 @@ def main():
             "P": P, "cameras_per_step": cams_per_step,
             "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
             "step_ms_hip_events": dict(step_stats(step_ms), first=round(step_ms[0], 4))}
+        if os.environ.get("ADGS_BENCH_DUMP_STEPS"):
+            config["step_ms_series"] = [round(x, 4) for x in step_ms[:int(os.environ["ADGS_BENCH_DUMP_STEPS"])]]
         if gpu_idle:
             config["gpu_idle"] = gpu_idle
         # ---- exchange / densify times (HIP events on rank 0's launch stream)
