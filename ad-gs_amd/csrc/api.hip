@@ -347,6 +347,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	if (gx > 65535 || gy > 65535) { set_error("image too large"); return -1; }
+	if (ntiles * 4 * (2 * (size_t)POOL_BLOCK + 1) > 0xffffffffull) { set_error("image too large: chunk slots are 32-bit"); return -1; }      // 4: wave tiles per 16x16 tile at most
 
 	if (use_v2(D_S)) {
 		const int cell_tiles = v2_cell_tiles(ntiles);
