@@ -429,3 +429,15 @@ def test_many_chunks_per_tile_at_four_pixels_per_lane(monkeypatch):
     monkeypatch.setenv("ADGS_RASTER_MODE", "classic")
     run_hip(sc)
     assert _lib.frame_stats()["num_rendered"] / 4096 > 300          # classic mode: (tile, Gaussian) pairs
+
+
+def test_opacities_above_the_alpha_clamp():
+    """Opacities in (0.99, 1]: the min(0.99, .) clamp of forward.cu:357 bites (alpha = 0.99 at the centre) for 40 % of the Gaussians."""
+    sc = synthetic.make_scene(12000, 256, 160, 220.0, seed=73, n_objects=2)
+    g = torch.Generator().manual_seed(3)
+    op = sc["opacities"].clone()
+    hot = torch.rand(op.shape[0], generator=g) < 0.4
+    op[hot] = 0.99 + 0.01 * torch.rand(int(hot.sum()), 1, generator=g)
+    op[0] = 1.0
+    sc["opacities"] = op.contiguous()
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 73))
