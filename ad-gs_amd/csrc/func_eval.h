@@ -59,7 +59,9 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 				for (int u = 0; u < U4; u++) {
 					in[u] = q + u * nthreads < total4;
 					so[u] = g * stride + c; cc[u] = c;
-					if (TO_LDS) v[u] = in[u] ? reinterpret_cast<const float4*>(slab)[q + u * nthreads] : make_float4(0.f, 0.f, 0.f, 0.f);
+					// UNCONDITIONAL load at a clamped index: a load under `in[u] ? ... : ...` sits in its own exec-masked block, whose end
+					// waits for it (s_waitcnt vmcnt(0)) -- the U4 round trips of a batch then run one after the other
+					if (TO_LDS) v[u] = reinterpret_cast<const float4*>(slab)[min(q + u * nthreads, total4 - 1)];
 					c += dr; g += dq;
 					if (c >= L) { c -= L; g++; }
 				}
@@ -76,6 +78,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 			e_begin = total4 << 2;            // at most three tail elements go through the generic loop
 		}
 	}
+	if (!scene && !obj) return;
 	int g = (e_begin + tid) / L, c = (e_begin + tid) - g * L;
 	const int dq = nthreads / L, dr = nthreads - dq * L;
 	for (int e = e_begin + tid; e < total; e += nthreads * U) {
@@ -91,8 +94,10 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 			if (c >= L) { c -= L; g++; }
 		}
 		if (TO_LDS) {
+			// unconditional loads (see above): an absent side / an element past the end reads a valid dummy address
+			PtrT dummy = scene ? scene : obj;
 #pragma unroll
-			for (int u = 0; u < U; u++) v[u] = p[u] ? *p[u] : 0.f;
+			for (int u = 0; u < U; u++) v[u] = *(p[u] ? p[u] : dummy);
 #pragma unroll
 			for (int u = 0; u < U; u++) if (p[u]) s[so[u]] = v[u];
 		} else {
