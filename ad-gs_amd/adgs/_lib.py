@@ -40,6 +40,7 @@ SIGNATURES = {
     "adgs_knn_workspace_bytes": (ctypes.c_size_t, [c_i]),
     "adgs_knn_dist2": (c_i, [c_i, c_p, c_p, c_p, c_p]),
     "adgs_get_frame_stats": (None, [c_p]),
+    "adgs_get_frame_status": (c_i, [c_p]),
     "adgs_raster_needs_zero_init": (c_i, [c_i]),
     "adgs_profile_enable": (None, [c_i]),
     "adgs_profile_reserve": (c_i, [c_i]),
@@ -63,6 +64,10 @@ SIGNATURES = {
     "adgs_flow_loss_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "adgs_bce_clip_forward": (c_i, [c_i, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p]),
     "adgs_bce_clip_backward": (c_i, [c_i, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p]),
+    "adgs_group_var_forward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_group_var_backward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_sigma_loss_forward": (c_i, [c_i, c_p, c_f, c_p, c_p, c_p]),
+    "adgs_sigma_loss_backward": (c_i, [c_i, c_p, c_f, c_p, c_p, c_p]),
     # include/adgs_optim.h
     "adgs_densification_stats": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_adam_step": (c_i, [c_p, c_i, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i, c_p]),
@@ -87,6 +92,7 @@ SIGNATURES = {
     "adgs_test_v2_tile_counters": (ctypes.c_longlong, [c_p, c_i, c_i, c_p, c_p, ctypes.c_longlong, c_p]),
     "adgs_test_v2_blend_batches": (ctypes.c_longlong, [c_p, c_i, c_i, c_p]),
     "adgs_test_v2_cell_ranges": (ctypes.c_longlong, [c_p, c_i, c_i, c_p, ctypes.c_longlong, c_p]),
+    "adgs_test_set_capacity_hints": (None, [ctypes.c_longlong, ctypes.c_longlong]),
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),
     "adgs_test_sort_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
@@ -98,6 +104,13 @@ SIGNATURES = {
 class FrameStats(ctypes.Structure):
     _fields_ = [("num_rendered", ctypes.c_int64), ("tiles", ctypes.c_int32), ("sort_bits", ctypes.c_int32),
                 ("sort_passes", ctypes.c_int32), ("reserved", ctypes.c_int32), ("fine_pairs", ctypes.c_int64)]
+
+
+class FrameStatus(ctypes.Structure):
+    """adgs_frame_status (include/adgs_rasterizer.h)."""
+    _fields_ = [("pairs", ctypes.c_int64), ("fine_pairs", ctypes.c_int64), ("capacity_pairs", ctypes.c_int64),
+                ("capacity_fine_pairs", ctypes.c_int64), ("overflow_count", ctypes.c_int64), ("eager_reruns", ctypes.c_int64),
+                ("overflow", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def lib():
@@ -138,6 +151,15 @@ def frame_stats():
     lib().adgs_get_frame_stats(ctypes.byref(st))
     return dict(num_rendered=int(st.num_rendered), tiles=int(st.tiles), sort_bits=int(st.sort_bits), sort_passes=int(st.sort_passes),
                 fine_pairs=int(st.fine_pairs), bucket_binning=int(st.reserved))
+
+
+def frame_status():
+    """Capacity status of this thread's most recent default-pipeline forward on the current device (adgs_get_frame_status):
+    call after the stream has been synchronised.  `overflow` / `overflow_count` matter for frames replayed from a HIP graph
+    (adgs.graph.GraphedStep); eager forwards repair themselves before they return (`eager_reruns`)."""
+    st = FrameStatus()
+    check(lib().adgs_get_frame_status(ctypes.byref(st)), "adgs_get_frame_status")
+    return {k: int(getattr(st, k)) for k, _ in FrameStatus._fields_ if k != "reserved"}
 
 
 class StageProfiler:

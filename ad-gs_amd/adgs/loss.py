@@ -214,3 +214,83 @@ def obj_loss(img_semantic, gt_semantic):
 def sky_loss(img_opacity, gt_sky):
     """train.py:100-103: binary_cross_entropy(1 - clip(img_opacity, 1e-3, 1 - 1e-3), gt_sky)."""
     return bce_clip_loss(img_opacity, gt_sky, invert=True)
+
+
+# ---------------------------------------------------------------- neighbourhood regularisers (train.py:104-113)
+class _GroupVar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, inner):
+        if not x.is_cuda or not idx.is_cuda:
+            raise RuntimeError("group variance loss: tensors must be on a HIP device; there is no CPU path")
+        if idx.dim() != 2 or idx.dtype != torch.int64:
+            raise ValueError("obj_near_idx must be an int64 [G, K] tensor")
+        xs, ix = x.contiguous().float(), idx.contiguous()
+        N = xs.shape[0]
+        D = xs.numel() // max(N, 1)
+        G, K = ix.shape
+        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=xs.device)
+        out = torch.zeros(1, dtype=torch.float32, device=xs.device)
+        if G and D:
+            with torch.cuda.device(xs.device):
+                _lib.check(_lib.lib().adgs_group_var_forward(N, G, K, D, int(inner), xs.data_ptr(), ix.data_ptr(), work.data_ptr(), out.data_ptr(),
+                                                             _stream(xs.device)), "adgs_group_var_forward")
+        ctx.save_for_backward(xs, ix)
+        ctx.dims, ctx.shape = (N, G, K, D, int(inner)), x.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        xs, ix = ctx.saved_tensors
+        N, G, K, D, inner = ctx.dims
+        out = torch.zeros_like(xs)
+        gl = g_loss.reshape(1).float().contiguous()
+        if G and D:
+            with torch.cuda.device(xs.device):
+                _lib.check(_lib.lib().adgs_group_var_backward(N, G, K, D, inner, xs.data_ptr(), ix.data_ptr(), gl.data_ptr(), out.data_ptr(),
+                                                              _stream(xs.device)), "adgs_group_var_backward")
+        return out.reshape(ctx.shape), None, None
+
+
+def reg_loss(xyz_deform_param, obj_near_idx):
+    """train.py:104-106: mean(sum(var(xyz_deform_param[obj_near_idx], dim=1), dim=-1)); xyz_deform_param [N,3,C], obj_near_idx [G,K]."""
+    return _GroupVar.apply(xyz_deform_param, obj_near_idx, xyz_deform_param.shape[-1])
+
+
+def reg_sigma_loss(gs_time_sigma, obj_near_idx):
+    """train.py:111-113: mean(sum(var(gs_time_sigma[obj_near_idx], dim=1), dim=-1)); gs_time_sigma [N,2]."""
+    return _GroupVar.apply(gs_time_sigma, obj_near_idx, gs_time_sigma.shape[-1])
+
+
+class _SigmaLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_sigma, frame_gap):
+        if not log_sigma.is_cuda:
+            raise RuntimeError("sigma_loss: tensors must be on a HIP device; there is no CPU path")
+        if log_sigma.dim() != 2 or log_sigma.shape[1] != 2:
+            raise ValueError("gs_time_sigma must be [N, 2]")
+        ls = log_sigma.contiguous().float()
+        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=ls.device)
+        out = torch.zeros(1, dtype=torch.float32, device=ls.device)
+        if ls.shape[0]:
+            with torch.cuda.device(ls.device):
+                _lib.check(_lib.lib().adgs_sigma_loss_forward(ls.shape[0], ls.data_ptr(), float(frame_gap), work.data_ptr(), out.data_ptr(),
+                                                              _stream(ls.device)), "adgs_sigma_loss_forward")
+        ctx.save_for_backward(ls)
+        ctx.gap = float(frame_gap)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (ls,) = ctx.saved_tensors
+        out = torch.empty_like(ls)
+        gl = g_loss.reshape(1).float().contiguous()
+        if ls.shape[0]:
+            with torch.cuda.device(ls.device):
+                _lib.check(_lib.lib().adgs_sigma_loss_backward(ls.shape[0], ls.data_ptr(), ctx.gap, gl.data_ptr(), out.data_ptr(), _stream(ls.device)),
+                           "adgs_sigma_loss_backward")
+        return out, None
+
+
+def sigma_loss(gs_time_sigma, frame_gap):
+    """train.py:108-110: mean(|frame_gap / mean(exp(gs_time_sigma), dim=-1)|)."""
+    return _SigmaLoss.apply(gs_time_sigma, frame_gap)

@@ -205,6 +205,7 @@ StageTimer::~StageTimer() {
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
 static std::atomic<size_t> g_hint_cells{0}, g_hint_fine{0};      // speculative binning capacities (v2 forward)
+static std::atomic<long long> g_reruns{0};                       // forwards whose capacity was too small (binning + blend enqueued twice)
 static uint32_t* pinned_word() {
 	static thread_local uint32_t* p = nullptr;
 	if (!p) { if (hipHostMalloc((void**)&p, 1024, hipHostMallocDefault) != hipSuccess) p = nullptr; }
@@ -215,7 +216,7 @@ static uint32_t* pinned_word() {
 // middle of the frame, and a driver-level wait (hipEventSynchronize / hipStreamSynchronize) for them was measured to fall
 // back to a ~10 ms timeout per call in the first process on a freshly booted box (frames at 11 ms instead of 1.7 ms with
 // every kernel at its normal duration).  A volatile read of host memory has no such mode.
-struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; };
+struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; size_t cap_cells, cap_fine; };      // cap_*: capacities of the last forward
 // one mailbox per (host thread, device): the device pointer of a mapped allocation belongs to the device that was current when
 // it was taken, so a thread that renders on several GPUs gets one per GPU (portable pinned memory)
 static MailboxRef* mailbox() {
@@ -229,39 +230,58 @@ static MailboxRef* mailbox() {
 		if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
 		if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
 		memset(h, 0, 256);
-		m.host = (Mailbox*)h; m.dev = (Mailbox*)d; m.next_seq = 1;
+		m.host = (Mailbox*)h; m.dev = (Mailbox*)d; m.next_seq = 1; m.cap_cells = m.cap_fine = 0;
 	}
 	return &m;
 }
-// What the forward decided from the environment (pipeline, cell size, pixels per lane), remembered per image-state buffer so that
-// the backward of THAT forward carves the saved buffers the same way even if the environment changed in between.  (The buffers are
-// opaque device memory; the host-side key is the pointer autograd hands back.)
+// What the forward decided from the environment (pipeline, cell size, pixels per lane), remembered per forward state so that the
+// backward of THAT forward carves the saved buffers the same way even if the environment changed in between.  The buffers are opaque
+// device memory, so the key is host-side: the (image, geometry) buffer addresses autograd hands back TOGETHER WITH the frame's shape
+// (W, H, P).  A state that reaches the backward under another address (cloned / offloaded saved tensors) or another shape is "not
+// found": the backward then carves by today's environment and zeroes the accumulator lines itself -- it never trusts a stale entry.
 struct FrameCfg { int v2; int cell_tiles; int ppl; int backwards = 0; };      // backwards: how many backward passes have consumed this forward's accumulator lines
+struct FrameKey {
+	const void* img; const void* geom; int W, H, P;
+	bool operator==(const FrameKey& o) const { return img == o.img && geom == o.geom && W == o.W && H == o.H && P == o.P; }
+};
 static std::mutex g_cfg_mu;
-static std::vector<std::pair<const void*, FrameCfg>> g_cfg_table;
-static void remember_frame(const void* img_buffer, const FrameCfg& c) {
+static std::vector<std::pair<FrameKey, FrameCfg>> g_cfg_table;
+static void remember_frame(const FrameKey& k, const FrameCfg& c) {
 	std::lock_guard<std::mutex> lk(g_cfg_mu);
-	for (auto& e : g_cfg_table) if (e.first == img_buffer) { e.second = c; return; }
+	// a new forward into these addresses supersedes whatever lived there (either buffer may have been recycled for another shape)
+	for (auto it = g_cfg_table.begin(); it != g_cfg_table.end();) it = (it->first.img == k.img || it->first.geom == k.geom) ? g_cfg_table.erase(it) : it + 1;
 	if (g_cfg_table.size() >= 256) g_cfg_table.erase(g_cfg_table.begin());
-	g_cfg_table.emplace_back(img_buffer, c);
+	g_cfg_table.emplace_back(k, c);
 }
-// counts a backward over this forward state; returns how many ran before it, or -1 if the forward is not in the table any more
-static int note_backward(const void* img_buffer) {
+// counts a backward over this forward state; returns how many ran before it, or -1 if the forward is not in the table (any more)
+static int note_backward(const FrameKey& k) {
 	std::lock_guard<std::mutex> lk(g_cfg_mu);
-	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it) if (it->first == img_buffer) return it->second.backwards++;
+	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it) if (it->first == k) return it->second.backwards++;
 	return -1;
 }
-static bool lookup_frame(const void* img_buffer, FrameCfg* c) {
+static bool lookup_frame(const FrameKey& k, FrameCfg* c) {
 	std::lock_guard<std::mutex> lk(g_cfg_mu);
-	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it) if (it->first == img_buffer) { *c = it->second; return true; }
+	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it) if (it->first == k) { *c = it->second; return true; }
 	return false;
 }
-__global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, const unsigned long long* __restrict__ fine_slots, Mailbox* box, uint32_t seq) {
+// the test hooks only know the image buffer and the image size
+static bool lookup_frame_by_image(const void* img, int W, int H, FrameCfg* c) {
+	std::lock_guard<std::mutex> lk(g_cfg_mu);
+	for (auto it = g_cfg_table.rbegin(); it != g_cfg_table.rend(); ++it)
+		if (it->first.img == img && it->first.W == W && it->first.H == H) { *c = it->second; return true; }
+	return false;
+}
+__global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, const unsigned long long* __restrict__ fine_slots, Mailbox* box, uint32_t seq,
+	uint32_t cap_cells, unsigned long long cap_fine, uint32_t* __restrict__ overflow_flag) {
 	unsigned long long f = threadIdx.x < SCAN_AUX_SLOTS ? fine_slots[threadIdx.x] : 0ull;
 #pragma unroll
 	for (int off = WAVE / 2; off > 0; off >>= 1) f += __shfl_xor(f, off, WAVE);
 	if (threadIdx.x == 0) {
-		box->r_cells = *total_cells; box->r_fine = f; box->oversize = 0u; box->n_groups = 0u;
+		const uint32_t total = *total_cells;
+		const uint32_t over = (total > cap_cells || f > cap_fine) ? 1u : 0u;      // the launches queued against the capacity must not blend
+		*overflow_flag = over;
+		box->r_cells = total; box->r_fine = f; box->oversize = 0u; box->n_groups = 0u; box->overflow = over;
+		if (over) box->overflow_count = box->overflow_count + 1u;
 		__threadfence_system();
 		box->seq = seq;                       // published last: the host spins on it
 	}
@@ -285,6 +305,21 @@ using namespace adgs;
 extern "C" const char* adgs_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_stats; }
+
+// Totals the device published for the calling thread's most recent v2 forward on the current device, and whether they fitted the
+// capacity that forward (eager or captured in a HIP graph) was enqueued against.  Reads host memory only; meaningful once the
+// stream the frame ran on has been synchronised (a graph replay publishes into the same mailbox as its capture did).
+extern "C" int adgs_get_frame_status(adgs_frame_status* out) {
+	if (!out) return -1;
+	memset(out, 0, sizeof(*out));
+	MailboxRef* mb = mailbox();
+	if (!mb) { set_error("hipHostMalloc (mapped) failed"); return -1; }
+	out->pairs = (int64_t)mb->host->r_cells; out->fine_pairs = (int64_t)mb->host->r_fine;
+	out->capacity_pairs = (int64_t)mb->cap_cells; out->capacity_fine_pairs = (int64_t)mb->cap_fine;
+	out->overflow = (int32_t)mb->host->overflow; out->overflow_count = (int64_t)mb->host->overflow_count;
+	out->eager_reruns = (int64_t)g_reruns.load();
+	return 0;
+}
 
 // 1 if the caller must zero-fill the outputs of forward/backward for this D_S (the classic,
 // atomics-into-outputs pipeline; also the reference's contract), 0 if every element is written.
@@ -364,7 +399,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
 		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, ncells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
-		remember_frame(ich, FrameCfg{ 1, cell_tiles, ppl });
+		remember_frame(FrameKey{ ich, gch, width, height, P }, FrameCfg{ 1, cell_tiles, ppl });
 
 		PreprocessArgs pa;
 		pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -401,15 +436,27 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream, zero_words, zero_words ? n_zero : 0) != 0) return -1; }
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
-		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning
-		// buffer.  Instead of draining the stream for them (the reference's blocking cudaMemcpy,
-		// rasterizer_impl.cu:288), binning + sort + ranges are enqueued against a speculative capacity
-		// (previous frames' counts + 25%) with the exact count read on the device; the host then waits only
-		// for the totals to be published -- the GPU keeps working on the speculative launches meanwhile -- and
-		// re-runs them with exact sizes in the rare case the capacity was too small.
+		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning buffer.  Instead of
+		// draining the stream for them (the reference's blocking cudaMemcpy, rasterizer_impl.cu:288) the WHOLE rest of the forward --
+		// binning, sort, ranges and the blend -- is enqueued against a capacity (previous frames' counts + 25%) before the host knows
+		// them; the device compares the exact totals with the capacity (cell_scan / publish_counts), and a frame that does not fit
+		// blends nothing (render_fwd_v2 leaves an empty replay state).  Only then does the host look at the totals the device
+		// published to its mailbox: the GPU has the complete forward queued by that time, so it never waits for the host, and in the
+		// rare case that the capacity was too small the binning and the blend are enqueued again with exact sizes.
+		// Under stream capture (HIP graphs) nothing can be read back: the frame is enqueued against the capacity and that is all;
+		// the caller checks adgs_get_frame_status() after a replay and re-captures after an eager frame when it reports an overflow.
 		MailboxRef* mb = mailbox();
 		if (!mb) { set_error("hipHostMalloc (mapped) failed"); return -1; }
 		const uint32_t seq = mb->next_seq++;
+		hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+		(void)hipStreamIsCapturing(stream, &cap_status);
+		const bool capturing = cap_status == hipStreamCaptureStatusActive;
+		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
+		const bool speculate = capturing || (env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99);
+		const size_t cap_cells = std::min<size_t>(std::max<size_t>(g_hint_cells.load(), (size_t)P + 4096), 0x7fffffffu);
+		const size_t cap_fine = std::max<size_t>(g_hint_fine.load(), (size_t)8 * P + 4096);
+		mb->cap_cells = cap_cells; mb->cap_fine = cap_fine;
+		uint32_t* overflow_flag = geom.d_counts() + 3;         // written by cell_scan / publish_counts in every frame
 		if (buckets) {
 			StageTimer t(ST_SCAN, stream);
 			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
@@ -417,6 +464,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 			sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
 			sa.chunks = geom.chunks; sa.max_chunks = (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))); sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
 			sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
+			sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
 			if (launch_cell_scan(sa, stream) != 0) return -1;
 		} else {
 			{
@@ -424,15 +472,12 @@ static int raster_forward_impl(const ShSource* sh_src,
 				// offsets of the (cell, Gaussian) pairs; the fine-tile bound of the chunk pool only needs its total
 				if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
 			}
-			hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(WAVE), 0, stream, (const uint32_t*)(geom.offsets + P), (const unsigned long long*)geom.fine_total, mb->dev, seq);
+			hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(WAVE), 0, stream, (const uint32_t*)(geom.offsets + P), (const unsigned long long*)geom.fine_total, mb->dev, seq,
+				speculate ? (uint32_t)cap_cells : 0xffffffffu, speculate ? (unsigned long long)cap_fine : ~0ull, overflow_flag);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);
-		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
-		const bool speculate = env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99;
 		const int bit = (int)higher_msb((uint32_t)ncells);
-		size_t cap_cells = std::max<size_t>(g_hint_cells.load(), (size_t)P + 4096);
-		size_t cap_fine = std::max<size_t>(g_hint_fine.load(), (size_t)8 * P + 4096);
 		BinStateV2 bin;
 		// rectangle-coverage masks in the key bits above (cell | depth): one bit per tile row and per tile column of a cell
 		const int mask_shift = (2 * cell_tiles + bit <= 32 && env_int("ADGS_KEY_MASKS", 1) != 0) ? 32 + bit : -1;
@@ -478,44 +523,60 @@ static int raster_forward_impl(const ShSource* sh_src,
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
 		};
-		if (speculate && enqueue_binning(cap_cells, cap_fine, buckets ? nullptr : geom.offsets + P) != 0) return -1;
+		auto launch_blend = [&]() -> int {      // on the binning state `bin` of the last enqueue_binning
+			RenderV2FwdArgs ra;
+			ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
+			ra.cell_keys = bin.keys; ra.mask_shift = mask_shift; ra.cell_entries = buckets ? bin.entries : nullptr;
+			ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
+			ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
+			ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
+			ra.bg = background; ra.bg_image = sh_src ? sh_src->bg_image : nullptr;
+			ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned; ra.tile_batches = img.tile_batches;
+			ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
+			ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
+			ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
+			ra.overflow_flag = overflow_flag;
+			{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
+			ADGS_LAUNCH_CHECK(debug, stream);
+			return 0;
+		};
+		if (speculate) {
+			if (enqueue_binning(cap_cells, cap_fine, buckets ? nullptr : geom.offsets + P) != 0) return -1;
+			if (launch_blend() != 0) return -1;
+		}
+		if (capturing) {
+			// nothing of this frame can be read back inside a capture: the totals stay in the mailbox for adgs_get_frame_status()
+			g_stats.num_rendered = (int64_t)cap_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = buckets ? 32 : 32 + bit;
+			g_stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8; g_stats.reserved = buckets ? 1 : 0; g_stats.fine_pairs = (int64_t)cap_fine;
+			return (int)cap_cells;
+		}
 		if (wait_mailbox(mb, seq, stream) != 0) return -1;
 		const size_t R_cells = mb->host->r_cells, R_fine = (size_t)mb->host->r_fine;
 		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu buckets=%d chunks=%u overflow=%u\n", P, ncells, R_cells, R_fine,
 			(int)buckets, mb->host->n_groups, mb->host->oversize);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
 		ADGS_DBG_STOP(0)
-		if (buckets && mb->host->oversize) {
-			// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
-			// per-Gaussian pair offsets first
-			buckets = false;
-			ADGS_HIP_CHECK(hipMemsetAsync(geom.fine_total, 0, SCAN_AUX_SLOTS * sizeof(unsigned long long), stream));
-			{ StageTimer t(ST_SCAN, stream);
-			  if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1; }
+		const bool chunk_table_full = buckets && mb->host->oversize;
+		if (!speculate || chunk_table_full || R_cells > cap_cells || R_fine > cap_fine) {
+			if (speculate) { g_reruns.fetch_add(1); ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream)); }      // the re-run fits by construction
+			if (chunk_table_full) {
+				// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
+				// per-Gaussian pair offsets first
+				buckets = false;
+				ADGS_HIP_CHECK(hipMemsetAsync(geom.fine_total, 0, SCAN_AUX_SLOTS * sizeof(unsigned long long), stream));
+				StageTimer t(ST_SCAN, stream);
+				if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
+			}
 			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
-		} else if (!speculate || R_cells > cap_cells || R_fine > cap_fine) {
-			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
+			ADGS_DBG_STOP(3)
+			if (launch_blend() != 0) return -1;
 		}
-		ADGS_DBG_STOP(3)
 		{	// capacity hints for the next frame: 25% head-room over this frame, slow decay of older peaks
 			const size_t want_c = R_cells + R_cells / 4 + 4096, want_f = R_fine + R_fine / 4 + 4096;
 			const size_t old_c = g_hint_cells.load(), old_f = g_hint_fine.load();
 			g_hint_cells.store(std::max(want_c, old_c - old_c / 16));
 			g_hint_fine.store(std::max(want_f, old_f - old_f / 16));
 		}
-		RenderV2FwdArgs ra;
-		ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
-		ra.cell_keys = bin.keys; ra.mask_shift = mask_shift; ra.cell_entries = buckets ? bin.entries : nullptr;
-		ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
-		ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
-		ra.has_flow = flow_points != nullptr; ra.has_sem = (semantic != nullptr) && D_S > 0;
-		ra.bg = background; ra.bg_image = sh_src ? sh_src->bg_image : nullptr;
-		ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned; ra.tile_batches = img.tile_batches;
-		ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
-		ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
-		ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
-		{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
-		ADGS_LAUNCH_CHECK(debug, stream);
 		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = buckets ? 32 : 32 + bit;
 		g_stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
 		g_stats.reserved = buckets ? 1 : 0; g_stats.fine_pairs = (int64_t)R_fine;       // reserved: 1 = bucket binning (the sort passes stay inside the CUs)
@@ -530,7 +591,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (!gchunk || !ichunk) { set_error("buffer allocator returned NULL"); return -1; }
 	GeomState geom = GeomState::carve(gchunk, P, nullptr);
 	ImgState img = ImgState::carve(ichunk, npix, ntiles, nullptr);
-	remember_frame(ichunk, FrameCfg{ 0, 1, 4 });
+	remember_frame(FrameKey{ ichunk, gchunk, width, height, P }, FrameCfg{ 0, 1, 4 });
 
 	PreprocessArgs pa;
 	pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -615,7 +676,8 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	FrameCfg cfg;
-	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = use_v2(D_S) ? 1 : 0; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }      // foreign buffers: today's environment
+	const FrameKey fkey{ img_buffer, geom_buffer, width, height, P };
+	if (!lookup_frame(fkey, &cfg)) { cfg.v2 = use_v2(D_S) ? 1 : 0; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }      // foreign buffers: today's environment
 	if (cfg.v2) {
 		const int cell_tiles = cfg.cell_tiles;
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
@@ -650,7 +712,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 			// accumulates into them as they are.  A second backward over the same forward state (retain_graph) -- or one whose
 			// forward has dropped out of the frame table -- gets them zeroed again here (64 B per Gaussian: the preprocess
 			// backward used to re-zero every line after reading it, 64 MB of writes per frame at C3 for a case that is rare).
-			if (note_backward(img_buffer) != 0) ADGS_HIP_CHECK(hipMemsetAsync(geom.gacc, 0, (size_t)P * GACC_STRIDE * sizeof(float), stream));
+			if (note_backward(fkey) != 0) ADGS_HIP_CHECK(hipMemsetAsync(geom.gacc, 0, (size_t)P * GACC_STRIDE * sizeof(float), stream));
 			if (binning_buffer && launch_render_bwd_v2(ra, stream) != 0) return -1;
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);
@@ -835,91 +897,68 @@ extern "C" int adgs_knn_dist2(int P, const float* points, float* meanDists, char
 
 // ---- test-only hooks (include/adgs_testing.h) ----
 #include "../../include/adgs_testing.h"
-extern "C" long long adgs_test_v2_published_entries(const char* img_buffer, int width, int height, void* stream_) {
-	if (!img_buffer || width <= 0 || height <= 0) return -1;
+// the image state of a v2 forward, carved the way that forward carved it
+namespace {
+struct V2ImageView { ImgStateV2 img; size_t wtiles, ncells; };
+bool v2_image_view(const char* img_buffer, int width, int height, V2ImageView* v) {
+	if (!img_buffer || width <= 0 || height <= 0) return false;
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	FrameCfg cfg;
-	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	if (!lookup_frame_by_image(img_buffer, width, height, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
 	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
-	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
-	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
-	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
-	std::vector<uint32_t> h(wtiles);
-	if (hipMemcpyAsync(h.data(), img.tile_consumed, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
-	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	v->ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
+	v->wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
+	v->img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, v->wtiles, v->ncells, nullptr);
+	return true;
+}
+long long sum_tile_words(const uint32_t* d_words, size_t n, hipStream_t stream) {
+	std::vector<uint32_t> h(n);
+	if (hipMemcpyAsync(h.data(), d_words, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+	if (hipStreamSynchronize(stream) != hipSuccess) return -1;
 	long long total = 0;
-	for (uint32_t v : h) total += v;
+	for (uint32_t x : h) total += x;
 	return total;
+}
+} // namespace
+extern "C" long long adgs_test_v2_published_entries(const char* img_buffer, int width, int height, void* stream_) {
+	V2ImageView v;
+	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
+	return sum_tile_words(v.img.tile_consumed, v.wtiles, (hipStream_t)stream_);
 }
 // per-tile counters of the last forward: out_consumed / out_scanned receive one uint32 per wave tile (returns the tile count)
 extern "C" long long adgs_test_v2_tile_counters(const char* img_buffer, int width, int height, uint32_t* out_consumed, uint32_t* out_scanned, long long capacity, void* stream_) {
-	if (!img_buffer || width <= 0 || height <= 0) return -1;
-	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
-	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	FrameCfg cfg;
-	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
-	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
-	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
-	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
-	if ((long long)wtiles > capacity) return (long long)wtiles;
-	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
-	if (out_consumed && hipMemcpyAsync(out_consumed, img.tile_consumed, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
-	if (out_scanned && hipMemcpyAsync(out_scanned, img.tile_scanned, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	V2ImageView v;
+	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
+	if ((long long)v.wtiles > capacity) return (long long)v.wtiles;
+	if (out_consumed && hipMemcpyAsync(out_consumed, v.img.tile_consumed, v.wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (out_scanned && hipMemcpyAsync(out_scanned, v.img.tile_scanned, v.wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
 	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
-	return (long long)wtiles;
+	return (long long)v.wtiles;
 }
 // number of batches (of <= 64 entries that passed the tile test) the forward handed to its blend loop, summed over the tiles
 extern "C" long long adgs_test_v2_blend_batches(const char* img_buffer, int width, int height, void* stream_) {
-	if (!img_buffer || width <= 0 || height <= 0) return -1;
-	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
-	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	FrameCfg cfg;
-	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
-	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
-	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
-	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
-	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
-	std::vector<uint32_t> h(wtiles);
-	if (hipMemcpyAsync(h.data(), img.tile_batches, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
-	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
-	long long total = 0;
-	for (uint32_t v : h) total += v;
-	return total;
+	V2ImageView v;
+	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
+	return sum_tile_words(v.img.tile_batches, v.wtiles, (hipStream_t)stream_);
 }
 // per-cell (start, end) ranges of the depth-sorted candidate lists of the last forward (returns the cell count)
 extern "C" long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height, uint32_t* out_ranges, long long capacity, void* stream_) {
-	if (!img_buffer || width <= 0 || height <= 0) return -1;
-	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
-	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	FrameCfg cfg;
-	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
-	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
-	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
-	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
-	if ((long long)ncells > capacity) return (long long)ncells;
-	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
-	if (out_ranges && hipMemcpyAsync(out_ranges, img.cell_ranges, ncells * sizeof(uint2), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	V2ImageView v;
+	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
+	if ((long long)v.ncells > capacity) return (long long)v.ncells;
+	if (out_ranges && hipMemcpyAsync(out_ranges, v.img.cell_ranges, v.ncells * sizeof(uint2), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
 	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
-	return (long long)ncells;
+	return (long long)v.ncells;
 }
 // sum over the wave tiles of the candidates of the cell list each tile's walk went through before all its pixels were saturated
 extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int width, int height, void* stream_) {
-	if (!img_buffer || width <= 0 || height <= 0) return -1;
-	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
-	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
-	FrameCfg cfg;
-	if (!lookup_frame(img_buffer, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
-	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
-	const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
-	const size_t wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
-	ImgStateV2 img = ImgStateV2::carve(const_cast<char*>(img_buffer), npix, wtiles, ncells, nullptr);
-	std::vector<uint32_t> h(wtiles);
-	if (hipMemcpyAsync(h.data(), img.tile_scanned, wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
-	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
-	long long total = 0;
-	for (uint32_t v : h) total += v;
-	return total;
+	V2ImageView v;
+	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
+	return sum_tile_words(v.img.tile_scanned, v.wtiles, (hipStream_t)stream_);
+}
+extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
+	g_hint_cells.store((size_t)std::max(0ll, pairs)); g_hint_fine.store((size_t)std::max(0ll, fine_pairs));
 }
 extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
 extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {

@@ -95,10 +95,13 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 	if (c == 0) {
 		a.cell_start[a.ncells] = total;
 		const uint32_t over = nchunks_total > a.max_chunks ? 1u : 0u;
-		a.d_counts[0] = total; a.d_counts[1] = nchunks_total; a.d_counts[2] = over;
 		unsigned long long fine = 0ull;
 		for (int k = 0; k < SCAN_AUX_SLOTS; k++) fine += a.fine_total[k];
-		a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total;
+		// the binning and blend launches behind this one were enqueued against a capacity: do the totals fit?
+		const uint32_t nofit = (over || total > a.cap_cells || fine > a.cap_fine) ? 1u : 0u;
+		a.d_counts[0] = total; a.d_counts[1] = nchunks_total; a.d_counts[2] = over; a.d_counts[3] = nofit;
+		a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit;
+		if (nofit) a.box->overflow_count = a.box->overflow_count + 1u;
 		__threadfence_system();
 		a.box->seq = a.seq;                       // published last: the host spins on it
 	}

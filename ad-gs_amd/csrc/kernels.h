@@ -101,7 +101,8 @@ constexpr int MAX_CELLS = 1024;         // coarse cells one cell_scan workgroup 
 constexpr int GS_NMAX = 8192;           // entries one chunk_sort workgroup sorts inside its CU
 constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
-struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, pad0, pad1; };
+// overflow: the totals exceed the capacity the frame's launches were enqueued against; overflow_count: such frames since the mailbox exists
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count; };
 struct CellScanArgs {
 	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
 	uint32_t* cell_start;               // [ncells + 1]
@@ -110,6 +111,7 @@ struct CellScanArgs {
 	uint32_t* d_counts;                 // [0] pairs, [1] chunks, [2] overflow flag (more chunks than the table holds)
 	const unsigned long long* fine_total;
 	Mailbox* box; uint32_t seq;
+	uint32_t cap_cells; unsigned long long cap_fine;      // capacities of the launches that follow (d_counts[3] = the totals exceed them)
 };
 int launch_cell_scan(const CellScanArgs& a, hipStream_t stream);
 int launch_cell_colscan(uint32_t* counts, int nblocks, int ncells, uint32_t* cell_count, hipStream_t stream);
@@ -141,6 +143,7 @@ struct RenderV2FwdArgs {
 	float* final_T; uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
 	int order_mode;                         // 1: workgroups walk the tiles bottom-up (default), 0: top-down
+	const uint32_t* overflow_flag;          // device word: != 0 = the frame does not fit the capacity of this launch (blend nothing)
 };
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
 

@@ -341,6 +341,65 @@ __global__ void __launch_bounds__(256) bce_clip_bwd_kernel(int n, const float* _
 
 using namespace adgs;
 
+// ---------------------------------------------------------------- neighbourhood regularisers (train.py:104-113)
+//   reg_loss       = mean(sum(var(xyz_deform_param[obj_near_idx], dim=1), dim=-1))     rows of D = 3 C floats, inner = C
+//   reg_sigma_loss = mean(sum(var(gs_time_sigma[obj_near_idx], dim=1), dim=-1))        rows of D = 2 floats,   inner = 2
+//   sigma_loss     = mean(|frame_gap / mean(exp(gs_time_sigma), dim=-1)|)
+// The reference gathers a [G, K, 3, C] copy of the rows (43 MB at C3), runs torch.var / sum / mean over it and scatters the
+// gradient back through index_put.  Here one thread owns one (group, column) pair: it reads its K values straight from the K
+// gathered rows (consecutive threads = consecutive columns of a row: coalesced), forms the unbiased variance in registers, and
+// the backward adds 2 (x - mean) / ((K - 1) denom) to the K rows with one atomic each (a Gaussian can sit in several groups).
+constexpr int GV_MAXK = 32;
+__global__ void __launch_bounds__(256) group_var_sum_kernel(int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
+	double denom, double* __restrict__ work) {
+	const long long total = (long long)G * D;
+	double sum = 0;
+	for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+		const int g = (int)(t / D), d = (int)(t % D);
+		float v[GV_MAXK], mean = 0.f;
+		for (int k = 0; k < K; k++) { v[k] = x[(size_t)idx[(size_t)g * K + k] * D + d]; mean += v[k]; }
+		mean /= (float)K;
+		float ss = 0.f;
+		for (int k = 0; k < K; k++) { const float c = v[k] - mean; ss += c * c; }
+		sum += (double)(ss / (float)(K - 1));
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
+	if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(work + (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % AUX_SLOTS) * 2, sum);
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(work + 1, denom);      // the "count" of the shared finish kernel
+}
+__global__ void __launch_bounds__(256) group_var_bwd_kernel(int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
+	float scale, const float* __restrict__ g_loss, float* __restrict__ dx) {
+	const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (long long)G * D) return;
+	const int g = (int)(t / D), d = (int)(t % D);
+	float v[GV_MAXK], mean = 0.f; long long row[GV_MAXK];
+	for (int k = 0; k < K; k++) { row[k] = idx[(size_t)g * K + k]; v[k] = x[(size_t)row[k] * D + d]; mean += v[k]; }
+	mean /= (float)K;
+	const float c = scale * g_loss[0];
+	for (int k = 0; k < K; k++) atomicAdd(dx + (size_t)row[k] * D + d, c * (v[k] - mean));
+}
+__global__ void __launch_bounds__(256) sigma_loss_sum_kernel(int N, const float* __restrict__ ls, float gap, double* __restrict__ work) {
+	double sum = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+		const float m = 0.5f * (expf(ls[2 * i]) + expf(ls[2 * i + 1]));
+		sum += (double)fabsf(gap / m);
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
+	if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(work + (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % AUX_SLOTS) * 2, sum);
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(work + 1, (double)N);
+}
+__global__ void __launch_bounds__(256) sigma_loss_bwd_kernel(int N, const float* __restrict__ ls, float gap, const float* __restrict__ g_loss, float* __restrict__ d) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= N) return;
+	const float e0 = expf(ls[2 * i]), e1 = expf(ls[2 * i + 1]);
+	const float m = 0.5f * (e0 + e1), q = gap / m;
+	const float sgn = q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f);
+	const float c = -sgn * q / m * 0.5f * g_loss[0] / (float)N;          // d|q|/dm = -sgn q / m;  dm/ds_j = e_j / 2
+	d[2 * i] = c * e0; d[2 * i + 1] = c * e1;
+}
+
 extern "C" int adgs_depth_loss_forward(int n, const float* prediction, const float* target, const float* mask, double* work, float* loss, void* stream_) {
 	if (n <= 0) return 0;
 	if (!prediction || !target || !work || !loss) { set_error("adgs_depth_loss_forward: NULL pointer"); return -1; }
@@ -435,6 +494,45 @@ extern "C" int adgs_bce_clip_backward(int n, const float* pred, const float* tar
 	if (n <= 0) return 0;
 	if (!pred || !target || !g_loss || !dL_dpred) { set_error("adgs_bce_clip_backward: NULL pointer"); return -1; }
 	hipLaunchKernelGGL(bce_clip_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, n, pred, target, lo, hi, invert, positive_target, g_loss, dL_dpred);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_group_var_forward(int N, int G, int K, int D, int inner, const float* x, const int64_t* idx, double* work, float* loss, void* stream_) {
+	if (G <= 0 || D <= 0) return 0;
+	if (!x || !idx || !work || !loss) { set_error("adgs_group_var_forward: NULL pointer"); return -1; }
+	if (K < 2 || K > GV_MAXK || inner <= 0 || D % inner != 0 || N <= 0) { set_error("adgs_group_var_forward: needs 2 <= K <= 32 neighbours and D a multiple of inner"); return -1; }
+	hipStream_t stream = (hipStream_t)stream_;
+	const long long total = (long long)G * D;
+	hipLaunchKernelGGL(group_var_sum_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, stream, G, K, D, x,
+		reinterpret_cast<const long long*>(idx), (double)G * (double)(D / inner), work);
+	hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_group_var_backward(int N, int G, int K, int D, int inner, const float* x, const int64_t* idx, const float* g_loss, float* dL_dx, void* stream_) {
+	if (G <= 0 || D <= 0) return 0;
+	if (!x || !idx || !g_loss || !dL_dx) { set_error("adgs_group_var_backward: NULL pointer"); return -1; }
+	if (K < 2 || K > GV_MAXK || inner <= 0 || D % inner != 0 || N <= 0) { set_error("adgs_group_var_backward: needs 2 <= K <= 32 neighbours and D a multiple of inner"); return -1; }
+	const long long total = (long long)G * D;
+	const float scale = (float)(2.0 / ((double)(K - 1) * (double)G * (double)(D / inner)));
+	hipLaunchKernelGGL(group_var_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, G, K, D, x,
+		reinterpret_cast<const long long*>(idx), scale, g_loss, dL_dx);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_sigma_loss_forward(int N, const float* log_sigma, float frame_gap, double* work, float* loss, void* stream_) {
+	if (N <= 0) return 0;
+	if (!log_sigma || !work || !loss) { set_error("adgs_sigma_loss_forward: NULL pointer"); return -1; }
+	hipStream_t stream = (hipStream_t)stream_;
+	hipLaunchKernelGGL(sigma_loss_sum_kernel, dim3(std::min((N + 255) / 256, 2048)), dim3(256), 0, stream, N, log_sigma, frame_gap, work);
+	hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+extern "C" int adgs_sigma_loss_backward(int N, const float* log_sigma, float frame_gap, const float* g_loss, float* dL_dlog_sigma, void* stream_) {
+	if (N <= 0) return 0;
+	if (!log_sigma || !g_loss || !dL_dlog_sigma) { set_error("adgs_sigma_loss_backward: NULL pointer"); return -1; }
+	hipLaunchKernelGGL(sigma_loss_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, N, log_sigma, frame_gap, g_loss, dL_dlog_sigma);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

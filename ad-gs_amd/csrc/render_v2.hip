@@ -112,6 +112,11 @@ __device__ __forceinline__ void eval_pixel(const EntryGeom& g, float py, float& 
 #ifndef ADGS_FWD_WAVES
 #define ADGS_FWD_WAVES 1
 #endif
+#ifdef ADGS_PROBE
+// experiment build (make variant TAG=probe DEFS=-DADGS_PROBE): [0..7] forward, [8..15] backward: shader cycles (s_memtime), 100 MHz ticks
+// (s_memrealtime), waves, contributing (pixel, entry) pairs, entries evaluated, entries with a contributing pixel, active strips
+__device__ unsigned long long g_probe[16];
+#endif
 #ifndef ADGS_BWD_WAVES
 #define ADGS_BWD_WAVES 1
 #endif
@@ -140,6 +145,13 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			tile = g * group + xcd * per_band + j;
 		}
 		tile = gridDim.x - 1u - tile;
+	}
+	if (*a.overflow_flag != 0u) {
+		// The frame does not fit the capacity this launch was enqueued against (api.hip: the totals are compared on the device): the
+		// lists are incomplete.  Blend nothing and leave an empty replay state; the host enqueues binning and blend again with exact
+		// sizes (or, under stream capture, reports the overflow through adgs_get_frame_status).
+		if (lane == 0) { a.tile_last_chunk[tile] = NO_CHUNK; a.tile_consumed[tile] = 0u; a.tile_scanned[tile] = 0u; a.tile_batches[tile] = 0u; }
+		return;
 	}
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	const uint32_t ty16 = ty / SUB;                           // row of the 16x16 tile grid the binning works on
@@ -173,6 +185,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	unsigned long long t_acc[4] = { 0ull, 0ull, 0ull, 0ull }, t_load = 0ull, n_rounds = 0ull, t_frec = 0ull, n_frec = 0ull;
 #endif
 	ADGS_T(t_wave0);
+#ifdef ADGS_PROBE
+	const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_r0 = wall_clock64();
+	unsigned pr_pairs = 0, pr_evals = 0, pr_live = 0, pr_strips = 0;
+#endif
 
 	while (true) {
 		bool mine_done = true;
@@ -310,6 +326,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
 #endif
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
+#ifdef ADGS_PROBE
+			pr_evals++;
+#endif
 			// "which pixels does the entry reach" as 64-bit lane masks on the scalar unit: the ballot of one comparison IS the
 			// comparison's result register, the two are combined by s_and and tested by s_cmp (a ballot of `a && b` would be
 			// rebuilt from a per-lane 0 / 1 value: two vector instructions per strip and entry)
@@ -323,6 +342,11 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				any_m |= actm[k];
 			}
 			if (any_m == 0ull) continue;
+#ifdef ADGS_PROBE
+			pr_live++;
+#pragma unroll
+			for (int k = 0; k < PPL; k++) { pr_pairs += (unsigned)__popcll(actm[k]); pr_strips += actm[k] != 0ull; }
+#endif
 			uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
 			asm volatile("" : "+v"(position));        // one copy into a vector register per entry (else: one v_mov per strip)
 			live |= 1ull << j;
@@ -363,6 +387,13 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		}
 	}
 	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = batches; }
+#ifdef ADGS_PROBE
+	if (lane == 0) {
+		atomicAdd(&g_probe[0], __builtin_readcyclecounter() - pr_c0); atomicAdd(&g_probe[1], wall_clock64() - pr_r0); atomicAdd(&g_probe[2], 1ull);
+		atomicAdd(&g_probe[3], (unsigned long long)pr_pairs); atomicAdd(&g_probe[4], (unsigned long long)pr_evals); atomicAdd(&g_probe[5], (unsigned long long)pr_live);
+		atomicAdd(&g_probe[6], (unsigned long long)pr_strips);
+	}
+#endif
 #ifdef ADGS_FWD_TIMING
 	{
 		ADGS_T(t_wave1);
@@ -483,6 +514,44 @@ __device__ __forceinline__ float wave_sum14_transposed(float x0, float x1, float
 	return z0;
 }
 
+// One 16x4 strip of one entry in the backward replay (backward.cu:545-644 for the lane's pixel of that strip).
+struct BwdSums { float op, mx, my, ca, cb, cc, c0, c1, c2, d, f0, f1, f2, s; };      // per-Gaussian partial sums of this lane
+struct BwdEntry { float r, g, b, dval, fx, fy, fz, sem, dx; };                       // the entry's payload (wave-uniform) and the lane's dx
+struct BwdPixel { float gC0, gC1, gC2, gD, gF0, gF1, gF2, gS, tfo, tfb; };           // the pixel's upstream gradients
+template <bool INIT>
+__device__ __forceinline__ void bwd_acc(float& s, float a, float b) { s = INIT ? a * b : fmaf(a, b, s); }
+template <bool INIT>
+__device__ __forceinline__ void bwd_strip(BwdSums& v, const BwdEntry& e, const BwdPixel& p, float al, float G, float dy, float& T, float& Bsum,
+	bool do_color, bool do_flow, bool do_sem, bool do_depth, bool do_opacity) {
+	const float rinv = __builtin_amdgcn_rcpf(1.f - al);
+	T = T * rinv;
+	const float dch = al * T;
+	// backward.cu:578-607 keeps, per channel, the blend A_ch of everything behind this entry
+	// (A' = A + alpha (c - A)) and forms dL/dalpha = sum_ch (c_ch - A_ch) g_ch.  Only the scalar
+	// B = sum_ch A_ch g_ch is ever used, and it obeys the same recurrence
+	//   B' = B + alpha (cg - B),  cg = sum_ch c_ch g_ch,
+	// so one accumulator per pixel replaces the eight per-channel ones.
+	float cg = 0.f;
+	if (do_color) {
+		cg += e.r * p.gC0; cg += e.g * p.gC1; cg += e.b * p.gC2;
+		bwd_acc<INIT>(v.c0, dch, p.gC0); bwd_acc<INIT>(v.c1, dch, p.gC1); bwd_acc<INIT>(v.c2, dch, p.gC2);
+	} else if (INIT) { v.c0 = v.c1 = v.c2 = 0.f; }
+	if (do_flow) {
+		cg += e.fx * p.gF0; cg += e.fy * p.gF1; cg += e.fz * p.gF2;
+		bwd_acc<INIT>(v.f0, dch, p.gF0); bwd_acc<INIT>(v.f1, dch, p.gF1); bwd_acc<INIT>(v.f2, dch, p.gF2);
+	} else if (INIT) { v.f0 = v.f1 = v.f2 = 0.f; }
+	if (do_sem) { cg += e.sem * p.gS; bwd_acc<INIT>(v.s, dch, p.gS); } else if (INIT) { v.s = 0.f; }
+	if (do_depth) { cg += e.dval * p.gD; bwd_acc<INIT>(v.d, dch, p.gD); } else if (INIT) { v.d = 0.f; }
+	float dL_dalpha = cg - Bsum;
+	Bsum += al * dL_dalpha;
+	if (do_opacity) dL_dalpha += p.tfo * rinv;  // before the *= T: reference quirk (backward.cu:612-614)
+	dL_dalpha = dL_dalpha * T - p.tfb * rinv;
+	const float L = G * dL_dalpha;
+	const float Lx = L * e.dx, Ly = L * dy;
+	bwd_acc<INIT>(v.op, G, dL_dalpha); bwd_acc<INIT>(v.mx, L, e.dx); bwd_acc<INIT>(v.my, L, dy);
+	bwd_acc<INIT>(v.ca, Lx, e.dx); bwd_acc<INIT>(v.cb, Lx, dy); bwd_acc<INIT>(v.cc, Ly, dy);
+}
+
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
 // the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
 template <int PPL, bool FULL>
@@ -543,6 +612,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
 	uint32_t chunk = a.tile_last_chunk[tile];
 	int base = (int)a.tile_consumed[tile];        // one past the last position of the current chunk
+#ifdef ADGS_PROBE
+	const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_r0 = wall_clock64();
+	unsigned pr_pairs = 0, pr_evals = 0, pr_live = 0, pr_strips = 0;
+#endif
 	while (chunk != NO_CHUNK) {
 		const uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
 		const uint32_t prev = c[0];
@@ -566,6 +639,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				const float4 q0 = s_splat[(j + 1) * 4 + 0], q1 = s_splat[(j + 1) * 4 + 1];
 				const float dx = q0.x - pxf;
 				const EntryGeom eg = entry_geom(q0, q1, dx);
+#ifdef ADGS_PROBE
+				pr_evals++;
+#endif
 				float alpha[PPL], G[PPL], dy[PPL]; uint64_t actm[PPL]; uint64_t any_m = 0ull;      // lane masks on the scalar unit, as in the forward
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
@@ -578,54 +654,49 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				if (any_m == 0ull) continue;
 				const float4 q2 = s_splat[(j + 1) * 4 + 2];
 				const float4 q3 = s_splat[(j + 1) * 4 + 3];
-				float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_s = 0.f, v_d = 0.f;
+#ifdef ADGS_PROBE
+				pr_live++;
+#pragma unroll
+				for (int k = 0; k < PPL; k++) { pr_pairs += (unsigned)__popcll(actm[k]); pr_strips += actm[k] != 0ull; }
+#endif
 				// geometric part: with L = G * dL/dalpha per pixel, the reference's six sums are linear in
 				//   S0 = sum L, Sx = sum L dx, Sy = sum L dy, Sxx = sum L dx^2, Sxy = sum L dx dy, Syy = sum L dy^2
 				// (dL/dmean2D = -op*(ca Sx + cb Sy)*W/2 ..., dL/dconic = -op/2 * S.., dL/dopacity = S0); the
 				// per-Gaussian factors are applied once per Gaussian in the preprocess backward.
-				float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
+				BwdSums v;
+				const BwdEntry be = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, dx };
+				// The first strip the entry reaches INITIALISES the 14 sums (every lane writes: a lane the entry does not reach computes
+				// with alpha = G = 0, i.e. adds exactly nothing and leaves its T and B as they are); the others accumulate under exec.
+				// (Only strip 0 can initialise: one straight-line path per possible first strip, or a flag carried through the unrolled
+				// loop, leaves hipcc with 10 - 30 register copies per entry at the joins -- more than the 14 zeroing moves it saves.)
+#define ADGS_BWD_PIXEL(k) const BwdPixel bp = { gC0[k], gC1[k], gC2[k], gD[k], gF0[k], gF1[k], gF2[k], gS[k], tfo[k], tfb[k] }
+#define ADGS_BWD_INITK(k) { ADGS_BWD_PIXEL(k); const bool act = __builtin_amdgcn_inverse_ballot_w64(actm[k]); \
+	bwd_strip<true>(v, be, bp, act ? alpha[k] : 0.f, act ? G[k] : 0.f, dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
+#define ADGS_BWD_ACCK(k) if (__builtin_amdgcn_inverse_ballot_w64(actm[k])) { ADGS_BWD_PIXEL(k); \
+	bwd_strip<false>(v, be, bp, alpha[k], G[k], dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
+				if (actm[0] != 0ull) { ADGS_BWD_INITK(0) }
+				else v.op = v.mx = v.my = v.ca = v.cb = v.cc = v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = 0.f;
 #pragma unroll
-				for (int k = 0; k < PPL; k++) {
-					if (__builtin_amdgcn_inverse_ballot_w64(actm[k])) {
-						const float al = alpha[k];
-						const float rinv = __builtin_amdgcn_rcpf(1.f - al);
-						T[k] = T[k] * rinv;
-						const float dch = al * T[k];
-						// backward.cu:578-607 keeps, per channel, the blend A_ch of everything behind this entry
-						// (A' = A + alpha (c - A)) and forms dL/dalpha = sum_ch (c_ch - A_ch) g_ch.  Only the scalar
-						// B = sum_ch A_ch g_ch is ever used, and it obeys the same recurrence
-						//   B' = B + alpha (cg - B),  cg = sum_ch c_ch g_ch,
-						// so one accumulator per pixel replaces the eight per-channel ones.
-						float cg = 0.f;
-						if (do_color) {
-							cg += q1.z * gC0[k]; cg += q1.w * gC1[k]; cg += q2.x * gC2[k];
-							v_c0 += dch * gC0[k]; v_c1 += dch * gC1[k]; v_c2 += dch * gC2[k];
-						}
-						if (do_flow) {
-							cg += q2.z * gF0[k]; cg += q2.w * gF1[k]; cg += q3.x * gF2[k];
-							v_f0 += dch * gF0[k]; v_f1 += dch * gF1[k]; v_f2 += dch * gF2[k];
-						}
-						if (do_sem) { cg += q3.y * gS[k]; v_s += dch * gS[k]; }
-						if (do_depth) { cg += q2.y * gD[k]; v_d += dch * gD[k]; }
-						float dL_dalpha = cg - Bsum[k];
-						Bsum[k] += al * dL_dalpha;
-						if (do_opacity) dL_dalpha += tfo[k] * rinv;  // before the *= T: reference quirk (backward.cu:612-614)
-						dL_dalpha = dL_dalpha * T[k] - tfb[k] * rinv;
-						const float L = G[k] * dL_dalpha;
-						const float Lx = L * dx, Ly = L * dy[k];
-						v_op += L; v_mx += Lx; v_my += Ly;
-						v_ca += Lx * dx; v_cb += Lx * dy[k]; v_cc += Ly * dy[k];
-					}
-				}
+				for (int k = 1; k < PPL; k++) { ADGS_BWD_ACCK(k) }
+#undef ADGS_BWD_PIXEL
+#undef ADGS_BWD_INITK
+#undef ADGS_BWD_ACCK
 				// 14 wave sums by a transposing reduction: every level halves the number of live registers
 				// (slot k of the 64-B gradient line ends up in the lanes with slot_of_lane == k) -> one
 				// atomic instruction on one 64-B line.  Absent channels stay exactly 0.
-				const float out = wave_sum14_transposed(v_op, v_mx, v_my, v_ca, v_cb, v_cc, v_c0, v_c1, v_c2, v_d, v_f0, v_f1, v_f2, v_s);
+				const float out = wave_sum14_transposed(v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
 				if (writer) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
 			}
 		}
 		chunk = prev;
 	}
+#ifdef ADGS_PROBE
+	if (lane == 0) {
+		atomicAdd(&g_probe[8], __builtin_readcyclecounter() - pr_c0); atomicAdd(&g_probe[9], wall_clock64() - pr_r0); atomicAdd(&g_probe[10], 1ull);
+		atomicAdd(&g_probe[11], (unsigned long long)pr_pairs); atomicAdd(&g_probe[12], (unsigned long long)pr_evals); atomicAdd(&g_probe[13], (unsigned long long)pr_live);
+		atomicAdd(&g_probe[14], (unsigned long long)pr_strips);
+	}
+#endif
 }
 
 // per-tile bookkeeping reset + pool cursor
@@ -710,6 +781,15 @@ int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 
 } // namespace adgs
 
+#ifdef ADGS_PROBE
+// experiment build only: read and reset the probe counters of the two blend kernels
+extern "C" int adgs_test_probe_read(unsigned long long* out16) {
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(adgs::g_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+	unsigned long long z[16] = { 0 };
+	if (hipMemcpyToSymbol(HIP_SYMBOL(adgs::g_probe), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+#endif
 #ifdef ADGS_FWD_TIMING
 // experiment build only: read and reset the phase counters of render_fwd_v2_kernel
 extern "C" int adgs_test_fwd_timing(unsigned long long* out16) {

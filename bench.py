@@ -36,11 +36,16 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, densify_every=10)}
 
 
-VALU_FMA_RATE = 0.36      # wave64 v_fma_f32 per SIMD and cycle, measured on MI355X (profiles/r02/valu_rates.txt)
+# VALU issue peak: a SIMD-32 retires one wave64 fp32 instruction per 2 cycles (MI355X_MICROARCH.md: 0.5 per SIMD and cycle), scaled by the
+# SUSTAINED shader clock under the blend kernels' load over the nominal 2.4 GHz -- measured with s_memtime against s_memrealtime inside
+# both kernels (tools/blend_probe.py, profiles/r03/blend_probe_c3.json: 2.35 - 2.36 GHz) and under pure VALU loops
+# (tools/microbench/valu_rates.hip, profiles/r03/valu_rates.txt: 2.24 - 2.43 GHz).  The clock does not sag: round 2's "0.36" was a
+# wall-time figure of a microbenchmark whose one-wave workgroups the dispatcher does not spread evenly over the SIMDs.
+VALU_PEAK_PER_SIMD_CYCLE = 0.5 * 2.35 / 2.4
 
 
 def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
@@ -125,13 +130,17 @@ class StaticFrame:
     deform_bytes = 0
     deform_desc = "none (static, already activated parameters)"
 
-    def __init__(self, sc, rasterizer, device, use_flow_sem):
+    def __init__(self, sc, rasterizer, device, use_flow_sem, share=None):
+        """share: another StaticFrame of the same scene (a camera pool renders ONE set of parameters)."""
         import torch
         self.rast = rasterizer
-        self.leaf = {k: sc[k].to(device).clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-        self.means2D = torch.zeros(sc["P"], 3, device=device, requires_grad=True)
-        self.flow = sc["flow_points"].to(device) if use_flow_sem else None
-        self.sem = sc["semantic"].to(device) if use_flow_sem else None
+        if share is not None:
+            self.leaf, self.means2D, self.flow, self.sem = share.leaf, share.means2D, share.flow, share.sem
+        else:
+            self.leaf = {k: sc[k].to(device).clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+            self.means2D = torch.zeros(sc["P"], 3, device=device, requires_grad=True)
+            self.flow = sc["flow_points"].to(device) if use_flow_sem else None
+            self.sem = sc["semantic"].to(device) if use_flow_sem else None
         self.last_radii = None
 
     def parameters(self):
@@ -227,17 +236,55 @@ def make_settings(cfg, cam, sc, device):
                                          d(cam["projmatrix"]), cfg["sh_degree"], d(cam["campos"]), False, True, False)
 
 
-def make_frame(sc, cfg, cam, device, use_fs, t=0.37, model=None):
+def make_frame(sc, cfg, cam, device, use_fs, t=0.37, model=None, share=None):
     from diff_gaussian_rasterization import GaussianRasterizer
     rast = GaussianRasterizer(make_settings(cfg, cam, sc, device))
     if cfg["n_objects"] > 0:
-        return DeformFrame(sc, rast, device, use_fs, t=t, model=model)
-    return StaticFrame(sc, rast, device, use_fs)
+        return DeformFrame(sc, rast, device, use_fs, t=t, model=model if model is not None else getattr(share, "model", None))
+    return StaticFrame(sc, rast, device, use_fs, share=share)
+
+
+def camera_pool(cfg, n, first=0, stride=1):
+    """The cameras / time stamps a training run cycles through (train.py:55-61 draws a random camera per iteration): pool entry 0
+    of rank 0 is the canonical SURVEY.md 8(d) camera (identity view, t = 0.37), the others are jittered in yaw / pitch / position
+    (adgs.synthetic.make_camera) at time stamps spread over [0.1, 0.9].  Returns [(camera, t)]; entry k has id first + k * stride."""
+    from adgs import synthetic
+    out = []
+    for k in range(n):
+        cid = first + k * stride
+        cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"], cam_seed=None if cid == 0 else cid)
+        out.append((cam, 0.37 if cid == 0 else 0.1 + 0.8 * ((cid * 7) % 16) / 15.0))
+    return out
+
+
+def frame_pool(sc, cfg, pool, device, use_fs):
+    frames = []
+    for cam, t in pool:
+        frames.append(make_frame(sc, cfg, cam, device, use_fs, t=t, share=frames[0] if frames else None))
+    return frames
+
+
+def graphed_steps(frames, ups):
+    """adgs.graph.GraphCache over a frame pool: key k replays forward + backward of frames[k] as one HIP graph and returns the
+    parameter gradients (static tensors of that graph)."""
+    import torch
+    from adgs import graph
+
+    def make_fn(k):
+        f = frames[k]
+
+        def fn():
+            torch.autograd.backward(f.forward(), ups)
+            grads = [p.grad for p in f.parameters()]
+            f.zero_grad()
+            return grads
+        return fn
+    return graph.GraphCache(make_fn, warmup=2)
 
 
 # ------------------------------------------------------------------ scene statistics
-def frame_work_figures(frame, settings, use_fs, device):
-    """(E, R, E_pub, scanned): E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published: an
+def frame_work_figures(frame, settings, use_fs, device, with_ref=True, full=False):
+    """(E, R, E_pub, scanned) -- with `full` also (V, Rc, fine_pairs) of that forward: E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published: an
     upper bound within #tiles x 63), R = the reference's num_rendered for the same frame (one extra forward in classic mode),
     E_pub = the entries at least one pixel blends (what the backward replays), scanned = candidates of the cell lists that the
     tiles' walks went through."""
@@ -260,47 +307,69 @@ def frame_work_figures(frame, settings, use_fs, device):
                                               s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, t["shs"], flow, sem, s.sh_degree,
                                               s.campos, s.prefiltered, s.inv_depth, False)
         out = call()
+        fstats = _lib.frame_stats()
         st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         chunks = int(_lib.lib().adgs_test_v2_blend_batches(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
         published = int(_lib.lib().adgs_test_v2_published_entries(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
         scanned = int(_lib.lib().adgs_test_v2_scanned_candidates(out[7].data_ptr(), int(s.image_width), int(s.image_height), st))
-        old = os.environ.get("ADGS_RASTER_MODE")
-        os.environ["ADGS_RASTER_MODE"] = "classic"
-        try:
-            r_ref = int(call()[0])
-        finally:
-            if old is None:
-                del os.environ["ADGS_RASTER_MODE"]
-            else:
-                os.environ["ADGS_RASTER_MODE"] = old
+        r_ref = 0
+        if with_ref:
+            old = os.environ.get("ADGS_RASTER_MODE")
+            os.environ["ADGS_RASTER_MODE"] = "classic"
+            try:
+                r_ref = int(call()[0])
+            finally:
+                if old is None:
+                    del os.environ["ADGS_RASTER_MODE"]
+                else:
+                    os.environ["ADGS_RASTER_MODE"] = old
+    if full:
+        return chunks * 64, r_ref, published, scanned, int((out[4] > 0).sum().item()), fstats["num_rendered"], fstats["fine_pairs"]
     return chunks * 64, r_ref, published, scanned
+
+
+def library_stamp():
+    """First 16 hex digits of the SHA-256 of the loaded libadgs_hip.so: the committed counter files carry the stamp of the build
+    they were collected on (tools/pmc_traffic.py, tools/pmc_blend.py), and are flagged stale when it differs."""
+    import hashlib
+    from adgs import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def committed_pmc(stage, config, measured_case):
     """HBM traffic / VALU issue rate of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's build
-    (profiles/r02/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
-    the case they were measured on (C3, flow+semantic, default pipeline); absent files leave `traffic` null."""
+    (profiles/r03/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
+    the case they were measured on (C3, flow+semantic, default pipeline); absent files leave `traffic` null; counters collected on
+    another build of the library are flagged (`counters_stale`)."""
     if config != "C3" or not measured_case:
         return {}
     kname = {"render_bwd": "render_bwd_v2_kernel", "render_fwd": "render_fwd_v2_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
              "preprocess_fwd": "preprocess_fwd_kernel"}.get(stage)
     out = {}
+    stamp = library_stamp()
     try:
         tr = json.load(open(os.path.join(PROFILE_DIR, "hbm_traffic_per_kernel.json")))
         for k, v in tr.items():
             if kname and kname in k:
                 out["traffic"] = v["hbm_bytes_per_launch"]
-                out["traffic_source"] = "profiles/r02/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, per launch)"
+                out["traffic_source"] = ("profiles/r03/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                         "FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, per launch)")
                 break
-        pm = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))["kernels"].get(kname)
+        pmf = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))
+        pm = pmf["kernels"].get(kname)
         if pm:
             out["valu_insts_per_simd_cycle"] = pm.get("valu_insts_per_simd_cycle")
-            out["valu_issue_frac_of_peak"] = None if pm.get("valu_insts_per_simd_cycle") is None else round(pm["valu_insts_per_simd_cycle"] / VALU_FMA_RATE, 3)
-            out["valu_note"] = ("the blend kernels are fp32-VALU-issue bound, not HBM bound (SURVEY.md 8(d)): wave64 VALU instructions per SIMD and "
-                                "cycle (profiles/r02/pmc_blend_kernels.json) against the MEASURED v_fma_f32 rate of gfx950, %.2f at 2+ waves per "
-                                "SIMD (tools/microbench/valu_rates.hip, profiles/r02/valu_rates.txt; v_mul 0.40, v_min / DPP 0.24, compare + "
-                                "select 0.30, v_exp 0.12)" % VALU_FMA_RATE)
-    except (OSError, ValueError, KeyError):
+            out["valu_issue_frac_of_peak"] = None if pm.get("valu_insts_per_simd_cycle") is None else round(pm["valu_insts_per_simd_cycle"] / VALU_PEAK_PER_SIMD_CYCLE, 3)
+            out["valu_note"] = ("the blend kernels are bound by fp32 VALU issue and per-wave latency, not by HBM (SURVEY.md 8(d)): wave64 VALU instructions "
+                                "per SIMD and cycle (rocprofv3 --pmc, profiles/r03/pmc_blend_kernels.json) against the datasheet issue rate 0.5 x the "
+                                "sustained shader clock measured inside the kernels over the nominal 2.4 GHz = %.3f (tools/blend_probe.py)" % VALU_PEAK_PER_SIMD_CYCLE)
+        built = tr.get("_library_sha256_16") if isinstance(tr, dict) else None
+        if out and (built is None or built != stamp):
+            out["counters_stale"] = "the committed counter files were collected on library build %s, this run loaded %s" % (built, stamp)
+    except (OSError, ValueError, KeyError, AttributeError):
         pass
     return out
 
@@ -310,8 +379,11 @@ def committed_frame_traffic(config, measured_case, fps_per_gpu):
         return {}
     try:
         tot = json.load(open(os.path.join(PROFILE_DIR, "hbm_traffic_per_frame.json")))
-        return {"measured_hbm_bytes_per_frame": int(tot["hbm_bytes_per_frame"]),
-                "measured_hbm_frac_of_8TBs": round(tot["hbm_bytes_per_frame"] * fps_per_gpu / 1e9 / HBM_PEAK_GBS, 4)}
+        out = {"measured_hbm_bytes_per_frame": int(tot["hbm_bytes_per_frame"]),
+               "measured_hbm_frac_of_8TBs": round(tot["hbm_bytes_per_frame"] * fps_per_gpu / 1e9 / HBM_PEAK_GBS, 4)}
+        if tot.get("_library_sha256_16") != library_stamp():
+            out["measured_hbm_stale"] = True
+        return out
     except (OSError, ValueError, KeyError):
         return {}
 
@@ -398,35 +470,52 @@ def step_stats(ms):
             "min": round(min(ms), 4), "max": round(max(ms), 4)} if ms else {}
 
 
-def quick_measure(config, steps, device, use_fs, variant="default", mode=None, with_stats=False, warm=15):
-    """frames/s of another workload in the same process (single GPU): secondary information next to the headline, never `value`."""
+def quick_measure(config, steps, device, use_fs, variant="default", mode=None, with_stats=False, warm=15, cameras=1, graph=False, env=None):
+    """frames/s of another workload in the same process (single GPU): secondary information next to the headline, never `value`.
+    cameras: size of the camera pool cycled per step; graph: forward + backward replayed as one HIP graph per camera
+    (adgs.graph); env: environment overrides for the duration of the measurement (e.g. the reference's call path:
+    ADGS_BENCH_RAW_SH=0, ADGS_BENCH_RAW_SCENE=0)."""
     import torch
     from adgs import synthetic, _lib
     cfg = synthetic.CONFIGS[config]
     sc = build_scene(config, variant)
-    cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
-    old = os.environ.get("ADGS_RASTER_MODE")
-    old_raw = os.environ.get("ADGS_BENCH_RAW_SH")
+    env = dict(env or {})
     if mode:
-        os.environ["ADGS_RASTER_MODE"] = mode
+        env["ADGS_RASTER_MODE"] = mode
         if mode == "classic":
-            os.environ["ADGS_BENCH_RAW_SH"] = "0"          # the raw-SH / raw-scene entries exist in the default pipeline only
+            env["ADGS_BENCH_RAW_SH"] = "0"          # the raw-SH / raw-scene entries exist in the default pipeline only
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
-        frame = make_frame(sc, cfg, cam, device, use_fs)
+        pool = camera_pool(cfg, cameras)
+        frames = frame_pool(sc, cfg, pool, device, use_fs)
+        frame, cam = frames[0], pool[0][0]
         up = synthetic.make_upstream_grads(sc, 0)
         d = lambda t: t.to(device)
         ups = [d(up["color"]), d(up["depth"]), d(up["img_opacity"])] + ([d(up["flow"]), d(up["semantic"])] if use_fs else [])
+        reruns0 = _lib.frame_status()["eager_reruns"]
+        if graph:
+            cache = graphed_steps(frames, ups)
 
-        def step(i=0):
-            torch.autograd.backward(frame.forward(), ups)
-            frame.zero_grad()
-        for _ in range(warm):
-            step()
+            def step(i=0):
+                cache(i % len(frames))
+        else:
+            def step(i=0):
+                f = frames[i % len(frames)]
+                torch.autograd.backward(f.forward(), ups)
+                f.zero_grad()
+        for i in range(max(warm, 2 * len(frames))):
+            step(i)
         elapsed, ms = timed_loop(step, steps, torch.cuda.synchronize)
         res = {"workload": "%s%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects" % (config, "" if variant == "default" else "/" + variant, cfg["P"], cfg["W"],
                                                                                          cfg["H"], cfg["sh_degree"], cfg["n_objects"]),
                "pipeline": mode or "v2", "frames_per_s": round(steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+               "cameras": len(frames), "launch": "HIP graph replay (one graph per camera)" if graph else "eager",
                "step_ms": step_stats(ms)}
+        if graph:
+            res["graph_replays_fitted_their_capacity"] = bool(cache.validate(repair=False))
+        else:
+            res["capacity_reruns"] = _lib.frame_status()["eager_reruns"] - reruns0
         if with_stats and not mode:
             frame.forward()
             st = _lib.frame_stats()
@@ -437,15 +526,11 @@ def quick_measure(config, steps, device, use_fs, variant="default", mode=None, w
                         "entries_per_tile": round(E / max(T, 1), 1)})
         return res, frame, sc, cam, cfg, up
     finally:
-        if mode:
-            if old is None:
-                os.environ.pop("ADGS_RASTER_MODE", None)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
             else:
-                os.environ["ADGS_RASTER_MODE"] = old
-            if old_raw is None:
-                os.environ.pop("ADGS_BENCH_RAW_SH", None)
-            else:
-                os.environ["ADGS_BENCH_RAW_SH"] = old_raw
+                os.environ[k] = v
 
 
 def self_launch(n):
@@ -468,6 +553,11 @@ def main():
     ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C4, C5")
     ap.add_argument("--cams-per-iter", type=int, default=0, help="iteration mode: cameras per iteration, dealt round-robin to the ranks (default: C4 3, C5 5)")
     ap.add_argument("--densify-every", type=int, default=-1, help="iteration mode: densify/prune every k iterations inside the timed loop (default: C5 10, else off)")
+    ap.add_argument("--cameras", type=int, default=int(os.environ.get("ADGS_BENCH_CAMERAS", "16")),
+                    help="cameras / time stamps in the pool every GPU cycles through, one per step (train.py:55-61 draws a random camera per iteration); "
+                         "1 = the same camera and time stamp every step (rounds 1-2).  Not used by the iteration configs C4 / C5")
+    ap.add_argument("--graph", choices=["on", "off"], default=os.environ.get("ADGS_BENCH_GRAPH", "off"),
+                    help="on: every camera's forward + backward is replayed as one HIP graph (adgs.graph; single GPU, not the iteration configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flow-sem", action="store_true", help="render without the flow / semantic outputs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements (other configs, scene sensitivity)")
@@ -526,15 +616,25 @@ def main():
         cam_times = [0.37 if n_cams == 1 else 0.1 + 0.8 * c / (n_cams - 1) for c in cam_ids]
     else:
         n_cams, densify_every = world, 0
-        cam_ids = [None] if world == 1 else list(range(world))
-        cam_times = [0.37] * world
-    cams = [synthetic.make_camera(W, H, cfg["focal"], cam_seed=c) for c in cam_ids]
-    my = [i for i in range(len(cams)) if i % world == rank]
+    pool_k = 1 if iteration_mode else max(1, args.cameras)
     frames, model = [], None
-    for i in my:
-        f = make_frame(sc, cfg, cams[i], device, use_fs, t=cam_times[i], model=model)
-        model = getattr(f, "model", None)
-        frames.append(f)
+    if iteration_mode:
+        cams = [synthetic.make_camera(W, H, cfg["focal"], cam_seed=c) for c in cam_ids]
+        my = [i for i in range(len(cams)) if i % world == rank]
+        for i in my:
+            f = make_frame(sc, cfg, cams[i], device, use_fs, t=cam_times[i], model=model)
+            model = getattr(f, "model", None)
+            frames.append(f)
+        my_pool = None
+        canonical_cam = cams[my[0]] if my else None
+    else:
+        # every rank cycles through its own pool of cameras / time stamps, one per step: rank r's entry k is camera r + world * k
+        # (rank 0's entry 0 is the canonical SURVEY.md 8(d) camera at t = 0.37); a step renders entry `it % pool_k` on every rank
+        pools = [camera_pool(cfg, pool_k, first=r, stride=world) for r in range(world)]
+        my_pool = frame_pool(sc, cfg, pools[rank], device, use_fs)
+        frames = [my_pool[0]]                         # what the statistics after the timed region look at
+        model = getattr(my_pool[0], "model", None)
+        canonical_cam = pools[rank][0][0]
     if not frames:                                    # a rank without a camera in this deal (C4 on 4 GPUs) still owns a replica
         from adgs.model import SyntheticGaussianModel
         model = SyntheticGaussianModel.from_scene(sc, device, seed=0)
@@ -558,8 +658,11 @@ def main():
         ex = dp.FactoredSHExchange(model, factor_xyz=(fused or not use_fs) and os.environ.get("ADGS_DP_FACTOR_XYZ", "1") != "0")
         ex.force_collectives = force_coll
         ex.timing = []
-        flow_times = [t + 0.05 if use_fs else None for t in cam_times]
-        cam_positions = [c["campos"].tolist() for c in cams]
+        if iteration_mode:
+            ex_args = [(cam_times, [c["campos"].tolist() for c in cams], [t + 0.05 if use_fs else None for t in cam_times])]
+        else:             # step k: the cameras all ranks render in that step
+            ex_args = [([pools[r][k][1] for r in range(world)], [pools[r][k][0]["campos"].tolist() for r in range(world)],
+                        [pools[r][k][1] + 0.05 if use_fs else None for r in range(world)]) for k in range(pool_k)]
         exchange = "factored SH%s gradients: all-gather of the factors + %s of the dense remainder + local expansion" % (
             " and xyz-deformation" if ex.factor_xyz() else "", "reduce-scatter + all-gather" if os.environ.get("ADGS_DP_COLLECTIVE") == "rs_ag" else "all-reduce")
     elif world > 1:
@@ -576,17 +679,26 @@ def main():
             ex._arena_setup()
     densify_thr = [None]
 
-    def step(it=0):
+    use_graph = args.graph == "on"
+    if use_graph and (world > 1 or force_coll or iteration_mode or factored):
+        raise SystemExit("--graph on: single GPU, one camera per step (the exchange of the multi-GPU step is issued eagerly)")
+    cache = graphed_steps(my_pool, up_list) if use_graph else None
+
+    def step(it=0, eager=False):
+        if cache is not None and not eager:
+            cache(it % pool_k)
+            return
         if factored:
             ex.begin(n_cams)                     # the all-gather starts from inside the backward, as soon as the last factor exists
-        for f in frames:
+        for f in (frames if iteration_mode else [my_pool[it % pool_k]]):
             outs = f.forward(sink_for=ex.sink_for if factored else None)
             torch.autograd.backward(outs, up_list)
             if densify_every:
                 with torch.no_grad():
                     model.add_densification_stats(dict(viewspace_points=f.last_means2D, radii=f.last_radii))
         if factored:
-            ex.reduce(cam_times, cam_positions, flow_times=flow_times)
+            ct, cp, ft = ex_args[0 if iteration_mode else it % pool_k]
+            ex.reduce(ct, cp, flow_times=ft)
         elif world > 1 or force_coll:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -626,14 +738,17 @@ def main():
     # (at most 8 windows), then the contract's W warm-up steps and K timed steps follow unchanged.
     it_counter = [0]
 
-    def run(n):
+    def run(n, eager=False):
         for _ in range(n):
-            step(it_counter[0]); it_counter[0] += 1
+            step(it_counter[0], eager); it_counter[0] += 1
+    settle_steps = 0
     if os.environ.get("ADGS_BENCH_SETTLE", "1") != "0":
         prev_w, agree = None, 0
+        win = max(20, pool_k)                      # a window sees every camera of the pool
         for _ in range(8):
             t_w = time.perf_counter()
-            run(20)
+            run(win)
+            settle_steps += win
             sync()
             w = time.perf_counter() - t_w
             if world > 1:             # every rank must run the SAME number of windows: decide on the maximum over the ranks
@@ -662,7 +777,7 @@ def main():
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_prof + 1)]
         evs[0].record()
         for i in range(n_prof):
-            run(1)
+            run(1, eager=True)                         # stage events cannot be recorded inside a graph replay
             evs[i + 1].record()
         sync()
         wprof.enable(False)
@@ -681,9 +796,12 @@ def main():
     if ex is not None:
         ex.timing = []
     del ex_events[:]; del densify_events[:]
+    reruns0 = _lib.frame_status()["eager_reruns"]
     elapsed, step_ms = timed_loop(lambda i: run(1), args.steps, sync, barrier)
     prof.enable(False)
     stages = prof.collect()
+    capacity_reruns = _lib.frame_status()["eager_reruns"] - reruns0
+    graph_ok = cache.validate(repair=False) if cache is not None else None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -703,11 +821,16 @@ def main():
             ("%d cameras/iteration dealt round-robin over %d GPU(s)%s" % (n_cams, world, ", densify/prune every %d iterations" % densify_every if densify_every else ""))
             if iteration_mode else "1 camera/GPU/step"),
             "P": P, "cameras_per_step": cams_per_step,
+            "camera_pool": ("%d cameras / time stamps per GPU, cycled one per step (train.py:55-61)" % pool_k) if not iteration_mode else "the iteration's cameras, every step",
+            "settle_steps": settle_steps, "capacity_reruns": capacity_reruns,
+            "launch": ("HIP graph replay, one graph per camera (adgs.graph); every replay fitted its capacity: %s" % graph_ok) if use_graph else "eager",
             "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
             "step_ms_hip_events": dict(step_stats(step_ms), first=round(step_ms[0], 4))}
         if os.environ.get("ADGS_BENCH_DUMP_STEPS"):
             config["step_ms_series"] = [round(x, 4) for x in step_ms[:int(os.environ["ADGS_BENCH_DUMP_STEPS"])]]
         if gpu_idle:
+            # the same figure against the UNPROFILED steps of the timed region (no event brackets, hence no bubbles of their own)
+            gpu_idle["timed_step_median_minus_sum_of_stage_ms"] = round(percentile(step_ms, 0.5) - gpu_idle["sum_of_stage_ms"], 4)
             config["gpu_idle"] = gpu_idle
         # ---- exchange / densify times (HIP events on rank 0's launch stream)
         if ex is not None and ex.timing:
@@ -732,18 +855,33 @@ def main():
             M = sc["shs"].shape[1]
             F, D_S = (1, 1) if use_fs else (0, 0)
             v2 = _lib.lib().adgs_raster_needs_zero_init(D_S) == 0
-            settings = make_settings(cfg, cams[my[0]], sc, device)
+            settings = make_settings(cfg, canonical_cam, sc, device)
             if v2:
-                # scene-level work figures: the reference's pair count R and what v2 actually blends
+                # scene-level work figures: the reference's pair count R and what v2 actually blends -- for the
+                # canonical camera, and (what the per-launch byte figures of the roofline use) the mean over the camera pool the
+                # timed steps cycled through
+                pool_fig = None
                 if os.environ.get("ADGS_BENCH_SKIP_STATS"):           # PMC passes: keep foreign launches out of the counter totals
                     E, R_ref, E_pub, scanned = 0, 0, 0, 0
                 else:
                     try:
                         E, R_ref, E_pub, scanned = frame_work_figures(frame, settings, use_fs, device)
+                        if my_pool is not None and len(my_pool) > 1:
+                            figs = [frame_work_figures(f, make_settings(cfg, c, sc, device), use_fs, device, with_ref=False, full=True)
+                                    for f, (c, _t) in zip(my_pool, pools[rank])]
+                            mean = lambda j: sum(x[j] for x in figs) / len(figs)
+                            pool_fig = {"cameras": len(figs), "blended_entries": round(mean(0)), "published_entries": round(mean(2)), "P_visible": round(mean(4)),
+                                        "cell_pairs_sorted": round(mean(5)), "published_entries_min_max": [min(x[2] for x in figs), max(x[2] for x in figs)],
+                                        "cell_pairs_sorted_min_max": [min(x[5] for x in figs), max(x[5] for x in figs)]}
                     except Exception as exc:                 # statistics only
                         print("bench: scene statistics failed: %r" % (exc,), file=sys.stderr)
                         E, R_ref, E_pub, scanned = 0, 0, 0, 0
-                ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub, bucket=bool(stats.get("bucket_binning")))
+                if pool_fig:
+                    ab = alg_bytes_v2(Pn, pool_fig["P_visible"], pool_fig["cell_pairs_sorted"], pool_fig["blended_entries"], X, T, M, F, D_S, stats["sort_passes"],
+                                      pool_fig["published_entries"], bucket=bool(stats.get("bucket_binning")))
+                    config["camera_pool_work"] = pool_fig
+                else:
+                    ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub, bucket=bool(stats.get("bucket_binning")))
                 config.update({"pipeline": "v2 (coarse cells, %s, lazy per-tile filtering)" % ("bucket binning: per-cell depth buckets sorted inside one CU each"
                                                                                                 if stats.get("bucket_binning") else "device-wide radix sort of (cell | depth) keys"), "P_visible": V, "tiles": T, "reference_pairs_R": R_ref,
                                "R_over_P": round(R_ref / max(Pn, 1), 2), "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E,
@@ -764,10 +902,15 @@ def main():
                 stages_all = stages
                 dom = max(stages, key=lambda k: stages[k][0] * max(stages[k][1], 1))
             dom_ms = stages[dom][0]                   # HIP events on the launch stream, over the timed region
+            roof_timing = "HIP events around the kernel in every step of the timed region"
+            if use_graph:                             # no event can be recorded inside a graph replay
+                dom_ms = stages_all[dom][0]
+                roof_timing = "HIP events around the kernel in the eager warm-up steps (the timed region replays HIP graphs)"
             achieved = ab.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(stages[dom][1])}
+                    "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4),
+                    "launches_timed": int((stages_all if use_graph else stages)[dom][1]), "timing": roof_timing}
             roof.update(committed_pmc(dom, args.config, use_fs and v2))
             if v2 and dom in ("render_fwd", "render_bwd"):
                 roof["pixel_entry_evals_per_s"] = round((config["published_entries"] if dom == "render_bwd" else config["blended_entries"]) * 256 / (dom_ms * 1e-3), 1)
@@ -788,15 +931,36 @@ def main():
             # saturate early, default pipeline against the reference-order ("classic") pipeline
             try:
                 others = []
-                r1, f1, sc1, cam1, cfg1, up1 = quick_measure("C1", 300, device, use_fs)
+                K = max(1, args.cameras)
+                r1, f1, sc1, cam1, cfg1, up1 = quick_measure("C1", 300, device, use_fs, cameras=K)
                 if not args.no_cpu_baseline:
                     upn = {k: v.numpy() for k, v in up1.items()}
                     r1["cpu_baseline_openmp"], _ = cpu_baseline(sc1, cam1, cfg1, use_fs, upn)
                     r1["cpu_baseline_single_thread"], _ = cpu_baseline(sc1, cam1, cfg1, use_fs, upn, threads=1)
                 others.append(r1)
-                others.append(quick_measure("C2", 300, device, use_fs)[0])
                 del f1
+                others.append(quick_measure("C2", 300, device, use_fs, cameras=K)[0])
+                # the same two workloads with every camera's frame replayed as one HIP graph: what a launch-bound frame gains when the
+                # forward needs no host decision in its middle (adgs.graph; rasterizer_impl.cu:288 makes this impossible for the reference)
+                for c in ("C1", "C2"):
+                    try:
+                        others.append(quick_measure(c, 300, device, use_fs, cameras=K, graph=True)[0])
+                    except Exception as exc:
+                        others.append({"workload": c, "launch": "HIP graph replay", "failed": repr(exc)})
+                    gc.collect(); torch.cuda.empty_cache()
                 result["other_configs"] = others
+                # C3 as a maintainer gets it who swaps ONLY the rasterizer submodule: gaussian_renderer/__init__.py:76-86 unchanged, i.e.
+                # GaussianRasterizer.forward with the materialised [N,16,3] SH tensor and torch-side cat / exp / sigmoid / normalize
+                # (scene/gaussian_model.py:89-152) -- no raw-SH / raw-scene entry points
+                try:
+                    result["reference_api_path"] = quick_measure("C3", 100, device, use_fs, cameras=K, env={"ADGS_BENCH_RAW_SH": "0", "ADGS_BENCH_RAW_SCENE": "0"})[0]
+                    result["reference_api_path"]["note"] = ("the reference's unchanged call path (materialised SH, activations in the deformation pass): what swapping "
+                                                            "only the rasterizer submodule gives; `value` uses this repository's render() path (raw-SH + raw-scene entries)")
+                    gc.collect(); torch.cuda.empty_cache()
+                    result["c3_graph_replay"] = quick_measure("C3", 100, device, use_fs, cameras=K, graph=True)[0]
+                    gc.collect(); torch.cuda.empty_cache()
+                except Exception as exc:
+                    result["reference_api_path"] = "failed: %r" % (exc,)
                 sens = []
                 for variant in ("translucent", "sky"):
                     a = quick_measure("C3", 40, device, use_fs, variant=variant, with_stats=True)[0]
@@ -815,7 +979,7 @@ def main():
             else:
                 sc_cpu = sc
             try:
-                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, cams[my[0]], cfg, use_fs, up)
+                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, canonical_cam, cfg, use_fs, up)
                 result["parity"] = parity_vs_oracle(outs, oracle_fwd)
             except Exception as exc:                     # e.g. the oracle library could not be built on this host
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (exc,)}

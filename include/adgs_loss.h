@@ -72,6 +72,22 @@ int adgs_bce_clip_forward(int n, const float* pred, const float* target, float l
 int adgs_bce_clip_backward(int n, const float* pred, const float* target, float lo, float hi, int invert, int positive_target,
 	const float* g_loss, float* dL_dpred, void* stream);
 
+/*
+ * Neighbourhood regularisers of the training loop (train.py:104-113), over GaussianModel.obj_near_idx [G, K] (int64 rows of
+ * the object range, scene/gaussian_model.py:825-833):
+ *   reg_loss       = mean(sum(var(xyz_deform_param[obj_near_idx], dim=1), dim=-1))   x = xyz_deform_param [N,3,C]: D = 3 C, inner = C
+ *   reg_sigma_loss = mean(sum(var(gs_time_sigma[obj_near_idx], dim=1), dim=-1))      x = gs_time_sigma [N,2]:      D = 2,   inner = 2
+ * i.e. loss = sum_g sum_d var_k(x[idx[g,k], d]) / (G D / inner) with torch.var's unbiased estimator (2 <= K <= 32).
+ * work: ADGS_AUX_WORK_DOUBLES device doubles, zero-initialised by the caller; loss: one device float.
+ * The backward ADDS into dL_dx [N, D] (zero-initialised by the caller: a Gaussian can sit in several neighbourhoods).
+ */
+int adgs_group_var_forward(int N, int G, int K, int D, int inner, const float* x, const int64_t* idx, double* work, float* loss, void* stream);
+int adgs_group_var_backward(int N, int G, int K, int D, int inner, const float* x, const int64_t* idx, const float* g_loss, float* dL_dx, void* stream);
+/* sigma_loss = mean(|frame_gap / mean(exp(gs_time_sigma), dim=-1)|) over gs_time_sigma [N,2] (train.py:108-110); every row of
+ * dL_dlog_sigma is written. */
+int adgs_sigma_loss_forward(int N, const float* log_sigma, float frame_gap, double* work, float* loss, void* stream);
+int adgs_sigma_loss_backward(int N, const float* log_sigma, float frame_gap, const float* g_loss, float* dL_dlog_sigma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,6 +207,28 @@ typedef struct adgs_frame_stats {
 } adgs_frame_stats;
 void adgs_get_frame_stats(adgs_frame_stats* out);
 
+/* Capacity status of the calling thread's most recent default-pipeline forward on the current device.
+ * The reference sizes its binning buffer after a blocking device->host copy of the pair count in the middle of the forward
+ * (RAST/cuda_rasterizer/rasterizer_impl.cu:288).  This library enqueues the whole forward against a capacity (previous
+ * frames' counts + 25 %), compares the exact totals on the device, and only afterwards reads the totals the device published
+ * to a host mailbox: a frame that did not fit blended nothing and is enqueued again with exact sizes before
+ * adgs_raster_forward returns (`eager_reruns` counts these).  Under stream capture (HIP graphs) nothing can be read back
+ * or re-enqueued: after a replay and a stream synchronisation the caller must check `overflow` (this frame) or
+ * `overflow_count` (frames since the mailbox exists); on overflow the captured frame's outputs are invalid, and an eager
+ * frame (which raises the capacity hints) followed by a new capture repairs it.  Single context per process: the hints and
+ * statistics are process-wide, the mailbox is per (host thread, device). */
+typedef struct adgs_frame_status {
+	int64_t pairs;                 /* (cell, Gaussian) pairs of the frame */
+	int64_t fine_pairs;            /* bound of the blended (tile, Gaussian) entries */
+	int64_t capacity_pairs;        /* what the frame's launches were enqueued against */
+	int64_t capacity_fine_pairs;
+	int64_t overflow_count;        /* frames that did not fit, since the mailbox exists */
+	int64_t eager_reruns;          /* eager forwards that were enqueued twice, process-wide */
+	int32_t overflow;              /* 1: this frame did not fit its capacity */
+	int32_t reserved;
+} adgs_frame_status;
+int adgs_get_frame_status(adgs_frame_status* out);
+
 /* Optional per-stage timing with HIP events recorded on the launch stream (used by bench.py
  * for the roofline figure).  Process-wide.  adgs_profile_collect() must be called after the
  * stream has been synchronised; it ADDS into total_ms[] / counts[] (adgs_profile_num_stages()

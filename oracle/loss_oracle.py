@@ -118,3 +118,30 @@ def bce_clip_loss(pred, target, lo=1e-3, hi=1.0 - 1e-3, invert=False, dtype=np.f
     loss = -(t * lq + (1.0 - t) * l1q).mean()
     dq = -(t / q - (1.0 - t) / (1.0 - q)) / x.size
     return loss, (-dq if invert else dq) * inside
+
+
+def group_var_loss(x, idx, dtype=np.float64):
+    """train.py:104-106 / 111-113: mean(sum(var(x[idx], dim=1), dim=-1)) with torch.var's unbiased estimator; x [N, ..., C],
+    idx [G, K].  Returns (loss, d loss / d x)."""
+    x = np.asarray(x, dtype)
+    idx = np.asarray(idx, np.int64)
+    G, K = idx.shape
+    v = x[idx]                                         # [G, K, ..., C]
+    mean = v.mean(axis=1, keepdims=True)
+    var = ((v - mean) ** 2).sum(axis=1) / (K - 1)      # [G, ..., C]
+    per = var.sum(axis=-1)                             # [G, ...]
+    loss = per.mean()
+    g = np.zeros_like(x)
+    np.add.at(g, idx, 2.0 * (v - mean) / ((K - 1) * per.size))
+    return float(loss), g
+
+
+def sigma_loss(log_sigma, frame_gap, dtype=np.float64):
+    """train.py:108-110: mean(|frame_gap / mean(exp(log_sigma), dim=-1)|); log_sigma [N, 2].  Returns (loss, d loss / d log_sigma)."""
+    s = np.asarray(log_sigma, dtype)
+    e = np.exp(s)
+    m = e.mean(axis=-1)
+    q = frame_gap / m
+    loss = np.abs(q).mean()
+    g = (-np.sign(q) * q / m / s.shape[0])[:, None] * (e / s.shape[1])
+    return float(loss), g

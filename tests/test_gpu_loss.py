@@ -177,3 +177,57 @@ def test_random_image_shapes_vs_oracle(seed):
     # |s p + t - g| has a kink: a residual within rounding of zero takes the other sign in fp32 (seen once in 300 seeds)
     bad = np.abs(p.grad.cpu().numpy() - o_grad) > 2e-3 * max(np.abs(o_grad).max(), 1e-9)
     assert bad.sum() <= max(2, 1e-4 * bad.size), (H, W, int(bad.sum()))
+
+
+GOLD3 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss3_golden.npz"))
+REG_CASES = sorted({k.split("/")[0] for k in GOLD3.files})
+
+
+@pytest.mark.parametrize("case", REG_CASES)
+def test_regularisers_match_the_train_py_expressions(case):
+    """reg_loss, sigma_loss, reg_sigma_loss (train.py:104-113): values and gradients against the golden vectors generated from
+    the reference's expressions (tests/golden/make_loss_golden.py)."""
+    from adgs import loss
+    x = torch.tensor(GOLD3[case + "/xyz_deform_param"]).cuda().requires_grad_(True)
+    s = torch.tensor(GOLD3[case + "/gs_time_sigma"]).cuda().requires_grad_(True)
+    idx = torch.tensor(GOLD3[case + "/obj_near_idx"]).cuda()
+    gap = float(GOLD3[case + "/frame_gap"])
+    for fn, args, wrt, key, gkey in ((loss.reg_loss, (x, idx), x, "reg_loss", "g_reg"), (loss.reg_sigma_loss, (s, idx), s, "reg_sigma_loss", "g_reg_sigma"),
+                                     (loss.sigma_loss, (s, gap), s, "sigma_loss", "g_sigma")):
+        val = fn(*args)
+        ref = float(GOLD3[case + "/" + key])
+        assert abs(float(val) - ref) <= 3e-6 * max(1.0, abs(ref)), (key, float(val), ref)
+        (g,) = torch.autograd.grad(2.5 * val, wrt)
+        ref_g = GOLD3[case + "/" + gkey]
+        np.testing.assert_allclose(g.cpu().numpy() / 2.5, ref_g, rtol=3e-5, atol=3e-6 * np.abs(ref_g).max())
+
+
+def test_regularisers_at_training_size_vs_oracle():
+    """C3's object range: 200 k Gaussians, K = 8 neighbours, 18 position-deformation parameters per axis."""
+    from adgs import loss
+    rng = np.random.default_rng(9)
+    No, K, C = 200_000, 8, 18
+    x_np = (0.05 * rng.standard_normal((No, 3, C))).astype(np.float32)
+    s_np = (np.log(0.02) + 0.3 * rng.standard_normal((No, 2))).astype(np.float32)
+    idx_np = rng.integers(0, No, size=(No // K, K), dtype=np.int64)
+    x = torch.tensor(x_np).cuda().requires_grad_(True); s = torch.tensor(s_np).cuda().requires_grad_(True); idx = torch.tensor(idx_np).cuda()
+    total = 0.5 * loss.reg_loss(x, idx) + 0.5 * loss.reg_sigma_loss(s, idx) + 0.01 * loss.sigma_loss(s, 0.02)
+    total.backward()
+    l1, g1 = loss_oracle.group_var_loss(x_np, idx_np)
+    l2, g2 = loss_oracle.group_var_loss(s_np, idx_np)
+    l3, g3 = loss_oracle.sigma_loss(s_np, 0.02)
+    want = 0.5 * l1 + 0.5 * l2 + 0.01 * l3
+    assert abs(float(total) - want) <= 2e-6 * abs(want)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 0.5 * g1, rtol=2e-4, atol=1e-6 * np.abs(g1).max())
+    np.testing.assert_allclose(s.grad.cpu().numpy(), 0.5 * g2 + 0.01 * g3, rtol=2e-4, atol=1e-6 * np.abs(g2).max())
+
+
+def test_regulariser_argument_errors():
+    from adgs import loss
+    x = torch.zeros(8, 3, 4, device="cuda")
+    with pytest.raises(ValueError):
+        loss.reg_loss(x, torch.zeros(2, 3, dtype=torch.int32, device="cuda"))
+    with pytest.raises(RuntimeError):
+        loss.reg_loss(x, torch.zeros(2, 1, dtype=torch.int64, device="cuda"))       # K = 1: torch.var is undefined there
+    with pytest.raises(ValueError):
+        loss.sigma_loss(torch.zeros(8, 3, device="cuda"), 0.1)

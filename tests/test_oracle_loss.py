@@ -78,3 +78,34 @@ def test_bce_clip_oracle_vs_train_py_expression():
     np.testing.assert_allclose(loss, float(g("obj")), rtol=1e-6); np.testing.assert_allclose(grad, g("g_obj"), rtol=2e-5, atol=1e-9)
     loss, grad = lo.bce_clip_loss(g("pred"), g("gt_sky"), invert=True)
     np.testing.assert_allclose(loss, float(g("sky")), rtol=1e-6); np.testing.assert_allclose(grad, g("g_sky"), rtol=2e-5, atol=1e-9)
+
+
+GOLD3 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss3_golden.npz"))
+REG_CASES = sorted({k.split("/")[0] for k in GOLD3.files})
+
+
+@pytest.mark.parametrize("case", REG_CASES)
+def test_regulariser_oracles_vs_train_py_expressions(case):
+    """reg_loss / sigma_loss / reg_sigma_loss (train.py:104-113) and their reference-autograd gradients."""
+    x, s, idx = GOLD3[case + "/xyz_deform_param"], GOLD3[case + "/gs_time_sigma"], GOLD3[case + "/obj_near_idx"]
+    loss, g = loss_oracle.group_var_loss(x, idx)
+    assert abs(loss - float(GOLD3[case + "/reg_loss"])) <= 2e-6 * max(1.0, abs(loss))
+    np.testing.assert_allclose(g, GOLD3[case + "/g_reg"], rtol=2e-5, atol=2e-6 * np.abs(g).max())      # the golden gradients are float32 autograd
+    loss, g = loss_oracle.group_var_loss(s, idx)
+    assert abs(loss - float(GOLD3[case + "/reg_sigma_loss"])) <= 2e-6 * max(1.0, abs(loss))
+    np.testing.assert_allclose(g, GOLD3[case + "/g_reg_sigma"], rtol=2e-5, atol=2e-6 * np.abs(g).max())
+    loss, g = loss_oracle.sigma_loss(s, float(GOLD3[case + "/frame_gap"]))
+    assert abs(loss - float(GOLD3[case + "/sigma_loss"])) <= 2e-6 * max(1.0, abs(loss))
+    np.testing.assert_allclose(g, GOLD3[case + "/g_sigma"], rtol=2e-5, atol=2e-6 * np.abs(g).max())
+
+
+def test_group_variance_finite_differences_and_repeated_rows():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((12, 3, 4))
+    idx = np.array([[0, 1, 2], [2, 3, 0], [5, 5, 7]])             # a row twice in one group, rows shared between groups, rows in none
+    loss, g = loss_oracle.group_var_loss(x, idx)
+    for i in [(0, 0, 0), (2, 1, 3), (5, 2, 1), (7, 0, 2), (9, 1, 1)]:
+        d = np.zeros_like(x); d[i] = 1e-6
+        fd = (loss_oracle.group_var_loss(x + d, idx)[0] - loss_oracle.group_var_loss(x - d, idx)[0]) / 2e-6
+        assert abs(fd - g[i]) <= 1e-7, (i, fd, g[i])
+    assert np.all(g[[4, 6, 8, 9, 10, 11]] == 0)

@@ -2,8 +2,10 @@
 // of (plain / packed fp32 FMA, mul, min, compare + select, exp2, rcp, DPP moves), at 1 / 2 / 4 / 8 waves per SIMD.
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates
 // Every kernel runs ITER iterations of 32 independent instructions of one kind (8 accumulator chains x 4), so neither dependent-issue
-// latency nor the loop overhead (2 scalar instructions per 32) limits it.  Cycles: s_memrealtime is a constant 100 MHz clock, so the
-// shader clock is taken from wall time x the clock rate reported by the runtime, and printed.
+// latency nor the loop overhead (2 scalar instructions per 32) limits it.  Cycles are MEASURED: every wave reads s_memtime (shader-clock
+// ticks, MI355X_MICROARCH.md "s_memtime tick = shader cycle") and s_memrealtime (constant 100 MHz) around its loop; their ratio is the
+// sustained shader clock under that instruction mix (the chip clocks down under VALU load: DVFS), and cycles per instruction are
+// s_memtime ticks, not wall time x the nominal 2.4 GHz.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +18,8 @@ constexpr int ITER = 4096;
 #define REP4(X) X X X X
 
 template <int KIND>
-__global__ void __launch_bounds__(64) rate_kernel(float* out, float seed) {
+__global__ void __launch_bounds__(64) rate_kernel(float* out, float seed, unsigned long long* clk) {
+	const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
 	float a[8], b = seed + threadIdx.x * 1e-7f, c = 1.0f - seed;
 	typedef float f2 __attribute__((ext_vector_type(2)));
 	f2 p[8], pb = { b, b }, pc = { c, c };
@@ -80,24 +83,34 @@ __global__ void __launch_bounds__(64) rate_kernel(float* out, float seed) {
 	float s = 0.f;
 #pragma unroll
 	for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+	if (threadIdx.x == 0) { atomicAdd(&clk[0], __builtin_readcyclecounter() - c0); atomicAdd(&clk[1], wall_clock64() - r0); atomicAdd(&clk[2], 1ull); }
 	if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
 template <int KIND>
 static void run(const char* name, int per_pair, float* d_out, int n_simd, double ghz) {
+	unsigned long long* d_clk; CHECK(hipMalloc(&d_clk, 3 * sizeof(unsigned long long)));
 	for (int waves : { 1, 2, 4, 8 }) {
 		hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
 		const int blocks = n_simd * waves;
-		hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(64), 0, 0, d_out, 0.5f);
+		// a few back-to-back launches first: the clock settles to what this instruction mix sustains
+		for (int w = 0; w < 8; w++) hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(64), 0, 0, d_out, 0.5f, d_clk);
 		CHECK(hipDeviceSynchronize());
+		CHECK(hipMemset(d_clk, 0, 3 * sizeof(unsigned long long)));
 		CHECK(hipEventRecord(e0));
-		hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(64), 0, 0, d_out, 0.5f);
+		constexpr int REP = 8;
+		for (int w = 0; w < REP; w++) hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(64), 0, 0, d_out, 0.5f, d_clk);
 		CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-		float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-		const double insts_per_simd = (double)ITER * 32 * per_pair * waves;
-		const double cycles = ms * 1e-3 * ghz * 1e9;
-		printf("%-34s waves/SIMD %d: %7.3f ms  %6.3f inst/SIMD/cycle  (%.2f cycles per wave64 instruction)\n", name, waves, ms, insts_per_simd / cycles, cycles / insts_per_simd);
+		float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= REP;
+		unsigned long long h[3]; CHECK(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
+		const double insts_per_wave = (double)ITER * 32 * per_pair;
+		const double clock_ghz = (double)h[0] / ((double)h[1] * 10.0);            // ticks per 10 ns
+		const double cyc_per_inst = (double)h[0] / (double)h[2] / insts_per_wave / waves;      // a SIMD's cycles per instruction it retired (waves share it)
+		const double nominal = ms * 1e-3 * ghz * 1e9 / (insts_per_wave * waves);
+		printf("%-34s waves/SIMD %d: %7.3f ms  sustained clock %.3f GHz  %.2f shader cycles per wave64 instruction = %.3f inst/SIMD/cycle  (at the nominal %.1f GHz it would read %.2f)\n",
+			name, waves, ms, clock_ghz, cyc_per_inst, 1.0 / cyc_per_inst, ghz, nominal);
 	}
+	CHECK(hipFree(d_clk));
 }
 
 int main() {

@@ -2,7 +2,13 @@
     python tools/pmc_blend.py <sq counter_collection.csv> <grbm counter_collection.csv> <out.json>
 Per-launch averages of the two blend kernels; valu_busy_frac = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * kernel cycles) with
 kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs (SQ *_CYCLES / ACTIVE / WAIT counters are quad-cycles summed over all waves)."""
-import collections, csv, json, sys
+import collections, csv, json, sys, hashlib, os
+def lib_stamp():
+    path = os.environ.get("ADGS_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ad-gs_amd", "lib", "libadgs_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.Counter())
     for r in csv.DictReader(open(path)):
@@ -23,6 +29,7 @@ for k in sq:
     d["valu_insts_per_simd"] = round(sq[k]["SQ_INSTS_VALU"] / 1024.0, 4)
     d["valu_insts_per_simd_cycle"] = round(sq[k]["SQ_INSTS_VALU"] / 1024.0 / d["kernel_cycles"], 4)     # full-rate fp32 peak: 0.5 (a wave64 op issues in 2 cycles)
     out["kernels"][k] = d
+out["_library_sha256_16"] = lib_stamp()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, d in out["kernels"].items():
     print(k, "VALU busy %.3f" % d["valu_busy_frac"], "cycles %.0f" % d["kernel_cycles"], "VALU insts/SIMD %.0f" % d["valu_insts_per_simd"])

@@ -2,7 +2,13 @@
 Units (MI355X_MICROARCH.md, HBM section): both counters are KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
 so wide coalesced reads are doubled.  Calibrated here on known launches of the same run: at::FillFunctor<float> writing
 the 12 MB means2D tensor reports WRITE_SIZE 11.7 MiB (x1), sort_scatter reading 12 B/pair reports FETCH_SIZE/2."""
-import csv, sys, collections, json, re
+import csv, sys, collections, json, re, hashlib, os
+def lib_stamp():      # the build the counters were collected on (bench.py flags committed counters of another build as stale)
+    path = os.environ.get("ADGS_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ad-gs_amd", "lib", "libadgs_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 def agg(path):
     rows = list(csv.DictReader(open(path)))
     a = collections.defaultdict(float); c = collections.Counter()
@@ -16,13 +22,13 @@ out = {}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0))):
     rd = 2.0 * fetch.get(k, 0.0) * 1024; wr = write.get(k, 0.0) * 1024
     out[k] = {"launches_sampled": int(cf.get(k, cw.get(k, 0))), "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr)}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
+json.dump(dict(out, _library_sha256_16=lib_stamp()), open(sys.argv[3], "w"), indent=1)
 if len(sys.argv) > 4:
     # per-frame total: all launches of the run (bench.py with ADGS_BENCH_SKIP_STATS=1) divided by the number of frames
     # = launches of the blend backward (exactly one per frame)
     frames = max(cf.get(next(k for k in cf if "render_bwd_v2_kernel" in k), 1), 1)
     tot = sum((2.0 * fetch.get(k, 0.0) * cf.get(k, 0) + write.get(k, 0.0) * cw.get(k, 0)) * 1024 for k in set(fetch) | set(write))
-    json.dump({"frames": int(frames), "hbm_bytes_per_frame": int(tot / frames),
+    json.dump({"frames": int(frames), "hbm_bytes_per_frame": int(tot / frames), "_library_sha256_16": lib_stamp(),
                "note": "sum over ALL kernels of the run of 2*FETCH_SIZE + WRITE_SIZE (KiB), divided by the number of frames"}, open(sys.argv[4], "w"), indent=1)
     print("frames", frames, "HBM bytes per frame %.1f MB" % (tot / frames / 1e6))
 for k, v in list(out.items())[:24]:
