@@ -961,6 +961,16 @@ def main():
                     gc.collect(); torch.cuda.empty_cache()
                 except Exception as exc:
                     result["reference_api_path"] = "failed: %r" % (exc,)
+                # a whole training iteration (train.py:47-167) at C3: render + every loss and regulariser + both Adam steps + the
+                # amortised neighbour-index / densification work, with per-stage HIP-event times (examples/train_iteration.py)
+                try:
+                    import importlib.util
+                    spec = importlib.util.spec_from_file_location("adgs_train_iteration", os.path.join(ROOT, "examples", "train_iteration.py"))
+                    ti = importlib.util.module_from_spec(spec); spec.loader.exec_module(ti)
+                    result["train_iteration"] = ti.run("C3", iters=int(os.environ.get("ADGS_BENCH_TRAIN_ITERS", "210")), cameras=K, device=device)
+                except Exception as exc:
+                    result["train_iteration"] = "failed: %r" % (exc,)
+                gc.collect(); torch.cuda.empty_cache()
                 sens = []
                 for variant in ("translucent", "sky"):
                     a = quick_measure("C3", 40, device, use_fs, variant=variant, with_stats=True)[0]

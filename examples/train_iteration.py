@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""One AD-GS training iteration (train.py:74-167 without data loading and the rare densify step) on the HIP path only:
-render() with deformation + flow + semantic + environment-map background, fused L1+SSIM loss plus simple depth / opacity /
-flow / semantic terms, backward, densification statistics, fused Adam on the Gaussian parameters and the environment map.
+"""One AD-GS training iteration, train.py:47-167 term for term, on the HIP path only:
 
-    python examples/train_iteration.py [--config C3] [--iters 50] [--env-res 8192]
+    camera draw -> render() (fused deformation, flow time, semantic mask, environment map composited in the blend epilogue)
+    -> L1 + SSIM, scale/shift-invariant depth loss, flow re-projection loss, object BCE, sky BCE (train.py:78-103)
+    -> the three regularisers reg_loss / sigma_loss / reg_sigma_loss over obj_near_idx (train.py:104-113)
+    -> backward -> densification statistics -> every `densification_interval` iterations densify_and_prune, otherwise every
+       `near_idx_reset_interval` iterations set_obj_near_idx (train.py:146-156) -> both Adam steps (train.py:163-167).
 
-Synthetic scene and targets; prints iterations/s and where the time goes.  This is NOT the headline
-metric (bench.py measures the rasterizer path as BASELINE.json defines it); it shows the drop-in pieces working together.
+    python examples/train_iteration.py [--config C3] [--iters 60] [--env-res 8192] [--cameras 16] [--json]
+
+Synthetic scene, cameras and targets; the lambdas and intervals are the reference's defaults
+(arguments/__init__.py:104-133).  The reference reads `loss.item()` every iteration (train.py:132: a host synchronisation per
+iteration); here the running loss stays on the device and is read when the progress bar would print it (every 10 iterations).
+This is NOT the headline metric (bench.py measures the rasterizer path as BASELINE.json defines it): it shows the drop-in pieces
+working together and where an iteration's time goes; bench.py attaches its summary as the secondary `train_iteration` object.
 """
 import argparse
+import json
 import os
 import sys
 import time
@@ -19,80 +27,171 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# arguments/__init__.py:104-133
+OPT = types.SimpleNamespace(lambda_dssim=0.2, lambda_l1=1.0, lambda_depth=0.1, lambda_flow=0.1, lambda_obj=0.1, lambda_sky=0.05, lambda_sigma=0.01,
+                            lambda_reg=0.5, lambda_sigma_reg=0.5, near_num=8, near_idx_reset_interval=10, densification_interval=200,
+                            densify_scene_grad_threshold=None, densify_obj_grad_threshold=None, env_lr=1e-2)
+STAGES = ("render", "losses", "backward", "densify_stats", "near_idx_or_densify", "adam_gaussians", "adam_env_map")
 
-def build(config, env_res, device):
+
+def build(config, env_res, device, n_cameras=16):
     import torch
-    from adgs import synthetic, env, optim
+    from adgs import synthetic, env
     from adgs.model import SyntheticGaussianModel
     cfg = synthetic.CONFIGS[config]
     sc = synthetic.make_config_scene(config)
     model = SyntheticGaussianModel.from_scene(sc, device=device, seed=0)
     model.raw_sh = True
     model.raw_scene = True          # scene-range activations inside the rasterizer's preprocess
-    cam = synthetic.camera_object(sc, time=0.37)
-    cam.cam_id = 0
+    model.frame_gap = 0.02          # scene/gaussian_model.py:266 (1 / number of frames)
+    lrs = {"scene_xyz": 1.6e-4, "obj_xyz": 1.6e-4, "scene_shs_dc": 2.5e-3, "obj_shs_dc": 2.5e-3, "scene_shs_rest": 1.25e-4, "obj_shs_rest": 1.25e-4,
+           "scene_opacity": 0.05, "obj_opacity": 0.05, "scene_scaling": 5e-3, "obj_scaling": 5e-3, "scene_rotation": 1e-3, "obj_rotation": 1e-3}
+    model.training_setup(lrs=lrs, scene_extent=20.0, object_extent=4.0, near_num=OPT.near_num)
     env_map = env.EnvironmentMap(env_res, 3, device=device)
-    env_map.training_setup(types.SimpleNamespace(env_lr=1e-2))
-    lrs = {"_scene_xyz": 1.6e-4, "_obj_xyz": 1.6e-4, "_scene_shs_dc": 2.5e-3, "_obj_shs_dc": 2.5e-3, "_scene_shs_rest": 1.25e-4, "_obj_shs_rest": 1.25e-4,
-           "_scene_opacity": 0.05, "_obj_opacity": 0.05, "_scene_scaling": 5e-3, "_obj_scaling": 5e-3, "_scene_rotation": 1e-3, "_obj_rotation": 1e-3}
-    from adgs.model import _RAW
-    groups = [{"params": [getattr(model, n)], "lr": lrs.get(n, 1e-3), "name": n} for n in _RAW if getattr(model, n, None) is not None and getattr(model, n).numel() > 0]
-    model.optimizer = optim.FusedAdam(groups, lr=0.0, eps=1e-15)
-    N = sc["P"]
-    stats = dict(accum=torch.zeros(N, 1, device=device), denom=torch.zeros(N, 1, device=device), max_r=torch.zeros(N, device=device))
+    env_map.training_setup(types.SimpleNamespace(env_lr=OPT.env_lr))
     g = torch.Generator().manual_seed(11)
     H, W = cfg["H"], cfg["W"]
-    targets = dict(image=torch.rand(3, H, W, generator=g).to(device), depth=torch.rand(H, W, generator=g).to(device) * 50,
-                   flow=torch.randn(3, H, W, generator=g).to(device), sem=(torch.rand(1, H, W, generator=g) > 0.8).float().to(device))
-    return cfg, model, cam, env_map, stats, targets
+    cams = []
+    import bench
+    for cam, t in bench.camera_pool(cfg, n_cameras):
+        c = synthetic.camera_object(cam, time=t)
+        c.cam_id = len(cams)
+        # per-camera supervision (scene/cameras.py: original_image, depth, semantic, sky, flow packages)
+        c.original_image = torch.rand(3, H, W, generator=g).to(device)
+        c.depth = (torch.rand(H, W, generator=g) * 0.5 + 0.01).to(device)                  # monocular inverse depth
+        c.semantic = (torch.rand(H, W, generator=g) > 0.8).float().to(device)
+        c.sky = (torch.rand(H, W, generator=g) > 0.7).float().to(device)
+        K = torch.tensor([[cfg["focal"], 0.0, W / 2.0], [0.0, cfg["focal"], H / 2.0], [0.0, 0.0, 1.0]])
+        flow = torch.stack([torch.rand(H, W, generator=g) * (W - 1), torch.rand(H, W, generator=g) * (H - 1)]).to(device)
+        vis = (torch.rand(H, W, generator=g) > 0.3).float().to(device)
+        c.flow = [(t + 0.05, K, cam["viewmatrix"][:3, :3].t().contiguous(), cam["viewmatrix"][3, :3].contiguous(), flow, vis)]
+        cams.append(c)
+    return cfg, model, cams, env_map
 
 
-def iteration(model, cam, env_map, stats, targets, lambda_dssim=0.2):
+class StageClock:
+    """HIP events around the stages of an iteration (recorded on the launch stream; read after a synchronisation)."""
+
+    def __init__(self, on):
+        import torch
+        self.on, self.torch, self.marks, self.iters = on, torch, [], []
+
+    def mark(self, name):
+        if self.on:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
+    def end_iteration(self):
+        if self.on:
+            self.iters.append(self.marks)
+            self.marks = []
+
+    def summary(self):
+        tot = {}
+        for marks in self.iters:
+            for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+                tot[name] = tot.get(name, 0.0) + a.elapsed_time(b)
+        n = max(len(self.iters), 1)
+        return {k: round(v / n, 4) for k, v in tot.items()}
+
+
+def iteration(it, model, cams, env_map, clock, state):
     import torch
-    from adgs import loss, optim
+    from adgs import loss
     from gaussian_renderer import render
+    opt = OPT
     pipe = types.SimpleNamespace(inv_depth=True, debug=False)
-    flow_pkg = (cam.time + 0.05, None, None, None, None, None)
-    pkg = render(cam, model, env_map, pipe, flow_pkg=flow_pkg, render_objmask=True)
-    total, l1, dssim = loss.photometric_loss(pkg["render"], targets["image"], lambda_dssim)
-    total = total + 0.01 * (pkg["depth"] - targets["depth"]).abs().mean() + 0.01 * (pkg["img_flow"] - targets["flow"]).abs().mean() \
-        + 0.01 * torch.nn.functional.binary_cross_entropy(pkg["img_semantic"].clamp(1e-6, 1 - 1e-6), targets["sem"]) \
-        + 0.01 * pkg["img_opacity"].mean()
-    total.backward()
+    cam = cams[it % len(cams)]                                               # train.py:55-61
+    flow_pkg = cam.flow[0]                                                   # :66-71
+    clock.mark("start")
+    pkg = render(cam, model, env_map, pipe, flow_pkg=flow_pkg, render_objmask=opt.lambda_obj > 0.0)      # :73
+    image = pkg["render"]
+    clock.mark("render")
+    Ll1, s = loss.l1_ssim(image, cam.original_image)                         # :78-80 (one fused kernel for both)
+    dssim = 1.0 - s
+    depth_loss = loss.get_depth_loss(pkg["depth"], cam.depth)                # :83-86
+    flow_loss = loss.get_flow_loss(pkg["img_flow"], flow_pkg, pkg["img_opacity"], dist=model.scene_extent * 1e-3)      # :88-89
+    obj_loss = loss.obj_loss(pkg["img_semantic"], cam.semantic)              # :91-94
+    sky_loss = loss.sky_loss(pkg["img_opacity"], cam.sky)                    # :96-99
+    reg_loss = loss.reg_loss(model.xyz_deform_param, model.obj_near_idx)     # :101-103
+    sigma_loss = loss.sigma_loss(model.gs_time_sigma, model.frame_gap)       # :105-107
+    reg_sigma_loss = loss.reg_sigma_loss(model.gs_time_sigma, model.obj_near_idx)      # :108-110
+    total = (1.0 - opt.lambda_dssim) * opt.lambda_l1 * Ll1 + opt.lambda_dssim * dssim
+    total = total + depth_loss * opt.lambda_depth + flow_loss * opt.lambda_flow
+    total = total + sky_loss * opt.lambda_sky + obj_loss * opt.lambda_obj
+    total = total + sigma_loss * opt.lambda_sigma + reg_loss * opt.lambda_reg + reg_sigma_loss * opt.lambda_sigma_reg      # :112-115
+    clock.mark("losses")
+    total.backward()                                                         # :116
+    clock.mark("backward")
     with torch.no_grad():
-        optim.add_densification_stats(stats["accum"], stats["denom"], stats["max_r"], pkg["viewspace_points"].grad, pkg["radii"])
-        model.optimizer.step(zero_grad=False)
-        env_map.optimizer.step(zero_grad=False)
-        for p in model.parameters():
-            p.grad = None
-        env_map.grid_map.grad = None
-    return total.detach(), l1.detach(), dssim.detach()
+        state["ema"] = 0.4 * total.detach() + 0.6 * state.get("ema", total.detach())       # :132, kept on the device
+        state["l1"] = Ll1.detach()
+        model.add_densification_stats(pkg)                                   # :148-150 (max_radii2D and the gradient statistics, one kernel)
+        clock.mark("densify_stats")
+        n = it + 1
+        if n % opt.densification_interval == 0:                              # :152-153
+            if state.get("thr") is None:
+                g = (model.xyz_gradient_accum / model.denom.clamp_min(1)).reshape(-1)
+                state["thr"] = float(torch.quantile(g[g > 0][:2_000_000], 0.999)) if bool((g > 0).any()) else 1.0      # ~0.1 % clone / split
+            model.densify_and_prune(state["thr"], state["thr"], 0.005, False)
+            state["densified"] = state.get("densified", 0) + 1
+        elif model.use_near_idx and n % opt.near_idx_reset_interval == 0:    # :154-155
+            model.set_obj_near_idx()
+        clock.mark("near_idx_or_densify")
+        model.optimizer.step(zero_grad=True)                                 # :163-167 (after a densification the new parameter tensors
+        clock.mark("adam_gaussians")                                         #  carry no gradient: that step is skipped, as in the reference)
+        env_map.optimizer.step(zero_grad=True)
+        clock.mark("adam_env_map")
+    clock.end_iteration()
+    return total.detach()
+
+
+def run(config="C3", iters=60, env_res=8192, cameras=16, warm=12, device=None, stages=True):
+    import torch
+    device = device or torch.device("cuda", 0)
+    cfg, model, cams, env_map = build(config, env_res, device, cameras)
+    state = {}
+    off = StageClock(False)
+    for i in range(warm):
+        iteration(i, model, cams, env_map, off, state)
+    torch.cuda.synchronize()
+    clock = StageClock(stages)
+    t0 = time.perf_counter()
+    first = last = None
+    for i in range(iters):
+        last = iteration(warm + i, model, cams, env_map, clock, state)
+        first = last if first is None else first
+        if (i + 1) % 10 == 0:
+            _ = float(state["ema"])                                          # what the progress bar prints (train.py:133-138)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"workload": "%s training iteration: render (deformation, flow, semantic, %d^2 environment map) + L1/SSIM + depth + flow + 2 BCE + 3 regularisers "
+                        "+ backward + densification statistics + fused Adam (Gaussians, environment map); set_obj_near_idx every %d and "
+                        "densify_and_prune every %d iterations; %d cameras" % (config, env_res, OPT.near_idx_reset_interval, OPT.densification_interval, len(cams)),
+            "iterations": iters, "ms_per_iteration": round(dt * 1e3, 4), "iterations_per_s": round(1.0 / dt, 2),
+            "stage_ms": clock.summary(), "densify_calls": state.get("densified", 0), "points_end": int(model.get_pts_num),
+            "loss_first_last": [round(float(first), 6), round(float(last), 6)],
+            "note": "stage_ms: HIP events on the launch stream, mean per iteration (near_idx_or_densify is amortised over the iterations)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--env-res", type=int, default=8192)
+    ap.add_argument("--cameras", type=int, default=16)
+    ap.add_argument("--json", action="store_true")
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X: there is no CPU fallback")
-    device = torch.device("cuda", 0)
-    cfg, model, cam, env_map, stats, targets = build(args.config, args.env_res, device)
-    for _ in range(5):
-        iteration(model, cam, env_map, stats, targets)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    first = last = None
-    for _ in range(args.iters):
-        total, l1, dssim = iteration(model, cam, env_map, stats, targets)
-        first = total if first is None else first
-        last = total
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.iters
-    print("%s: %.2f ms/iteration = %.1f iterations/s (render + env map %d^2 + L1/SSIM + aux losses + backward + densify stats + Adam); "
-          "loss %.5f -> %.5f" % (args.config, dt * 1e3, 1.0 / dt, args.env_res, float(first), float(last)))
+    res = run(args.config, args.iters, args.env_res, args.cameras)
+    if args.json:
+        print(json.dumps(res))
+    else:
+        print("%s\n%.3f ms/iteration = %.1f iterations/s; stages (ms): %s; loss %.5f -> %.5f" % (
+            res["workload"], res["ms_per_iteration"], res["iterations_per_s"], res["stage_ms"], res["loss_first_last"][0], res["loss_first_last"][1]))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
-"""The drop-in pieces together: render() (deformation, flow, semantic, environment map) -> fused L1+SSIM -> backward ->
-densification statistics -> fused Adam, for a few iterations on a small synthetic scene (examples/train_iteration.py)."""
+"""The drop-in pieces together: render() (deformation, flow, semantic, environment map) -> the losses and regularisers of
+train.py:78-115 -> backward -> densification statistics -> neighbour index / densify_and_prune -> fused Adam, for a few
+iterations on a small synthetic scene (examples/train_iteration.py)."""
 import importlib.util
 import os
 
@@ -16,17 +17,30 @@ def test_a_few_training_iterations_run_and_reduce_the_loss():
     from adgs import synthetic
     synthetic.CONFIGS["T0"] = dict(P=6000, W=208, H=130, focal=150.0, sh_degree=3, n_objects=2, seed=9)
     try:
-        cfg, model, cam, env_map, stats, targets = ti.build("T0", 256, torch.device("cuda", 0))
-        with torch.no_grad():                       # make the target reachable: the scene's own first render
+        cfg, model, cams, env_map = ti.build("T0", 256, torch.device("cuda", 0), n_cameras=2)
+        assert model.obj_near_idx.shape == (model.get_obj_pts_num // 8, 8)
+        with torch.no_grad():                       # make the targets reachable: the scene's own first renders
             from gaussian_renderer import render
             import types
-            pkg = render(cam, model, env_map, types.SimpleNamespace(inv_depth=True, debug=False), flow_pkg=(cam.time + 0.05,) + (None,) * 5, render_objmask=True)
-            targets["image"] = (pkg["render"] * 0.8 + 0.1).clamp(0, 1)
-        losses = [float(ti.iteration(model, cam, env_map, stats, targets)[1]) for _ in range(12)]
+            for cam in cams:
+                pkg = render(cam, model, env_map, types.SimpleNamespace(inv_depth=True, debug=False), flow_pkg=cam.flow[0], render_objmask=True)
+                cam.original_image = (pkg["render"] * 0.8 + 0.1).clamp(0, 1)
+        state, clock = {}, ti.StageClock(True)
+        ti.OPT.densification_interval = 8           # one densify_and_prune and one neighbour-index reset inside the run
+        ti.OPT.near_idx_reset_interval = 5
+        l1 = []
+        for it in range(12):
+            total = ti.iteration(it, model, cams, env_map, clock, state)
+            assert torch.isfinite(total)
+            l1.append(float(state["l1"]))
+        torch.cuda.synchronize()
+        stages = clock.summary()
     finally:
         del synthetic.CONFIGS["T0"]
-    assert all(l == l for l in losses) and losses[-1] < losses[0], losses           # L1 to the target goes down
-    assert float(stats["denom"].sum()) > 0 and float(stats["max_r"].max()) > 0
+    assert all(l == l for l in l1) and min(l1[-2:]) < min(l1[:2]), l1           # L1 to the targets goes down (two cameras alternate)
+    assert set(ti.STAGES) <= set(stages) and all(v >= 0 for v in stages.values()), stages
+    assert state.get("densified") == 1
+    assert float(model.denom.sum()) > 0 and float(model.max_radii2D.max()) > 0
     for p in model.parameters():
         assert torch.isfinite(p).all()
     assert torch.isfinite(env_map.grid_map).all() and float(env_map.grid_map.abs().max()) > 1e-4
@@ -127,8 +141,10 @@ def test_side_stream_gives_the_same_results_as_the_default_stream():
         for stream in (None, side):
             ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream())
             with ctx:
-                cfg, model, cam, env_map, stats, targets = ti.build("T2", 256, torch.device("cuda", 0))
-                losses = [float(ti.iteration(model, cam, env_map, stats, targets)[1]) for _ in range(6)]
+                torch.manual_seed(0)                 # the neighbour-index anchors are drawn with torch.randperm
+                cfg, model, cams, env_map = ti.build("T2", 256, torch.device("cuda", 0), n_cameras=2)
+                state = {}
+                losses = [float(ti.iteration(it, model, cams, env_map, ti.StageClock(False), state)) for it in range(6)]
                 torch.cuda.current_stream().synchronize()
             runs.append(losses)
     finally:
