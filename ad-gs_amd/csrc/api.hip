@@ -126,6 +126,8 @@ struct BinStateV2 {
 	uint4* rec_unsorted; uint2* key_stage; uint32_t* mask_stage; uint2* entries;
 	// every tile's own block + blocks drawn from the cursor, each of which may end partly used
 	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + (2 * (size_t)POOL_BLOCK + 1) * ntiles + 1; }
+	// chunks of a frame: every cell has full chunks + one partial
+	static size_t max_chunks(size_t R_cells, size_t ncells) { return std::min<size_t>((size_t)MAX_CHUNKS, ncells + R_cells / GS_NMAX + 1); }
 	static BinStateV2 carve_buckets(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
 		Carver c(chunk); BinStateV2 b;
 		b.pool_cursor = c.take<uint32_t>(64);
@@ -177,7 +179,7 @@ static int v2_cell_tiles(size_t ntiles16) {
 }
 static int v2_pixels_per_lane(size_t ntiles16) {
 	const int e = env_int("ADGS_V2_PPL", 0);
-	if (e == 2 || e == 4) return e;
+	if (e == 1 || e == 2 || e == 4) return e;
 	return ntiles16 < 4096 ? 2 : 4;
 }
 
@@ -388,8 +390,19 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const int cell_tiles = v2_cell_tiles(ntiles);
 		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
 		const size_t ncells = (size_t)cgx * cgy;
+		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs) unless the cell grid has more than MAX_CELLS cells,
+		// the previous frames averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of 8192 pairs per cell, or ADGS_BINNING=sort asks
+		// for the device-wide radix sort of (cell | depth) keys.  (A cell of k chunks pays k - 1 rank searches per entry in the merge,
+		// each against a whole staged chunk; measured crossover against the device-wide sort at about 4 chunks per cell -- C5's 3 M
+		// Gaussians, 9 chunks per cell, take the sort.  A merge over sampled WINDOWS of the other chunks -- linear in k -- was built
+		// and measured in round 3: bit-identical, but slower at both sizes; EXPERIMENTS.md.)
+		const char* binning_env = getenv("ADGS_BINNING");
+		const std::string binning_mode = binning_env ? binning_env : "";
+		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
+			(binning_mode == "bucket" || g_hint_cells.load() <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells);
 		size_t gb = 0, ib = 0;
-		GeomStateV2::carve(nullptr, P, &gb, ncells);
+		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] exists for bucket binning only
+		GeomStateV2::carve(nullptr, P, &gb, count_cells);
 		char* gch = geometryBuffer(geometryUser, gb);
 		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
 		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);                    // rows of wave tiles
@@ -397,7 +410,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		ImgStateV2::carve(nullptr, npix, wtiles, ncells, &ib);
 		char* ich = imageBuffer(imageUser, ib);
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
-		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, ncells);
+		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, count_cells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
 		remember_frame(FrameKey{ ich, gch, width, height, P }, FrameCfg{ 1, cell_tiles, ppl });
 
@@ -415,15 +428,6 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.rects = geom.rects; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
-		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs, 4 launches) unless the cell grid has more than
-		// MAX_CELLS cells or ADGS_BINNING=sort asks for the device-wide radix sort of (cell | depth) keys.
-		// (A cell of more than ~4 chunks -- tens of thousands of pairs per cell, C5's 3 M Gaussians on 70 cells -- pays k - 1 rank
-		// searches per entry in the merge; measured crossover against the device-wide sort at about 4 chunks per cell, so the
-		// previous frames' pair count picks the path unless ADGS_BINNING=bucket|sort forces one.)
-		const char* binning_env = getenv("ADGS_BINNING");
-		const std::string binning_mode = binning_env ? binning_env : "";
-		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
-			(binning_mode == "bucket" || g_hint_cells.load() <= (size_t)4 * GS_NMAX * ncells);
 		pa.bucket_count = nullptr;
 		// bucket binning accumulates the fine-tile total and a few device words: zeroed by the sh0 kernel on the raw-SH path (one
 		// launch less), by a memset otherwise
@@ -496,7 +500,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 				ChunkSortArgs ga;
 				ga.chunks = geom.chunks; ga.d_counts = geom.d_counts(); ga.rec_u = bin.rec_unsorted; ga.key_s = bin.key_stage; ga.mask_s = bin.mask_stage;
 				ga.ent_f = bin.entries; ga.cap = cap;
-				const size_t grid = std::min<size_t>((size_t)MAX_CHUNKS, ncells + cells / GS_NMAX + 1);      // every cell: full chunks + one partial
+				const size_t grid = BinStateV2::max_chunks(cells, ncells);
 				{ StageTimer t(ST_SORT, stream); if (launch_chunk_sort(ga, (uint32_t)grid, stream) != 0) return -1; }
 				{ StageTimer t(ST_RANGES, stream); if (launch_chunk_merge(ga, (uint32_t)grid, stream) != 0) return -1; }      // "tile_ranges" slot: the merge of multi-chunk cells
 				ADGS_LAUNCH_CHECK(debug, stream);

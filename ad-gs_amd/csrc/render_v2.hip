@@ -710,7 +710,8 @@ __global__ void __launch_bounds__(256) reset_tiles_kernel(uint32_t T, uint32_t* 
 
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;           // a.gy counts WAVE tiles (16 x 4*ppl pixels)
-	if (a.ppl == 2) hipLaunchKernelGGL(render_fwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
+	if (a.ppl == 1) hipLaunchKernelGGL(render_fwd_v2_kernel<1>, dim3(T), dim3(WAVE), 0, stream, a);
+	else if (a.ppl == 2) hipLaunchKernelGGL(render_fwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
 	else hipLaunchKernelGGL(render_fwd_v2_kernel<4>, dim3(T), dim3(WAVE), 0, stream, a);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
@@ -768,7 +769,10 @@ int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;
 	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity && a.dL_dpix_opacity != nullptr;
-	if (a.ppl == 2) {
+	if (a.ppl == 1) {
+		if (full) hipLaunchKernelGGL((render_bwd_v2_kernel<1, true>), dim3(T), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL((render_bwd_v2_kernel<1, false>), dim3(T), dim3(WAVE), 0, stream, a);
+	} else if (a.ppl == 2) {
 		if (full) hipLaunchKernelGGL((render_bwd_v2_kernel<2, true>), dim3(T), dim3(WAVE), 0, stream, a);
 		else hipLaunchKernelGGL((render_bwd_v2_kernel<2, false>), dim3(T), dim3(WAVE), 0, stream, a);
 	} else {

@@ -802,6 +802,53 @@ def main():
     stages = prof.collect()
     capacity_reruns = _lib.frame_status()["eager_reruns"] - reruns0
     graph_ok = cache.validate(repair=False) if cache is not None else None
+    multi_gpu = None
+    if world > 1 or force_coll:
+        # Self-verifying multi-GPU figures (for the day a multi-GPU node runs this): the rank count RCCL itself reports (an
+        # all-reduce of ones), every rank's own time per step and pair counts (cameras differ: load imbalance), and the exchange
+        # timed with BOTH forms of the dense reduction in this one run (a short untimed loop with the other form).
+        ones = torch.ones(1, device=device, dtype=torch.float32)
+        dist.all_reduce(ones)
+        st_r = _lib.frame_status()
+        mine = torch.tensor([elapsed / args.steps * 1e3, float(st_r["pairs"]), float(st_r["fine_pairs"]), float(capacity_reruns)], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        multi_gpu = {"world_size": dist.get_world_size(), "rccl_ranks": int(round(float(ones.item()))), "backend": dist.get_backend(),
+                     "per_rank_ms_per_step": [round(float(x[0]), 4) for x in allr], "per_rank_cell_pairs_last_frame": [int(x[1]) for x in allr],
+                     "per_rank_fine_pairs_last_frame": [int(x[2]) for x in allr], "per_rank_capacity_reruns": [int(x[3]) for x in allr]}
+        main_form = "rs_ag" if os.environ.get("ADGS_DP_COLLECTIVE") == "rs_ag" else "all_reduce"
+
+        def exchange_summary():
+            if ex is not None and ex.timing:
+                tm = ex.timing
+                avg = lambda a, b: round(sum(t_[a].elapsed_time(t_[b]) for t_ in tm) / len(tm), 4)
+                return {"total": avg(0, 3), "allgather_wait": avg(0, 1), "expansion": avg(1, 2), "dense_reduction_wait": avg(2, 3), "calls": len(tm)}
+            if ex_events:
+                return {"total": round(sum(a.elapsed_time(b) for a, b in ex_events) / len(ex_events), 4), "calls": len(ex_events)}
+            return None
+        sync()
+        by_form = {main_form: exchange_summary()}
+        saved_timing, saved_events = (list(ex.timing) if ex is not None else None), list(ex_events)
+        other = "all_reduce" if main_form == "rs_ag" else "rs_ag"
+        old_form = os.environ.get("ADGS_DP_COLLECTIVE")
+        os.environ["ADGS_DP_COLLECTIVE"] = other
+        try:
+            if ex is not None:
+                ex.timing = []
+            del ex_events[:]
+            run(min(10, max(2, args.steps)))
+            sync()
+            by_form[other] = exchange_summary()
+        finally:
+            if old_form is None:
+                os.environ.pop("ADGS_DP_COLLECTIVE", None)
+            else:
+                os.environ["ADGS_DP_COLLECTIVE"] = old_form
+            if ex is not None:
+                ex.timing = saved_timing
+            ex_events[:] = saved_events
+        multi_gpu["exchange_ms_by_collective"] = by_form
+        multi_gpu["note"] = "exchange_ms_by_collective[%s] is from the timed region, the other form from %d extra steps after it" % (main_form, min(10, max(2, args.steps)))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -828,6 +875,8 @@ def main():
             "step_ms_hip_events": dict(step_stats(step_ms), first=round(step_ms[0], 4))}
         if os.environ.get("ADGS_BENCH_DUMP_STEPS"):
             config["step_ms_series"] = [round(x, 4) for x in step_ms[:int(os.environ["ADGS_BENCH_DUMP_STEPS"])]]
+        if multi_gpu:
+            config["multi_gpu"] = multi_gpu
         if gpu_idle:
             # the same figure against the UNPROFILED steps of the timed region (no event brackets, hence no bubbles of their own)
             gpu_idle["timed_step_median_minus_sum_of_stage_ms"] = round(percentile(step_ms, 0.5) - gpu_idle["sum_of_stage_ms"], 4)

@@ -32,6 +32,15 @@ def test_ranks_finish_and_print_one_json_line(config, exchange, world):
     assert abs(d["value"] - world * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3          # whole-job frames / max-over-ranks time
     want = "factored" if (exchange == "factored" and config == "T3") else "dense"               # static configs have no raw-SH path
     assert d["config"]["gradient_exchange"].startswith(want), d["config"]["gradient_exchange"]
+    # the self-verifying multi-GPU figures: the rank count the collective library itself reports, per-rank step times and pair
+    # counts, the exchange under both forms of the dense reduction
+    mg = d["config"]["multi_gpu"]
+    assert mg["world_size"] == world and mg["rccl_ranks"] == world
+    assert len(mg["per_rank_ms_per_step"]) == world and all(x > 0 for x in mg["per_rank_ms_per_step"])
+    assert len(mg["per_rank_cell_pairs_last_frame"]) == world and all(x > 0 for x in mg["per_rank_cell_pairs_last_frame"])
+    assert set(mg["exchange_ms_by_collective"]) == {"all_reduce", "rs_ag"}
+    assert all(v is not None and v["total"] >= 0 and v["calls"] > 0 for v in mg["exchange_ms_by_collective"].values())
+    assert d["config"]["camera_pool"].startswith("16 cameras")
 
 
 @pytest.mark.parametrize("world,cams,densify,collective,self_launch", [(2, 3, 0, "all_reduce", False), (4, 3, 0, "rs_ag", False), (2, 5, 3, "rs_ag", True),
