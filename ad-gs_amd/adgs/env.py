@@ -87,7 +87,9 @@ class EnvironmentMap:
 
     def training_setup(self, training_args):
         """scene/env.py:78-83 with the fused Adam."""
-        self.optimizer = FusedAdam([{"params": [self.grid_map], "lr": training_args.env_lr, "name": "env"}], lr=0.0, eps=1e-15)
+        # the cameras of a sequence see a small part of the sphere: texels that never receive a gradient keep zero moments, and the
+        # Adam step leaves them exactly where they are -- skip_dormant_tiles does that at 4 instead of 28 bytes per texel
+        self.optimizer = FusedAdam([{"params": [self.grid_map], "lr": training_args.env_lr, "name": "env"}], lr=0.0, eps=1e-15, skip_dormant_tiles=True)
 
     def save_weights(self, weights_path):
         torch.save(self.grid_map, weights_path)

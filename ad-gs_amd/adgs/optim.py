@@ -21,16 +21,26 @@ MAX_GROUPS = 32
 
 class AdamGroup(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
-                ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_int32)]
+                ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_int32), ("tile_active", ctypes.c_void_p)]
+
+
+ADAM_TILE = 4096           # ADGS_ADAM_TILE
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, skip_dormant_tiles=False):
+        """skip_dormant_tiles: keep, per parameter, one byte per 4096 elements saying whether that tile has ever seen a non-zero
+        gradient; a tile that has not is left untouched by the step -- which is exactly what Adam does to it (zero moments, zero
+        update) at 4 instead of 28 bytes of traffic per element.  For parameters most of which never receive a gradient (the
+        environment map).  Only valid while nothing but this optimizer writes the moments: moments that arrive from elsewhere
+        (a loaded or edited state) are detected by their address and size and treated as active everywhere."""
+        self.skip_dormant_tiles = bool(skip_dormant_tiles)
         if weight_decay != 0 or amsgrad:
             raise ValueError("FusedAdam implements the configuration the reference uses: no weight decay, no amsgrad")
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._tile_maps = {}        # id(param) -> (byte map, exp_avg address, exp_avg_sq address, numel)
 
     @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
@@ -66,13 +76,25 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)          # same state layout as torch.optim.Adam
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if self.skip_dormant_tiles:
+                        self._tile_maps[id(p)] = (torch.zeros((p.numel() + ADAM_TILE - 1) // ADAM_TILE, dtype=torch.uint8, device=p.device),
+                                                  st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
                 st["step"] += 1
                 if p.numel() == 0:
                     continue
                 if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
                     st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+                tile_map = None
+                if self.skip_dormant_tiles:
+                    ent = self._tile_maps.get(id(p))
+                    if ent is None or ent[1:] != (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()):
+                        # moments this optimizer did not create as zeros (loaded / edited state): every tile counts as active
+                        ent = (torch.ones((p.numel() + ADAM_TILE - 1) // ADAM_TILE, dtype=torch.uint8, device=p.device),
+                               st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                        self._tile_maps[id(p)] = ent
+                    tile_map = ent[0]
                 ag = AdamGroup(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
-                               int(st["step"]))
+                               int(st["step"]), tile_map.data_ptr() if tile_map is not None else None)
                 keep.append(g)
                 batches.setdefault((p.device, float(b1), float(b2), float(group["eps"])), []).append((ag, p, g))
         lib = _lib.lib()

@@ -13,6 +13,7 @@ constexpr int AB = 256;                 // threads per block
 constexpr int AV = 4;                   // elements per thread per iteration (one 16-byte access per array)
 constexpr int AI = 4;                   // iterations per thread
 constexpr int ATILE = AB * AV * AI;     // elements per block
+static_assert(ATILE == ADGS_ADAM_TILE, "adgs_adam_group.tile_active is indexed by the kernel's tile");
 
 struct AdamTable {
 	adgs_adam_group g[ADGS_ADAM_MAX_GROUPS];
@@ -40,6 +41,23 @@ __global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
 	const int64_t base = (int64_t)(blockIdx.x - t.first_block[lo]) * ATILE;
 	const bool vec = ((reinterpret_cast<uintptr_t>(G.param) | reinterpret_cast<uintptr_t>(G.grad) | reinterpret_cast<uintptr_t>(G.exp_avg) |
 	                   reinterpret_cast<uintptr_t>(G.exp_avg_sq)) & 15) == 0;
+	if (G.tile_active) {
+		// a tile whose gradients and moments have been zero in every step so far: the update is the identity -- read the
+		// gradient only (4 of the 28 bytes per element) and leave while it is still all zero
+		const int64_t tile = (int64_t)(blockIdx.x - t.first_block[lo]);
+		if (G.tile_active[tile] == 0) {
+			bool nz = false;
+#pragma unroll
+			for (int it = 0; it < AI; it++) {
+				const int64_t i = base + ((int64_t)it * AB + threadIdx.x) * AV;
+				if (i >= G.numel) break;
+				if (vec && i + AV <= G.numel) { const float4 g = *reinterpret_cast<const float4*>(G.grad + i); nz = nz || g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f; }
+				else for (int k = 0; k < AV && i + k < G.numel; k++) nz = nz || G.grad[i + k] != 0.f;
+			}
+			if (!__syncthreads_or(nz ? 1 : 0)) return;
+			if (threadIdx.x == 0) G.tile_active[tile] = 1;
+		}
+	}
 #pragma unroll
 	for (int it = 0; it < AI; it++) {
 		const int64_t i = base + ((int64_t)it * AB + threadIdx.x) * AV;

@@ -29,7 +29,15 @@ typedef struct adgs_adam_group {
 	int64_t numel;
 	float lr;
 	int32_t step;           /* t of this parameter after the increment (>= 1) */
+	/* Optional (NULL = off): one byte per tile of ADGS_ADAM_TILE consecutive elements, 0 = "every element of the tile has had
+	 * g = m = v = 0 in every step so far".  For such a tile the Adam update is the identity, bit for bit (m and v stay 0, the
+	 * parameter moves by step_size * 0 / (0 + eps) = 0): the kernel reads only the tile's gradient, and leaves everything else
+	 * untouched while that is still all zero; the first non-zero gradient sets the byte to 1 for good.  Caller-owned, zero-
+	 * initialised when the moments are created as zeros, ALL ONES if the moments come from anywhere else.  Pays for parameters
+	 * most of which never receive a gradient: the 8192^2 environment map (scene/env.py) under a few dozen cameras. */
+	uint8_t* tile_active;
 } adgs_adam_group;
+#define ADGS_ADAM_TILE 4096
 
 /* n_groups <= ADGS_ADAM_MAX_GROUPS per call (call again for more).  Returns 0, or a negative
  * code with adgs_last_error() set. */

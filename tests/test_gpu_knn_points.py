@@ -70,3 +70,33 @@ def test_set_obj_near_idx_and_errors():
         knn_points(torch.zeros(1, 4, 3), torch.zeros(1, 9, 3), K=2)
     with pytest.raises(RuntimeError):
         knn_points(torch.zeros(1, 4, 3, device="cuda"), torch.zeros(1, 9, 3, device="cuda"), K=33)
+
+
+@pytest.mark.parametrize("N,A,D,K,lattice", [(300, 300, 3, 8, True), (5000, 700, 4, 8, True), (6000, 6000, 3, 32, False), (200_000, 25_000, 4, 8, False)])
+def test_slab_search_equals_brute_force(monkeypatch, N, A, D, K, lattice):
+    """The two exact paths (slab search along the axis of largest extent / tiled brute force) return identical index lists and
+    distances -- also on a coarse lattice (exact distance ties, equal axis coordinates) and at the training size (200 k object
+    Gaussians in clusters, time as the fourth coordinate)."""
+    from adgs.knn import knn_points
+    rng = np.random.default_rng(77 + N + K)
+    if N >= 100_000:      # clustered like the object Gaussians of C3: 8 clusters of radius ~2 m, time * scene_extent on axis 3
+        centres = rng.uniform(-20, 20, size=(8, 3)).astype(np.float32)
+        pts = (centres[rng.integers(0, 8, N)] + rng.normal(scale=1.0, size=(N, 3))).astype(np.float32)
+        pts = np.concatenate([pts, (rng.random((N, 1)) * 20.0).astype(np.float32)], 1) if D == 4 else pts
+    else:
+        pts = rng.normal(size=(N, D)).astype(np.float32)
+    if lattice:
+        pts = np.round(pts * 2) / 2
+    anchors = pts[rng.permutation(N)[:A]]
+    a, p = torch.tensor(anchors, device="cuda")[None], torch.tensor(pts, device="cuda")[None]
+    out = {}
+    for mode in ("slab", "brute"):
+        monkeypatch.setenv("ADGS_KNN_POINTS", mode)
+        res = knn_points(a, p, K=K)
+        torch.cuda.synchronize()
+        out[mode] = (res.idx[0].cpu().numpy(), res.dists[0].cpu().numpy())
+    assert np.array_equal(out["slab"][0], out["brute"][0])
+    assert np.array_equal(out["slab"][1], out["brute"][1])
+    if N <= 6000:
+        dist, idx = ko.knn_points(anchors, pts, K)
+        assert np.array_equal(out["slab"][0], idx) and np.array_equal(out["slab"][1], dist)

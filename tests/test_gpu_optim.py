@@ -192,3 +192,38 @@ def test_fused_adam_fuzz(seed):
             for k, bound in (("exp_avg", hist), ("exp_avg_sq", hist * hist)):
                 u, v = of.state[a][k].cpu().double().numpy(), o64.state[b][k].numpy()
                 np.testing.assert_allclose(u, v, rtol=2e-5, atol=1e-6 * bound, err_msg=str(s) + k)
+
+
+def test_dormant_tiles_are_skipped_exactly():
+    """skip_dormant_tiles: a tile of 4096 elements that has never seen a non-zero gradient is left untouched -- bit for bit what the
+    dense step does to it -- and wakes up for good with its first non-zero gradient; moments from elsewhere switch the shortcut off."""
+    from adgs.optim import FusedAdam, ADAM_TILE
+    torch.manual_seed(3)
+    n = 5 * ADAM_TILE + 123
+    p0 = torch.randn(n, device="cuda")
+    a = torch.nn.Parameter(p0.clone()); b = torch.nn.Parameter(p0.clone())
+    oa = FusedAdam([{"params": [a], "lr": 1e-2}], eps=1e-15, skip_dormant_tiles=True)
+    ob = FusedAdam([{"params": [b], "lr": 1e-2}], eps=1e-15)
+    touched = [set(), {1}, {1}, {1, 3}, {5}, set(), {3}]          # tiles with a non-zero gradient in step i
+    seen = set()
+    for step, tiles in enumerate(touched):
+        g = torch.zeros(n, device="cuda")
+        for t in tiles:
+            lo, hi = t * ADAM_TILE, min((t + 1) * ADAM_TILE, n)
+            g[lo + 7:hi:97] = torch.randn(len(range(lo + 7, hi, 97)), device="cuda")
+        seen |= tiles
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+        assert torch.equal(a, b), step
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa.state[a][k], ob.state[b][k]), (step, k)
+        amap = oa._tile_maps[id(a)][0].cpu().tolist()
+        assert [i for i, v in enumerate(amap) if v] == sorted(seen), (step, amap)
+    assert torch.equal(a[:ADAM_TILE], p0[:ADAM_TILE]) and torch.equal(a[2 * ADAM_TILE:3 * ADAM_TILE], p0[2 * ADAM_TILE:3 * ADAM_TILE])   # never touched
+    # moments replaced behind the optimizer's back (what densification / load_state_dict do): every tile is treated as active
+    oa.state[a]["exp_avg"] = oa.state[a]["exp_avg"].clone() + 0.5
+    ob.state[b]["exp_avg"] = ob.state[b]["exp_avg"].clone() + 0.5
+    a.grad, b.grad = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    oa.step(); ob.step()
+    assert torch.equal(a, b) and not torch.equal(a[:ADAM_TILE], p0[:ADAM_TILE])
+    assert all(oa._tile_maps[id(a)][0].cpu().tolist())
