@@ -706,6 +706,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		ra.do_opacity = grad_img_opacity != nullptr || (ra.bg_image != nullptr && ra.do_color);      // the per-pixel background's term rides on the opacity path
 		ra.gacc = geom.gacc;
 		ra.tile_order = nullptr;
+		ra.tl_start = env_int("ADGS_TIMELINE_BWD", 0) ? img.tile_scanned : nullptr; ra.tl_end = img.tile_batches;      // experiment build only
 		{
 			StageTimer t(ST_RENDER_BWD, stream);
 			if (wtiles >= 2048 && env_int("ADGS_TILE_ORDER", 1) != 0) {      // fewer tiles than wave slots: nothing to balance
@@ -937,6 +938,16 @@ extern "C" long long adgs_test_v2_tile_counters(const char* img_buffer, int widt
 	if ((long long)v.wtiles > capacity) return (long long)v.wtiles;
 	if (out_consumed && hipMemcpyAsync(out_consumed, v.img.tile_consumed, v.wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
 	if (out_scanned && hipMemcpyAsync(out_scanned, v.img.tile_scanned, v.wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
+	return (long long)v.wtiles;
+}
+// experiment builds (-DADGS_TIMELINE): the raw tile_scanned / tile_batches words of an image state
+extern "C" long long adgs_test_v2_tile_words(const char* img_buffer, int width, int height, uint32_t* out_scanned, uint32_t* out_batches, long long capacity, void* stream_) {
+	V2ImageView v;
+	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
+	if ((long long)v.wtiles > capacity) return (long long)v.wtiles;
+	if (out_scanned && hipMemcpyAsync(out_scanned, v.img.tile_scanned, v.wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
+	if (out_batches && hipMemcpyAsync(out_batches, v.img.tile_batches, v.wtiles * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess) return -1;
 	if (hipStreamSynchronize((hipStream_t)stream_) != hipSuccess) return -1;
 	return (long long)v.wtiles;
 }

@@ -156,6 +156,7 @@ struct RenderV2BwdArgs {
 	bool do_color, do_flow, do_sem, do_depth, do_opacity;
 	float* gacc;                     // [P][GACC_STRIDE], zero-initialised
 	const uint32_t* tile_order;      // workgroup -> tile, longest lists first (launch_tile_order); nullptr: identity
+	uint32_t* tl_start; uint32_t* tl_end;      // -DADGS_TIMELINE experiment build: per-tile wave start / end (100 MHz ticks); else unused
 };
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream);
 // order[i] = tile with the i-th largest number of consumed entries (bucketed): the backward starts the long tiles first

@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	unsigned long long t_acc[4] = { 0ull, 0ull, 0ull, 0ull }, t_load = 0ull, n_rounds = 0ull, t_frec = 0ull, n_frec = 0ull;
 #endif
 	ADGS_T(t_wave0);
+#ifdef ADGS_TIMELINE
+	const unsigned long long tl_r0 = wall_clock64();
+#endif
 #ifdef ADGS_PROBE
 	const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_r0 = wall_clock64();
 	unsigned pr_pairs = 0, pr_evals = 0, pr_live = 0, pr_strips = 0;
@@ -387,6 +390,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		}
 	}
 	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = batches; }
+#ifdef ADGS_TIMELINE
+	// experiment build: the wave's life instead of the statistics -- start and end in 100 MHz ticks (s_memrealtime, low 32 bits)
+	if (lane == 0) { a.tile_scanned[tile] = (uint32_t)tl_r0; a.tile_batches[tile] = (uint32_t)wall_clock64(); }
+#endif
 #ifdef ADGS_PROBE
 	if (lane == 0) {
 		atomicAdd(&g_probe[0], __builtin_readcyclecounter() - pr_c0); atomicAdd(&g_probe[1], wall_clock64() - pr_r0); atomicAdd(&g_probe[2], 1ull);
@@ -514,6 +521,34 @@ __device__ __forceinline__ float wave_sum14_transposed(float x0, float x1, float
 	return z0;
 }
 
+// Fourteen wave64 sums through LDS instead of the register butterfly above.  Measured on gfx950 (tools/microbench/valu_rates.hip,
+// profiles/r03/valu_rates.txt): v_permlane32_swap / v_permlane16_swap retire at a QUARTER of the fp32 rate (8.2 cycles per wave64
+// instruction, like v_exp_f32), DPP adds at half rate (4.3) -- the butterfly's 11 swaps + 11 adds + 10 DPP adds are ~165 VALU cycles
+// per entry, a fifth of the backward's time per entry -- while the LDS pipe idles.  Here every lane stores its 14 partial sums
+// ([value][lane], conflict-free), lane l reads back a quarter (l & 3) of value l >> 2 as four 16-byte words (value rows padded
+// to 68 floats: the sixteen lanes of a read group hit sixteen different bank quads), adds its 16 numbers, and two quad DPP adds
+// finish: 15 full-rate adds + 2 DPP adds of VALU work.  The LDS operations of one wave execute in order: no barrier.
+#ifndef ADGS_BWD_LDS_REDUCE
+#define ADGS_BWD_LDS_REDUCE 1
+#endif
+constexpr int RED_STRIDE = WAVE + 4;      // floats per value row
+__device__ __forceinline__ float wave_sum14_lds(float* s_red, int lane, float x0, float x1, float x2, float x3, float x4, float x5, float x6,
+	float x7, float x8, float x9, float x10, float x11, float x12, float x13) {
+	float* w = s_red + lane;
+	w[0 * RED_STRIDE] = x0; w[1 * RED_STRIDE] = x1; w[2 * RED_STRIDE] = x2; w[3 * RED_STRIDE] = x3; w[4 * RED_STRIDE] = x4;
+	w[5 * RED_STRIDE] = x5; w[6 * RED_STRIDE] = x6; w[7 * RED_STRIDE] = x7; w[8 * RED_STRIDE] = x8; w[9 * RED_STRIDE] = x9;
+	w[10 * RED_STRIDE] = x10; w[11 * RED_STRIDE] = x11; w[12 * RED_STRIDE] = x12; w[13 * RED_STRIDE] = x13;
+	// rows 14 and 15 are never written: their lanes read whatever the buffer holds and nobody uses the result
+	const float4* r = reinterpret_cast<const float4*>(s_red + (lane >> 2) * RED_STRIDE + (lane & 3) * 16);
+	const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+	float v = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+	v += ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
+	int x = __float_as_int(v);
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = __float_as_int(v);      // quad_perm [1,0,3,2]
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));                               // quad_perm [2,3,0,1]
+	return v;
+}
+
 // One 16x4 strip of one entry in the backward replay (backward.cu:545-644 for the lane's pixel of that strip).
 struct BwdSums { float op, mx, my, ca, cb, cc, c0, c1, c2, d, f0, f1, f2, s; };      // per-Gaussian partial sums of this lane
 struct BwdEntry { float r, g, b, dval, fx, fy, fz, sem, dx; };                       // the entry's payload (wave-uniform) and the lane's dx
@@ -560,6 +595,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
 	__shared__ float4 s_splat[(WAVE + 1) * 4];      // entry j lives in row j+1 (row 0: prefetch padding)
 	__shared__ uint32_t s_id[WAVE];
+#if ADGS_BWD_LDS_REDUCE
+	__shared__ __attribute__((aligned(16))) float s_red[16 * RED_STRIDE];
+#endif
 	const int lane = threadIdx.x;
 	const uint32_t tile = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
@@ -574,7 +612,11 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	float Bsum[PPL];          // sum_ch A_ch * dL/dC_ch of the suffix blend A behind the current entry (see below)
 	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gS[PPL];
 	int max_contrib = 0;
+#if ADGS_BWD_LDS_REDUCE
+	const int slot = lane >> 2;
+#else
 	const int slot = slot_of_lane(lane);
+#endif
 	const bool writer = (lane & 3) == 0 && slot < GACC_USED;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
@@ -612,6 +654,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
 	uint32_t chunk = a.tile_last_chunk[tile];
 	int base = (int)a.tile_consumed[tile];        // one past the last position of the current chunk
+#ifdef ADGS_TIMELINE
+	const unsigned long long tl_r0 = wall_clock64();
+#endif
 #ifdef ADGS_PROBE
 	const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_r0 = wall_clock64();
 	unsigned pr_pairs = 0, pr_evals = 0, pr_live = 0, pr_strips = 0;
@@ -684,12 +729,19 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				// 14 wave sums by a transposing reduction: every level halves the number of live registers
 				// (slot k of the 64-B gradient line ends up in the lanes with slot_of_lane == k) -> one
 				// atomic instruction on one 64-B line.  Absent channels stay exactly 0.
+#if ADGS_BWD_LDS_REDUCE
+				const float out = wave_sum14_lds(s_red, lane, v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
+#else
 				const float out = wave_sum14_transposed(v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
+#endif
 				if (writer) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
 			}
 		}
 		chunk = prev;
 	}
+#ifdef ADGS_TIMELINE
+	if (lane == 0 && a.tl_start) { a.tl_start[tile] = (uint32_t)tl_r0; a.tl_end[tile] = (uint32_t)wall_clock64(); }
+#endif
 #ifdef ADGS_PROBE
 	if (lane == 0) {
 		atomicAdd(&g_probe[8], __builtin_readcyclecounter() - pr_c0); atomicAdd(&g_probe[9], wall_clock64() - pr_r0); atomicAdd(&g_probe[10], 1ull);

@@ -1,0 +1,17 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/r3h; mkdir -p $o; cd $R
+L=$R/ad-gs_amd/lib
+for v in default regreduce default regreduce; do
+  lib=$L/libadgs_hip_$v.so; [ $v = default ] && lib=$L/libadgs_hip.so
+  ADGS_LIB=$lib python bench.py --steps 100 --warmup 10 --no-secondary --no-cpu-baseline --cameras 1 > $o/bench_$v.json 2> $o/bench_$v.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open("$o/bench_$v.json").read().strip().splitlines()[-1])
+    print("$v", d["value"], "fwd", d["stages_ms"]["render_fwd"], "bwd", d["stages_ms"]["render_bwd"], d["config"]["step_ms_hip_events"]["median"])
+except Exception as e:
+    print("$v failed", e)
+PY
+done
+timeout 1500 python -m pytest tests/test_gpu_raster.py tests/test_gpu_full_path.py tests/test_gpu_gate_flips.py tests/test_gpu_random_configs.py -m gpu -x -q -p no:cacheprovider > $o/parity.log 2>&1
+tail -4 $o/parity.log
