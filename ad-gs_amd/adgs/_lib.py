@@ -92,6 +92,7 @@ SIGNATURES = {
     "adgs_test_v2_tile_counters": (ctypes.c_longlong, [c_p, c_i, c_i, c_p, c_p, ctypes.c_longlong, c_p]),
     "adgs_test_v2_blend_batches": (ctypes.c_longlong, [c_p, c_i, c_i, c_p]),
     "adgs_test_v2_cell_ranges": (ctypes.c_longlong, [c_p, c_i, c_i, c_p, ctypes.c_longlong, c_p]),
+    "adgs_test_abi_sizeof": (ctypes.c_size_t, [c_i]),
     "adgs_test_set_capacity_hints": (None, [ctypes.c_longlong, ctypes.c_longlong]),
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),

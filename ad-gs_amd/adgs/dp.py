@@ -146,9 +146,11 @@ class _ExpandCam(ctypes.Structure):
     _fields_ = [("rgb", ctypes.c_void_p), ("xyz_tail", ctypes.c_void_p), ("campos", ctypes.c_float * 3), ("reserved", ctypes.c_float)]
 
 
-class _ExpandGrads(ctypes.Structure):
-    """adgs_sh_grads (include/adgs_rasterizer.h)."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor")]
+def _expand_grads():
+    """adgs_sh_grads (include/adgs_rasterizer.h): ONE ctypes mirror for both users of the struct (the rasterizer backward and the
+    expansion), so that its size cannot drift from the C side again; tests/test_abi_and_oracle_knn.py checks sizeof against the library."""
+    from diff_gaussian_rasterization._C import ShGrads
+    return ShGrads()
 
 
 def hip_sh_grad_expand(cams, W, C, P, Ns, row0, xyz_head, D, M, outs, _cache=None):
@@ -172,7 +174,7 @@ def hip_sh_grad_expand(cams, W, C, P, Ns, row0, xyz_head, D, M, outs, _cache=Non
                 arr[c].campos[i] = key[c][2][i]
         if _cache is not None:
             _cache.clear(); _cache[key] = arr
-    g = _ExpandGrads()
+    g = _expand_grads()
     for n, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), outs):
         setattr(g, n, ptr(t))
     with torch.cuda.device(dev):

@@ -972,6 +972,18 @@ extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int
 	if (!v2_image_view(img_buffer, width, height, &v)) return -1;
 	return sum_tile_words(v.img.tile_scanned, v.wtiles, (hipStream_t)stream_);
 }
+// sizeof of the structs that cross the ABI by pointer: lets a binding check its mirror (which: 0 adgs_sh_source, 1 adgs_sh_grads,
+// 2 adgs_frame_stats, 3 adgs_frame_status, 4 adgs_func_eval)
+extern "C" size_t adgs_test_abi_sizeof(int which) {
+	switch (which) {
+	case 0: return sizeof(adgs_sh_source);
+	case 1: return sizeof(adgs_sh_grads);
+	case 2: return sizeof(adgs_frame_stats);
+	case 3: return sizeof(adgs_frame_status);
+	case 4: return sizeof(adgs_func_eval);
+	default: return 0;
+	}
+}
 extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
 	g_hint_cells.store((size_t)std::max(0ll, pairs)); g_hint_fine.store((size_t)std::max(0ll, fine_pairs));
 }

@@ -94,8 +94,10 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 			if (c >= L) { c -= L; g++; }
 		}
 		if (TO_LDS) {
-			// unconditional loads (see above): an absent side / an element past the end reads a valid dummy address
-			PtrT dummy = scene ? scene : obj;
+			// unconditional loads (see above): an absent side / an element past the end reads a valid dummy address -- one from the side
+			// that HAS rows in this block (a non-null pointer to a zero-row tensor must never be dereferenced: foreign C callers)
+			const bool scene_rows = scene && gi0 < Ns, obj_rows = obj && gi0 + count > Ns;
+			PtrT dummy = scene_rows ? scene + (size_t)gi0 * L : (obj_rows ? obj + (size_t)(max(gi0, Ns) - Ns) * L : (scene ? scene : obj));
 #pragma unroll
 			for (int u = 0; u < U; u++) v[u] = *(p[u] ? p[u] : dummy);
 #pragma unroll

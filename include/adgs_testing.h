@@ -30,6 +30,10 @@ long long adgs_test_v2_blend_batches(const char* img_buffer, int width, int heig
 /* (start, end) of every coarse cell's depth-sorted candidate list (host array of 2 x `capacity` uint32); returns the number of cells. */
 long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height, uint32_t* out_ranges, long long capacity, void* stream);
 
+/* sizeof of the structs that cross the ABI by pointer (0 adgs_sh_source, 1 adgs_sh_grads, 2 adgs_frame_stats, 3 adgs_frame_status,
+ * 4 adgs_func_eval): a binding checks its mirror against it. */
+size_t adgs_test_abi_sizeof(int which);
+
 /* Overwrites the process-wide capacity hints the next default-pipeline forward is enqueued against (pairs, fine pairs; the
  * forward still uses at least P + 4096 / 8 P + 4096): lets a test force the "frame does not fit its capacity" path. */
 void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs);

@@ -77,3 +77,17 @@ def test_knn_oracle_known_answer():
     d = oracle.knn_dist2(pts)
     np.testing.assert_allclose(d[3:7], 2.0, rtol=1e-6)
     np.testing.assert_allclose(d[0], (1 + 4 + 9) / 3.0, rtol=1e-6)
+
+
+def test_ctypes_mirrors_have_the_size_of_the_c_structs():
+    """The structs that cross the ABI by pointer: a Python mirror that falls behind the header reads or writes past the C object
+    (adgs_sh_grads grew to 12 members while one mirror kept 7)."""
+    import ctypes
+    from adgs import _lib, deform
+    from adgs.optim import AdamGroup
+    from diff_gaussian_rasterization._C import ShSource, ShGrads
+    lib = _lib.lib()
+    mirrors = {0: ShSource, 1: ShGrads, 2: _lib.FrameStats, 3: _lib.FrameStatus, 4: deform.FuncEval}
+    for which, cls in mirrors.items():
+        assert ctypes.sizeof(cls) == lib.adgs_test_abi_sizeof(which), (which, cls.__name__)
+    assert ctypes.sizeof(AdamGroup) == 56          # adgs_adam_group: 4 pointers, int64, float, int32, pointer
