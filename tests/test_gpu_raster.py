@@ -365,7 +365,7 @@ def test_backward_uses_the_forwards_configuration_not_the_environment(monkeypatc
     torch.autograd.backward([out[0], out[2], out[3], out[4], out[5]], [dev(g["color"]), dev(g["depth"]), dev(g["img_opacity"]), dev(g["flow"]), dev(g["semantic"])])
     torch.cuda.synchronize()
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
-        assert_close("grad_" + k, L[k].grad.cpu().numpy(), ref["grads"][k].cpu().numpy(), tol=2e-5, max_frac=1e-5, rel_l2=2e-5)
+        assert_close("grad_" + k, L[k].grad.cpu().numpy(), ref["grads"][k].cpu().numpy(), tol=2e-5, max_frac=1e-4, rel_l2=2e-5)      # two runs: the order of the float atomics differs
 
 
 def test_repeated_backward_over_one_forward_state():
