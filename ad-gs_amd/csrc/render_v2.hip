@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				any_m |= actm[k];
 			}
 			if (any_m == 0ull) continue;
+
 #ifdef ADGS_PROBE
 			pr_live++;
 #pragma unroll
