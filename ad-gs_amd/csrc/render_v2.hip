@@ -582,10 +582,14 @@ __device__ __forceinline__ void bwd_strip(BwdSums& v, const BwdEntry& e, const B
 	Bsum += al * dL_dalpha;
 	if (do_opacity) dL_dalpha += p.tfo * rinv;  // before the *= T: reference quirk (backward.cu:612-614)
 	dL_dalpha = dL_dalpha * T - p.tfb * rinv;
+	// the lane's four pixels share the column, i.e. dx: only S0 = sum L, Sy = sum L dy, Syy = sum L dy^2 are accumulated per strip;
+	// Sx = dx S0, Sxx = dx^2 S0, Sxy = dx Sy are formed once per entry (bwd_finish_moments)
 	const float L = G * dL_dalpha;
-	const float Lx = L * e.dx, Ly = L * dy;
-	bwd_acc<INIT>(v.op, G, dL_dalpha); bwd_acc<INIT>(v.mx, L, e.dx); bwd_acc<INIT>(v.my, L, dy);
-	bwd_acc<INIT>(v.ca, Lx, e.dx); bwd_acc<INIT>(v.cb, Lx, dy); bwd_acc<INIT>(v.cc, Ly, dy);
+	const float Ly = L * dy;
+	bwd_acc<INIT>(v.op, G, dL_dalpha); bwd_acc<INIT>(v.my, L, dy); bwd_acc<INIT>(v.cc, Ly, dy);
+}
+__device__ __forceinline__ void bwd_finish_moments(BwdSums& v, float dx) {
+	v.mx = dx * v.op; v.ca = dx * v.mx; v.cb = dx * v.my;
 }
 
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
@@ -721,9 +725,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 #define ADGS_BWD_ACCK(k) if (__builtin_amdgcn_inverse_ballot_w64(actm[k])) { ADGS_BWD_PIXEL(k); \
 	bwd_strip<false>(v, be, bp, alpha[k], G[k], dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
 				if (actm[0] != 0ull) { ADGS_BWD_INITK(0) }
-				else v.op = v.mx = v.my = v.ca = v.cb = v.cc = v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = 0.f;
+				else v.op = v.my = v.cc = v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = 0.f;
 #pragma unroll
 				for (int k = 1; k < PPL; k++) { ADGS_BWD_ACCK(k) }
+				bwd_finish_moments(v, dx);
 #undef ADGS_BWD_PIXEL
 #undef ADGS_BWD_INITK
 #undef ADGS_BWD_ACCK

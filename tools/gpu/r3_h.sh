@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/r3h; mkdir -p $o; cd $R
 L=$R/ad-gs_amd/lib
-for v in default notree default notree; do
+for v in default oldmom default oldmom; do
   lib=$L/libadgs_hip_$v.so; [ $v = default ] && lib=$L/libadgs_hip.so
   ADGS_LIB=$lib python bench.py --steps 100 --warmup 10 --no-secondary --no-cpu-baseline --cameras 1 > $o/bench_$v.json 2> $o/bench_$v.err
   python - <<PY
