@@ -160,12 +160,14 @@ static int env_int(const char* name, int dflt) {
 	return (v && *v) ? atoi(v) : dflt;
 }
 // "classic" reproduces the reference pipeline stage by stage (full (tile|depth) sort, num_rendered
-// equal to the reference's); "v2" (default) is the coarse-binned lazy pipeline.  Multi-channel
-// semantics (D_S > 1) always take the classic kernels.
+// equal to the reference's); "v2" (default) is the coarse-binned lazy pipeline.  v2 blends semantic channel 0 in the main kernels
+// and replays the published lists once more per extra channel (render_sem_fwd_v2 / render_bwd_v2 with sem_src; AD-GS uses 1 channel.
+// C3 with 4 / 32 channels: 2.6 / 14.6 ms per frame against 23.8 / 46.5 ms on the classic kernels).  ADGS_V2_MAX_SEMANTIC (default 32
+// = all) sends larger D_S to the classic kernels.
 static bool use_v2(int D_S) {
 	const char* m = getenv("ADGS_RASTER_MODE");
 	if (m && std::string(m) == "classic") return false;
-	return D_S <= 1;
+	return D_S <= std::min(env_int("ADGS_V2_MAX_SEMANTIC", 32), (int)MAX_SEMANTIC);
 }
 
 // Pixels per lane of the v2 blend kernels: one wave per 16x16 tile (4 px/lane) when that already gives the chip enough
@@ -540,7 +542,15 @@ static int raster_forward_impl(const ShSource* sh_src,
 			ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
 			ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
 			ra.overflow_flag = overflow_flag;
-			{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd_v2(ra, stream) != 0) return -1; }
+			{ StageTimer t(ST_RENDER_FWD, stream);
+			  if (launch_render_fwd_v2(ra, stream) != 0) return -1;
+			  for (int c0 = 1; ra.has_sem && c0 < D_S; c0 += 4) {      // semantic channels beyond the Splat's slot: a replay of the published lists
+				RenderV2SemFwdArgs sa;
+				sa.splats = geom.splats; sa.pool = bin.pool; sa.tile_last_chunk = img.tile_last_chunk; sa.tile_consumed = img.tile_consumed; sa.n_contrib = img.n_contrib;
+				sa.W = width; sa.H = height; sa.gx = gx; sa.gy = wgy; sa.ppl = ppl;
+				sa.semantic = semantic; sa.D_S = D_S; sa.c0 = c0; sa.nch = std::min(4, D_S - c0); sa.out_semantic = img_semantic;
+				if (launch_render_sem_fwd_v2(sa, stream) != 0) return -1;
+			  } }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
 		};
@@ -612,7 +622,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.rects = nullptr; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
 	pa.bucket_count = nullptr;
-	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
+	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
@@ -718,7 +728,22 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 			// forward has dropped out of the frame table -- gets them zeroed again here (64 B per Gaussian: the preprocess
 			// backward used to re-zero every line after reading it, 64 MB of writes per frame at C3 for a case that is rare).
 			if (note_backward(fkey) != 0) ADGS_HIP_CHECK(hipMemsetAsync(geom.gacc, 0, (size_t)P * GACC_STRIDE * sizeof(float), stream));
+			ra.sem_src = nullptr; ra.sem_dst = nullptr; ra.sem_stride = 0;
 			if (binning_buffer && launch_render_bwd_v2(ra, stream) != 0) return -1;
+			if (binning_buffer && ra.do_sem && D_S > 1) {
+				// channels 1 .. D_S-1: dL/dalpha is linear in the channels, so each channel's replay adds its share of the geometric
+				// sums to the gacc lines and its own sum_k alpha_k T_k dL/dS to dL_dsemantic[:, c] (zeroed here; channel 0 is written
+				// by the preprocess backward with every other output row)
+				ADGS_HIP_CHECK(hipMemsetAsync(dL_dsemantic, 0, (size_t)P * D_S * sizeof(float), stream));
+				RenderV2BwdArgs rc = ra;
+				rc.do_color = rc.do_flow = rc.do_depth = rc.do_opacity = false; rc.do_sem = true;
+				rc.dL_dpix = nullptr; rc.dL_dpix_depth = nullptr; rc.dL_dpix_flow = nullptr; rc.dL_dpix_opacity = nullptr;
+				rc.bg_image = nullptr; rc.dL_dbg_image = nullptr; rc.sem_stride = D_S;
+				for (int c = 1; c < D_S; c++) {
+					rc.dL_dpix_sem = dL_dpix_semantic + (size_t)c * npix; rc.sem_src = semantic + c; rc.sem_dst = dL_dsemantic + c;
+					if (launch_render_bwd_v2(rc, stream) != 0) return -1;
+				}
+			}
 		}
 		ADGS_LAUNCH_CHECK(debug, stream);
 		PreprocessBwdArgs pa;
@@ -775,7 +800,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy; pa.inv_depth = inv_depth;
 	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
 	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
-	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline and D_S <= 1"); return -1; }
+	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); memset(&pa.sh_dst, 0, sizeof(pa.sh_dst));
 	pa.gacc = nullptr; pa.splats = nullptr; pa.W = width; pa.H = height; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
 	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;

@@ -157,8 +157,23 @@ struct RenderV2BwdArgs {
 	float* gacc;                     // [P][GACC_STRIDE], zero-initialised
 	const uint32_t* tile_order;      // workgroup -> tile, longest lists first (launch_tile_order); nullptr: identity
 	uint32_t* tl_start; uint32_t* tl_end;      // -DADGS_TIMELINE experiment build: per-tile wave start / end (100 MHz ticks); else unused
+	// extra semantic channels (D_S > 1): one more replay per channel c >= 1 with only do_sem set -- the entry's value is read from
+	// sem_src[id * sem_stride] instead of the Splat, its gradient sum goes to sem_dst[id * sem_stride] instead of the gacc line; the
+	// geometric sums add into the gacc line as in the main pass (dL/dalpha is linear in the channels).  nullptr: the main pass.
+	const float* sem_src; float* sem_dst; int sem_stride;
 };
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream);
+
+// Forward of the semantic channels 1 .. D_S-1 (channel 0 rides in the Splat and is blended by render_fwd_v2): a back-to-front
+// replay of the chunk lists the main forward published, S = s a + (1 - a) S per contributing entry (the same sum as forward.cu:372
+// written as a Horner recurrence), up to 4 channels per launch.
+struct RenderV2SemFwdArgs {
+	const Splat* splats; const uint32_t* pool; const uint32_t* tile_last_chunk; const uint32_t* tile_consumed; const uint32_t* n_contrib;
+	int W, H, gx, gy, ppl;
+	const float* semantic; int D_S, c0, nch;      // channels c0 .. c0 + nch - 1 of semantic[P, D_S]
+	float* out_semantic;                          // [D_S, H, W]
+};
+int launch_render_sem_fwd_v2(const RenderV2SemFwdArgs& a, hipStream_t stream);
 // order[i] = tile with the i-th largest number of consumed entries (bucketed): the backward starts the long tiles first
 int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream);
 

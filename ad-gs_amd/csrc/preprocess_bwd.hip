@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			if (a.out_depth) a.out_depth[idx] = 0.f;
 			if (a.out_color) { a.out_color[3 * (size_t)idx] = 0.f; a.out_color[3 * (size_t)idx + 1] = 0.f; a.out_color[3 * (size_t)idx + 2] = 0.f; }
 			if (a.out_flow && !rs) { a.out_flow[3 * (size_t)idx] = 0.f; a.out_flow[3 * (size_t)idx + 1] = 0.f; a.out_flow[3 * (size_t)idx + 2] = 0.f; }
-			if (a.out_sem && a.D_S == 1) a.out_sem[idx] = 0.f;
+			if (a.out_sem && a.D_S >= 1) a.out_sem[(size_t)idx * a.D_S] = 0.f;      // channels >= 1: api.hip (extra replays)
 			if (rs) {      // raw scene row: the gradients of the raw tensors are what the caller reads
 				float* gx = a.sh_dst.scene_xyz + 3 * (size_t)idx; gx[0] = 0.f; gx[1] = 0.f; gx[2] = 0.f;
 				float* gs = a.sh_dst.scene_scaling + 3 * (size_t)idx; gs[0] = 0.f; gs[1] = 0.f; gs[2] = 0.f;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		if (a.out_depth) a.out_depth[idx] = gd;
 		if (a.out_flow && rs) { gflow[0] = u2.z; gflow[1] = u2.w; gflow[2] = u3.x; }
 		else if (a.out_flow) { a.out_flow[3 * (size_t)idx] = u2.z; a.out_flow[3 * (size_t)idx + 1] = u2.w; a.out_flow[3 * (size_t)idx + 2] = u3.x; }
-		if (a.out_sem && a.D_S == 1) a.out_sem[idx] = u3.y;
+		if (a.out_sem && a.D_S >= 1) a.out_sem[(size_t)idx * a.D_S] = u3.y;
 	} else {
 		dcon_x = a.dL_dconic[4 * (size_t)idx]; dcon_y = a.dL_dconic[4 * (size_t)idx + 1]; dcon_z = a.dL_dconic[4 * (size_t)idx + 3];
 		g2x = a.dL_dmean2D[3 * (size_t)idx]; g2y = a.dL_dmean2D[3 * (size_t)idx + 1];

@@ -679,7 +679,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				s_splat[(lane + 1) * 4 + 0] = src[0];
 				s_splat[(lane + 1) * 4 + 1] = src[1];
 				s_splat[(lane + 1) * 4 + 2] = src[2];
-				s_splat[(lane + 1) * 4 + 3] = src[3];
+				float4 q3s = src[3];
+				if (!FULL && a.sem_src) q3s.y = a.sem_src[(size_t)id * a.sem_stride];      // an extra semantic channel's replay
+				s_splat[(lane + 1) * 4 + 3] = q3s;
 				s_id[lane] = id;
 			}
 			__syncthreads();
@@ -740,7 +742,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 #else
 				const float out = wave_sum14_transposed(v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
 #endif
-				if (writer) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
+				if (!FULL && a.sem_dst) {
+					if (writer && (slot < 6 || slot == GACC_USED - 1)) atomicAdd(slot == GACC_USED - 1 ? a.sem_dst + (size_t)s_id[j] * a.sem_stride : a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
+				} else if (writer) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
 			}
 		}
 		chunk = prev;
@@ -755,6 +759,82 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 		atomicAdd(&g_probe[14], (unsigned long long)pr_strips);
 	}
 #endif
+}
+
+// Semantic channels 1 .. D_S-1 of the forward image (RenderV2SemFwdArgs): the replay loop of the backward without the gradients.
+template <int PPL>
+__global__ void __launch_bounds__(WAVE, 8) render_sem_fwd_v2_kernel(RenderV2SemFwdArgs a) {
+	constexpr int ROWS = 4 * PPL, NCH = 4;
+	__shared__ float4 s_geo[WAVE * 2];
+	__shared__ float4 s_sem[WAVE];
+	const int lane = threadIdx.x;
+	const uint32_t tile = blockIdx.x;
+	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
+	const uint32_t px = tx * TILE_X + (lane & 15);
+	const uint32_t py0 = ty * ROWS + (lane >> 4);
+	const float pxf = (float)px, pyf0 = (float)py0;
+	const size_t HW = (size_t)a.H * a.W;
+	bool inside[PPL]; int last_contributor[PPL]; float S[PPL][NCH];
+	int max_contrib = 0;
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		const uint32_t py = py0 + 4 * k;
+		inside[k] = px < (uint32_t)a.W && py < (uint32_t)a.H;
+		last_contributor[k] = inside[k] ? (int)a.n_contrib[(size_t)a.W * py + px] : 0;
+		max_contrib = max(max_contrib, last_contributor[k]);
+#pragma unroll
+		for (int i = 0; i < NCH; i++) S[k][i] = 0.f;
+	}
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
+	uint32_t chunk = a.tile_last_chunk[tile];
+	int base = (int)a.tile_consumed[tile];
+	while (chunk != NO_CHUNK) {
+		const uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
+		const uint32_t prev = c[0];
+		const int n = (int)c[1];
+		base -= n;
+		if (base < max_contrib) {
+			__syncthreads();
+			if (lane < n) {
+				const uint32_t id = c[2 + lane];
+				const float4* src = reinterpret_cast<const float4*>(a.splats + id);
+				s_geo[lane * 2 + 0] = src[0];
+				s_geo[lane * 2 + 1] = src[1];
+				const float* sv = a.semantic + (size_t)id * a.D_S + a.c0;
+				float4 q = make_float4(sv[0], 0.f, 0.f, 0.f);
+				if (a.nch > 1) q.y = sv[1];
+				if (a.nch > 2) q.z = sv[2];
+				if (a.nch > 3) q.w = sv[3];
+				s_sem[lane] = q;
+			}
+			__syncthreads();
+			for (int j = n - 1; j >= 0; j--) {
+				const int contributor = base + j;
+				if (contributor >= max_contrib) continue;
+				const float4 q0 = s_geo[j * 2 + 0], q1 = s_geo[j * 2 + 1];
+				const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
+				const float4 sv = s_sem[j];
+#pragma unroll
+				for (int k = 0; k < PPL; k++) {
+					float dy, power, G, alpha;
+					eval_pixel(eg, pyf0 + (float)(4 * k), dy, power, G, alpha);
+					const bool act = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+					const float al = act ? alpha : 0.f;
+					S[k][0] = fmaf(al, sv.x - S[k][0], S[k][0]); S[k][1] = fmaf(al, sv.y - S[k][1], S[k][1]);
+					S[k][2] = fmaf(al, sv.z - S[k][2], S[k][2]); S[k][3] = fmaf(al, sv.w - S[k][3], S[k][3]);
+				}
+			}
+		}
+		chunk = prev;
+	}
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		if (!inside[k]) continue;
+		const size_t pix_id = (size_t)a.W * (py0 + 4 * k) + px;
+#pragma unroll
+		for (int i = 0; i < NCH; i++) if (i < a.nch) a.out_semantic[(size_t)(a.c0 + i) * HW + pix_id] = S[k][i];
+	}
 }
 
 // per-tile bookkeeping reset + pool cursor
@@ -824,9 +904,18 @@ int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order
 	return 0;
 }
 
+int launch_render_sem_fwd_v2(const RenderV2SemFwdArgs& a, hipStream_t stream) {
+	const uint32_t T = (uint32_t)a.gx * a.gy;
+	if (a.ppl == 1) hipLaunchKernelGGL(render_sem_fwd_v2_kernel<1>, dim3(T), dim3(WAVE), 0, stream, a);
+	else if (a.ppl == 2) hipLaunchKernelGGL(render_sem_fwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
+	else hipLaunchKernelGGL(render_sem_fwd_v2_kernel<4>, dim3(T), dim3(WAVE), 0, stream, a);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
 int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;
-	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity && a.dL_dpix_opacity != nullptr;
+	const bool full = a.do_color && a.do_flow && a.do_sem && a.do_depth && a.do_opacity && a.dL_dpix_opacity != nullptr && !a.sem_src && !a.sem_dst;
 	if (a.ppl == 1) {
 		if (full) hipLaunchKernelGGL((render_bwd_v2_kernel<1, true>), dim3(T), dim3(WAVE), 0, stream, a);
 		else hipLaunchKernelGGL((render_bwd_v2_kernel<1, false>), dim3(T), dim3(WAVE), 0, stream, a);

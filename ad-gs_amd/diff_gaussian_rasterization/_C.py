@@ -210,8 +210,8 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     D_S = semantic.size(1) if semantic.size(0) != 0 else 0
-    if D_S > 1 or lib.adgs_raster_needs_zero_init(D_S) != 0:
-        raise RuntimeError("the raw-SH path needs the default pipeline and at most one semantic channel")
+    if lib.adgs_raster_needs_zero_init(D_S) != 0:
+        raise RuntimeError("the raw-SH path needs the default pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)")
     M = 1 + sh_raw[2].size(1)
     if sh_raw[0].size(0) + sh_raw[1].size(0) != P:
         raise RuntimeError("raw SH tensors do not match the number of Gaussians")

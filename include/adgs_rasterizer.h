@@ -125,7 +125,7 @@ int adgs_raster_backward(
  * tensors -- scene || object, coefficient 0 = dc + f_shs(t), coefficients 1.. = rest
  * (scene/gaussian_model.py:198-205) -- instead of a materialised [P, M, 3] tensor, and the SH
  * gradients are written straight into the layout of those raw tensors (every element written).
- * Needs the default pipeline (D_S <= 1, not ADGS_RASTER_MODE=classic); scales/rotations only. */
+ * Needs the default pipeline (not ADGS_RASTER_MODE=classic); scales/rotations only. */
 typedef struct adgs_sh_source {
 	int32_t Ns;                               /* scene Gaussians come first; No = P - Ns */
 	const float *scene_dc, *obj_dc;           /* [Ns,1,3] [No,1,3] */

@@ -161,6 +161,14 @@ def test_raw_sh_path_matches_materialised_sh_path(seed):
     _raw_vs_materialised(sc, seed, max(3 - seed, 2), None, 0.37, 0.42)
 
 
+def test_raw_sh_path_with_three_semantic_channels():
+    """The raw-SH entry points with D_S = 3 (channels 1, 2 are replayed on top of the main blend): == the materialised path, incl. the
+    gradient of the semantic values."""
+    from adgs import synthetic
+    sc = synthetic.make_scene(5000, 208, 130, 150.0, sh_degree=3, seed=4, n_objects=2)
+    _raw_vs_materialised(sc, 4, 3, None, 0.37, 0.42, D_S=3)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_RAWSH_SEEDS", "8"))))
 def test_raw_sh_path_fuzz(seed):
     """The same over random scene sizes, image shapes, active SH degrees, object counts, basis mixes of every deformation function
@@ -177,11 +185,11 @@ def test_raw_sh_path_fuzz(seed):
     _raw_vs_materialised(sc, seed, int(rng.randint(0, 4)), oa, float(rng.rand()), float(rng.rand()))
 
 
-def _raw_vs_materialised(sc, seed, degree, order_args, t, t_flow):
+def _raw_vs_materialised(sc, seed, degree, order_args, t, t_flow, D_S=1):
     from adgs import synthetic, deform
     from adgs.model import SyntheticGaussianModel
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    g = synthetic.make_upstream_grads(sc, seed)
+    g = synthetic.make_upstream_grads(sc, seed, D_S=D_S)
     d = lambda x: x.cuda()
     s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], d(sc["bg"]), 1.0, d(sc["viewmatrix"]), d(sc["projmatrix"]),
                                       degree, d(sc["campos"]), False, True, False)
@@ -193,6 +201,8 @@ def _raw_vs_materialised(sc, seed, degree, order_args, t, t_flow):
         flow = model.get_deformed_xyz(t_flow)
         m2 = torch.zeros_like(pkg["xyz"], requires_grad=True)
         sem = model.get_obj_mask.float()[:, None].contiguous()
+        if D_S > 1:
+            sem = torch.cat([sem, torch.rand(sem.shape[0], D_S - 1, generator=torch.Generator().manual_seed(seed)).cuda()], 1).requires_grad_(True)
         if raw:
             assert not torch.is_tensor(pkg["shs"])
             out = rast.forward_rawsh(pkg["xyz"], m2, pkg["opacity"], pkg["shs"], pkg["scales"], pkg["rotation"], flow_points=flow, semantic=sem)
@@ -201,8 +211,11 @@ def _raw_vs_materialised(sc, seed, degree, order_args, t, t_flow):
                        flow_points=flow, semantic=sem)
         color, radii, depth, op, fl, se = out
         torch.autograd.backward([color, depth, op, fl, se], [d(g["color"]), d(g["depth"]), d(g["img_opacity"]), d(g["flow"]), d(g["semantic"])])
-        res.append((out, model, m2))
-    (o0, m0, a0), (o1, m1, a1) = res
+        res.append((out, model, m2, sem))
+    if D_S > 1:
+        close("semantic grad", res[1][3].grad.cpu().numpy(), res[0][3].grad.cpu().numpy(), tol=1e-4)
+        assert float(res[1][3].grad[:, 1:].abs().max()) > 0
+    (o0, m0, a0, _), (o1, m1, a1, _) = res
     assert torch.equal(o0[1], o1[1])
     for x, y, n in zip(o0, o1, ("color", "radii", "depth", "opacity", "flow", "sem")):
         if n != "radii":

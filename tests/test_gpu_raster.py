@@ -187,12 +187,49 @@ def test_no_flow_no_semantic_no_colour():
     assert float(h["color"].abs().max()) == 0.0 and float(h["img_opacity"].max()) > 0
 
 
-def test_multi_channel_semantic():
+@pytest.mark.parametrize("mode", ["default", "classic"])
+def test_multi_channel_semantic(monkeypatch, mode):
+    if mode == "classic":
+        monkeypatch.setenv("ADGS_RASTER_MODE", "classic")
     sc = synthetic.make_scene(1500, 128, 96, 100.0, seed=12)
     sem = torch.rand(sc["P"], 5, generator=torch.Generator().manual_seed(3))
     compare(sc, semantic=sem, grads=synthetic.make_upstream_grads(sc, 12, D_S=5))
     sem32 = torch.rand(sc["P"], 32, generator=torch.Generator().manual_seed(4))
     compare(sc, semantic=sem32, grads=synthetic.make_upstream_grads(sc, 13, D_S=32))
+
+
+@pytest.mark.parametrize("D_S", [2, 3, 4])
+def test_semantic_channels_on_default_pipeline(monkeypatch, D_S):
+    """Several semantic channels on the default (v2) pipeline: channel 0 in the main blend kernels, the others by replaying the
+    published lists (forward: Horner form of forward.cu:372; backward: one more replay per channel, backward.cu:597-603, whose
+    share of dL/dalpha adds into the same per-Gaussian sums).  Against the oracle, and against the classic kernels."""
+    from adgs import _lib
+    assert _lib.lib().adgs_raster_needs_zero_init(D_S) == 0          # = the default pipeline serves this D_S
+    sc = synthetic.make_scene(4000, 260, 150, 180.0, seed=40 + D_S, n_objects=2)
+    sem = torch.rand(sc["P"], D_S, generator=torch.Generator().manual_seed(D_S)) * 2 - 0.5
+    grads = synthetic.make_upstream_grads(sc, 40 + D_S, D_S=D_S)
+    h, _ = compare(sc, semantic=sem, grads=grads)
+    assert float(h["grads"]["sem"][:, 1:].abs().max()) > 0
+    monkeypatch.setenv("ADGS_RASTER_MODE", "classic")
+    c = run_hip(sc, semantic=sem, grads=grads)
+    assert_close("sem_vs_classic", h["img_semantic"].detach().cpu().numpy(), c["img_semantic"].detach().cpu().numpy())
+    for k in ("means3D", "opacities", "scales", "rotations", "sem"):
+        assert_close("grad_vs_classic_" + k, h["grads"][k].cpu().numpy(), c["grads"][k].cpu().numpy(), max_frac=max(2e-4, 4.5 / h["grads"][k].numel()))
+
+
+def test_semantic_channels_limit_raised_and_semantic_only_backward(monkeypatch):
+    """ADGS_V2_MAX_SEMANTIC moves the boundary to the classic kernels; 7 channels = two forward replays of 4 + 2 channels; a backward
+    that carries only a semantic gradient (every other upstream gradient zero) exercises the extra replays on their own."""
+    from adgs import _lib
+    assert _lib.lib().adgs_raster_needs_zero_init(32) == 0
+    monkeypatch.setenv("ADGS_V2_MAX_SEMANTIC", "8")
+    assert _lib.lib().adgs_raster_needs_zero_init(7) == 0 and _lib.lib().adgs_raster_needs_zero_init(9) == 1
+    sc = synthetic.make_scene(2500, 200, 120, 150.0, seed=51)
+    sem = torch.rand(sc["P"], 7, generator=torch.Generator().manual_seed(5))
+    grads = synthetic.make_upstream_grads(sc, 51, D_S=7)
+    compare(sc, semantic=sem, grads=grads)
+    only = {k: (v if k == "semantic" else torch.zeros_like(v)) for k, v in grads.items()}
+    compare(sc, semantic=sem, grads=only)
 
 
 def test_empty_and_all_culled():

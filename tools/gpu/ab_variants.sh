@@ -1,7 +1,10 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/r3h; mkdir -p $o; cd $R
+# A/B of library builds on one box: `gpurun -- 'bash tools/gpu/ab_variants.sh default lds0 default lds0'` runs the C3 bench frame
+# (one camera, 100 steps) once per named build, alternating so that box-to-box and drift effects show, then the blend-kernel parity tests
+# on the default build.  A build <tag> is ad-gs_amd/lib/libadgs_hip_<tag>.so (`make variant TAG=<tag> DEFS=...`); "default" = libadgs_hip.so.
+R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/ab; mkdir -p $o; cd $R
 L=$R/ad-gs_amd/lib
-for v in default oldmom default oldmom; do
+for v in "$@"; do
   lib=$L/libadgs_hip_$v.so; [ $v = default ] && lib=$L/libadgs_hip.so
   ADGS_LIB=$lib python bench.py --steps 100 --warmup 10 --no-secondary --no-cpu-baseline --cameras 1 > $o/bench_$v.json 2> $o/bench_$v.err
   python - <<PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-# whole GPU suite + the driver-settings bench line
+# whole GPU suite + the driver-settings bench line: gpurun --timeout 3600 -- "bash tools/gpu/full_suite_and_bench.sh <tag>" -> gpurun_out/<tag>/
 R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/${1:-r3full}; mkdir -p $o; cd $R
 timeout 3000 python -m pytest tests -m gpu -q -p no:cacheprovider > $o/gpu_tests.log 2>&1
 tail -6 $o/gpu_tests.log

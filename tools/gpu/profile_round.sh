@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 profiles of `bench.py` (C3, driver settings): rocprofv3 kernel stats, HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes), SQ / GRBM
+# Profiles of `bench.py` (C3, driver settings): rocprofv3 kernel stats, HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes), SQ / GRBM
 # counters of the blend kernels, the whole training iteration, the blend-kernel probe and wave timelines, the VALU microbenchmark.
 # Counter passes never share a run with a trace domain; the program itself follows `--` (no env / shell hop).
 R=$GRAFT_REPO_ROOT
-o=$R/gpurun_out/r3prof; mkdir -p $o
+o=$R/gpurun_out/${1:-prof}; mkdir -p $o
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o stats -- $B > $o/stats.log 2>&1
