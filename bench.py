@@ -869,7 +869,7 @@ def main():
             if iteration_mode else "1 camera/GPU/step"),
             "P": P, "cameras_per_step": cams_per_step,
             "camera_pool": ("%d cameras / time stamps per GPU, cycled one per step (train.py:55-61)" % pool_k) if not iteration_mode else "the iteration's cameras, every step",
-            "settle_steps": settle_steps, "capacity_reruns": capacity_reruns,
+            "settle_steps": settle_steps, "capacity_reruns": capacity_reruns, "library_sha256_16": library_stamp(),
             "launch": ("HIP graph replay, one graph per camera (adgs.graph); every replay fitted its capacity: %s" % graph_ok) if use_graph else "eager",
             "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
             "step_ms_hip_events": dict(step_stats(step_ms), first=round(step_ms[0], 4))}
