@@ -128,6 +128,46 @@ def make_upstream_grads(scene, seed=0, D_S=1):
                 semantic=torch.randn(D_S, H, W, generator=g) / n)
 
 
+# cam0 -> world rotation of a z-up world whose +x is the canonical camera's viewing direction (x right, y down, z forward ->
+# X forward, Y left, Z up), and its quaternion (w, x, y, z)
+Z_UP = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+Z_UP_QUAT = (0.5, -0.5, 0.5, -0.5)
+
+
+def to_z_up_world(scene):
+    """The same scene expressed in a driving-dataset world frame (z up, the canonical camera looks along +x) instead of the
+    canonical camera's own frame: positions, flow points and the Gaussians' orientations are rotated, the camera becomes
+    `camera_to_z_up(camera)`.  The rendered images are the same up to rounding; what changes is everything that depends on WORLD
+    directions -- the environment map (scene/env.py:63-76: elevation = angle to the world's xy-plane, so a camera looking along
+    world +z stares at the map's pole)."""
+    out = dict(scene)
+    A = Z_UP
+    out["means3D"] = (scene["means3D"] @ A.t()).contiguous()
+    if "flow_points" in scene:
+        out["flow_points"] = (scene["flow_points"] @ A.t()).contiguous()
+    aw, ax, ay, az = Z_UP_QUAT
+    q = scene["rotations"]
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    out["rotations"] = torch.stack([aw * w - ax * x - ay * y - az * z, aw * x + ax * w + ay * z - az * y,
+                                    aw * y - ax * z + ay * w + az * x, aw * z + ax * y - ay * x + az * w], 1).contiguous()
+    cam = camera_to_z_up(scene)
+    out.update({k: cam[k] for k in ("viewmatrix", "projmatrix", "campos")})
+    return out
+
+
+def camera_to_z_up(cam):
+    """make_camera()'s dict with the world rotated as in to_z_up_world (world -> camera: first back into the canonical frame)."""
+    out = dict(cam)
+    w2c = cam["viewmatrix"].t().double().clone()
+    w2c[:3, :3] = w2c[:3, :3] @ Z_UP.t().double()
+    view = w2c.t().contiguous()
+    proj = projection_matrix(0.01, 100.0, cam["fovx"], cam["fovy"]).transpose(0, 1).double()
+    out["viewmatrix"] = view.float()
+    out["projmatrix"] = (view @ proj).float().contiguous()
+    out["campos"] = view.inverse()[3, :3].float().contiguous()
+    return out
+
+
 class CameraObject:
     """The attributes gaussian_renderer.render() reads from the reference Camera (scene/cameras.py:17-100)."""
 

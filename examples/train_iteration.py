@@ -39,7 +39,9 @@ def build(config, env_res, device, n_cameras=16):
     from adgs import synthetic, env
     from adgs.model import SyntheticGaussianModel
     cfg = synthetic.CONFIGS[config]
-    sc = synthetic.make_config_scene(config)
+    # driving-dataset world frame (z up, cameras look horizontally): in the canonical camera's own frame every camera would stare
+    # at the environment map's pole, where neighbouring pixels land on texels all around the azimuth circle
+    sc = synthetic.to_z_up_world(synthetic.make_config_scene(config))
     model = SyntheticGaussianModel.from_scene(sc, device=device, seed=0)
     model.raw_sh = True
     model.raw_scene = True          # scene-range activations inside the rasterizer's preprocess
@@ -54,6 +56,7 @@ def build(config, env_res, device, n_cameras=16):
     cams = []
     import bench
     for cam, t in bench.camera_pool(cfg, n_cameras):
+        cam = synthetic.camera_to_z_up(cam)
         c = synthetic.camera_object(cam, time=t)
         c.cam_id = len(cams)
         # per-camera supervision (scene/cameras.py: original_image, depth, semantic, sky, flow packages)

@@ -402,3 +402,24 @@ def test_f32_build_matches_f64_build(seed):
     if same.all() and a["num_rendered"] == b["num_rendered"]:
         for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
             np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=1e-4, err_msg=k)
+
+
+def test_z_up_world_frame_renders_the_same_image():
+    """synthetic.to_z_up_world / camera_to_z_up (the driving-dataset world frame examples/train_iteration.py renders in) is a
+    rigid change of coordinates: with view-independent colours (SH degree 0) the oracle's images of the rotated scene under the
+    rotated camera equal those of the canonical scene; the central ray lies in the world's xy-plane (elevation 0 of the
+    environment map, scene/env.py:63-76) instead of along world +z (its pole)."""
+    sc = small_scene(P=80, seed=5)
+    sz = synthetic.to_z_up_world(sc)
+    _, a = run_oracle(sc, degree=0, flow=False)
+    _, b = run_oracle(sz, degree=0, flow=False)
+    for k in ("color", "depth", "img_opacity", "img_semantic"):
+        np.testing.assert_allclose(b[k], a[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    np.testing.assert_array_equal(a["radii"], b["radii"])
+    ray = sz["viewmatrix"][:3, :3] @ torch.tensor([0.0, 0.0, 1.0])
+    assert abs(float(ray[2])) < 1e-6 and float(ray[0]) > 0.999
+    cam = synthetic.make_camera(sc["W"], sc["H"], 40.0, cam_seed=3)          # a jittered camera maps consistently too
+    cz = synthetic.camera_to_z_up(cam)
+    p = torch.cat([sc["means3D"], torch.ones(sc["P"], 1)], 1)
+    pz = torch.cat([sz["means3D"], torch.ones(sc["P"], 1)], 1)
+    np.testing.assert_allclose((pz @ cz["projmatrix"]).numpy(), (p @ cam["projmatrix"]).numpy(), rtol=1e-5, atol=1e-5)
