@@ -55,6 +55,7 @@ SIGNATURES = {
     # include/adgs_envmap.h
     "adgs_envmap_forward": (c_i, [c_i, c_i, c_i, c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
     "adgs_envmap_backward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_envmap_backward_marked": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     # include/adgs_loss.h
     "adgs_l1_ssim_forward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_l1_ssim_backward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

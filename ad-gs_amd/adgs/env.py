@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .optim import FusedAdam
+from .optim import FusedAdam, ADAM_TILE
 
 
 def fov2focal(fov, pixels):
@@ -23,7 +23,7 @@ def fov2focal(fov, pixels):
 
 class _EnvBackground(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grid_map, H, W, focal, R9):
+    def forward(ctx, grid_map, H, W, focal, R9, marked=None):
         if not grid_map.is_cuda:
             raise RuntimeError("EnvironmentMap: grid_map must be on a HIP device; there is no CPU path")
         gm = grid_map.contiguous().float()
@@ -35,29 +35,42 @@ class _EnvBackground(torch.autograd.Function):
                                                       ctypes.c_void_p(torch.cuda.current_stream(gm.device).cuda_stream)), "adgs_envmap_forward")
         ctx.save_for_backward(out)
         ctx.meta = (tuple(grid_map.shape), C, Hm, Wm, H, W, float(focal), Rarr)
+        ctx.marked = marked
         return out
 
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
         shape, C, Hm, Wm, H, W, focal, Rarr = ctx.meta
-        gg = torch.zeros(shape, dtype=torch.float32, device=out.device)           # dense, like grid_sample's backward
+        mk = ctx.marked
+        gg = mk.take() if mk is not None else None        # a buffer the optimizer left all zero (adgs.optim.MarkedGradient)
+        if gg is None or tuple(gg.shape) != shape or gg.device != out.device:
+            gg = torch.zeros(shape, dtype=torch.float32, device=out.device)       # dense, like grid_sample's backward
         g = g.contiguous().float()
         with torch.cuda.device(out.device):
-            _lib.check(_lib.lib().adgs_envmap_backward(C, Hm, Wm, H, W, focal, Rarr, out.data_ptr(), g.data_ptr(), gg.data_ptr(),
-                                                       ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), "adgs_envmap_backward")
-        return gg, None, None, None, None
+            _lib.check(_lib.lib().adgs_envmap_backward_marked(C, Hm, Wm, H, W, focal, Rarr, out.data_ptr(), g.data_ptr(), gg.data_ptr(),
+                                                              mk.marks.data_ptr() if mk is not None else None, ADAM_TILE,
+                                                              ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), "adgs_envmap_backward")
+        if mk is not None:
+            mk.issued(gg)
+        return gg, None, None, None, None, None
 
 
 def image_background(grid_map, H, W, focal, R):
     """sigmoid(bilinear(grid_map)) along the pixel rays of a pinhole camera: [C, H, W].  R = world_view_transform[:3,:3]
     (anything convertible to nine floats, row-major)."""
     R9 = [float(v) for v in (R.detach().cpu().reshape(-1).tolist() if torch.is_tensor(R) else [x for row in R for x in row])]
-    return _EnvBackground.apply(grid_map, int(H), int(W), float(focal), R9)
+    return _EnvBackground.apply(grid_map, int(H), int(W), float(focal), R9, None)
 
 
 class EnvironmentMap:
-    def __init__(self, resolution, num_channel=3, use_cache=True, device="cuda"):
+    def __init__(self, resolution, num_channel=3, use_cache=True, device="cuda", sparse_grad=False):
+        """sparse_grad (extension; the default False is the reference's behaviour step for step): the backward marks the 256-element
+        tiles of the map it writes into in the optimizer's tile map and reuses one gradient buffer the optimizer keeps zero outside
+        them, so a step costs neither a fill pass nor a scan of the dense 3 x 8192^2 gradient (0.8 GB each).  Valid while the map's
+        gradient comes from get_image_background only and is consumed by `self.optimizer.step(zero_grad=True)` (or step() followed by
+        zero_grad(), which only saves the scan); any gradient that reaches the optimizer as another tensor is handled densely."""
+        self.sparse_grad = bool(sparse_grad)
         self.resolution = resolution
         grid_map = (torch.rand((1, num_channel, resolution, resolution), dtype=torch.float32, device=device) * 2.0 - 1.0) * 1e-4
         self.grid_map = nn.Parameter(grid_map.requires_grad_(True))
@@ -77,7 +90,8 @@ class EnvironmentMap:
 
     def get_image_background(self, cam, use_cache=True, return_grid=False):
         focal, R9 = self._camera(cam, use_cache and self.use_cache)
-        bg = _EnvBackground.apply(self.grid_map, int(cam.image_height), int(cam.image_width), float(focal), R9)
+        marked = self.optimizer.marked_gradient(self.grid_map) if (self.sparse_grad and self.optimizer is not None and torch.is_grad_enabled()) else None
+        bg = _EnvBackground.apply(self.grid_map, int(cam.image_height), int(cam.image_width), float(focal), R9, marked)
         if return_grid:
             dev = self.grid_map.device
             grid = torch.stack(torch.meshgrid(torch.arange(0, cam.image_width, dtype=torch.float32, device=dev),

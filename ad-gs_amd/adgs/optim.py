@@ -21,15 +21,36 @@ MAX_GROUPS = 32
 
 class AdamGroup(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
-                ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_int32), ("tile_active", ctypes.c_void_p)]
+                ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_int32), ("tile_active", ctypes.c_void_p),
+                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-ADAM_TILE = 4096           # ADGS_ADAM_TILE
+ADAM_TILE = 256            # ADGS_ADAM_TILE
+TILES_MARKED, ZERO_GRAD = 1, 2          # adgs_adam_group.flags
+
+
+class MarkedGradient:
+    """What a gradient producer that marks the tiles it writes (adgs_envmap_backward_marked) shares with the optimizer of that
+    parameter (FusedAdam.marked_gradient): the tile byte map, and a gradient buffer that is known to be all zero outside marked
+    tiles.  Protocol: the producer calls take() for its output buffer (None: allocate zeros yourself) and issued(t) with the tensor
+    it returns to autograd; the optimizer treats the tiles as marked only while p.grad IS that tensor (a gradient summed with
+    another source arrives as a new tensor and is scanned like any other), zero-fills the tiles it updates when the step drops
+    the gradient (step(zero_grad=True)), and puts the buffer back."""
+
+    def __init__(self, marks):
+        self.marks, self.buffer, self.live_ptr = marks, None, None
+
+    def take(self):
+        b, self.buffer = self.buffer, None
+        return b
+
+    def issued(self, t):
+        self.live_ptr = t.data_ptr()
 
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, skip_dormant_tiles=False):
-        """skip_dormant_tiles: keep, per parameter, one byte per 4096 elements saying whether that tile has ever seen a non-zero
+        """skip_dormant_tiles: keep, per parameter, one byte per 256 elements saying whether that tile has ever seen a non-zero
         gradient; a tile that has not is left untouched by the step -- which is exactly what Adam does to it (zero moments, zero
         update) at 4 instead of 28 bytes of traffic per element.  For parameters most of which never receive a gradient (the
         environment map).  Only valid while nothing but this optimizer writes the moments: moments that arrive from elsewhere
@@ -41,6 +62,30 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tile_maps = {}        # id(param) -> (byte map, exp_avg address, exp_avg_sq address, numel)
+        self._marked = {}           # id(param) -> MarkedGradient
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)          # same state layout as torch.optim.Adam
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if self.skip_dormant_tiles:
+                self._tile_maps[id(p)] = (torch.zeros((p.numel() + ADAM_TILE - 1) // ADAM_TILE, dtype=torch.uint8, device=p.device),
+                                          st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+        return st
+
+    def marked_gradient(self, p):
+        """The MarkedGradient of parameter p (needs skip_dormant_tiles): hand it to the one producer of p's gradient.  Only valid
+        if nothing else writes into p.grad in place (a second loss term on p in the same backward is fine: autograd sums into a
+        new tensor, which this optimizer recognises as foreign)."""
+        if not self.skip_dormant_tiles:
+            raise ValueError("marked_gradient needs skip_dormant_tiles=True")
+        mg = self._marked.get(id(p))
+        if mg is None:
+            self._init_state(p)
+            mg = self._marked[id(p)] = MarkedGradient(self._tile_maps[id(p)][0])
+        return mg
 
     @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
@@ -59,6 +104,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         batches = {}       # (device, betas, eps) -> list of AdamGroup
         keep = []
+        recycle = []       # (MarkedGradient, its gradient buffer): zero again after this step
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -71,14 +117,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if not p.is_contiguous():
                     raise RuntimeError("FusedAdam: parameters must be contiguous")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)          # same state layout as torch.optim.Adam
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if self.skip_dormant_tiles:
-                        self._tile_maps[id(p)] = (torch.zeros((p.numel() + ADAM_TILE - 1) // ADAM_TILE, dtype=torch.uint8, device=p.device),
-                                                  st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                st = self._init_state(p)
                 st["step"] += 1
                 if p.numel() == 0:
                     continue
@@ -93,8 +132,21 @@ class FusedAdam(torch.optim.Optimizer):
                                st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
                         self._tile_maps[id(p)] = ent
                     tile_map = ent[0]
+                flags = 0
+                mg = self._marked.get(id(p))
+                if mg is not None:
+                    if tile_map is mg.marks and g is p.grad and g.data_ptr() == mg.live_ptr:
+                        # the producer's own buffer: its marks say which tiles hold anything.  Dropping the gradient with the step =
+                        # zero the updated tiles in the same pass; the buffer is all zero again and goes back to the producer.
+                        flags = TILES_MARKED | (ZERO_GRAD if zero_grad is True else 0)
+                        if zero_grad is True:
+                            recycle.append((mg, g))
+                    elif tile_map is not mg.marks:
+                        # the tile map was replaced (foreign moments): the producer keeps marking the old one, which nobody reads
+                        self._marked.pop(id(p))
+                    mg.live_ptr = None
                 ag = AdamGroup(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
-                               int(st["step"]), tile_map.data_ptr() if tile_map is not None else None)
+                               int(st["step"]), tile_map.data_ptr() if tile_map is not None else None, flags, 0)
                 keep.append(g)
                 batches.setdefault((p.device, float(b1), float(b2), float(group["eps"])), []).append((ag, p, g))
         lib = _lib.lib()
@@ -110,6 +162,8 @@ class FusedAdam(torch.optim.Optimizer):
                     p.grad.zero_()          # the kernel zeroed the contiguous copy
                 elif zero_grad is True:
                     p.grad = None
+        for mg, g in recycle:
+            mg.buffer = g
         return loss
 
 

@@ -927,6 +927,7 @@ extern "C" int adgs_knn_dist2(int P, const float* points, float* meanDists, char
 
 // ---- test-only hooks (include/adgs_testing.h) ----
 #include "../../include/adgs_testing.h"
+#include "../../include/adgs_optim.h"
 // the image state of a v2 forward, carved the way that forward carved it
 namespace {
 struct V2ImageView { ImgStateV2 img; size_t wtiles, ncells; };
@@ -998,7 +999,7 @@ extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int
 	return sum_tile_words(v.img.tile_scanned, v.wtiles, (hipStream_t)stream_);
 }
 // sizeof of the structs that cross the ABI by pointer: lets a binding check its mirror (which: 0 adgs_sh_source, 1 adgs_sh_grads,
-// 2 adgs_frame_stats, 3 adgs_frame_status, 4 adgs_func_eval)
+// 2 adgs_frame_stats, 3 adgs_frame_status, 4 adgs_func_eval, 5 adgs_adam_group)
 extern "C" size_t adgs_test_abi_sizeof(int which) {
 	switch (which) {
 	case 0: return sizeof(adgs_sh_source);
@@ -1006,6 +1007,7 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 	case 2: return sizeof(adgs_frame_stats);
 	case 3: return sizeof(adgs_frame_status);
 	case 4: return sizeof(adgs_func_eval);
+	case 5: return sizeof(adgs_adam_group);
 	default: return 0;
 	}
 }

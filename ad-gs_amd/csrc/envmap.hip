@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) envmap_fwd_kernel(EnvCam a, const float* 
 // does not fit (the azimuth seam, the poles) fall back to direct atomics.
 constexpr int TEXCAP = 2048;            // texels of the LDS footprint image (x MAXC channels would be 64 KiB: sized per launch)
 
-__global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* __restrict__ bg, const float* __restrict__ g_bg, float* __restrict__ g_grid) {
+__global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* __restrict__ bg, const float* __restrict__ g_bg, float* __restrict__ g_grid,
+	uint8_t* __restrict__ marks, int tile_elems) {
 	extern __shared__ float s_acc[];                     // [C][TEXCAP]
 	__shared__ int s_box[4];                             // minx, miny, maxx, maxy over the valid corners of the block
 	const int tid = threadIdx.x;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* 
 			const size_t dst = (size_t)(miny + ly) * a.Wm + (minx + lx);
 			for (int c = 0; c < a.C; c++) {
 				const float v = s_acc[c * TEXCAP + i];
-				if (v != 0.f) atomicAdd(g_grid + c * plane + dst, v);
+				if (v != 0.f) { atomicAdd(g_grid + c * plane + dst, v); if (marks) marks[(c * plane + dst) / (size_t)tile_elems] = 1; }
 			}
 		}
 		return;
@@ -120,6 +121,13 @@ __global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* 
 		if (t.ok[1]) atomicAdd(g + base + 1, gr * t.w[1]);
 		if (t.ok[2]) atomicAdd(g + base + a.Wm, gr * t.w[2]);
 		if (t.ok[3]) atomicAdd(g + base + a.Wm + 1, gr * t.w[3]);
+		if (marks) {
+			const size_t e = c * plane + base;
+			if (t.ok[0]) marks[e / (size_t)tile_elems] = 1;
+			if (t.ok[1]) marks[(e + 1) / (size_t)tile_elems] = 1;
+			if (t.ok[2]) marks[(e + a.Wm) / (size_t)tile_elems] = 1;
+			if (t.ok[3]) marks[(e + a.Wm + 1) / (size_t)tile_elems] = 1;
+		}
 	}
 }
 
@@ -146,13 +154,19 @@ extern "C" int adgs_envmap_forward(int C, int Hm, int Wm, const float* grid_map,
 	return 0;
 }
 
-extern "C" int adgs_envmap_backward(int C, int Hm, int Wm, int H, int W, float focal, const float* R9,
-	const float* background, const float* dL_dbackground, float* dL_dgrid_map, void* stream) {
+extern "C" int adgs_envmap_backward_marked(int C, int Hm, int Wm, int H, int W, float focal, const float* R9,
+	const float* background, const float* dL_dbackground, float* dL_dgrid_map, uint8_t* tile_marks, int tile_elems, void* stream) {
 	if (H <= 0 || W <= 0) return 0;
 	EnvCam a;
 	if (make_cam(a, C, Hm, Wm, H, W, focal, R9, "adgs_envmap_backward") != 0) return -1;
 	if (!background || !dL_dbackground || !dL_dgrid_map) { set_error("adgs_envmap_backward: NULL pointer"); return -1; }
-	hipLaunchKernelGGL(envmap_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), (size_t)C * TEXCAP * sizeof(float), (hipStream_t)stream, a, background, dL_dbackground, dL_dgrid_map);
+	if (tile_marks && tile_elems <= 0) { set_error("adgs_envmap_backward_marked: tile_elems must be positive"); return -1; }
+	hipLaunchKernelGGL(envmap_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), (size_t)C * TEXCAP * sizeof(float), (hipStream_t)stream, a, background, dL_dbackground, dL_dgrid_map,
+		tile_marks, tile_elems);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
+}
+extern "C" int adgs_envmap_backward(int C, int Hm, int Wm, int H, int W, float focal, const float* R9,
+	const float* background, const float* dL_dbackground, float* dL_dgrid_map, void* stream) {
+	return adgs_envmap_backward_marked(C, Hm, Wm, H, W, focal, R9, background, dL_dbackground, dL_dgrid_map, nullptr, 0, stream);
 }

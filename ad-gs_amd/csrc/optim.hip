@@ -13,7 +13,7 @@ constexpr int AB = 256;                 // threads per block
 constexpr int AV = 4;                   // elements per thread per iteration (one 16-byte access per array)
 constexpr int AI = 4;                   // iterations per thread
 constexpr int ATILE = AB * AV * AI;     // elements per block
-static_assert(ATILE == ADGS_ADAM_TILE, "adgs_adam_group.tile_active is indexed by the kernel's tile");
+static_assert(WAVE * AV == ADGS_ADAM_TILE && ATILE % ADGS_ADAM_TILE == 0, "adgs_adam_group.tile_active: one byte per wave and iteration");
 
 struct AdamTable {
 	adgs_adam_group g[ADGS_ADAM_MAX_GROUPS];
@@ -39,29 +39,32 @@ __global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
 	const adgs_adam_group& G = t.g[lo];
 	const float step_size = t.step_size[lo], ibc2 = t.inv_bc2_sqrt[lo];
 	const int64_t base = (int64_t)(blockIdx.x - t.first_block[lo]) * ATILE;
+	const bool zero_grad = t.zero_grad || (G.flags & ADGS_ADAM_ZERO_GRAD);
 	const bool vec = ((reinterpret_cast<uintptr_t>(G.param) | reinterpret_cast<uintptr_t>(G.grad) | reinterpret_cast<uintptr_t>(G.exp_avg) |
 	                   reinterpret_cast<uintptr_t>(G.exp_avg_sq)) & 15) == 0;
-	if (G.tile_active) {
-		// a tile whose gradients and moments have been zero in every step so far: the update is the identity -- read the
-		// gradient only (4 of the 28 bytes per element) and leave while it is still all zero
-		const int64_t tile = (int64_t)(blockIdx.x - t.first_block[lo]);
-		if (G.tile_active[tile] == 0) {
-			bool nz = false;
-#pragma unroll
-			for (int it = 0; it < AI; it++) {
-				const int64_t i = base + ((int64_t)it * AB + threadIdx.x) * AV;
-				if (i >= G.numel) break;
-				if (vec && i + AV <= G.numel) { const float4 g = *reinterpret_cast<const float4*>(G.grad + i); nz = nz || g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f; }
-				else for (int k = 0; k < AV && i + k < G.numel; k++) nz = nz || G.grad[i + k] != 0.f;
-			}
-			if (!__syncthreads_or(nz ? 1 : 0)) return;
-			if (threadIdx.x == 0) G.tile_active[tile] = 1;
-		}
-	}
 #pragma unroll
 	for (int it = 0; it < AI; it++) {
 		const int64_t i = base + ((int64_t)it * AB + threadIdx.x) * AV;
-		if (i >= G.numel) break;
+		// the 64 lanes of a wave cover one tile of ADGS_ADAM_TILE = 256 consecutive elements per iteration (i0 = its first element):
+		// everything about the tile map is wave-uniform
+		const int64_t i0 = base + ((int64_t)it * AB + (threadIdx.x & ~(WAVE - 1))) * AV;
+		if (i0 >= G.numel) break;
+		if (G.tile_active) {
+			// a tile whose gradients and moments have been zero in every step so far: the update is the identity -- read the
+			// gradient only (4 of the 28 bytes per element) and skip the tile while that is still all zero
+			const int64_t tile = i0 / ADGS_ADAM_TILE;
+			if (G.tile_active[tile] == 0) {
+				if (G.flags & ADGS_ADAM_TILES_MARKED) continue;      // the gradient's producer marks the tiles it writes: nothing to look at
+				bool nz = false;
+				if (i < G.numel) {
+					if (vec && i + AV <= G.numel) { const float4 g = *reinterpret_cast<const float4*>(G.grad + i); nz = g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f; }
+					else for (int k = 0; k < AV && i + k < G.numel; k++) nz = nz || G.grad[i + k] != 0.f;
+				}
+				if (__ballot(nz) == 0ull) continue;
+				if ((threadIdx.x & (WAVE - 1)) == 0) G.tile_active[tile] = 1;
+			}
+		}
+		if (i >= G.numel) continue;
 		if (vec && i + AV <= G.numel) {
 			float4 p = *reinterpret_cast<float4*>(G.param + i), g = *reinterpret_cast<const float4*>(G.grad + i);
 			float4 m = *reinterpret_cast<float4*>(G.exp_avg + i), v = *reinterpret_cast<float4*>(G.exp_avg_sq + i);
@@ -72,13 +75,13 @@ __global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
 			*reinterpret_cast<float4*>(G.param + i) = p;
 			*reinterpret_cast<float4*>(G.exp_avg + i) = m;
 			*reinterpret_cast<float4*>(G.exp_avg_sq + i) = v;
-			if (t.zero_grad) *reinterpret_cast<float4*>(G.grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (zero_grad) *reinterpret_cast<float4*>(G.grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 		} else {
 			for (int k = 0; k < AV && i + k < G.numel; k++) {
 				float p = G.param[i + k], m = G.exp_avg[i + k], v = G.exp_avg_sq[i + k];
 				adam_update(p, m, v, G.grad[i + k], t.beta1, t.beta2, t.eps, step_size, ibc2);
 				G.param[i + k] = p; G.exp_avg[i + k] = m; G.exp_avg_sq[i + k] = v;
-				if (t.zero_grad) G.grad[i + k] = 0.f;
+				if (zero_grad) G.grad[i + k] = 0.f;
 			}
 		}
 	}

@@ -27,6 +27,12 @@ int adgs_envmap_forward(int C, int Hm, int Wm, const float* grid_map, int H, int
 int adgs_envmap_backward(int C, int Hm, int Wm, int H, int W, float focal, const float* R9,
 	const float* background, const float* dL_dbackground, float* dL_dgrid_map, void* stream);
 
+/* The same, and tile_marks[e / tile_elems] = 1 for every element e of dL_dgrid_map (flat index over [C, Hm, Wm]) that receives a
+ * contribution: the byte map adgs_adam_group.tile_active of the map's optimizer (ADGS_ADAM_TILES_MARKED, include/adgs_optim.h), so
+ * that neither a fill pass over the dense gradient nor a scan of it is needed per step.  tile_marks == NULL: adgs_envmap_backward. */
+int adgs_envmap_backward_marked(int C, int Hm, int Wm, int H, int W, float focal, const float* R9,
+	const float* background, const float* dL_dbackground, float* dL_dgrid_map, uint8_t* tile_marks, int tile_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,10 +34,20 @@ typedef struct adgs_adam_group {
 	 * parameter moves by step_size * 0 / (0 + eps) = 0): the kernel reads only the tile's gradient, and leaves everything else
 	 * untouched while that is still all zero; the first non-zero gradient sets the byte to 1 for good.  Caller-owned, zero-
 	 * initialised when the moments are created as zeros, ALL ONES if the moments come from anywhere else.  Pays for parameters
-	 * most of which never receive a gradient: the 8192^2 environment map (scene/env.py) under a few dozen cameras. */
+	 * most of which never receive a gradient: the 8192^2 environment map (scene/env.py) under a few dozen cameras.  (A tile is 1 KiB of a
+	 * map row: 4096-element tiles -- half a row of that map, 180 degrees of azimuth -- left 5x more of it active than the cameras see.) */
 	uint8_t* tile_active;
+	/* Bit 0 (ADGS_ADAM_TILES_MARKED): whoever produced this gradient set tile_active[tile] = 1 for every tile it wrote a non-zero
+	 * value into (adgs_envmap_backward_marked does), so a tile whose byte is 0 is not even read: an 8192^2 x 3 map costs 0.8 GB of
+	 * gradient reads per step otherwise.  Only valid if NOTHING else has written into the gradient.
+	 * Bit 1 (ADGS_ADAM_ZERO_GRAD): zero the gradient of the tiles that are updated, whatever adgs_adam_step's zero_grad says --
+	 * with bit 0 the buffer is then all zero again and can take the next backward without a fill pass. */
+	int32_t flags;
+	int32_t reserved;
 } adgs_adam_group;
-#define ADGS_ADAM_TILE 4096
+#define ADGS_ADAM_TILES_MARKED 1
+#define ADGS_ADAM_ZERO_GRAD 2
+#define ADGS_ADAM_TILE 256
 
 /* n_groups <= ADGS_ADAM_MAX_GROUPS per call (call again for more).  Returns 0, or a negative
  * code with adgs_last_error() set. */

@@ -81,3 +81,61 @@ def test_random_maps_cameras_and_image_shapes_vs_oracle(seed):
     assert bad.sum() <= max(3, 1e-3 * bad.size), (Hm, Wm, H, W, int(bad.sum()), float(np.abs(got - ref).max()))   # a sample on a texel edge may round across it
     gbad = np.abs(gm.grad.cpu().numpy()[0] - gref) > 1e-4 * max(np.abs(gref).max(), 1.0) + tol * np.abs(wts).max() * 4
     assert gbad.sum() <= max(6, 2e-3 * gbad.size), (Hm, Wm, H, W, int(gbad.sum()))
+
+
+def _env_cam(yaw, pitch, cid, W=640, H=400):
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    R = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    w2v = torch.eye(4); w2v[:3, :3] = torch.tensor(R, dtype=torch.float32)
+    return types.SimpleNamespace(FoVx=0.9, image_width=W, image_height=H, world_view_transform=w2v.cuda(), cam_id=cid)
+
+
+@pytest.mark.parametrize("fused_zero", [True, False])
+def test_sparse_gradient_protocol_equals_the_dense_path(fused_zero):
+    """EnvironmentMap(sparse_grad=True): the backward marks the optimizer's tiles and reuses the buffer the optimizer zeroes.  Over 9
+    steps and three cameras (one at the azimuth seam, whose workgroups take the direct-atomics path) the map and its moments equal,
+    bit for bit, those of a plain dense FusedAdam fed the SAME gradient tensors (the float atomics of two backward runs differ in
+    the last bit, and Adam with eps = 1e-15 is discontinuous at g = 0: the two paths are compared on identical gradients);
+    every tile holding a non-zero gradient is marked; a gradient that arrives summed with a second term (a new tensor) falls back
+    to the dense handling by itself."""
+    from adgs import env
+    from adgs.optim import FusedAdam, ADAM_TILE
+    e = env.EnvironmentMap(1024, 3, sparse_grad=True)
+    with torch.no_grad():
+        e.grid_map.copy_(torch.randn(e.grid_map.shape, generator=torch.Generator().manual_seed(1)).cuda() * 0.3)
+    e.training_setup(types.SimpleNamespace(env_lr=1e-2))
+    ref = torch.nn.Parameter(e.grid_map.detach().clone())
+    ref_opt = FusedAdam([{"params": [ref], "lr": 1e-2}], lr=0.0, eps=1e-15)
+    cams = [_env_cam(0.3, 0.05, 0), _env_cam(-0.2, -0.1, 1), _env_cam(np.pi / 2 + 1.57, 0.02, 2)]
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(3, 400, 640, generator=g).cuda() for _ in range(3)]
+    adopted = 0
+    for it in range(9):
+        bg = e.get_image_background(cams[it % 3])
+        loss = (bg * ws[it % 3]).sum()
+        if it == 6:
+            loss = loss + (e.grid_map ** 2).sum() * 1e-3          # a second gradient source: autograd hands over gg + other
+        loss.backward()
+        mg = e.optimizer.marked_gradient(e.grid_map)
+        own = e.grid_map.grad.data_ptr() == mg.live_ptr
+        assert own == (it != 6), it
+        adopted += own
+        ref.grad = e.grid_map.grad.detach().clone()
+        if own:          # every tile that holds a gradient is marked
+            nz = (ref.grad.reshape(-1, ADAM_TILE) != 0).any(1)
+            assert bool(mg.marks[nz].all()), it
+        if fused_zero:
+            e.optimizer.step(zero_grad=True)
+            buf = mg.buffer
+            assert (buf is not None) == own
+            if buf is not None:
+                assert float(buf.abs().max()) == 0.0      # handed back, all zero
+            del buf          # a second reference would make autograd clone the next gradient instead of adopting it (-> dense handling)
+        else:
+            e.optimizer.step()
+            e.optimizer.zero_grad(set_to_none=True)
+        ref_opt.step(zero_grad=True)
+        st, rst = e.optimizer.state[e.grid_map], ref_opt.state[ref]
+        assert torch.equal(e.grid_map.detach(), ref.detach()), it
+        assert torch.equal(st["exp_avg"], rst["exp_avg"]) and torch.equal(st["exp_avg_sq"], rst["exp_avg_sq"]), it
+    assert adopted == 8 and float(st["exp_avg"].abs().max()) > 0

@@ -195,16 +195,16 @@ def test_fused_adam_fuzz(seed):
 
 
 def test_dormant_tiles_are_skipped_exactly():
-    """skip_dormant_tiles: a tile of 4096 elements that has never seen a non-zero gradient is left untouched -- bit for bit what the
+    """skip_dormant_tiles: a tile of 256 elements (several kernel blocks, a partial last tile) that has never seen a non-zero gradient is left untouched -- bit for bit what the
     dense step does to it -- and wakes up for good with its first non-zero gradient; moments from elsewhere switch the shortcut off."""
     from adgs.optim import FusedAdam, ADAM_TILE
     torch.manual_seed(3)
-    n = 5 * ADAM_TILE + 123
+    n = 37 * ADAM_TILE + 123
     p0 = torch.randn(n, device="cuda")
     a = torch.nn.Parameter(p0.clone()); b = torch.nn.Parameter(p0.clone())
     oa = FusedAdam([{"params": [a], "lr": 1e-2}], eps=1e-15, skip_dormant_tiles=True)
     ob = FusedAdam([{"params": [b], "lr": 1e-2}], eps=1e-15)
-    touched = [set(), {1}, {1}, {1, 3}, {5}, set(), {3}]          # tiles with a non-zero gradient in step i
+    touched = [set(), {1}, {1}, {1, 3}, {5, 20}, set(), {3, 37}]          # tiles with a non-zero gradient in step i
     seen = set()
     for step, tiles in enumerate(touched):
         g = torch.zeros(n, device="cuda")
