@@ -122,10 +122,10 @@ def iteration(it, model, cams, env_map, clock, state):
     reg_loss = loss.reg_loss(model.xyz_deform_param, model.obj_near_idx)     # :101-103
     sigma_loss = loss.sigma_loss(model.gs_time_sigma, model.frame_gap)       # :105-107
     reg_sigma_loss = loss.reg_sigma_loss(model.gs_time_sigma, model.obj_near_idx)      # :108-110
-    total = (1.0 - opt.lambda_dssim) * opt.lambda_l1 * Ll1 + opt.lambda_dssim * dssim
-    total = total + depth_loss * opt.lambda_depth + flow_loss * opt.lambda_flow
-    total = total + sky_loss * opt.lambda_sky + obj_loss * opt.lambda_obj
-    total = total + sigma_loss * opt.lambda_sigma + reg_loss * opt.lambda_reg + reg_sigma_loss * opt.lambda_sigma_reg      # :112-115
+    # :112-115 -- the reference's chain of python scalar products and sums is ~40 launches of 2 - 4 us; same total in three
+    total = loss.weighted_total([((1.0 - opt.lambda_dssim) * opt.lambda_l1, Ll1), (opt.lambda_dssim, dssim), (opt.lambda_depth, depth_loss),
+                                 (opt.lambda_flow, flow_loss), (opt.lambda_sky, sky_loss), (opt.lambda_obj, obj_loss), (opt.lambda_sigma, sigma_loss),
+                                 (opt.lambda_reg, reg_loss), (opt.lambda_sigma_reg, reg_sigma_loss)])
     clock.mark("losses")
     total.backward()                                                         # :116
     clock.mark("backward")
