@@ -1,8 +1,11 @@
 // Fused L1 + SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward and backward for gfx950.
-// Reference: utils/loss_utils.py:20-68 (called at train.py:79-80).  One 16x16 output tile per workgroup:
-// the 26x26 input halo of both images is staged in LDS, the separable window runs as a horizontal pass
-// (into LDS) and a vertical pass (registers).  HBM-streaming: forward reads 8 B and writes 12 B per pixel,
-// backward reads 20 B and writes 4 B.
+// Reference: utils/loss_utils.py:20-68 (called at train.py:79-80).  One 32x16 output tile per workgroup:
+// the 42x26 input halo is staged in LDS, the separable window runs as a horizontal pass (into LDS) and a
+// vertical pass, both as SLIDING WINDOWS IN REGISTERS: a thread forms 4 neighbouring outputs of a row from
+// 14 inputs read as four 16-byte LDS words (instead of 4 x 11 scalar reads), and 2 outputs of a column from
+// 12 reads (instead of 22).  The 16x16-tile, one-output-per-thread form of round 2 was LDS-bound (11 reads
+// per output and pass, 2-way bank conflicts, one L2 round trip per staged element): 129 + 93 us per C3 frame;
+// now 99 + 75.  The arithmetic per output (tap order, fused multiply-adds) is unchanged.
 #include "common.h"
 #include "../../include/adgs_loss.h"
 #include <algorithm>
@@ -10,13 +13,17 @@
 namespace adgs {
 namespace {
 
-constexpr int TS = 16;                    // output tile edge
+constexpr int TSX = 32, TSY = 16;         // output tile
 constexpr int WR = 5;                     // window radius (11 taps)
-constexpr int HS = TS + 2 * WR;           // halo edge (26)
+constexpr int NT = 2 * WR + 1;
+constexpr int HSX = TSX + 2 * WR, HSY = TSY + 2 * WR;      // halo 42 x 26
+constexpr int SSTR = 44;                  // floats per staged row (16-byte aligned; 4 sx + 15 <= 43)
+constexpr int HSTR = TSX + 4;             // floats per row of the horizontally filtered images
+constexpr int LT = 256;                   // threads per workgroup
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 
 // gaussian(11, 1.5) of utils/loss_utils.py:26-28: exp(-(x-5)^2 / (2 sigma^2)) normalised by the sum (float32)
-struct Window { float g[2 * WR + 1]; };
+struct Window { float g[NT]; };
 static Window make_window() {
 	Window w; float s = 0.f;
 	for (int x = 0; x < 2 * WR + 1; x++) { w.g[x] = (float)std::exp(-(double)((x - WR) * (x - WR)) / (2.0 * 1.5 * 1.5)); s += w.g[x]; }
@@ -24,57 +31,119 @@ static Window make_window() {
 	return w;
 }
 
-__global__ void __launch_bounds__(TS * TS) l1_ssim_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Window win,
-	double* __restrict__ sums, float* __restrict__ d_mu1, float* __restrict__ d_e11, float* __restrict__ d_e12) {
-	__shared__ float s1[HS][HS + 1], s2[HS][HS + 1];
-	__shared__ float h[5][HS][TS + 1];              // horizontally filtered x1, x2, x1^2, x2^2, x1 x2
-	__shared__ double red[2][TS * TS / WAVE];
-	const int tx = threadIdx.x % TS, ty = threadIdx.x / TS, tid = threadIdx.x;
-	const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
-	const size_t plane = (size_t)blockIdx.z * H * W;
-	for (int i = tid; i < HS * HS; i += TS * TS) {
-		const int ly = i / HS, lx = i - ly * HS, gy = y0 + ly - WR, gx = x0 + lx - WR;
+// Staging of NA halo images at once: zero padding outside the image (F.conv2d padding=5).  All loads of a thread (5 per image, at
+// clamped addresses, unconditional) are issued before the first LDS store: a rolled loop of conditional loads paid one L2 round
+// trip per element and image -- the staging, not the window arithmetic, was what these kernels' time went into.
+template <int NA>
+__device__ __forceinline__ void stage_halos(float (*const (&s)[NA])[SSTR], const float* const (&src)[NA], size_t plane, int x0, int y0, int H, int W, int tid) {
+	constexpr int NIT = (HSY * HSX + LT - 1) / LT;
+	float v[NA][NIT];
+#pragma unroll
+	for (int it = 0; it < NIT; it++) {
+		const int i = min(tid + it * LT, HSY * HSX - 1);
+		const int ly = i / HSX, lx = i - ly * HSX;
+		const int gy = min(max(y0 + ly - WR, 0), H - 1), gx = min(max(x0 + lx - WR, 0), W - 1);
+#pragma unroll
+		for (int a = 0; a < NA; a++) v[a][it] = src[a][plane + (size_t)gy * W + gx];
+	}
+#pragma unroll
+	for (int it = 0; it < NIT; it++) {
+		const int i = tid + it * LT;
+		if (i >= HSY * HSX) break;
+		const int ly = i / HSX, lx = i - ly * HSX, gy = y0 + ly - WR, gx = x0 + lx - WR;
 		const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-		s1[ly][lx] = in ? img[plane + (size_t)gy * W + gx] : 0.f;      // zero padding (F.conv2d padding=5)
-		s2[ly][lx] = in ? gt[plane + (size_t)gy * W + gx] : 0.f;
+#pragma unroll
+		for (int a = 0; a < NA; a++) s[a][ly][lx] = in ? v[a][it] : 0.f;
+	}
+}
+// 16 consecutive floats of a staged row (14 are used) as four 16-byte LDS reads
+__device__ __forceinline__ void load_run(const float* row, float (&u)[16]) {
+	const float4* r = reinterpret_cast<const float4*>(row);
+#pragma unroll
+	for (int q = 0; q < 4; q++) { const float4 v = r[q]; u[4 * q] = v.x; u[4 * q + 1] = v.y; u[4 * q + 2] = v.z; u[4 * q + 3] = v.w; }
+}
+__device__ __forceinline__ float4 window4(const Window& win, const float (&u)[16]) {
+	float o[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		float a = 0.f;
+#pragma unroll
+		for (int k = 0; k < NT; k++) a += win.g[k] * u[j + k];
+		o[j] = a;
+	}
+	return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void __launch_bounds__(LT) l1_ssim_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Window win,
+	double* __restrict__ sums, float* __restrict__ d_mu1, float* __restrict__ d_e11, float* __restrict__ d_e12) {
+	__shared__ __attribute__((aligned(16))) float s1[HSY][SSTR], s2[HSY][SSTR];
+	__shared__ __attribute__((aligned(16))) float h[5][HSY][HSTR];      // horizontally filtered x1, x2, x1^2, x2^2, x1 x2
+	__shared__ double red[2][LT / WAVE];
+	const int tid = threadIdx.x;
+	const int x0 = blockIdx.x * TSX, y0 = blockIdx.y * TSY;
+	const size_t plane = (size_t)blockIdx.z * H * W;
+	{
+		float (*const dst[2])[SSTR] = { s1, s2 };
+		const float* const src[2] = { img, gt };
+		stage_halos<2>(dst, src, plane, x0, y0, H, W, tid);
 	}
 	__syncthreads();
-	for (int i = tid; i < HS * TS; i += TS * TS) {
-		const int ly = i / TS, lx = i - ly * TS;
-		float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+	{	// horizontal pass: row r, outputs 4 sx .. 4 sx + 3
+		const int r = tid >> 3, sx = tid & 7;
+		if (r < HSY) {
+			float u[16], v[16], t[16];
+			load_run(&s1[r][4 * sx], u); load_run(&s2[r][4 * sx], v);
+			*reinterpret_cast<float4*>(&h[0][r][4 * sx]) = window4(win, u);
+			*reinterpret_cast<float4*>(&h[1][r][4 * sx]) = window4(win, v);
 #pragma unroll
-		for (int k = 0; k < 2 * WR + 1; k++) {
-			const float w = win.g[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
-			a += w * u; b += w * v; aa += w * (u * u); bb += w * (v * v); ab += w * (u * v);
+			for (int i = 0; i < 16; i++) t[i] = u[i] * u[i];
+			*reinterpret_cast<float4*>(&h[2][r][4 * sx]) = window4(win, t);
+#pragma unroll
+			for (int i = 0; i < 16; i++) t[i] = v[i] * v[i];
+			*reinterpret_cast<float4*>(&h[3][r][4 * sx]) = window4(win, t);
+#pragma unroll
+			for (int i = 0; i < 16; i++) t[i] = u[i] * v[i];
+			*reinterpret_cast<float4*>(&h[4][r][4 * sx]) = window4(win, t);
 		}
-		h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
 	}
 	__syncthreads();
-	float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+	// vertical pass: column tx, outputs rows 2 g and 2 g + 1
+	const int tx = tid & (TSX - 1), g = tid >> 5;
+	float acc[5][2];
 #pragma unroll
-	for (int k = 0; k < 2 * WR + 1; k++) {
-		const float w = win.g[k];
-		mu1 += w * h[0][ty + k][tx]; mu2 += w * h[1][ty + k][tx]; e11 += w * h[2][ty + k][tx]; e22 += w * h[3][ty + k][tx]; e12 += w * h[4][ty + k][tx];
+	for (int q = 0; q < 5; q++) {
+		float c[NT + 1];
+#pragma unroll
+		for (int j = 0; j < NT + 1; j++) c[j] = h[q][2 * g + j][tx];
+#pragma unroll
+		for (int o = 0; o < 2; o++) {
+			float a = 0.f;
+#pragma unroll
+			for (int k = 0; k < NT; k++) a += win.g[k] * c[o + k];
+			acc[q][o] = a;
+		}
 	}
-	const int gx = x0 + tx, gy = y0 + ty;
-	const bool in = gx < W && gy < H;
 	double l1 = 0.0, sm = 0.0;
-	if (in) {
+#pragma unroll
+	for (int o = 0; o < 2; o++) {
+		const int ty = 2 * g + o, gx = x0 + tx, gy = y0 + ty;
+		if (gx >= W || gy >= H) continue;
+		const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
 		const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
 		const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
 		const float A1 = 2.f * mu12 + C1, A2 = 2.f * sg12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = sg1 + sg2 + C2;
 		const float D = B1 * B2, inv = 1.f / D;
-		sm = (double)((A1 * A2) * inv);
-		l1 = (double)fabsf(s1[ty + WR][tx + WR] - s2[ty + WR][tx + WR]);
+		sm += (double)((A1 * A2) * inv);
+		l1 += (double)fabsf(s1[ty + WR][tx + WR] - s2[ty + WR][tx + WR]);
 		if (d_mu1) {
-			const size_t o = plane + (size_t)gy * W + gx;
+			const size_t oo = plane + (size_t)gy * W + gx;
 			// partial derivatives of the map w.r.t. the window means mu1, E[x1^2], E[x1 x2] (mu2, E[x2^2] belong to gt)
 			const float num = A1 * A2;
 			const float dnum = 2.f * mu2 * A2 - 2.f * mu2 * A1;           // dA1 = 2 mu2, dA2 = -2 mu2
 			const float dden = 2.f * mu1 * B2 - 2.f * mu1 * B1;           // dB1 = 2 mu1, dB2 = -2 mu1
-			d_mu1[o] = (dnum * D - num * dden) * (inv * inv);
-			d_e11[o] = -num * inv / B2;                                   // dB2 = 1
-			d_e12[o] = 2.f * A1 * inv;                                    // dA2 = 2
+			d_mu1[oo] = (dnum * D - num * dden) * (inv * inv);
+			d_e11[oo] = -num * inv / B2;                                  // dB2 = 1
+			d_e12[oo] = 2.f * A1 * inv;                                   // dA2 = 2
 		}
 	}
 #pragma unroll
@@ -83,46 +152,65 @@ __global__ void __launch_bounds__(TS * TS) l1_ssim_fwd_kernel(int H, int W, cons
 	__syncthreads();
 	if (tid < 2) {
 		double t = 0.0;
-		for (int w = 0; w < TS * TS / WAVE; w++) t += red[tid][w];
+		for (int w = 0; w < LT / WAVE; w++) t += red[tid][w];
 		const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 		atomicAdd(sums + 2 * (b % ADGS_LOSS_SLOTS) + tid, t);
 	}
 }
 
-__global__ void __launch_bounds__(TS * TS) l1_ssim_bwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Window win,
+__global__ void __launch_bounds__(LT) l1_ssim_bwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, Window win,
 	const float* __restrict__ d_mu1, const float* __restrict__ d_e11, const float* __restrict__ d_e12,
 	const float* __restrict__ g_l1, const float* __restrict__ g_ssim, float inv_n, float* __restrict__ out) {
-	__shared__ float s[3][HS][HS + 1];
-	__shared__ float h[3][HS][TS + 1];
-	const int tx = threadIdx.x % TS, ty = threadIdx.x / TS, tid = threadIdx.x;
-	const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+	__shared__ __attribute__((aligned(16))) float s[3][HSY][SSTR];
+	__shared__ __attribute__((aligned(16))) float h[3][HSY][HSTR];
+	const int tid = threadIdx.x;
+	const int x0 = blockIdx.x * TSX, y0 = blockIdx.y * TSY;
 	const size_t plane = (size_t)blockIdx.z * H * W;
-	for (int i = tid; i < HS * HS; i += TS * TS) {
-		const int ly = i / HS, lx = i - ly * HS, gy = y0 + ly - WR, gx = x0 + lx - WR;
-		const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;        // map pixels outside the image do not exist: contribute 0
-		const size_t o = plane + (size_t)gy * W + gx;
-		s[0][ly][lx] = in ? d_mu1[o] : 0.f; s[1][ly][lx] = in ? d_e11[o] : 0.f; s[2][ly][lx] = in ? d_e12[o] : 0.f;
+	// map pixels outside the image do not exist: contribute 0
+	{
+		float (*const dst[3])[SSTR] = { s[0], s[1], s[2] };
+		const float* const src[3] = { d_mu1, d_e11, d_e12 };
+		stage_halos<3>(dst, src, plane, x0, y0, H, W, tid);
 	}
 	__syncthreads();
-	for (int i = tid; i < HS * TS; i += TS * TS) {
-		const int ly = i / TS, lx = i - ly * TS;
-		float a = 0.f, b = 0.f, c = 0.f;
+	{
+		const int r = tid >> 3, sx = tid & 7;
+		if (r < HSY) {
 #pragma unroll
-		for (int k = 0; k < 2 * WR + 1; k++) { const float w = win.g[k]; a += w * s[0][ly][lx + k]; b += w * s[1][ly][lx + k]; c += w * s[2][ly][lx + k]; }
-		h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
+			for (int q = 0; q < 3; q++) {
+				float u[16];
+				load_run(&s[q][r][4 * sx], u);
+				*reinterpret_cast<float4*>(&h[q][r][4 * sx]) = window4(win, u);
+			}
+		}
 	}
 	__syncthreads();
-	float a = 0.f, b = 0.f, c = 0.f;
+	const int tx = tid & (TSX - 1), g = tid >> 5;
+	float acc[3][2];
 #pragma unroll
-	for (int k = 0; k < 2 * WR + 1; k++) { const float w = win.g[k]; a += w * h[0][ty + k][tx]; b += w * h[1][ty + k][tx]; c += w * h[2][ty + k][tx]; }
-	const int gx = x0 + tx, gy = y0 + ty;
-	if (gx >= W || gy >= H) return;
-	const size_t o = plane + (size_t)gy * W + gx;
-	const float x1 = img[o], x2 = gt[o];
+	for (int q = 0; q < 3; q++) {
+		float c[NT + 1];
+#pragma unroll
+		for (int j = 0; j < NT + 1; j++) c[j] = h[q][2 * g + j][tx];
+#pragma unroll
+		for (int o = 0; o < 2; o++) {
+			float a = 0.f;
+#pragma unroll
+			for (int k = 0; k < NT; k++) a += win.g[k] * c[o + k];
+			acc[q][o] = a;
+		}
+	}
 	const float gs = g_ssim ? g_ssim[0] : 0.f, gl = g_l1 ? g_l1[0] : 0.f;
-	const float dx = x1 - x2;
-	const float sgn = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f);             // torch.abs backward: sign(), 0 at 0
-	out[o] = gl * sgn * inv_n + gs * inv_n * (a + 2.f * x1 * b + x2 * c);
+#pragma unroll
+	for (int o = 0; o < 2; o++) {
+		const int gx = x0 + tx, gy = y0 + 2 * g + o;
+		if (gx >= W || gy >= H) continue;
+		const size_t oo = plane + (size_t)gy * W + gx;
+		const float x1 = img[oo], x2 = gt[oo];
+		const float dx = x1 - x2;
+		const float sgn = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f);             // torch.abs backward: sign(), 0 at 0
+		out[oo] = gl * sgn * inv_n + gs * inv_n * (acc[0][o] + 2.f * x1 * acc[1][o] + x2 * acc[2][o]);
+	}
 }
 
 // ---------------------------------------------------------------- scale/shift-invariant depth loss
@@ -428,8 +516,8 @@ extern "C" int adgs_l1_ssim_forward(int planes, int H, int W, const float* image
 	if ((d_mu1 != nullptr) != (d_e11 != nullptr) || (d_mu1 != nullptr) != (d_e12 != nullptr)) { set_error("adgs_l1_ssim_forward: pass all three derivative maps or none"); return -1; }
 	if (planes > 65535) { set_error("adgs_l1_ssim_forward: more than 65535 planes"); return -1; }
 	static const Window win = make_window();
-	const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
-	hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(TS * TS), 0, (hipStream_t)stream, H, W, image, gt, win, sums, d_mu1, d_e11, d_e12);
+	const dim3 grid((W + TSX - 1) / TSX, (H + TSY - 1) / TSY, planes);
+	hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(LT), 0, (hipStream_t)stream, H, W, image, gt, win, sums, d_mu1, d_e11, d_e12);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -440,9 +528,9 @@ extern "C" int adgs_l1_ssim_backward(int planes, int H, int W, const float* imag
 	if (!image || !gt || !d_mu1 || !d_e11 || !d_e12 || !dL_dimage) { set_error("adgs_l1_ssim_backward: NULL pointer"); return -1; }
 	if (planes > 65535) { set_error("adgs_l1_ssim_backward: more than 65535 planes"); return -1; }
 	static const Window win = make_window();
-	const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+	const dim3 grid((W + TSX - 1) / TSX, (H + TSY - 1) / TSY, planes);
 	const float inv_n = (float)(1.0 / ((double)planes * H * W));
-	hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(TS * TS), 0, (hipStream_t)stream, H, W, image, gt, win, d_mu1, d_e11, d_e12, g_l1, g_ssim, inv_n, dL_dimage);
+	hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(LT), 0, (hipStream_t)stream, H, W, image, gt, win, d_mu1, d_e11, d_e12, g_l1, g_ssim, inv_n, dL_dimage);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
