@@ -60,7 +60,9 @@ __global__ void __launch_bounds__(256) cell_colscan_kernel(uint32_t* __restrict_
 	for (int b0 = 0; b0 < nblocks; b0 += 256 * 8) {
 		uint32_t v[8], sum = 0;
 #pragma unroll
-		for (int k = 0; k < 8; k++) { const int b = b0 + tid * 8 + k; v[k] = b < nblocks ? counts[(size_t)b * ncells + c] : 0u; sum += v[k]; }
+		for (int k = 0; k < 8; k++) v[k] = counts[(size_t)min(b0 + tid * 8 + k, nblocks - 1) * ncells + c];      // unconditional, clamped: all eight in flight
+#pragma unroll
+		for (int k = 0; k < 8; k++) { if (b0 + tid * 8 + k >= nblocks) v[k] = 0u; sum += v[k]; }
 		const uint32_t incl = wave_incl_scan_u32(sum, lane);
 		if (lane == WAVE - 1) s_w[wid] = incl;
 		__syncthreads();
@@ -114,10 +116,10 @@ __global__ void __launch_bounds__(256) cell_scatter_kernel(int P, const uint4* _
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (idx == 0) *pool_cursor = 0u;              // bookkeeping reset for the blend forward that follows on this stream
 	// this workgroup's slice of every cell's range: cell start + pairs of the workgroups before it (cell_colscan)
+	const uint4 d = dupinfo[min(idx, P - 1)];      // (rect min, rect max, depth bits, -): one coalesced 16-byte load, requested before the prologue's loads and its barrier
 	for (int c = threadIdx.x; c < ncells; c += 256) { s_cnt[c] = 0u; s_base[c] = cell_start[c] + counts[(size_t)blockIdx.x * ncells + c]; }
 	__syncthreads();
 	if (idx >= P) return;
-	const uint4 d = dupinfo[idx];                  // (rect min, rect max, depth bits, -): one coalesced 16-byte load
 	const uint32_t minx = d.x & 0xFFFFu, miny = d.x >> 16, maxx = d.y & 0xFFFFu, maxy = d.y >> 16;
 	if (maxx <= minx || maxy <= miny) return;
 	const uint32_t c0x = minx / cell_tiles, c1x = (maxx - 1) / cell_tiles, c0y = miny / cell_tiles, c1y = (maxy - 1) / cell_tiles;

@@ -101,9 +101,15 @@ __global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* 
 		__syncthreads();
 		if (valid) {
 			const int lx = t.x0 - minx, ly = t.y0 - miny;
-			for (int c = 0; c < a.C; c++) {
-				const float b = bg[(size_t)c * a.H * a.W + o];
-				const float gr = g_bg[(size_t)c * a.H * a.W + o] * (b * (1.f - b));
+			// all channel loads first (a rolled loop over a run-time C pays one round trip per channel before its four LDS atomics)
+			float bv[MAXC], gv[MAXC];
+#pragma unroll
+			for (int c = 0; c < MAXC; c++) { const size_t oc = (size_t)min(c, a.C - 1) * a.H * a.W + o; bv[c] = bg[oc]; gv[c] = g_bg[oc]; }
+#pragma unroll
+			for (int c = 0; c < MAXC; c++) {
+				if (c >= a.C) break;
+				const float b = bv[c];
+				const float gr = gv[c] * (b * (1.f - b));
 				float* acc = s_acc + c * TEXCAP;
 				if (t.ok[0]) atomicAdd(acc + ly * fw + lx, gr * t.w[0]);
 				if (t.ok[1]) atomicAdd(acc + ly * fw + lx + 1, gr * t.w[1]);

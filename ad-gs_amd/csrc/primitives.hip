@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(SPB) sort_hist_kernel(const KeyT* __restrict__
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const size_t i = tile0 + (size_t)r * SPB + tid;
-		kk[r] = i < n ? keys[i] : (KeyT)0;
+		kk[r] = keys[min(i, n ? n - 1 : (size_t)0)];      // unconditional, clamped (the buffer holds at least one key): all loads of the thread in flight
 	}
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(256) sort_row_scan_kernel(uint32_t* __restrict
 	for (uint32_t base = 0; base < nblocks; base += 8 * WAVE) {
 		uint32_t v[8];
 #pragma unroll
-		for (int k = 0; k < 8; k++) { const uint32_t i = base + k * WAVE + lane; v[k] = i < nblocks ? h[i] : 0u; }
+		for (int k = 0; k < 8; k++) v[k] = h[min(base + k * WAVE + lane, nblocks - 1)];
+#pragma unroll
+		for (int k = 0; k < 8; k++) if (base + k * WAVE + lane >= nblocks) v[k] = 0u;
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
 			const uint32_t i = base + k * WAVE + lane;
@@ -239,9 +241,9 @@ __global__ void __launch_bounds__(SPB) sort_scatter_kernel(const KeyT* __restric
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const size_t i = tile0 + (size_t)r * SPB + tid;
-		const bool valid = i < n;
-		keys[r] = valid ? keys_in[i] : (KeyT)0;
-		vals[r] = valid ? vals_in[i] : 0u;
+		const size_t ic = min(i, n ? n - 1 : (size_t)0);      // unconditional, clamped: all loads of the thread in flight
+		keys[r] = keys_in[ic];
+		vals[r] = vals_in[ic];
 	}
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {

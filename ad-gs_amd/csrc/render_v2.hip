@@ -872,7 +872,9 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t*
 	const bool fits = T <= 1024 * PER;
 	if (fits) {
 #pragma unroll
-		for (int k = 0; k < PER; k++) { const int t = tid + k * 1024; b[k] = t < T ? (uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1)) : 0xffffffffu; }
+		for (int k = 0; k < PER; k++) b[k] = consumed[min(tid + k * 1024, T - 1)];      // unconditional, clamped: all loads in flight (a load under `t < T ?` waits at the end of its own exec-masked block)
+#pragma unroll
+		for (int k = 0; k < PER; k++) b[k] = tid + k * 1024 < T ? (uint32_t)(NB - 1) - min(b[k], (uint32_t)(NB - 1)) : 0xffffffffu;
 #pragma unroll
 		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) atomicAdd(&hist[b[k]], 1u);
 	} else {
