@@ -101,6 +101,14 @@ class StageClock:
         return {k: round(v / n, 4) for k, v in tot.items()}
 
 
+def densify_threshold(model):
+    """A gradient threshold that clones / splits ~0.1 % of the Gaussians on this synthetic scene (the reference's thresholds are tuned to real
+    data, arguments/__init__.py:118-119): the 99.9 % quantile of the accumulated statistics.  One-off (a torch sort + a host read)."""
+    import torch
+    g = (model.xyz_gradient_accum / model.denom.clamp_min(1)).reshape(-1)
+    return float(torch.quantile(g[g > 0][:2_000_000], 0.999)) if bool((g > 0).any()) else 1.0
+
+
 def iteration(it, model, cams, env_map, clock, state):
     import torch
     from adgs import loss
@@ -137,8 +145,7 @@ def iteration(it, model, cams, env_map, clock, state):
         n = it + 1
         if n % opt.densification_interval == 0:                              # :152-153
             if state.get("thr") is None:
-                g = (model.xyz_gradient_accum / model.denom.clamp_min(1)).reshape(-1)
-                state["thr"] = float(torch.quantile(g[g > 0][:2_000_000], 0.999)) if bool((g > 0).any()) else 1.0      # ~0.1 % clone / split
+                state["thr"] = densify_threshold(model)
             model.densify_and_prune(state["thr"], state["thr"], 0.005, False)
             state["densified"] = state.get("densified", 0) + 1
         elif model.use_near_idx and n % opt.near_idx_reset_interval == 0:    # :154-155
@@ -160,6 +167,7 @@ def run(config="C3", iters=60, env_res=8192, cameras=16, warm=12, device=None, s
     off = StageClock(False)
     for i in range(warm):
         iteration(i, model, cams, env_map, off, state)
+    state["thr"] = densify_threshold(model)          # from the warm-up's statistics: not part of an iteration
     torch.cuda.synchronize()
     clock = StageClock(stages)
     t0 = time.perf_counter()
