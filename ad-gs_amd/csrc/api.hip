@@ -209,6 +209,7 @@ StageTimer::~StageTimer() {
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
 static std::atomic<size_t> g_hint_cells{0}, g_hint_fine{0};      // speculative binning capacities (v2 forward)
+static std::atomic<unsigned> g_hint_max_cell_chunks{0};            // chunks of the fullest cell of the last bucket-binned frame
 static std::atomic<long long> g_reruns{0};                       // forwards whose capacity was too small (binning + blend enqueued twice)
 static uint32_t* pinned_word() {
 	static thread_local uint32_t* p = nullptr;
@@ -284,7 +285,7 @@ __global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, 
 		const uint32_t total = *total_cells;
 		const uint32_t over = (total > cap_cells || f > cap_fine) ? 1u : 0u;      // the launches queued against the capacity must not blend
 		*overflow_flag = over;
-		box->r_cells = total; box->r_fine = f; box->oversize = 0u; box->n_groups = 0u; box->overflow = over;
+		box->r_cells = total; box->r_fine = f; box->oversize = 0u; box->n_groups = 0u; box->overflow = over; box->max_cell_chunks = 0u;
 		if (over) box->overflow_count = box->overflow_count + 1u;
 		__threadfence_system();
 		box->seq = seq;                       // published last: the host spins on it
@@ -401,7 +402,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const char* binning_env = getenv("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
-			(binning_mode == "bucket" || g_hint_cells.load() <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells);
+			(binning_mode == "bucket" || (g_hint_cells.load() <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells &&
+			                              g_hint_max_cell_chunks.load() <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));      // ... or ONE cell held more than 16 chunks
 		size_t gb = 0, ib = 0;
 		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] exists for bucket binning only
 		GeomStateV2::carve(nullptr, P, &gb, count_cells);
@@ -590,6 +592,10 @@ static int raster_forward_impl(const ShSource* sh_src,
 			const size_t old_c = g_hint_cells.load(), old_f = g_hint_fine.load();
 			g_hint_cells.store(std::max(want_c, old_c - old_c / 16));
 			g_hint_fine.store(std::max(want_f, old_f - old_f / 16));
+			// the fullest cell of a bucket-binned frame; a sorted frame does not report one: the old figure decays, so that a scene
+			// with a persistent hot cell re-tries the bucket path once in a few dozen frames instead of every other frame
+			const unsigned old_m = g_hint_max_cell_chunks.load();
+			g_hint_max_cell_chunks.store(std::max(buckets ? mb->host->max_cell_chunks : 0u, old_m - std::max(1u, old_m / 16) * (old_m ? 1u : 0u)));
 		}
 		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = buckets ? 32 : 32 + bit;
 		g_stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
@@ -1012,7 +1018,7 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 	}
 }
 extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
-	g_hint_cells.store((size_t)std::max(0ll, pairs)); g_hint_fine.store((size_t)std::max(0ll, fine_pairs));
+	g_hint_cells.store((size_t)std::max(0ll, pairs)); g_hint_fine.store((size_t)std::max(0ll, fine_pairs)); g_hint_max_cell_chunks.store(0u);
 }
 extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
 extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {

@@ -88,6 +88,18 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 	const uint32_t start = block_excl_scan_1024(n, s_wave, &total);
 	const uint32_t nch = (n + GS_NMAX - 1) / GS_NMAX;
 	const uint32_t g0 = block_excl_scan_1024(nch, s_wave, &nchunks_total);
+	// the fullest cell (chunks): a cell of k chunks pays k - 1 rank searches per entry in the merge, so ONE hot cell (a close-up object)
+	// is a cliff the average does not show; the host keeps the next frames of such a scene on the device-wide sort (api.hip)
+	__shared__ uint32_t s_maxch;
+	if (c == 0) s_maxch = 0u;
+	__syncthreads();
+	{
+		uint32_t m = nch;
+#pragma unroll
+		for (int off = WAVE / 2; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, WAVE));
+		if ((c & (WAVE - 1)) == 0) atomicMax(&s_maxch, m);
+	}
+	__syncthreads();
 	if (c < a.ncells) {
 		a.cell_start[c] = start;
 		a.cell_ranges[c] = make_uint2(start, start + n);
@@ -102,7 +114,7 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 		// the binning and blend launches behind this one were enqueued against a capacity: do the totals fit?
 		const uint32_t nofit = (over || total > a.cap_cells || fine > a.cap_fine) ? 1u : 0u;
 		a.d_counts[0] = total; a.d_counts[1] = nchunks_total; a.d_counts[2] = over; a.d_counts[3] = nofit;
-		a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit;
+		a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit; a.box->max_cell_chunks = s_maxch;
 		if (nofit) a.box->overflow_count = a.box->overflow_count + 1u;
 		__threadfence_system();
 		a.box->seq = a.seq;                       // published last: the host spins on it

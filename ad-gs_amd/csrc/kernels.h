@@ -102,7 +102,7 @@ constexpr int GS_NMAX = 8192;           // entries one chunk_sort workgroup sort
 constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
 // overflow: the totals exceed the capacity the frame's launches were enqueued against; overflow_count: such frames since the mailbox exists
-struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count; };
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks; };      // max_cell_chunks: bucket binning, the fullest cell's chunks
 struct CellScanArgs {
 	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
 	uint32_t* cell_start;               // [ncells + 1]

@@ -104,6 +104,33 @@ def test_cells_with_several_chunks():
     assert st["bucket_binning"] == 1 and st["num_rendered"] > 3 * 8192
 
 
+def test_a_hot_cell_moves_the_next_frames_to_the_device_wide_sort(monkeypatch):
+    """The merge of a cell costs (chunks - 1) rank searches per entry: a frame whose FULLEST cell held more than
+    ADGS_BUCKET_MAX_CELL_CHUNKS chunks (default 16; 3 here, the cell holds 5 or more) sends the following frames to the device-wide
+    sort although the average per cell is small; the figure decays, so the bucket path is tried again later.  Same images either way."""
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+    monkeypatch.delenv("ADGS_BINNING")                     # the library's own choice, not the fixture's
+    monkeypatch.setenv("ADGS_BUCKET_MAX_CELL_CHUNKS", "3")
+    sc = synthetic.make_scene(45000, 512, 384, 480.0, seed=48, scale_mult=0.0008, near_frac=0.0)
+    m = sc["means3D"].clone()                              # everything into the top-left 128-pixel cell of the 4 x 3 cell grid:
+    z = m[:, 2]                                            # the average per cell stays below one chunk, that cell holds five
+    m[:, 0] = z * sc["tanfovx"] * (-0.76 + 0.2 * m[:, 0] / (1.1 * z * sc["tanfovx"]))
+    m[:, 1] = z * sc["tanfovy"] * (-0.68 + 0.25 * m[:, 1] / (1.1 * z * sc["tanfovy"]))
+    sc["means3D"] = m.contiguous(); sc["flow_points"] = m.clone()
+    sc["opacities"] = (sc["opacities"] * 0.08 + 0.01).contiguous()
+    a = run_hip(sc)
+    assert _stats()["bucket_binning"] == 1 and _stats()["num_rendered"] > 4 * 8192                # nothing known about the scene yet
+    b = run_hip(sc)
+    assert _stats()["bucket_binning"] == 0                 # the fullest cell of the previous frame had >= 5 chunks
+    for k in ("color", "depth", "img_opacity"):
+        assert torch.equal(a[k], b[k]), k
+    paths = []
+    for _ in range(8):
+        run_hip(sc); paths.append(_stats()["bucket_binning"])
+    assert 1 in paths and paths.count(0) >= 3, paths       # 5 -> 4 -> 3: the bucket path is tried again, found hot again
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+
+
 def test_chunk_table_overflow_falls_back_to_the_device_wide_sort(monkeypatch):
     """More chunks than the chunk table holds (134 M pairs in production; forced here with a 3-entry table): cell_scan flags the
     overflow, the host re-bins the frame with the device-wide radix sort, and the result still matches the oracle."""
