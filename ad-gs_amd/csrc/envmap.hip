@@ -99,22 +99,44 @@ __global__ void __launch_bounds__(256) envmap_bwd_kernel(EnvCam a, const float* 
 		const int ntex = fw * fh;
 		for (int c = 0; c < a.C; c++) for (int i = tid; i < ntex; i += 256) s_acc[c * TEXCAP + i] = 0.f;
 		__syncthreads();
-		if (valid) {
+		{
+			// Neighbouring pixels of a row (lanes 2j, 2j+1) land in the same or in adjacent texel columns (~1.6 pixels per texel at
+			// C3): the pair's contributions to a shared texel are summed in registers and issued once -- LDS float atomics retire about
+			// one LANE per cycle and CU and were 120 of this kernel's 190 us.  Same column: the even lane issues all four taps of
+			// both pixels; adjacent column: the even lane takes the odd lane's left taps into its right ones (8 -> 6 atomics).
 			const int lx = t.x0 - minx, ly = t.y0 - miny;
-			// all channel loads first (a rolled loop over a run-time C pays one round trip per channel before its four LDS atomics)
+			const int kx = valid ? t.x0 : -0x40000000, ky = valid ? t.y0 : -0x40000000;       // an invalid pixel pairs with nobody
+			const int px_ = __shfl_xor(kx, 1, WAVE), py_ = __shfl_xor(ky, 1, WAVE);
+			const bool odd = tid & 1;
+			const int ex = odd ? px_ : kx, ey = odd ? py_ : ky, ox = odd ? kx : px_, oy = odd ? ky : py_;      // the pair's even / odd pixel
+			const bool both = ex > -0x40000000 && ox > -0x40000000 && ey == oy;
+			const bool same = both && ox == ex, adj = both && ox == ex + 1;
+			// all channel loads first (a rolled loop over a run-time C pays one round trip per channel before its LDS atomics)
 			float bv[MAXC], gv[MAXC];
 #pragma unroll
-			for (int c = 0; c < MAXC; c++) { const size_t oc = (size_t)min(c, a.C - 1) * a.H * a.W + o; bv[c] = bg[oc]; gv[c] = g_bg[oc]; }
+			for (int c = 0; c < MAXC; c++) { const size_t oc = (size_t)min(c, a.C - 1) * a.H * a.W + (valid ? o : 0); bv[c] = bg[oc]; gv[c] = g_bg[oc]; }
 #pragma unroll
 			for (int c = 0; c < MAXC; c++) {
 				if (c >= a.C) break;
 				const float b = bv[c];
-				const float gr = gv[c] * (b * (1.f - b));
+				const float gr = valid ? gv[c] * (b * (1.f - b)) : 0.f;
+				float v0 = t.ok[0] && valid ? gr * t.w[0] : 0.f, v1 = t.ok[1] && valid ? gr * t.w[1] : 0.f;
+				float v2 = t.ok[2] && valid ? gr * t.w[2] : 0.f, v3 = t.ok[3] && valid ? gr * t.w[3] : 0.f;
+				const float p0 = __shfl_xor(v0, 1, WAVE), p1 = __shfl_xor(v1, 1, WAVE), p2 = __shfl_xor(v2, 1, WAVE), p3 = __shfl_xor(v3, 1, WAVE);
+				bool i0 = t.ok[0], i1 = t.ok[1], i2 = t.ok[2], i3 = t.ok[3];          // which of its taps this lane issues
+				if (!odd) {
+					if (same) { v0 += p0; v1 += p1; v2 += p2; v3 += p3; }
+					else if (adj) { v1 += p0; v3 += p2; }
+				} else {
+					if (same) i0 = i1 = i2 = i3 = false;
+					else if (adj) i0 = i2 = false;
+				}
+				if (!valid) continue;
 				float* acc = s_acc + c * TEXCAP;
-				if (t.ok[0]) atomicAdd(acc + ly * fw + lx, gr * t.w[0]);
-				if (t.ok[1]) atomicAdd(acc + ly * fw + lx + 1, gr * t.w[1]);
-				if (t.ok[2]) atomicAdd(acc + (ly + 1) * fw + lx, gr * t.w[2]);
-				if (t.ok[3]) atomicAdd(acc + (ly + 1) * fw + lx + 1, gr * t.w[3]);
+				if (i0) atomicAdd(acc + ly * fw + lx, v0);
+				if (i1) atomicAdd(acc + ly * fw + lx + 1, v1);
+				if (i2) atomicAdd(acc + (ly + 1) * fw + lx, v2);
+				if (i3) atomicAdd(acc + (ly + 1) * fw + lx + 1, v3);
 			}
 		}
 		__syncthreads();
