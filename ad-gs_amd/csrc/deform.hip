@@ -462,6 +462,40 @@ __global__ void __launch_bounds__(256) deform_shs_fwd_kernel(ShsFwdArgs a) {
 	else { for (int k = 0; k < 4; k++) if (e0 + k < total) a.out[e0 + k] = v[k]; }
 }
 
+// M = 16 (the reference's max_sh_degree 3): coefficient 0 is written by the sh0 kernel with a 48-float stride; this kernel moves the 45 floats of
+// `rest` per Gaussian -- one thread per 16-byte word of the output, constant divisions, consecutive lanes on consecutive addresses on both
+// sides.  (The generic kernel above computes e / row and e % row with run-time divisors per ELEMENT and evaluates f_shs in every 12th lane:
+// 328 us at C3 for 372 MB.)
+__global__ void __launch_bounds__(256) shs_rest_interleave_kernel(int Ns, int N, const float* __restrict__ scene_rest, const float* __restrict__ obj_rest, float* __restrict__ out) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)N * 12) return;
+	const int n = (int)(i / 12), q = (int)(i - (size_t)n * 12);
+	const bool is_obj = n >= Ns;
+	const float* r = (is_obj ? obj_rest : scene_rest) + (size_t)(is_obj ? n - Ns : n) * 45;
+	float* o = out + (size_t)n * 48 + 4 * q;
+	if (q == 0) { o[3] = r[0]; return; }
+	const float a = r[4 * q - 3], b = r[4 * q - 2], c = r[4 * q - 1], d = r[4 * q];
+	*reinterpret_cast<float4*>(o) = make_float4(a, b, c, d);
+}
+// the inverse for the gradient [N,16,3] -> dc / rest gradients
+__global__ void __launch_bounds__(256) shs_grad_split_kernel(int Ns, int N, const float* __restrict__ g, float* __restrict__ g_scene_dc, float* __restrict__ g_obj_dc,
+	float* __restrict__ g_scene_rest, float* __restrict__ g_obj_rest) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)N * 12) return;
+	const int n = (int)(i / 12), q = (int)(i - (size_t)n * 12);
+	const bool is_obj = n >= Ns;
+	const size_t m = is_obj ? n - Ns : n;
+	const float4 v = *reinterpret_cast<const float4*>(g + (size_t)n * 48 + 4 * q);
+	float* rest = is_obj ? g_obj_rest : g_scene_rest;
+	if (q == 0) {
+		float* dc = is_obj ? g_obj_dc : g_scene_dc;
+		if (dc) { dc[3 * m] = v.x; dc[3 * m + 1] = v.y; dc[3 * m + 2] = v.z; }
+		if (rest) rest[m * 45] = v.w;
+		return;
+	}
+	if (rest) { float* r = rest + m * 45 + 4 * q - 3; r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+}
+
 struct ShsBwdArgs {
 	int Ns, N, M;
 	const float* g;                                   // [N, M, 3]
@@ -853,7 +887,7 @@ namespace {
 // words -- consecutive threads own consecutive rows, so the loads are perfectly coalesced without any staging -- and dots
 // with the dense basis vector (zero where the family has no term).  General kernel: rows staged through LDS.
 template <int NV4>
-__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero) {
+__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero, int ostride) {
 	__shared__ float s_w[NV4 * 4];
 	if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;      // counters the next kernel accumulates into (saves a memset launch)
 	__shared__ float s_part[256 * NV4 + 4];
@@ -896,7 +930,8 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 			float acc = 0.f;
 #pragma unroll
 			for (int k = 0; k < NV4; k++) acc += s_part[threadIdx.x * NV4 + k];
-			out[e0 + threadIdx.x] = dc + acc;
+			const int e = e0 + threadIdx.x, n = e / 3;
+			out[(size_t)n * ostride + (e - 3 * n)] = dc + acc;      // ostride = 3: the compact [N,3] array; 3 M: coefficient 0 inside [N,M,3]
 		}
 		return;
 	}
@@ -917,9 +952,9 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 		for (int k = 0; k < NV4; k++) acc += q[k].x * s_w[4 * k] + q[k].y * s_w[4 * k + 1] + q[k].z * s_w[4 * k + 2] + q[k].w * s_w[4 * k + 3];
 		v = v + acc;
 	}
-	out[e] = v;
+	out[(size_t)n * ostride + (e - 3 * n)] = v;
 }
-__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero) {
+__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero, int ostride) {
 	extern __shared__ float s_rows[];
 	if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
 	const int tid = threadIdx.x, B = blockDim.x, base = blockIdx.x * B, count = min(B, N - base);
@@ -939,7 +974,7 @@ __global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __re
 	for (int c = 0; c < 3; c++) {
 		float v = dc[c];
 		if (has_row) v = v + lin_eval(s_rows + tid * stride + c * np, s.f);
-		out[3 * (size_t)n + c] = v;
+		out[(size_t)ostride * n + c] = v;
 	}
 }
 } // namespace
@@ -954,7 +989,7 @@ static int pick_block(int row_floats, size_t* lds) {
 	return 64;
 }
 
-int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words, int n_zero) {
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words, int n_zero, int ostride) {
 	if (N <= 0) return 0;
 	const int np = s.f.n_params;
 	const bool lin = (s.scene_sp || s.obj_sp) && (s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2]) > 0 && np > 0;
@@ -962,14 +997,14 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_
 	if (lin && np % 4 == 0 && np <= 32 && aligned) {
 		const unsigned blocks = (unsigned)(((size_t)N * 3 + 255) / 256);
 		switch (np / 4) {
-			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
-			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero); break;
+			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
 		}
 		ADGS_HIP_CHECK(hipGetLastError());
 		return 0;
@@ -978,7 +1013,7 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_
 	const int B = pick_block((3 * np) | 1, &lds);
 	if (lds > MAX_STAGING_LDS) { set_error("launch_sh0: SH deformation rows too large for the LDS staging buffer (more than 207 parameters per channel)"); return -1; }
 	if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out, zero_words, n_zero);
+	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out, zero_words, n_zero, ostride);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -1098,7 +1133,16 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 		sa.scene_dc = p->scene_shs_dc; sa.obj_dc = p->obj_shs_dc; sa.scene_rest = p->scene_shs_rest; sa.obj_rest = p->obj_shs_rest;
 		sa.sp_scene = p->shs_deform_param_scene; sa.sp_obj = p->shs_deform_param_obj; sa.fs = fs; sa.out = shs_out;
 		const size_t quads = ((size_t)N * p->sh_coeffs * 3 + 3) / 4;
-		hipLaunchKernelGGL(deform_shs_fwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, sa);
+		if (p->sh_coeffs == 16 && (reinterpret_cast<uintptr_t>(shs_out) & 15) == 0 && (sa.scene_dc || sa.obj_dc)) {
+			ShSource src;
+			memset(&src, 0, sizeof(src));
+			src.Ns = sa.Ns; src.scene_dc = sa.scene_dc ? sa.scene_dc : sa.obj_dc; src.obj_dc = sa.obj_dc ? sa.obj_dc : sa.scene_dc;
+			src.scene_sp = sa.sp_scene; src.obj_sp = sa.sp_obj; src.f = fs;
+			if (launch_sh0(N, src, shs_out, stream, nullptr, 0, 48) != 0) return -1;
+			hipLaunchKernelGGL(shs_rest_interleave_kernel, dim3((unsigned)(((size_t)N * 12 + 255) / 256)), dim3(256), 0, stream, sa.Ns, N, sa.scene_rest, sa.obj_rest, shs_out);
+		} else {
+			hipLaunchKernelGGL(deform_shs_fwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, sa);
+		}
 		ADGS_HIP_CHECK(hipGetLastError());
 	}
 	return 0;
@@ -1158,7 +1202,10 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 		sb.Ns = p->Ns; sb.N = N; sb.M = M; sb.g = dL_dshs;
 		sb.g_scene_dc = grads->scene_shs_dc; sb.g_obj_dc = grads->obj_shs_dc; sb.g_scene_rest = grads->scene_shs_rest; sb.g_obj_rest = grads->obj_shs_rest;
 		const size_t tot = (size_t)N * M * 3;
-		hipLaunchKernelGGL(deform_shs_bwd_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, sb);
+		if (M == 16 && (reinterpret_cast<uintptr_t>(dL_dshs) & 15) == 0)
+			hipLaunchKernelGGL(shs_grad_split_kernel, dim3((unsigned)(((size_t)N * 12 + 255) / 256)), dim3(256), 0, stream, sb.Ns, N, dL_dshs, sb.g_scene_dc, sb.g_obj_dc, sb.g_scene_rest, sb.g_obj_rest);
+		else
+			hipLaunchKernelGGL(deform_shs_bwd_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, sb);
 		ADGS_HIP_CHECK(hipGetLastError());
 		for (int part = 0; part < 2; part++) {
 			float* out = part == 0 ? grads->shs_deform_param_scene : grads->shs_deform_param_obj;

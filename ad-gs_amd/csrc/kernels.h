@@ -182,7 +182,7 @@ int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* 
 int launch_lin_param_grad2(int count_a, const float* g_a, float* out_a, int count_b, const float* g_b, float* out_b, int D, int gstride,
 	const adgs_func_eval& f, hipStream_t stream);
 // sh0[N,3] = dc + f_shs(t); optionally zeroes n_zero 32-bit words for the next kernel's counters
-int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words = nullptr, int n_zero = 0);
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words = nullptr, int n_zero = 0, int ostride = 3);      // ostride: floats per Gaussian in `out`
 inline bool has_lin_host(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0 && f.n_params > 0; }
 
 int knn_run(int P, const float* points, float* meanDists, char* workspace, hipStream_t stream);
