@@ -13,6 +13,7 @@
 #include <vector>
 #include <cstdlib>
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace adgs {
@@ -175,9 +176,13 @@ static bool use_v2(int D_S) {
 // ADGS_V2_PPL=2|4 overrides; forward and backward of a frame must see the same value.
 // Edge of a coarse cell in 16x16 tiles.  Larger cells mean fewer (cell, Gaussian) pairs to sort but longer candidate lists for
 // every tile to filter; measured on MI355X (frames/s, cell edge 8 / 10 / 12 tiles): C3 1920x1280 (9600 tiles) 636 / 640 / 643,
-// C5 395 / 400 / 405, C2 1242x375 (1872 tiles) 1324 / 1279 / 1152 -- so 12 for large tile grids, 8 otherwise.
+// C5 395 / 400 / 405, C2 1242x375 (1872 tiles) 1324 / 1279 / 1152 -- so 12 for large tile grids (round 1, device-wide sort).
+// Re-measured in round 3 with bucket binning (the cells' lists are sorted inside the CUs: more, smaller cells cost little): C2 cell edge
+// 8 / 6 / 5 / 4 / 3: binning 73 / 66 / 60 / 56 / 51 us, forward 138 / 131 / 128 / 126 / 127 us; C1 as graph replays 10 380 / 10 790 / - / 10 980
+// frames/s; C3 12 / 10 / 8: 857 / 860 / 826 frames/s.  Small tile grids therefore aim at ~110 cells.
 static int v2_cell_tiles(size_t ntiles16) {
-	return std::max(1, env_int("ADGS_CELL_TILES", ntiles16 >= 4096 ? 12 : 8));
+	const int small = std::min(8, std::max(3, (int)std::lround(std::sqrt((double)ntiles16 / 110.0))));
+	return std::max(1, env_int("ADGS_CELL_TILES", ntiles16 >= 4096 ? 12 : small));
 }
 static int v2_pixels_per_lane(size_t ntiles16) {
 	const int e = env_int("ADGS_V2_PPL", 0);

@@ -17,10 +17,14 @@ def _stats():
 
 
 @pytest.fixture(autouse=True)
-def _force_bucket_binning(monkeypatch):
+def _force_bucket_binning(monkeypatch, request):
     """The library picks bucket or sort binning from the previous frames' pair count (cells of many chunks favour the sort);
-    these tests exercise the bucket path on purpose, whatever ran before them."""
+    these tests exercise the bucket path on purpose, whatever ran before them.  Their small images are built to fill ONE 128-pixel
+    cell with several chunks: the cell edge is pinned to the 8 tiles they were designed for (the library's own choice for small
+    tile grids is ~110 cells per image since round 3); the C5-size test keeps the library's choice."""
     monkeypatch.setenv("ADGS_BINNING", "bucket")
+    if "c5_size" not in request.node.name:
+        monkeypatch.setenv("ADGS_CELL_TILES", "8")
 
 
 def test_default_is_bucket_binning_and_equals_sort_binning_bit_for_bit(monkeypatch):
