@@ -112,7 +112,7 @@ class FrameStatus(ctypes.Structure):
     """adgs_frame_status (include/adgs_rasterizer.h)."""
     _fields_ = [("pairs", ctypes.c_int64), ("fine_pairs", ctypes.c_int64), ("capacity_pairs", ctypes.c_int64),
                 ("capacity_fine_pairs", ctypes.c_int64), ("overflow_count", ctypes.c_int64), ("eager_reruns", ctypes.c_int64),
-                ("overflow", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("overflow", ctypes.c_int32), ("reserved", ctypes.c_int32), ("unrepaired_overflow_count", ctypes.c_int64)]
 
 
 def lib():

@@ -10,6 +10,8 @@ tens of microseconds of GPU work under 0.3 ms of Python) needs, and what removes
     step = GraphedStep(fn)        # fn(): forward + backward on STATIC inputs (parameters, camera, upstream gradients in place)
     step()                        # replay
     step.validate()               # after a synchronisation: did every replay since the last check fit its capacity?
+                                  # A replay that did not fit is a defined EMPTY render (background colour, no gradients); validate
+                                  # BEFORE the optimizer consumes its gradients, or use step.checked() which does both.
 
 Rules (torch.cuda.graphs): nothing may keep the autograd graph of an EARLIER eager call of fn alive (a retained loss or output
 with a grad_fn pins the leaves' AccumulateGrad nodes to the stream of that call, and the capture then crosses streams: detach
@@ -46,7 +48,7 @@ class GraphedStep:
         with torch.cuda.graph(self.graph, pool=self._pool):
             self.result = self.fn()
         torch.cuda.synchronize()
-        self._seen_overflows = _lib.frame_status()["overflow_count"]
+        self._seen_overflows = _lib.frame_status()["unrepaired_overflow_count"]
 
     def pool(self):
         return self.graph.pool()
@@ -55,13 +57,19 @@ class GraphedStep:
         self.graph.replay()
         return self.result
 
+    def checked(self):
+        """Replay, synchronise, validate: the results, or None if this replay did not fit (the step has been re-captured; call again)."""
+        out = self()
+        torch.cuda.synchronize()
+        return out if self.validate() else None
+
     def validate(self, repair=True):
         """Call with the stream synchronised.  True: every replay since the last call fitted the capacity it was captured with.
         False: at least one did not -- its results are invalid; with `repair` the step has been re-captured (an eager frame first,
         which raises the capacity hints) and the caller must redo the affected steps."""
         st = _lib.frame_status()
-        ok = st["overflow_count"] == self._seen_overflows
-        self._seen_overflows = st["overflow_count"]
+        ok = st["unrepaired_overflow_count"] == self._seen_overflows      # eager frames (warm-ups of other captures, evaluation renders) repair themselves and do not count
+        self._seen_overflows = st["unrepaired_overflow_count"]
         if not ok and repair:
             self.recaptures += 1
             self._capture(1)
@@ -85,7 +93,7 @@ class GraphCache:
             if self._pool is None:
                 self._pool = step.pool()
             if self._seen_overflows is None:
-                self._seen_overflows = _lib.frame_status()["overflow_count"]
+                self._seen_overflows = _lib.frame_status()["unrepaired_overflow_count"]
         self._used.add(key)
         return step()
 
@@ -93,13 +101,13 @@ class GraphCache:
         """Call with the stream synchronised.  The overflow counter is shared by every frame of this thread and device, so a change
         condemns every key replayed since the last call: True = all of them fitted; False = they are re-captured (with `repair`)
         and the caller must redo those steps."""
-        now = _lib.frame_status()["overflow_count"]
+        now = _lib.frame_status()["unrepaired_overflow_count"]
         ok = self._seen_overflows is None or now == self._seen_overflows
         if not ok and repair:
             for key in self._used:
                 self.steps[key]._capture(1)
                 self.recaptures += 1
-            now = _lib.frame_status()["overflow_count"]
+            now = _lib.frame_status()["unrepaired_overflow_count"]
         self._seen_overflows = now
         self._used = set()
         return ok

@@ -40,5 +40,5 @@ def set_obj_near_idx(model, K=None):
     if getattr(model, "use_time_mask", False):
         xyz = torch.cat([xyz, model.gs_time * model.scene_extent], dim=-1)
     anchor = xyz[torch.randperm(xyz.shape[0], device=xyz.device)[:xyz.shape[0] // K]]
-    model.obj_near_idx = knn_points(anchor[None], xyz[None], K=K).idx.squeeze()
+    model.obj_near_idx = knn_points(anchor[None], xyz[None], K=K).idx.squeeze(0)      # [G, K] also for a single anchor (the reference's .squeeze() would drop that axis too)
     return model.obj_near_idx

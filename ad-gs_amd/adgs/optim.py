@@ -33,19 +33,38 @@ class MarkedGradient:
     """What a gradient producer that marks the tiles it writes (adgs_envmap_backward_marked) shares with the optimizer of that
     parameter (FusedAdam.marked_gradient): the tile byte map, and a gradient buffer that is known to be all zero outside marked
     tiles.  Protocol: the producer calls take() for its output buffer (None: allocate zeros yourself) and issued(t) with the tensor
-    it returns to autograd; the optimizer treats the tiles as marked only while p.grad IS that tensor (a gradient summed with
-    another source arrives as a new tensor and is scanned like any other), zero-fills the tiles it updates when the step drops
-    the gradient (step(zero_grad=True)), and puts the buffer back."""
+    it returns to autograd; the optimizer treats the tiles as marked only while p.grad is that buffer UNTOUCHED, zero-fills the
+    tiles it updates when the step drops the gradient (step(zero_grad=True)), and puts the buffer back.
+
+    "That buffer untouched" is decided by is_live(g): same storage object, same address, and the version counter the buffer had
+    when it was issued.  An address alone proves nothing: with grad mode off autograd accumulates IN PLACE -- AccumulateGrad does
+    `p.grad += new` for a second backward, the engine's input buffer may add a second loss term of the same backward into the
+    first-arriving tensor -- and a non-marking source (image_background(), a regulariser on the map) would then put values into
+    unmarked tiles of a buffer whose address still matches; every in-place write bumps the version counter that p.grad shares with
+    the issued tensor (autograd installs `new_grad.detach()`).  The storage is held (not the tensor: a second reference to the
+    tensor would make AccumulateGrad clone it instead of installing it) so that its address cannot be handed to another tensor
+    while the record is live.  Anything else is a foreign gradient: dense scan, no recycling."""
 
     def __init__(self, marks):
-        self.marks, self.buffer, self.live_ptr = marks, None, None
+        self.marks, self.buffer = marks, None
+        self._live = None           # (storage, data_ptr, version at issue)
 
     def take(self):
         b, self.buffer = self.buffer, None
+        self._live = None           # an issued gradient nobody stepped on is dropped here (its marks stay set: harmless, only cost)
         return b
 
     def issued(self, t):
-        self.live_ptr = t.data_ptr()
+        self._live = (t.untyped_storage(), t.data_ptr(), t._version)
+
+    def is_live(self, g):
+        if self._live is None:
+            return False
+        st, ptr, ver = self._live
+        return g.data_ptr() == ptr and g._version == ver and g.untyped_storage()._cdata == st._cdata
+
+    def retire(self):
+        self._live = None
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -76,9 +95,9 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def marked_gradient(self, p):
-        """The MarkedGradient of parameter p (needs skip_dormant_tiles): hand it to the one producer of p's gradient.  Only valid
-        if nothing else writes into p.grad in place (a second loss term on p in the same backward is fine: autograd sums into a
-        new tensor, which this optimizer recognises as foreign)."""
+        """The MarkedGradient of parameter p (needs skip_dormant_tiles): hand it to the one producer of p's gradient.  Other sources
+        of gradient for p are allowed -- whether autograd sums them into a new tensor or in place into the producer's buffer, step()
+        sees that the buffer is no longer the one that was issued (MarkedGradient.is_live) and scans it densely."""
         if not self.skip_dormant_tiles:
             raise ValueError("marked_gradient needs skip_dormant_tiles=True")
         mg = self._marked.get(id(p))
@@ -135,7 +154,7 @@ class FusedAdam(torch.optim.Optimizer):
                 flags = 0
                 mg = self._marked.get(id(p))
                 if mg is not None:
-                    if tile_map is mg.marks and g is p.grad and g.data_ptr() == mg.live_ptr:
+                    if tile_map is mg.marks and g is p.grad and mg.is_live(g):
                         # the producer's own buffer: its marks say which tiles hold anything.  Dropping the gradient with the step =
                         # zero the updated tiles in the same pass; the buffer is all zero again and goes back to the producer.
                         flags = TILES_MARKED | (ZERO_GRAD if zero_grad is True else 0)
@@ -144,7 +163,7 @@ class FusedAdam(torch.optim.Optimizer):
                     elif tile_map is not mg.marks:
                         # the tile map was replaced (foreign moments): the producer keeps marking the old one, which nobody reads
                         self._marked.pop(id(p))
-                    mg.live_ptr = None
+                    mg.retire()
                 ag = AdamGroup(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
                                int(st["step"]), tile_map.data_ptr() if tile_map is not None else None, flags, 0)
                 keep.append(g)

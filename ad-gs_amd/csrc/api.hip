@@ -226,7 +226,8 @@ static uint32_t* pinned_word() {
 // middle of the frame, and a driver-level wait (hipEventSynchronize / hipStreamSynchronize) for them was measured to fall
 // back to a ~10 ms timeout per call in the first process on a freshly booted box (frames at 11 ms instead of 1.7 ms with
 // every kernel at its normal duration).  A volatile read of host memory has no such mode.
-struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; size_t cap_cells, cap_fine; };      // cap_*: capacities of the last forward
+struct MailboxRef { Mailbox* host; Mailbox* dev; uint32_t next_seq; size_t cap_cells, cap_fine;      // cap_*: capacities of the last host-side forward
+	long long repaired; };      // eager frames whose overflow this library repaired itself (they bump the device-side overflow_count too)
 // one mailbox per (host thread, device): the device pointer of a mapped allocation belongs to the device that was current when
 // it was taken, so a thread that renders on several GPUs gets one per GPU (portable pinned memory)
 static MailboxRef* mailbox() {
@@ -292,6 +293,7 @@ __global__ void publish_counts_kernel(const uint32_t* __restrict__ total_cells, 
 		*overflow_flag = over;
 		box->r_cells = total; box->r_fine = f; box->oversize = 0u; box->n_groups = 0u; box->overflow = over; box->max_cell_chunks = 0u;
 		if (over) box->overflow_count = box->overflow_count + 1u;
+		box->cap_cells = cap_cells; box->cap_fine = cap_fine;
 		__threadfence_system();
 		box->seq = seq;                       // published last: the host spins on it
 	}
@@ -325,9 +327,13 @@ extern "C" int adgs_get_frame_status(adgs_frame_status* out) {
 	MailboxRef* mb = mailbox();
 	if (!mb) { set_error("hipHostMalloc (mapped) failed"); return -1; }
 	out->pairs = (int64_t)mb->host->r_cells; out->fine_pairs = (int64_t)mb->host->r_fine;
-	out->capacity_pairs = (int64_t)mb->cap_cells; out->capacity_fine_pairs = (int64_t)mb->cap_fine;
+	// the capacity the frame's own kernels compared against (a graph replay: that of its capture; 0xffffffff / ~0: an eager frame that
+	// waited for the exact counts)
+	out->capacity_pairs = mb->host->cap_cells == 0xffffffffu ? (int64_t)mb->host->r_cells : (int64_t)mb->host->cap_cells;
+	out->capacity_fine_pairs = mb->host->cap_fine == ~0ull ? (int64_t)mb->host->r_fine : (int64_t)mb->host->cap_fine;
 	out->overflow = (int32_t)mb->host->overflow; out->overflow_count = (int64_t)mb->host->overflow_count;
 	out->eager_reruns = (int64_t)g_reruns.load();
+	out->unrepaired_overflow_count = (int64_t)mb->host->overflow_count - (int64_t)mb->repaired;
 	return 0;
 }
 
@@ -577,9 +583,13 @@ static int raster_forward_impl(const ShSource* sh_src,
 			(int)buckets, mb->host->n_groups, mb->host->oversize);
 #define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
 		ADGS_DBG_STOP(0)
+		if (mb->host->overflow) mb->repaired++;      // an eager frame that did not fit is enqueued again below, before this call returns
 		const bool chunk_table_full = buckets && mb->host->oversize;
 		if (!speculate || chunk_table_full || R_cells > cap_cells || R_fine > cap_fine) {
-			if (speculate) { g_reruns.fetch_add(1); ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream)); }      // the re-run fits by construction
+			if (speculate) g_reruns.fetch_add(1);
+			// the re-run fits by construction; the device word can also be set without speculation (cell_scan raises it when the chunk
+			// table is full), and a blend launched with it set renders nothing
+			ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream));
 			if (chunk_table_full) {
 				// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
 				// per-Gaussian pair offsets first

@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 		a.d_counts[0] = total; a.d_counts[1] = nchunks_total; a.d_counts[2] = over; a.d_counts[3] = nofit;
 		a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit; a.box->max_cell_chunks = s_maxch;
 		if (nofit) a.box->overflow_count = a.box->overflow_count + 1u;
+		a.box->cap_cells = a.cap_cells; a.box->cap_fine = a.cap_fine;
 		__threadfence_system();
 		a.box->seq = a.seq;                       // published last: the host spins on it
 	}

@@ -25,7 +25,7 @@ struct __attribute__((aligned(64))) Splat {
 	float fx, fy, fz;        // flow point (world position at the other time)
 	float sem0;              // first semantic channel
 	float zview;             // raw view-space depth
-	float pad;
+	float lean;             // 1.0: neither `power > 0` nor the 0.99 clamp can fire for this Gaussian (preprocess.hip); else 0.0
 };
 static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 

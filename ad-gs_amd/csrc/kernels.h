@@ -87,7 +87,8 @@ struct PreprocessBwdArgs {
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
 
 // ---- v2 pipeline (render_v2.hip) ----
-constexpr int CHUNK_WORDS = 2 + WAVE;   // [prev chunk, count, 64 Gaussian ids]
+constexpr int CHUNK_WORDS = 2 + WAVE;   // [64 Gaussian ids, prev chunk, count]: the ids first, so that a wave reads `c[lane]` and the link words with two
+constexpr int CHUNK_PREV = WAVE, CHUNK_COUNT = WAVE + 1;      // independent vector loads (the backward prefetches the next chunk of its list)
 // Chunk slots are handed out in blocks of POOL_BLOCK: tile t owns slots [t * POOL_BLOCK, (t + 1) * POOL_BLOCK) outright and draws further
 // blocks from the shared cursor (which counts from #tiles * POOL_BLOCK).  One returning atomic per BATCH on one address -- 28 800 per
 // C3 frame -- was what the forward blend kernel's time consisted of: the serialised atomics back up the CUs' memory pipelines, and
@@ -102,7 +103,8 @@ constexpr int GS_NMAX = 8192;           // entries one chunk_sort workgroup sort
 constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
 // overflow: the totals exceed the capacity the frame's launches were enqueued against; overflow_count: such frames since the mailbox exists
-struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks; };      // max_cell_chunks: bucket binning, the fullest cell's chunks
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest cell's chunks
+	uint32_t cap_cells; unsigned long long cap_fine; };      // the capacity THIS frame was enqueued against, as its kernels saw it (a graph replay reports its capture's)
 struct CellScanArgs {
 	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
 	uint32_t* cell_start;               // [ncells + 1]

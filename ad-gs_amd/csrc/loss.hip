@@ -437,15 +437,19 @@ using namespace adgs;
 // gradient back through index_put.  Here one thread owns one (group, column) pair: it reads its K values straight from the K
 // gathered rows (consecutive threads = consecutive columns of a row: coalesced), forms the unbiased variance in registers, and
 // the backward adds 2 (x - mean) / ((K - 1) denom) to the K rows with one atomic each (a Gaussian can sit in several groups).
+// Row indices follow the reference's fancy indexing (`param[obj_near_idx]`): a negative index counts from the end; anything outside
+// [-N, N) raises IndexError there.  A kernel cannot raise without a host round trip, so an out-of-range index (a stale obj_near_idx from
+// before a prune) makes the LOSS NaN -- loud, and no out-of-bounds access -- and its row receives no gradient.
 constexpr int GV_MAXK = 32;
-__global__ void __launch_bounds__(256) group_var_sum_kernel(int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
+__device__ __forceinline__ long long gv_row(long long i, int N) { if (i < 0) i += N; return (i < 0 || i >= N) ? -1 : i; }
+__global__ void __launch_bounds__(256) group_var_sum_kernel(int N, int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
 	double denom, double* __restrict__ work) {
 	const long long total = (long long)G * D;
 	double sum = 0;
 	for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
 		const int g = (int)(t / D), d = (int)(t % D);
 		float v[GV_MAXK], mean = 0.f;
-		for (int k = 0; k < K; k++) { v[k] = x[(size_t)idx[(size_t)g * K + k] * D + d]; mean += v[k]; }
+		for (int k = 0; k < K; k++) { const long long r = gv_row(idx[(size_t)g * K + k], N); v[k] = r < 0 ? __int_as_float(0x7fc00000) : x[(size_t)r * D + d]; mean += v[k]; }
 		mean /= (float)K;
 		float ss = 0.f;
 		for (int k = 0; k < K; k++) { const float c = v[k] - mean; ss += c * c; }
@@ -456,16 +460,16 @@ __global__ void __launch_bounds__(256) group_var_sum_kernel(int G, int K, int D,
 	if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(work + (size_t)((blockIdx.x * 4 + threadIdx.x / WAVE) % AUX_SLOTS) * 2, sum);
 	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(work + 1, denom);      // the "count" of the shared finish kernel
 }
-__global__ void __launch_bounds__(256) group_var_bwd_kernel(int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
+__global__ void __launch_bounds__(256) group_var_bwd_kernel(int N, int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
 	float scale, const float* __restrict__ g_loss, float* __restrict__ dx) {
 	const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= (long long)G * D) return;
 	const int g = (int)(t / D), d = (int)(t % D);
 	float v[GV_MAXK], mean = 0.f; long long row[GV_MAXK];
-	for (int k = 0; k < K; k++) { row[k] = idx[(size_t)g * K + k]; v[k] = x[(size_t)row[k] * D + d]; mean += v[k]; }
+	for (int k = 0; k < K; k++) { row[k] = gv_row(idx[(size_t)g * K + k], N); v[k] = row[k] < 0 ? __int_as_float(0x7fc00000) : x[(size_t)row[k] * D + d]; mean += v[k]; }
 	mean /= (float)K;
 	const float c = scale * g_loss[0];
-	for (int k = 0; k < K; k++) atomicAdd(dx + (size_t)row[k] * D + d, c * (v[k] - mean));
+	for (int k = 0; k < K; k++) if (row[k] >= 0) atomicAdd(dx + (size_t)row[k] * D + d, c * (v[k] - mean));
 }
 __global__ void __launch_bounds__(256) sigma_loss_sum_kernel(int N, const float* __restrict__ ls, float gap, double* __restrict__ work) {
 	double sum = 0;
@@ -591,7 +595,7 @@ extern "C" int adgs_group_var_forward(int N, int G, int K, int D, int inner, con
 	if (K < 2 || K > GV_MAXK || inner <= 0 || D % inner != 0 || N <= 0) { set_error("adgs_group_var_forward: needs 2 <= K <= 32 neighbours and D a multiple of inner"); return -1; }
 	hipStream_t stream = (hipStream_t)stream_;
 	const long long total = (long long)G * D;
-	hipLaunchKernelGGL(group_var_sum_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, stream, G, K, D, x,
+	hipLaunchKernelGGL(group_var_sum_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, stream, N, G, K, D, x,
 		reinterpret_cast<const long long*>(idx), (double)G * (double)(D / inner), work);
 	hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
 	ADGS_HIP_CHECK(hipGetLastError());
@@ -603,7 +607,7 @@ extern "C" int adgs_group_var_backward(int N, int G, int K, int D, int inner, co
 	if (K < 2 || K > GV_MAXK || inner <= 0 || D % inner != 0 || N <= 0) { set_error("adgs_group_var_backward: needs 2 <= K <= 32 neighbours and D a multiple of inner"); return -1; }
 	const long long total = (long long)G * D;
 	const float scale = (float)(2.0 / ((double)(K - 1) * (double)G * (double)(D / inner)));
-	hipLaunchKernelGGL(group_var_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, G, K, D, x,
+	hipLaunchKernelGGL(group_var_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, N, G, K, D, x,
 		reinterpret_cast<const long long*>(idx), scale, g_loss, dL_dx);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;

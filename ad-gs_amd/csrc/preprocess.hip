@@ -249,13 +249,18 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	else { s.fx = 0.f; s.fy = 0.f; s.fz = 0.f; }
 	s.sem0 = (a.semantic && a.D_S > 0) ? a.semantic[(size_t)idx * a.D_S] : 0.f;
 	s.zview = vz;
-	s.pad = 0.f;
+	// "lean" Gaussians (render_v2.hip, eval_pixel<true>): opacity <= 0.99 and a conic that is positive definite with a relative margin of
+	// 1e-4 on its determinant.  For these neither `power > 0` (forward.cu:345-346) nor the 0.99 clamp (forward.cu:353) can fire for any pixel
+	// offset: the quadratic form is >= 5e-5 (A dx^2 + C dy^2) while an fp32 evaluation of it in any order is off by < 1e-6 of that sum, and
+	// exp of a non-positive argument never exceeds 1 -- so the blend kernels skip both tests for them, bit for bit the same result.
+	const bool lean = s.opacity <= 0.99f && s.ca > 0.f && s.cc > 0.f && s.cb * s.cb <= 0.9999f * (s.ca * s.cc);
+	s.lean = lean ? 1.f : 0.f;
 	// one 64-byte line, four 16-byte stores
 	float4* dst = reinterpret_cast<float4*>(a.splats + idx);
 	dst[0] = make_float4(s.x, s.y, s.ca, s.cb);
 	dst[1] = make_float4(s.cc, s.opacity, s.r, s.g);
 	dst[2] = make_float4(s.b, s.dval, s.fx, s.fy);
-	dst[3] = make_float4(s.fz, s.sem0, s.zview, s.pad);
+	dst[3] = make_float4(s.fz, s.sem0, s.zview, s.lean);
 	a.clamped[idx] = clamp_bits;
 	a.radii[idx] = (int)my_radius;
 	if (a.gacc) {     // the blend backward accumulates into this 64-B line (rows of culled Gaussians are never read)

@@ -16,13 +16,14 @@
 //
 // One workgroup = one wave64 = one tile (or half of one for small images: PPL = 2); each lane owns PPL pixels
 // (column x = lane&15, rows (lane>>4) + 4k).  Per-Gaussian data is broadcast from LDS once per PPL pixels, 16x4-pixel
-// strips an entry does not reach are skipped wave-uniformly, the backward's cross-lane reductions (a transposing
-// butterfly of permlane swaps and bank-masked DPP adds, no LDS) are amortised over the whole tile and
-// the 14 per-Gaussian partial sums go out as ONE atomic instruction onto one 64-byte line.
+// strips an entry does not reach are skipped wave-uniformly, the backward's cross-lane reductions (through LDS:
+// wave_sum14_lds) are amortised over the whole tile and the 14 per-Gaussian partial sums go out as ONE atomic
+// instruction onto one 64-byte line.
 // The consumed (tile, Gaussian) sequence is written to a chunk pool (linked 64-entry chunks) so
 // the backward replays exactly what the forward blended, back to front.
 #include "common.h"
 #include "kernels.h"
+#include "blend_instrument.h"
 #include <cstdlib>
 
 namespace adgs {
@@ -36,13 +37,22 @@ constexpr float PIXEL_DONE = 3.0e38f;      // row coordinate of a pixel that tak
 // half tile: twice the waves, a shorter dependent chain per wave); PPL is a template parameter of both blend kernels
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
 
-#ifndef ADGS_FWD_PREFETCH
-#define ADGS_FWD_PREFETCH 0
-#endif
+// The exponent is kept in log2 units (entry_geom scales the conic by log2 e once per entry): G = 2^pw is ONE v_exp_f32 per pixel
+// (~1 ulp), not v_mul + v_exp.  ADGS_PRECISE_EXP: libm's exp2f (parity experiments: the share of gate flips the fast exp owns).
 #ifndef ADGS_PRECISE_EXP
-#define ADGS_EXP(x) __expf(x)      // v_exp_f32(x * log2 e): ~3e-7 relative, far inside the 1e-4 budget
+#define ADGS_EXP2(x) __builtin_amdgcn_exp2f(x)
 #else
-#define ADGS_EXP(x) expf(x)
+#define ADGS_EXP2(x) exp2f(x)
+#endif
+#ifndef ADGS_LEAN
+#define ADGS_LEAN 1                // 0: every entry takes the general evaluation (A/B builds)
+#endif
+#ifndef ADGS_SETPRIO
+#define ADGS_SETPRIO 1             // 0: no s_setprio around the memory phases (A/B builds)
+#endif
+constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ADGS_KO
+#define ADGS_KO 0                  // knock-out experiment builds (WRONG results, timing only): 1 no atomic, 2 no LDS reduction, 4 no strip bodies (backward), 8 no channel FMAs (forward)
 #endif
 
 // Can Gaussian `f` reach alpha >= 1/255 on any pixel centre of tile (tx,ty)?  Exact minimum of the
@@ -80,42 +90,49 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 // wave-uniform per-strip branches below skip ~22 % of the strip work).
 
 // Per-entry, per-lane part of the Gaussian evaluation (the lane's 4 pixels share the column x):
-//   power = -0.5 (A dx^2 + C dy^2) - B dx dy = a0 + dy (b0 + c0 dy)
+//   power * log2 e = log2 e (-0.5 (A dx^2 + C dy^2) - B dx dy) = a0 + dy (b0 + c0 dy)
 // Forward and backward evaluate alpha through this one function, so both take identical
 // per-pixel decisions (power > 0, alpha < 1/255) on identical bits.
+// LEAN entries (Splat::lean, set by the preprocess: opacity <= 0.99 and a conic safely inside the positive-definite cone) need neither
+// the `power > 0` test nor the 0.99 clamp -- both provably never fire for them (preprocess.hip) -- which is 2 of 9 vector
+// instructions and 1 of 2 compares per pixel; the choice is wave-uniform per entry (a bit of a 64-bit scalar mask per batch).
 struct EntryGeom { float y, a0, b0, c0, op; };
 // wave-uniform "does any lane ...": the ballot compared on the scalar unit (hipcc turns __any() of a value that already lives in
 // an SGPR mask into v_cndmask + v_cmp_ne + s_cbranch_vccz: two vector instructions, ~7 cycles of the SIMD, per test)
-#ifdef ADGS_FWD_TIMING
-// experiment build (make variant TAG=timing DEFS=-DADGS_FWD_TIMING): shader-clock cycles every wave spends in the phases of the forward,
-// summed over the launch: [0] key-stream scan, [1] filter-record test, [2] Splat gather + staging, [3] blend loop, [4] whole wave, [5] waves
-__device__ unsigned long long g_fwd_timing[16];
-#define ADGS_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define ADGS_TACC(slot, a, b) t_acc[slot] += (b) - (a)
-#else
-#define ADGS_T(var)
-#define ADGS_TACC(slot, a, b)
-#endif
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ EntryGeom entry_geom(const float4 q0, const float4 q1, float dx) {
 	EntryGeom g;
-	g.y = q0.y; g.a0 = (-0.5f * q0.z * dx) * dx; g.b0 = -q0.w * dx; g.c0 = -0.5f * q1.x; g.op = q1.y;
+	g.y = q0.y; g.a0 = ((-0.5f * LOG2E) * q0.z * dx) * dx; g.b0 = (-LOG2E * q0.w) * dx; g.c0 = (-0.5f * LOG2E) * q1.x; g.op = q1.y;
 	return g;
 }
+template <bool LEAN>
 __device__ __forceinline__ void eval_pixel(const EntryGeom& g, float py, float& dy, float& pw, float& G, float& al) {
 	dy = g.y - py;
 	pw = fmaf(dy, fmaf(g.c0, dy, g.b0), g.a0);
-	G = ADGS_EXP(pw);
-	al = fminf(ALPHA_MAX, g.op * G);
+	G = ADGS_EXP2(pw);
+	al = LEAN ? g.op * G : fminf(ALPHA_MAX, g.op * G);
+}
+// the four (PPL) pixels of a lane against one entry: alpha and the lane masks of the pixels that pass the gates (forward.cu:345-356)
+template <bool LEAN, int PPL>
+__device__ __forceinline__ uint64_t eval_entry_fwd(const EntryGeom& eg, const float (&pyf)[PPL], float (&alpha)[PPL], uint64_t (&actm)[PPL]) {
+	uint64_t any_m = 0ull;
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		float dy, pw, G;
+		// a finished (or out-of-image) pixel sits at row 3e38: its exponent is -inf, alpha 0, so it needs no flag here
+		eval_pixel<LEAN>(eg, pyf[k], dy, pw, G, alpha[k]);
+		// "which pixels does the entry reach" as 64-bit lane masks on the scalar unit: the ballot of one comparison IS the
+		// comparison's result register, two are combined by s_and and tested by s_cmp (a ballot of `a && b` would be
+		// rebuilt from a per-lane 0 / 1 value: two vector instructions per strip and entry)
+		actm[k] = LEAN ? __builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN))
+		               : (__builtin_amdgcn_ballot_w64(!(pw > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN)));
+		any_m |= actm[k];
+	}
+	return any_m;
 }
 
 #ifndef ADGS_FWD_WAVES
 #define ADGS_FWD_WAVES 1
-#endif
-#ifdef ADGS_PROBE
-// experiment build (make variant TAG=probe DEFS=-DADGS_PROBE): [0..7] forward, [8..15] backward: shader cycles (s_memtime), 100 MHz ticks
-// (s_memrealtime), waves, contributing (pixel, entry) pairs, entries evaluated, entries with a contributing pixel, active strips
-__device__ unsigned long long g_probe[16];
 #endif
 #ifndef ADGS_BWD_WAVES
 #define ADGS_BWD_WAVES 1
@@ -133,27 +150,29 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	// objects of the synthetic configs) the lower image rows carry the long lists, and tiles dispatched last run on a draining
 	// machine.  Measured at C3: 0.409 -> 0.400 ms; a strided permutation of the tiles: 0.412 ms.  ADGS_FWD_ORDER=0: top-down.
 	uint32_t tile = a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-	if (a.order_mode == 2) {
-		// XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule; only speed depends on it).  Neighbouring tiles gather
-		// the same 64-byte Splat lines and walk the same cell lists, and every XCD has its own L2: with the linear order each line is
-		// fetched by all eight.  Here XCD k sweeps whole bands of `band` tile rows (bands k, k + 8, ... from the bottom up), so a line
-		// is fetched by one or two XCDs; the rows that do not fill a group of 8 bands keep the linear order.
-		const uint32_t band = 2u * (uint32_t)(TILE_Y / (4 * PPL)), per_band = band * a.gx, group = 8u * per_band;
-		const uint32_t b = blockIdx.x, full = (gridDim.x / group) * group;
-		if (b < full) {
-			const uint32_t g = b / group, r = b % group, xcd = r % 8u, j = r / 8u;      // j-th workgroup of this XCD inside the group
-			tile = g * group + xcd * per_band + j;
-		}
-		tile = gridDim.x - 1u - tile;
-	}
+	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	if (*a.overflow_flag != 0u) {
 		// The frame does not fit the capacity this launch was enqueued against (api.hip: the totals are compared on the device): the
-		// lists are incomplete.  Blend nothing and leave an empty replay state; the host enqueues binning and blend again with exact
-		// sizes (or, under stream capture, reports the overflow through adgs_get_frame_status).
+		// lists are incomplete.  Blend nothing, leave an empty replay state and a DEFINED empty render (background colour, opacity 0,
+		// no contributors: a graph replay that overflowed hands these to the caller, whose loss and optimizer step must not see stale
+		// pool memory -- a NaN that has reached the Adam moments cannot be redone); the host enqueues binning and blend again with
+		// exact sizes (or, under stream capture, reports the overflow through adgs_get_frame_status).
 		if (lane == 0) { a.tile_last_chunk[tile] = NO_CHUNK; a.tile_consumed[tile] = 0u; a.tile_scanned[tile] = 0u; a.tile_batches[tile] = 0u; }
+		const uint32_t ex = tx * TILE_X + (lane & 15);
+		const size_t eHW = (size_t)a.H * a.W;
+#pragma unroll
+		for (int k = 0; k < PPL; k++) {
+			const uint32_t ey = ty * (4 * PPL) + (lane >> 4) + 4 * k;
+			if (ex < (uint32_t)a.W && ey < (uint32_t)a.H) {
+				const size_t pix_id = (size_t)a.W * ey + ex;
+				a.final_T[pix_id] = 0.f; a.n_contrib[pix_id] = 0u; a.out_depth[pix_id] = 0.f;
+				if (a.has_color) for (int c = 0; c < 3; c++) a.out_color[c * eHW + pix_id] = a.bg[c] + (a.bg_image ? a.bg_image[c * eHW + pix_id] : 0.f);
+				if (a.has_flow) for (int c = 0; c < 3; c++) a.out_flow[c * eHW + pix_id] = 0.f;
+				if (a.has_sem) a.out_semantic[pix_id] = 0.f;
+			}
+		}
 		return;
 	}
-	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	const uint32_t ty16 = ty / SUB;                           // row of the 16x16 tile grid the binning works on
 	const uint32_t cell = (ty16 / a.cell_tiles) * a.cgx + (tx / a.cell_tiles);
 	const uint2 range = a.cell_ranges[cell];
@@ -181,17 +200,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	const int row_bit = (int)(ty16 % a.cell_tiles), col_bit = a.cell_tiles + (int)(tx % a.cell_tiles);
 	// a candidate = (Gaussian id, rectangle-coverage mask): one 8-byte entry (bucket binning) or the list id + the bits above
 	// (cell | depth) of its sort key
-#ifdef ADGS_FWD_TIMING
-	unsigned long long t_acc[4] = { 0ull, 0ull, 0ull, 0ull }, t_load = 0ull, n_rounds = 0ull, t_frec = 0ull, n_frec = 0ull;
-#endif
-	ADGS_T(t_wave0);
-#ifdef ADGS_TIMELINE
-	const unsigned long long tl_r0 = wall_clock64();
-#endif
-#ifdef ADGS_PROBE
-	const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_r0 = wall_clock64();
-	unsigned pr_pairs = 0, pr_evals = 0, pr_live = 0, pr_strips = 0;
-#endif
+	PT_DECL(10); PT(t_wave0); TL_DECL; PROBE_DECL;
 
 	while (true) {
 		bool mine_done = true;
@@ -199,17 +208,22 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		for (int k = 0; k < PPL; k++) mine_done = mine_done && (pyf[k] == PIXEL_DONE);
 		const bool all_done = !wave_any(!mine_done);
 		if (all_done) break;
+		// The memory phases (refill, gather) are a few dozen instructions between long waits; under the SIMD's oldest-first arbitration a
+		// young wave in such a phase starves behind older waves that are in their blend loops (tools/blend_phase_timing.py: 10 000 cycles
+		// "waiting" per filter round, 750 of them for the load).  Raised priority lets it issue its loads at once; the blend loops, which
+		// only need throughput, fill the rest.
+		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(2);
 		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction), in two stages.
 		// Stage 1 scans the sorted KEY stream: the key bits above (cell | depth) say which tile rows and columns of the cell the
 		// Gaussian's rectangle covers (duplicate_cells), so the rectangle test costs 8 sequential, prefetched bytes and two
 		// shifts per candidate -- at C3 a tile scans ~2100 candidates to blend ~180 entries.  Only candidates whose rectangle
 		// holds the tile go on to stage 2, 64 at a time: gather of the 32-byte filter record + the exact ellipse test.
 		while (qcount < WAVE && (pos < range.y || ccount > 0)) {
-			ADGS_T(t_s1a);
+			PT(t_s1a);
 			// A super-round = SCAN_ROUNDS x 64 candidates with all their loads in flight before the first is looked at: one exposed
 			// memory round trip per 256 candidates.  (One round of 64 with the next round prefetched still waited ~a full round
 			// trip per round -- a round is ~30 instructions --, and the key-stream scan was 52 % of a wave's life at C3:
-			// tools/fwd_phase_timing.py.)  The ring holds a whole super-round on top of a stage-2 batch.
+			// tools/blend_phase_timing.py.)  The ring holds a whole super-round on top of a stage-2 batch.
 			while (ccount < WAVE && pos < range.y) {
 				uint32_t key[SCAN_ROUNDS], id[SCAN_ROUNDS];
 				// UNCONDITIONAL loads at clamped indices, the bucket / sort distinction outside the unrolled loop: a load inside a
@@ -234,14 +248,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 #pragma unroll
 					for (int r = 0; r < SCAN_ROUNDS; r++) key[r] = a.mask_shift >= 0 ? (uint32_t)(kk[r] >> a.mask_shift) : 0u;
 				}
-#ifdef ADGS_FWD_TIMING
-				{
-					ADGS_T(t_l0);
-					asm volatile("s_waitcnt vmcnt(0)" : "+v"(key[0]), "+v"(key[1]), "+v"(key[2]), "+v"(key[3]), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]) :: "memory");
-					ADGS_T(t_l1);
-					t_load += t_l1 - t_l0; n_rounds += 1ull;
-				}
-#endif
+				PT_WAIT_VM8(6, 7, key[0], key[1], key[2], key[3], id[0], id[1], id[2], id[3]);
 #pragma unroll
 				for (int r = 0; r < SCAN_ROUNDS; r++) {
 					const bool have = pos + r * WAVE + lane < range.y;
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				}
 				pos += SCAN_ROUNDS * WAVE;
 			}
-			ADGS_T(t_s1b); ADGS_TACC(0, t_s1a, t_s1b);
+			PT(t_s1b); PT_ACC(0, t_s1a, t_s1b);
 			const uint32_t nc = min(ccount, (uint32_t)WAVE);
 			if (nc == 0) break;
 			__syncthreads();
@@ -261,14 +268,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				id = s_cand[(chead + lane) & (CAND_RING - 1)];
 				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
 				float4 f0 = fr[0], f1 = fr[1];
-#ifdef ADGS_FWD_TIMING
-				{
-					ADGS_T(t_f0);
-					asm volatile("s_waitcnt vmcnt(0)" : "+v"(f0.x), "+v"(f0.y), "+v"(f0.z), "+v"(f0.w), "+v"(f1.x), "+v"(f1.y), "+v"(f1.z), "+v"(f1.w) :: "memory");
-					ADGS_T(t_f1);
-					t_frec += t_f1 - t_f0; n_frec += 1ull;
-				}
-#endif
+				PT_WAIT_VM8(8, 9, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w);
 				// both halves of the record are requested together (otherwise the compiler sinks the first
 				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
 				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
@@ -278,21 +278,25 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			const uint64_t m = __ballot(pass);
 			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
 			qcount += __popcll(m);
-			ADGS_T(t_s2b); ADGS_TACC(1, t_s1b, t_s2b);
+			PT(t_s2b); PT_ACC(1, t_s1b, t_s2b);
 		}
 		const uint32_t n = min(qcount, (uint32_t)WAVE);
 		if (n == 0) break;
-		ADGS_T(t_g0);
+		PT(t_g0);
 		__syncthreads();
 		uint32_t myid = 0;
+		bool my_lean = false;
 		if ((uint32_t)lane < n) {
 			myid = s_queue[(qhead + lane) & (2 * WAVE - 1)];
 			const float4* src = reinterpret_cast<const float4*>(a.splats + myid);
+			const float4 s3 = src[3];
 			s_splat[lane * 4 + 0] = src[0];
 			s_splat[lane * 4 + 1] = src[1];
 			s_splat[lane * 4 + 2] = src[2];
-			s_splat[lane * 4 + 3] = src[3];
+			s_splat[lane * 4 + 3] = s3;
+			my_lean = ADGS_LEAN && s3.w != 0.f;
 		}
+		const uint64_t lean_m = __builtin_amdgcn_ballot_w64(my_lean);      // bit j: entry j of this batch takes the lean evaluation
 		qhead = (qhead + n) & (2 * WAVE - 1); qcount -= n;
 		// the chunk slot of this batch: the next one of the tile's current block; a new block of POOL_BLOCK slots is drawn from the
 		// shared cursor only when the block is used up -- now, so that the atomic's round trip hides behind the blend loop (a
@@ -306,60 +310,23 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		// the backward replay (at C3 22 % of the entries that pass the tile test are blended by no pixel -- the test is a bound
 		// over the tile rectangle, and pixels saturate), and positions (n_contrib) count live entries only.
 		uint64_t live = 0ull;
-		ADGS_T(t_b0); ADGS_TACC(2, t_g0, t_b0);
-#if ADGS_FWD_PREFETCH >= 1
-		// software pipeline: the LDS reads of entry j + 1 are issued before entry j is evaluated (hipcc emits `ds_read; s_waitcnt`
-		// back to back at the top of every iteration otherwise: two exposed LDS round trips per entry; PMC: 61 % of the wave
-		// cycles of this kernel were spent parked at s_waitcnt).  Row n of s_splat exists (WAVE + 1 rows) and is never used.
-		float4 nq0 = s_splat[0], nq1 = s_splat[1];
-#if ADGS_FWD_PREFETCH >= 2
-		float4 nq2 = s_splat[2], nq3 = s_splat[3];
-#endif
-#endif
+		PT(t_b0); PT_ACC(2, t_g0, t_b0);
+		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
 		for (uint32_t j = 0; j < n; j++) {
-#if ADGS_FWD_PREFETCH >= 1
-			const float4 q0 = nq0, q1 = nq1;
-			nq0 = s_splat[(j + 1) * 4 + 0]; nq1 = s_splat[(j + 1) * 4 + 1];
-#if ADGS_FWD_PREFETCH >= 2
-			const float4 pq2 = nq2, pq3 = nq3;
-			nq2 = s_splat[(j + 1) * 4 + 2]; nq3 = s_splat[(j + 1) * 4 + 3];
-#endif
-#else
 			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
 			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
-#endif
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
-#ifdef ADGS_PROBE
-			pr_evals++;
-#endif
-			// "which pixels does the entry reach" as 64-bit lane masks on the scalar unit: the ballot of one comparison IS the
-			// comparison's result register, the two are combined by s_and and tested by s_cmp (a ballot of `a && b` would be
-			// rebuilt from a per-lane 0 / 1 value: two vector instructions per strip and entry)
-			float alpha[PPL]; uint64_t actm[PPL]; uint64_t any_m = 0ull;
-#pragma unroll
-			for (int k = 0; k < PPL; k++) {
-				float dy, pw, G;
-				// a finished (or out-of-image) pixel sits at row 3e38: its exponent is -inf, alpha 0, so it needs no flag here
-				eval_pixel(eg, pyf[k], dy, pw, G, alpha[k]);
-				actm[k] = __builtin_amdgcn_ballot_w64(!(pw > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN));
-				any_m |= actm[k];
-			}
+			PROBE_EVAL();
+			float alpha[PPL]; uint64_t actm[PPL];
+			const uint64_t any_m = ((lean_m >> j) & 1ull) ? eval_entry_fwd<true, PPL>(eg, pyf, alpha, actm) : eval_entry_fwd<false, PPL>(eg, pyf, alpha, actm);
 			if (any_m == 0ull) continue;
 
-#ifdef ADGS_PROBE
-			pr_live++;
-#pragma unroll
-			for (int k = 0; k < PPL; k++) { pr_pairs += (unsigned)__popcll(actm[k]); pr_strips += actm[k] != 0ull; }
-#endif
+			PROBE_LIVE(actm, PPL);
 			uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
 			asm volatile("" : "+v"(position));        // one copy into a vector register per entry (else: one v_mov per strip)
 			live |= 1ull << j;
-#if ADGS_FWD_PREFETCH >= 2
-			const float4 q2 = pq2, q3 = pq3;
-#else
 			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
-			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview pad
-#endif
+			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview lean
 #pragma unroll
 			for (int k = 0; k < PPL; k++) {
 				if (actm[k] == 0ull) continue;           // wave-uniform: a 16x4 pixel strip the entry does not reach costs nothing
@@ -369,14 +336,16 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				const bool up = __builtin_amdgcn_inverse_ballot_w64(actm[k] & ~stopm);
 				pyf[k] = stop ? PIXEL_DONE : pyf[k];
 				const float w = up ? alpha[k] * T[k] : 0.f;   // pixels that do not blend this entry add exactly 0
+				if (!(ADGS_KO & 8)) {
 				C0[k] = fmaf(q1.z, w, C0[k]); C1[k] = fmaf(q1.w, w, C1[k]); C2[k] = fmaf(q2.x, w, C2[k]);
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
 				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
+				} else C0[k] += w;
 				T[k] = up ? test_T : T[k];
 				last_contrib[k] = up ? position : last_contrib[k];
 			}
 		}
-		ADGS_T(t_b1); ADGS_TACC(3, t_b0, t_b1);
+		PT(t_b1); PT_ACC(3, t_b0, t_b1);
 		// ---- publish the live entries of this batch, in order, as one chunk of the backward's replay list
 		const uint32_t nlive = (uint32_t)__popcll(live);
 		if (draw) { blk_next = gridDim.x * (uint32_t)POOL_BLOCK + __shfl(new_block, 0, WAVE); blk_left = POOL_BLOCK; }
@@ -384,35 +353,16 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			const uint32_t chunk = blk_next;
 			blk_next++; blk_left--;
 			uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
-			if (lane == 0) { c[0] = prev_chunk; c[1] = nlive; }
-			if ((live >> lane) & 1ull) c[2 + __popcll(live & lt_mask)] = myid;
+			if (lane == 0) { c[CHUNK_PREV] = prev_chunk; c[CHUNK_COUNT] = nlive; }
+			if ((live >> lane) & 1ull) c[__popcll(live & lt_mask)] = myid;
 			prev_chunk = chunk;
 			consumed += nlive;
 		}
 	}
 	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = batches; }
-#ifdef ADGS_TIMELINE
-	// experiment build: the wave's life instead of the statistics -- start and end in 100 MHz ticks (s_memrealtime, low 32 bits)
-	if (lane == 0) { a.tile_scanned[tile] = (uint32_t)tl_r0; a.tile_batches[tile] = (uint32_t)wall_clock64(); }
-#endif
-#ifdef ADGS_PROBE
-	if (lane == 0) {
-		atomicAdd(&g_probe[0], __builtin_readcyclecounter() - pr_c0); atomicAdd(&g_probe[1], wall_clock64() - pr_r0); atomicAdd(&g_probe[2], 1ull);
-		atomicAdd(&g_probe[3], (unsigned long long)pr_pairs); atomicAdd(&g_probe[4], (unsigned long long)pr_evals); atomicAdd(&g_probe[5], (unsigned long long)pr_live);
-		atomicAdd(&g_probe[6], (unsigned long long)pr_strips);
-	}
-#endif
-#ifdef ADGS_FWD_TIMING
-	{
-		ADGS_T(t_wave1);
-		if (lane == 0) {
-			for (int i = 0; i < 4; i++) atomicAdd(&g_fwd_timing[i], t_acc[i]);
-			atomicAdd(&g_fwd_timing[4], t_wave1 - t_wave0); atomicAdd(&g_fwd_timing[5], 1ull);
-			atomicAdd(&g_fwd_timing[6], t_load); atomicAdd(&g_fwd_timing[7], n_rounds);
-			atomicAdd(&g_fwd_timing[8], t_frec); atomicAdd(&g_fwd_timing[9], n_frec);
-		}
-	}
-#endif
+	TL_STORE(lane, a.tile_scanned, a.tile_batches, tile);      // timeline build: the wave's life instead of the statistics
+	PROBE_FLUSH(0, lane);
+	{ PT(t_wave1); PT_ACC(4, t_wave0, t_wave1); PT_ADD(5, 1ull); PT_FLUSH(0, 10, lane); }
 	const size_t HW = (size_t)a.H * a.W;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
@@ -436,112 +386,32 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	}
 }
 
-// wave64 sum with DPP (no LDS): quad xor1, xor2, row_ror 4, row_ror 8, row_bcast15, row_bcast31.
-// The total ends up in lane 63.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-	int x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false)); x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false)); x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false)); x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false)); x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
-	return v;
+// Fourteen wave64 sums through LDS (round 2 used a transposing register butterfly of permlane swaps and bank-masked DPP adds: git
+// history, EXPERIMENTS.md).  Measured on gfx950 (tools/microbench/valu_rates.hip, profiles/r03/valu_rates.txt): v_permlane32_swap /
+// v_permlane16_swap retire at a QUARTER of the fp32 rate (8.2 cycles per wave64 instruction, like v_exp_f32), DPP adds at half rate
+// (4.3) -- the butterfly's 11 swaps + 11 adds + 10 DPP adds were ~165 VALU cycles per entry -- while the LDS pipe idled.  Here every
+// lane stores its 14 partial sums ([value][lane], conflict-free; rows of exactly 64 floats, so that seven ds_write2st64_b32 address
+// all rows from ONE base register), lane l reads back a quarter (l & 3) of value row l >> 2 as four 16-byte words and adds its 16
+// numbers; two quad DPP adds finish: 15 full-rate adds + 2 DPP adds of VALU work.  With rows of 64 floats the sixteen lanes of a
+// ds_read_b128 group (four rows x four quarters) would hit the same four bank quads, so the i-th read of a lane starts at word
+// (i + row) & 3 of its quarter: the four rows of a group (0,3,5,6 / 1,2,4,7 / 8,11,13,10 / 9,10,12,11 -- lanes 56..63 re-read rows
+// 10 and 11, nobody uses their sums) differ mod 4.  The LDS operations of one wave execute in order: no barrier.
+constexpr int RED_ROWS = 14, RED_STRIDE = WAVE;      // floats per value row
+struct RedAddr { const float4* r[4]; };
+__device__ __forceinline__ RedAddr red_addresses(const float* s_red, int lane) {
+	const int row = (lane >> 2) < RED_ROWS ? (lane >> 2) : (lane >> 2) - 4;
+	RedAddr ra;
+#pragma unroll
+	for (int i = 0; i < 4; i++) ra.r[i] = reinterpret_cast<const float4*>(s_red + row * RED_STRIDE + (lane & 3) * 16 + 4 * ((i + row) & 3));
+	return ra;
 }
-
-// Seven independent wave64 sums at once.  Each step is one v_add_f32 with a DPP source on the value
-// itself (dst tied to the operand, so rows masked off by row_mask simply keep their value); the seven
-// chains are interleaved so that consecutive instructions never depend on each other and no wait
-// state is needed between the VALU write and the DPP read of the same register (a DPP operand needs
-// 2 wait states after a VALU write: 6 independent instructions sit in between).  Totals in lane 63.
-#define ADGS_DPP_STEP(ctrl) \
-	"v_add_f32_dpp %0, %0, %0 " ctrl "\n\t" "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t" "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t" \
-	"v_add_f32_dpp %3, %3, %3 " ctrl "\n\t" "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t" "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t" \
-	"v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"
-__device__ __forceinline__ void wave_sum7(float& a, float& b, float& c, float& d, float& e, float& f, float& g) {
-	asm volatile(
-		"s_nop 1\n\t"
-		ADGS_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-		ADGS_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-		ADGS_DPP_STEP("row_ror:4 row_mask:0xf bank_mask:0xf")
-		ADGS_DPP_STEP("row_ror:8 row_mask:0xf bank_mask:0xf")
-		ADGS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-		ADGS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-		"s_nop 1"
-		: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g));
-}
-template <int LANE_DST>
-__device__ __forceinline__ float put_lane(float out, float v) {
-	// out[LANE_DST] = v[63]
-	const int s = __builtin_amdgcn_readlane(__float_as_int(v), 63);
-	asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(out) : "s"(s), "n"(LANE_DST));
-	return out;
-}
-__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
-
-// Fourteen wave64 sums with a transposing butterfly (32 instructions instead of 14 x 6 DPP adds + 14
-// lane moves).  Level 1 pairs registers with v_permlane32_swap (lanes l <-> l+32), level 2 with
-// v_permlane16_swap (row r <-> r^1); a pair (X, Y) becomes ONE register holding X's partial sums in
-// one half of the lanes and Y's in the other.  Levels 3 and 4 do the same across the four quads of a
-// row with bank-masked DPP adds (bank_mask enables quads; row_half_mirror pairs quad 0<->1, 2<->3 and
-// row_ror:8 pairs 0<->2, 1<->3), and two quad_perm steps finish the sum inside each quad.  Value k
-// is complete in every lane with slot_of_lane(lane) == k.
-__device__ __forceinline__ float pair32(float x, float y) {
-	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float pair16(float x, float y) {
-	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ int slot_of_lane(int lane) {
-	return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 2) & 1) << 2) | (((lane >> 3) & 1) << 3);
-}
-__device__ __forceinline__ float wave_sum14_transposed(float x0, float x1, float x2, float x3, float x4, float x5, float x6,
-	float x7, float x8, float x9, float x10, float x11, float x12, float x13) {
-	const float y0 = pair32(x0, x1), y1 = pair32(x2, x3), y2 = pair32(x4, x5), y3 = pair32(x6, x7);
-	const float y4 = pair32(x8, x9), y5 = pair32(x10, x11), y6 = pair32(x12, x13);
-	float z0 = pair16(y0, y1), z1 = pair16(y2, y3), z2 = pair16(y4, y5), z3 = pair16(y6, y6);
-	// a DPP source needs 2 wait states after the VALU write of that register: the s_nops / the
-	// interleaving below provide them (the compiler does not look inside the asm block).
-	asm volatile(
-		"s_nop 1\n\t"
-		"v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-		"v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-		"v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-		"v_add_f32_dpp %2, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-		"s_nop 0\n\t"
-		"v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-		"v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-		"s_nop 1\n\t"
-		"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-		"s_nop 1\n\t"
-		"v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-		"s_nop 1"
-		: "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
-	return z0;
-}
-
-// Fourteen wave64 sums through LDS instead of the register butterfly above.  Measured on gfx950 (tools/microbench/valu_rates.hip,
-// profiles/r03/valu_rates.txt): v_permlane32_swap / v_permlane16_swap retire at a QUARTER of the fp32 rate (8.2 cycles per wave64
-// instruction, like v_exp_f32), DPP adds at half rate (4.3) -- the butterfly's 11 swaps + 11 adds + 10 DPP adds are ~165 VALU cycles
-// per entry, a fifth of the backward's time per entry -- while the LDS pipe idles.  Here every lane stores its 14 partial sums
-// ([value][lane], conflict-free), lane l reads back a quarter (l & 3) of value l >> 2 as four 16-byte words (value rows padded
-// to 68 floats: the sixteen lanes of a read group hit sixteen different bank quads), adds its 16 numbers, and two quad DPP adds
-// finish: 15 full-rate adds + 2 DPP adds of VALU work.  The LDS operations of one wave execute in order: no barrier.
-#ifndef ADGS_BWD_LDS_REDUCE
-#define ADGS_BWD_LDS_REDUCE 1
-#endif
-constexpr int RED_STRIDE = WAVE + 4;      // floats per value row
-__device__ __forceinline__ float wave_sum14_lds(float* s_red, int lane, float x0, float x1, float x2, float x3, float x4, float x5, float x6,
+__device__ __forceinline__ float wave_sum14_lds(float* s_red, const RedAddr& ra, int lane, float x0, float x1, float x2, float x3, float x4, float x5, float x6,
 	float x7, float x8, float x9, float x10, float x11, float x12, float x13) {
 	float* w = s_red + lane;
 	w[0 * RED_STRIDE] = x0; w[1 * RED_STRIDE] = x1; w[2 * RED_STRIDE] = x2; w[3 * RED_STRIDE] = x3; w[4 * RED_STRIDE] = x4;
 	w[5 * RED_STRIDE] = x5; w[6 * RED_STRIDE] = x6; w[7 * RED_STRIDE] = x7; w[8 * RED_STRIDE] = x8; w[9 * RED_STRIDE] = x9;
 	w[10 * RED_STRIDE] = x10; w[11 * RED_STRIDE] = x11; w[12 * RED_STRIDE] = x12; w[13 * RED_STRIDE] = x13;
-	// rows 14 and 15 are never written: their lanes read whatever the buffer holds and nobody uses the result
-	const float4* r = reinterpret_cast<const float4*>(s_red + (lane >> 2) * RED_STRIDE + (lane & 3) * 16);
-	const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+	const float4 a = *ra.r[0], b = *ra.r[1], c = *ra.r[2], d = *ra.r[3];
 	float v = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
 	v += ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
 	int x = __float_as_int(v);
@@ -592,17 +462,35 @@ __device__ __forceinline__ void bwd_finish_moments(BwdSums& v, float dx) {
 	v.mx = dx * v.op; v.ca = dx * v.mx; v.cb = dx * v.my;
 }
 
+// The lane's pixels against one entry of the replay: alpha, G, dy and the lane masks of the pixels the entry contributed to.  LEAN: the
+// entry needs neither the power test nor the clamp (eval_pixel) AND lies before every pixel's last contributor (wave-uniform: the
+// position test of backward.cu:553 is then true for all of them).
+template <bool LEAN, int PPL>
+__device__ __forceinline__ uint64_t eval_entry_bwd(const EntryGeom& eg, float pyf0, int contributor, const int (&last_contributor)[PPL],
+	float (&alpha)[PPL], float (&G)[PPL], float (&dy)[PPL], uint64_t (&actm)[PPL]) {
+	uint64_t any_m = 0ull;
+#pragma unroll
+	for (int k = 0; k < PPL; k++) {
+		float power;
+		eval_pixel<LEAN>(eg, pyf0 + (float)(4 * k), dy[k], power, G[k], alpha[k]);
+		actm[k] = LEAN ? __builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN))
+		               : (__builtin_amdgcn_ballot_w64(contributor < last_contributor[k]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+		                  __builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN)));
+		any_m |= actm[k];
+	}
+	return any_m;
+}
+
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
 // the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
 template <int PPL, bool FULL>
 __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(RenderV2BwdArgs a) {
 	constexpr int ROWS = 4 * PPL;
 	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
-	__shared__ float4 s_splat[(WAVE + 1) * 4];      // entry j lives in row j+1 (row 0: prefetch padding)
-	__shared__ uint32_t s_id[WAVE];
-#if ADGS_BWD_LDS_REDUCE
-	__shared__ __attribute__((aligned(16))) float s_red[16 * RED_STRIDE];
-#endif
+	// 4096 + 3584 bytes: 21 one-wave workgroups per CU (8768 bytes until round 3 capped the kernel at 18 = 4.5 waves per SIMD whatever
+	// its registers allowed)
+	__shared__ float4 s_splat[WAVE * 4];
+	__shared__ __attribute__((aligned(16))) float s_red[RED_ROWS * RED_STRIDE];
 	const int lane = threadIdx.x;
 	const uint32_t tile = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
@@ -616,12 +504,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	int last_contributor[PPL];
 	float Bsum[PPL];          // sum_ch A_ch * dL/dC_ch of the suffix blend A behind the current entry (see below)
 	float gC0[PPL], gC1[PPL], gC2[PPL], gF0[PPL], gF1[PPL], gF2[PPL], gD[PPL], gS[PPL];
-	int max_contrib = 0;
-#if ADGS_BWD_LDS_REDUCE
-	const int slot = lane >> 2;
-#else
-	const int slot = slot_of_lane(lane);
-#endif
+	int max_contrib = 0, min_contrib = 0x7fffffff;
+	const int slot = lane >> 2;                      // the gacc slot this lane's quad finishes in wave_sum14_lds
+	const RedAddr red = red_addresses(s_red, lane);
 	const bool writer = (lane & 3) == 0 && slot < GACC_USED;
 #pragma unroll
 	for (int k = 0; k < PPL; k++) {
@@ -633,6 +518,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 		T[k] = T_final;
 		last_contributor[k] = inside[k] ? (int)a.n_contrib[pix_id] : 0;
 		max_contrib = max(max_contrib, last_contributor[k]);
+		min_contrib = min(min_contrib, last_contributor[k]);      // an out-of-image pixel has 0: a tile with one never takes the lean path
 		Bsum[k] = 0.f;
 		gC0[k] = gC1[k] = gC2[k] = gF0[k] = gF1[k] = gF2[k] = gD[k] = gS[k] = 0.f;
 		if (inside[k]) {
@@ -656,61 +542,85 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 		tfo[k] = gO * T_final; tfb[k] = T_final * b;
 	}
 #pragma unroll
-	for (int off = WAVE / 2; off > 0; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
+	for (int off = WAVE / 2; off > 0; off >>= 1) {
+		max_contrib = max(max_contrib, __shfl_xor(max_contrib, off, WAVE));
+		min_contrib = min(min_contrib, __shfl_xor(min_contrib, off, WAVE));
+	}
+	max_contrib = __builtin_amdgcn_readfirstlane(max_contrib);      // wave-uniform from here: the per-entry tests against them are scalar
+	min_contrib = __builtin_amdgcn_readfirstlane(min_contrib);
 	uint32_t chunk = a.tile_last_chunk[tile];
 	int base = (int)a.tile_consumed[tile];        // one past the last position of the current chunk
-#ifdef ADGS_TIMELINE
-	const unsigned long long tl_r0 = wall_clock64();
+	TL_DECL; PROBE_DECL;
+	PT_DECL(9); PT(t_wave0);
+	{
+		// timing build: the prologue's pixel-state loads have landed when the first of them can be used
+		float pt_probe = gC0[0] + T[0];
+		(void)pt_probe;
+#ifdef ADGS_PHASE_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(pt_probe) :: "memory");
 #endif
-#ifdef ADGS_PROBE
-	const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_r0 = wall_clock64();
-	unsigned pr_pairs = 0, pr_evals = 0, pr_live = 0, pr_strips = 0;
-#endif
-	while (chunk != NO_CHUNK) {
+		PT(t_p1); PT_ACC(8, t_wave0, t_p1);
+	}
+	// The replay list is a chain of chunks ([64 ids, prev, count]).  Ids and link words of a chunk are two independent vector loads, and
+	// those of the NEXT chunk are requested before the current chunk's entry loop, so that at a chunk boundary only the Splat gather is
+	// an exposed round trip (until round 3: header -> ids -> gather, three dependent ones per 64 entries).
+	uint32_t my_id = 0, link = 0;                 // lane j: id of entry j; lanes 0 / 1: prev chunk / entry count
+	if (chunk != NO_CHUNK) {
 		const uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
-		const uint32_t prev = c[0];
-		const int n = (int)c[1];
+		my_id = c[lane]; link = c[CHUNK_PREV + (lane & 1)];
+	}
+	while (chunk != NO_CHUNK) {
+		PT(t_c0);
+		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(2);      // a chunk boundary is a dozen instructions between two waits: do not starve behind the older waves' entry loops
+		const uint32_t prev = (uint32_t)__builtin_amdgcn_readlane((int)link, 0);
+		const int n = __builtin_amdgcn_readlane((int)link, 1);
+#ifdef ADGS_PHASE_TIMING
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+		PT(t_c1); PT_ACC(0, t_c0, t_c1); PT_ADD(6, 1ull);
 		base -= n;
+		const uint32_t cur_id = my_id;
+		if (prev != NO_CHUNK) {
+			const uint32_t* cn = a.pool + (size_t)prev * CHUNK_WORDS;
+			my_id = cn[lane]; link = cn[CHUNK_PREV + (lane & 1)];
+		}
 		if (base < max_contrib) {
 			__syncthreads();
+			bool my_lean = false;
 			if (lane < n) {
-				const uint32_t id = c[2 + lane];
-				const float4* src = reinterpret_cast<const float4*>(a.splats + id);
-				s_splat[(lane + 1) * 4 + 0] = src[0];
-				s_splat[(lane + 1) * 4 + 1] = src[1];
-				s_splat[(lane + 1) * 4 + 2] = src[2];
+				const float4* src = reinterpret_cast<const float4*>(a.splats + cur_id);
+				s_splat[lane * 4 + 0] = src[0];
+				s_splat[lane * 4 + 1] = src[1];
+				s_splat[lane * 4 + 2] = src[2];
 				float4 q3s = src[3];
-				if (!FULL && a.sem_src) q3s.y = a.sem_src[(size_t)id * a.sem_stride];      // an extra semantic channel's replay
-				s_splat[(lane + 1) * 4 + 3] = q3s;
-				s_id[lane] = id;
+				my_lean = ADGS_LEAN && q3s.w != 0.f;
+				if (!FULL && a.sem_src) q3s.y = a.sem_src[(size_t)cur_id * a.sem_stride];      // an extra semantic channel's replay
+				s_splat[lane * 4 + 3] = q3s;
 			}
+			// bit j: entry j takes the lean evaluation -- its Gaussian allows it and its position lies before every pixel's last contributor
+			// (contributor = base + j < min_contrib: the position test holds for all pixels)
+			const int n_before = min_contrib - base;
+			const uint64_t lean_m = __builtin_amdgcn_ballot_w64(my_lean) & (n_before >= WAVE ? ~0ull : n_before <= 0 ? 0ull : ((1ull << n_before) - 1ull));
 			__syncthreads();
+			if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
+			PT(t_g1); PT_ACC(1, t_c1, t_g1);
 			for (int j = n - 1; j >= 0; j--) {
 				const int contributor = base + j;
 				if (contributor >= max_contrib) continue;
-				const float4 q0 = s_splat[(j + 1) * 4 + 0], q1 = s_splat[(j + 1) * 4 + 1];
+				PT_ADD(7, 1ull);
+				const float4 q0 = s_splat[j * 4 + 0], q1 = s_splat[j * 4 + 1];
 				const float dx = q0.x - pxf;
 				const EntryGeom eg = entry_geom(q0, q1, dx);
-#ifdef ADGS_PROBE
-				pr_evals++;
-#endif
-				float alpha[PPL], G[PPL], dy[PPL]; uint64_t actm[PPL]; uint64_t any_m = 0ull;      // lane masks on the scalar unit, as in the forward
-#pragma unroll
-				for (int k = 0; k < PPL; k++) {
-					float power;
-					eval_pixel(eg, pyf0 + (float)(4 * k), dy[k], power, G[k], alpha[k]);
-					actm[k] = __builtin_amdgcn_ballot_w64(contributor < last_contributor[k]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
-						__builtin_amdgcn_ballot_w64(!(alpha[k] < ALPHA_MIN));
-					any_m |= actm[k];
-				}
+				// the entry's Gaussian: a scalar from the id register (lane j holds entry j), early -- its only use is the atomic's address
+				const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur_id, j);
+				PROBE_EVAL();
+				float alpha[PPL], G[PPL], dy[PPL]; uint64_t actm[PPL];      // lane masks on the scalar unit, as in the forward
+				const uint64_t any_m = ((lean_m >> j) & 1ull) ? eval_entry_bwd<true, PPL>(eg, pyf0, contributor, last_contributor, alpha, G, dy, actm)
+				                            : eval_entry_bwd<false, PPL>(eg, pyf0, contributor, last_contributor, alpha, G, dy, actm);
 				if (any_m == 0ull) continue;
-				const float4 q2 = s_splat[(j + 1) * 4 + 2];
-				const float4 q3 = s_splat[(j + 1) * 4 + 3];
-#ifdef ADGS_PROBE
-				pr_live++;
-#pragma unroll
-				for (int k = 0; k < PPL; k++) { pr_pairs += (unsigned)__popcll(actm[k]); pr_strips += actm[k] != 0ull; }
-#endif
+				const float4 q2 = s_splat[j * 4 + 2];
+				const float4 q3 = s_splat[j * 4 + 3];
+				PROBE_LIVE(actm, PPL);
 				// geometric part: with L = G * dL/dalpha per pixel, the reference's six sums are linear in
 				//   S0 = sum L, Sx = sum L dx, Sy = sum L dy, Sxx = sum L dx^2, Sxy = sum L dx dy, Syy = sum L dy^2
 				// (dL/dmean2D = -op*(ca Sx + cb Sy)*W/2 ..., dL/dconic = -op/2 * S.., dL/dopacity = S0); the
@@ -726,39 +636,36 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	bwd_strip<true>(v, be, bp, act ? alpha[k] : 0.f, act ? G[k] : 0.f, dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
 #define ADGS_BWD_ACCK(k) if (__builtin_amdgcn_inverse_ballot_w64(actm[k])) { ADGS_BWD_PIXEL(k); \
 	bwd_strip<false>(v, be, bp, alpha[k], G[k], dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
+				if (ADGS_KO & 4) { v.op = alpha[0] + alpha[PPL - 1]; v.my = G[0]; v.cc = dy[0]; v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = q2.x + q3.x; }
+				else {
 				if (actm[0] != 0ull) { ADGS_BWD_INITK(0) }
 				else v.op = v.my = v.cc = v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = 0.f;
 #pragma unroll
 				for (int k = 1; k < PPL; k++) { ADGS_BWD_ACCK(k) }
+				}
 				bwd_finish_moments(v, dx);
 #undef ADGS_BWD_PIXEL
 #undef ADGS_BWD_INITK
 #undef ADGS_BWD_ACCK
-				// 14 wave sums by a transposing reduction: every level halves the number of live registers
-				// (slot k of the 64-B gradient line ends up in the lanes with slot_of_lane == k) -> one
-				// atomic instruction on one 64-B line.  Absent channels stay exactly 0.
-#if ADGS_BWD_LDS_REDUCE
-				const float out = wave_sum14_lds(s_red, lane, v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
-#else
-				const float out = wave_sum14_transposed(v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
-#endif
+				// 14 wave sums through LDS (slot k of the 64-byte gradient line ends up in the quad of lanes 4k .. 4k+3) -> one atomic
+				// instruction on one 64-byte line.  Absent channels stay exactly 0.
+				PT(t_r0);
+				const float out = (ADGS_KO & 2) ? (((v.op + v.mx) + (v.my + v.ca)) + ((v.cb + v.cc) + (v.c0 + v.c1))) + (((v.c2 + v.d) + (v.f0 + v.f1)) + (v.f2 + v.s))
+					: wave_sum14_lds(s_red, red, lane, v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
 				if (!FULL && a.sem_dst) {
-					if (writer && (slot < 6 || slot == GACC_USED - 1)) atomicAdd(slot == GACC_USED - 1 ? a.sem_dst + (size_t)s_id[j] * a.sem_stride : a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
-				} else if (writer) atomicAdd(a.gacc + (size_t)s_id[j] * GACC_STRIDE + slot, out);
+					if (writer && (slot < 6 || slot == GACC_USED - 1)) atomicAdd(slot == GACC_USED - 1 ? a.sem_dst + (size_t)gid * a.sem_stride : a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
+				} else if (ADGS_KO & 1) { if (out == 123.456f) a.gacc[(size_t)gid * GACC_STRIDE + slot] = out; }
+				else if (writer) atomicAdd(a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
+				PT(t_r1); PT_ACC(3, t_r0, t_r1);
 			}
+			PT(t_e1); PT_ACC(2, t_g1, t_e1);
 		}
 		chunk = prev;
 	}
-#ifdef ADGS_TIMELINE
-	if (lane == 0 && a.tl_start) { a.tl_start[tile] = (uint32_t)tl_r0; a.tl_end[tile] = (uint32_t)wall_clock64(); }
-#endif
-#ifdef ADGS_PROBE
-	if (lane == 0) {
-		atomicAdd(&g_probe[8], __builtin_readcyclecounter() - pr_c0); atomicAdd(&g_probe[9], wall_clock64() - pr_r0); atomicAdd(&g_probe[10], 1ull);
-		atomicAdd(&g_probe[11], (unsigned long long)pr_pairs); atomicAdd(&g_probe[12], (unsigned long long)pr_evals); atomicAdd(&g_probe[13], (unsigned long long)pr_live);
-		atomicAdd(&g_probe[14], (unsigned long long)pr_strips);
-	}
-#endif
+	if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
+	{ PT(t_wave1); PT_ACC(4, t_wave0, t_wave1); PT_ADD(5, 1ull); PT_FLUSH(16, 9, lane); }
+	TL_STORE(lane, a.tl_start, a.tl_end, tile);
+	PROBE_FLUSH(8, lane);
 }
 
 // Semantic channels 1 .. D_S-1 of the forward image (RenderV2SemFwdArgs): the replay loop of the backward without the gradients.
@@ -791,13 +698,13 @@ __global__ void __launch_bounds__(WAVE, 8) render_sem_fwd_v2_kernel(RenderV2SemF
 	int base = (int)a.tile_consumed[tile];
 	while (chunk != NO_CHUNK) {
 		const uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
-		const uint32_t prev = c[0];
-		const int n = (int)c[1];
+		const uint32_t prev = c[CHUNK_PREV];
+		const int n = (int)c[CHUNK_COUNT];
 		base -= n;
 		if (base < max_contrib) {
 			__syncthreads();
 			if (lane < n) {
-				const uint32_t id = c[2 + lane];
+				const uint32_t id = c[lane];
 				const float4* src = reinterpret_cast<const float4*>(a.splats + id);
 				s_geo[lane * 2 + 0] = src[0];
 				s_geo[lane * 2 + 1] = src[1];
@@ -818,7 +725,7 @@ __global__ void __launch_bounds__(WAVE, 8) render_sem_fwd_v2_kernel(RenderV2SemF
 #pragma unroll
 				for (int k = 0; k < PPL; k++) {
 					float dy, power, G, alpha;
-					eval_pixel(eg, pyf0 + (float)(4 * k), dy, power, G, alpha);
+					eval_pixel<false>(eg, pyf0 + (float)(4 * k), dy, power, G, alpha);      // same bits as the lean form where that one applies
 					const bool act = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
 					const float al = act ? alpha : 0.f;
 					S[k][0] = fmaf(al, sv.x - S[k][0], S[k][0]); S[k][1] = fmaf(al, sv.y - S[k][1], S[k][1]);
@@ -934,21 +841,3 @@ int launch_render_bwd_v2(const RenderV2BwdArgs& a, hipStream_t stream) {
 
 } // namespace adgs
 
-#ifdef ADGS_PROBE
-// experiment build only: read and reset the probe counters of the two blend kernels
-extern "C" int adgs_test_probe_read(unsigned long long* out16) {
-	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(adgs::g_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-	unsigned long long z[16] = { 0 };
-	if (hipMemcpyToSymbol(HIP_SYMBOL(adgs::g_probe), z, sizeof(z)) != hipSuccess) return -1;
-	return 0;
-}
-#endif
-#ifdef ADGS_FWD_TIMING
-// experiment build only: read and reset the phase counters of render_fwd_v2_kernel
-extern "C" int adgs_test_fwd_timing(unsigned long long* out16) {
-	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(adgs::g_fwd_timing), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-	unsigned long long z[16] = { 0 };
-	if (hipMemcpyToSymbol(HIP_SYMBOL(adgs::g_fwd_timing), z, sizeof(z)) != hipSuccess) return -1;
-	return 0;
-}
-#endif

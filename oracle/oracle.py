@@ -129,6 +129,16 @@ class RasterOracle:
         self.R = int(R)
         return out
 
+    def gate_margins(self):
+        """After forward(): how close every pixel's walk came to one of the three hard gates of forward.cu:345-361, in units of the
+        rounding error of a float32 evaluation (raster_oracle.cpp: gate_margins), and per Gaussian the minimum over the pixels it
+        takes part in.  tests/parity.py uses them to tell a gate flip from a wrong result."""
+        pix = np.full((self.H, self.W), 1e30, self.real)
+        gauss = np.full((self.P,), 1e30, self.real)
+        if self.P != 0:
+            getattr(lib(), "adgs_oracle_gate_margins_" + self.suf)(self._h, _ptr(pix), _ptr(gauss))
+        return dict(pixel=pix, gauss=gauss)
+
     def state(self):
         """Internal buffers (geometry / binning / image state) for white-box tests."""
         P, R, r = self.P, self.R, self.real

@@ -436,6 +436,92 @@ struct Oracle {
 		return R;
 	}
 
+	// ------------------------------------------------------------------ gate margins (test infrastructure of the test infrastructure)
+	// forward.cu:345-361 has three hard gates on computed values: `power > 0`, `alpha < 1/255`, `T (1 - alpha) < 0.0001`.  Two correct
+	// float32 evaluations of the same frame can take a gate differently when the gated value lies within their rounding error of the
+	// threshold, and the pixel (and every Gaussian that pixel feeds a gradient to) then differs by far more than 1e-4.  This pass
+	// re-walks every pixel's list and reports how close each pixel came to a gate, in units of the rounding error of a float32
+	// evaluation, so that a parity test can tell an EXPLAINED deviation (margin <= a few float32 ulps) from a wrong result:
+	//   power gate:  |power| / S                              S = |0.5 A dx^2| + |0.5 C dy^2| + |B dx dy|  (the terms' magnitudes)
+	//   alpha gate:  |op exp(power) - 1/255| / (1/255 (1 + S))    (an absolute error e in power is a relative error e in alpha)
+	//   T gate:      |T (1 - alpha) - 1e-4| / (1e-4 (1 + E))      E = sum over the factors of T so far (this one included) of
+	//                1 + (1 + S) alpha / (1 - alpha): the product's roundings plus what alpha's relative error does to 1 - alpha
+	//                (an alpha clamped to 0.99 is exact)
+	// pix_margin[pixel] = the minimum over its walk; gauss_margin[g] = the minimum pix_margin over the pixels in whose walk g takes part
+	// (passes the power and alpha gates, or misses one of them by less than 1e-3 relative) -- the walk is continued past the T stop
+	// for this purpose, because a flipped stop lets the Gaussians behind it contribute.
+	void gate_margins(real* pix_margin /*H*W*/, real* gauss_margin /*P*/) {
+		const real INF = (real)1e30;
+		for (size_t i = 0; i < (size_t)W * H; i++) pix_margin[i] = INF;
+		std::vector<std::vector<real>> gm_thread;
+		int nthreads = 1;
+#ifdef _OPENMP
+		nthreads = omp_get_max_threads();
+#endif
+		gm_thread.assign(nthreads, std::vector<real>());
+#pragma omp parallel
+		{
+			int tid = 0;
+#ifdef _OPENMP
+			tid = omp_get_thread_num();
+#endif
+			std::vector<real>& gm = gm_thread[tid];
+			gm.assign((size_t)P, INF);
+			std::vector<uint32_t> walk;
+#pragma omp for schedule(dynamic, 1)
+			for (int tile = 0; tile < gx * gy; tile++) {
+				int tx = tile % gx, ty = tile / gx;
+				uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+				for (int ly = 0; ly < BLOCK_Y; ly++) for (int lx = 0; lx < BLOCK_X; lx++) {
+					int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+					if (!(px < W && py < H)) continue;
+					size_t pix_id = (size_t)W * py + px;
+					real pixfx = (real)px, pixfy = (real)py;
+					real T = 1, m = INF, E = 0;
+					bool done = false;
+					walk.clear();
+					for (uint32_t k = r0; k < r1; k++) {
+						uint32_t g = point_list[k];
+						real dx = means2D[2 * g] - pixfx, dy = means2D[2 * g + 1] - pixfy;
+						const real* co = &conic_opacity[4 * (size_t)g];
+						real ta = (real)0.5 * co[0] * dx * dx, tc = (real)0.5 * co[2] * dy * dy, tb = co[1] * dx * dy;
+						real S = std::abs(ta) + std::abs(tc) + std::abs(tb);
+						real power = -(ta + tc) - tb;
+						real araw = co[3] * std::exp(std::min(power, (real)0));
+						const real amin = fc<real>(1.0f / 255.0f);
+						real m_alpha = std::abs(araw - amin) / (amin * (1 + S));
+						real m_pow = S > 0 ? std::abs(power) / S : INF;
+						// the power gate only matters where alpha would pass
+						bool near_alpha = m_alpha < (real)1e-3, near_pow = m_pow < (real)1e-3 && araw >= amin * (real)0.999;
+						bool passes = !(power > 0) && !(araw < amin);
+						if (!done) {
+							if (near_alpha) m = std::min(m, m_alpha);
+							if (near_pow) m = std::min(m, m_pow);
+						}
+						if (!(passes || near_alpha || near_pow)) continue;
+						walk.push_back(g);
+						if (!passes || done) continue;
+						real alpha = std::min(fc<real>(0.99f), araw);
+						real test_T = T * (1 - alpha);
+						const real tstop = fc<real>(0.0001f);
+						E += 1 + (araw < fc<real>(0.99f) ? (1 + S) * alpha / (1 - alpha) : (real)0);
+						real m_T = std::abs(test_T - tstop) / (tstop * (1 + E));
+						m = std::min(m, m_T);
+						if (test_T < tstop) { done = true; continue; }
+						T = test_T;
+					}
+					pix_margin[pix_id] = m;
+					for (uint32_t g : walk) gm[g] = std::min(gm[g], m);
+				}
+			}
+		}
+		for (int g = 0; g < P; g++) {
+			real v = INF;
+			for (auto& gm : gm_thread) if (!gm.empty()) v = std::min(v, gm[g]);
+			gauss_margin[g] = v;
+		}
+	}
+
 	// ------------------------------------------------------------------ backward
 	// backward.cu:417-646 (renderCUDA).  The reference scatters with fp32
 	// atomicAdd in an unspecified order; this restatement accumulates every
@@ -804,6 +890,7 @@ extern "C" void adgs_oracle_backward_##SUF(void* h, const float* dL_dpix, const 
 extern "C" void adgs_oracle_mark_visible_##SUF(void* h, int P, const float* means, const float* view, const float* proj, uint8_t* present) { \
 	((Oracle<real>*)h)->markVisible(P, means, view, proj, present); } \
 extern "C" int adgs_oracle_num_rendered_##SUF(void* h) { return ((Oracle<real>*)h)->R; } \
+extern "C" void adgs_oracle_gate_margins_##SUF(void* h, real* pix_margin, real* gauss_margin) { ((Oracle<real>*)h)->gate_margins(pix_margin, gauss_margin); } \
 extern "C" void adgs_oracle_get_state_##SUF(void* h, real* means2D, real* depths, real* cov3D, real* rgb, real* conic_opacity, \
 	uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_list, uint64_t* keys, uint32_t* ranges, uint32_t* n_contrib) { \
 	Oracle<real>* o = (Oracle<real>*)h; \

@@ -3,8 +3,14 @@
 Three independent constraints per tensor, because gradient tensors are heavy-tailed and a tolerance relative to the tensor's
 maximum alone lets every element far below the maximum pass with O(1) relative error:
 
-  1. element-wise: |got - ref| <= tol |ref| + tol max|ref| for all but a `max_frac` fraction of the elements (gate flips at
-     alpha = 1/255, power = 0 and T = 1e-4 are hard thresholds on exp() outputs), every outlier bounded by `outlier_rel` max|ref|;
+  1. element-wise: |got - ref| <= tol |ref| + tol max|ref| for EVERY element -- except those a gate flip explains: `alpha >= 1/255`,
+     `power <= 0` and `T (1 - alpha) >= 1e-4` (forward.cu:345-361) are hard thresholds on computed values, and two correct float32
+     evaluations take a gate differently when the value lies within their rounding error of the threshold.  With `explained` (a mask
+     built from the oracle's own gate margins, raster_oracle.cpp: gate_margins -- True for the pixels whose walk came within GATE_EPS
+     of a gate, measured in units of the float32 rounding error of the gated quantity, and for the Gaussians those pixels feed) an
+     element outside the tolerance passes only if it is explained; every such outlier is still bounded by `outlier_rel` max|ref|.
+     Without a mask (HIP-vs-HIP comparisons of tensors no oracle pass describes) the round-1..3 rule applies: at most a `max_frac`
+     fraction of bounded outliers;
   2. relative L2: ||got - ref||_2 <= rel_l2 ||ref||_2 -- the whole tensor, tail included, weighted by energy;
   3. rows ([P, ...] tensors): the per-row error relative to the row's own norm, with a floor of `tol` x the RMS row norm (NOT the
      maximum), may exceed 1e-3 on at most 1 % and 1e-2 on at most 0.1 % of the non-zero rows (`row_tol`).
@@ -18,6 +24,28 @@ oracle: relative L2 1e-5 ... 4e-5 at C2 / C3 / C5 (7e-5 on the rotation gradient
 import numpy as np
 
 TOL = 1e-4
+# A gate counts as "within rounding error" up to this margin (raster_oracle.cpp: gate_margins normalises by the magnitude of the terms of
+# the gated quantity, so the figure is a multiple of the float32 unit round-off 6e-8: ~100 ulps, what a dozen-operation float32
+# evaluation plus a 1-ulp v_exp_f32 and the forward's running product can be off by).  Measured (tools/parity_stats.py, C2 / C3 and
+# the fuzz sweeps of EXPERIMENTS.md): every observed flip sits below 2e-6; 6e-6 flags ~1e-4 of the pixels of a frame.
+GATE_EPS = 6e-6
+
+
+def explained_masks(margins, eps=GATE_EPS):
+    """Boolean masks (pixel [H, W], gauss [P]) from RasterOracle.gate_margins(): True where a deviation beyond the tolerance is
+    explainable by a gate flip."""
+    return dict(pixel=np.asarray(margins["pixel"]) <= eps, gauss=np.asarray(margins["gauss"]) <= eps)
+
+
+def _broadcast_mask(mask, shape, name):
+    m = np.asarray(mask, dtype=bool)
+    if m.shape == tuple(shape):
+        return m
+    if len(shape) == 3 and m.shape == tuple(shape[1:]):             # [C, H, W] image, [H, W] pixel mask
+        return np.broadcast_to(m[None], shape)
+    if m.ndim == 1 and m.shape[0] == shape[0]:                      # [P, ...] rows, [P] Gaussian mask
+        return np.broadcast_to(m.reshape((-1,) + (1,) * (len(shape) - 1)), shape)
+    raise ValueError("%s: explained mask of shape %s does not fit a tensor of shape %s" % (name, m.shape, tuple(shape)))
 
 
 def error_stats(got, ref, tol=TOL):
@@ -27,7 +55,7 @@ def error_stats(got, ref, tol=TOL):
     scale = max(float(np.abs(ref).max()), 1e-30) if ref.size else 1e-30
     bad = err > tol * np.abs(ref) + tol * scale
     nref = float(np.sqrt((ref ** 2).sum()))
-    st = dict(n=int(got.size), scale=scale, max_err=float(err.max()) if got.size else 0.0, n_bad=int(bad.sum()),
+    st = dict(_bad=bad, n=int(got.size), scale=scale, max_err=float(err.max()) if got.size else 0.0, n_bad=int(bad.sum()),
               frac_bad=float(bad.mean()) if got.size else 0.0, rel_l2=float(np.sqrt((err ** 2).sum()) / max(nref, 1e-300)),
               max_bad_err=float(err[bad].max()) if bad.any() else 0.0)
     if got.ndim >= 2 and got.shape[0] > 1:
@@ -40,17 +68,28 @@ def error_stats(got, ref, tol=TOL):
             st.update(row_rms=rms, row_rel_p50=float(np.median(rel)), row_rel_p99=float(np.percentile(rel, 99)),
                       row_rel_p9999=float(np.percentile(rel, 99.99)), row_rel_max=float(rel.max()), rows=int(nz.sum()))
             st["_row_rel"] = rel
+            st["_row_nz"] = nz
     return st
 
 
-def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=1e-4, row_tol=((1e-3, 1e-2), (1e-2, 1e-3))):
+def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=1e-4, row_tol=((1e-3, 1e-2), (1e-2, 1e-3)), explained=None):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     if got.size == 0:
         return None
     st = error_stats(got, ref, tol)
-    assert st["frac_bad"] <= max_frac, "%s: %.3g of elements outside tol (max err %.3g, scale %.3g)" % (name, st["frac_bad"], st["max_err"], st["scale"])
+    ex_rows = None
+    if explained is not None:
+        ex = _broadcast_mask(explained, got.shape, name)
+        unexplained = st["_bad"] & ~ex
+        st["n_unexplained"] = int(unexplained.sum())
+        assert st["n_unexplained"] == 0, "%s: %d element(s) outside tol that no gate flip explains (of %d outside tol; max unexplained err %.3g, scale %.3g; %d elements flagged)" % (
+            name, st["n_unexplained"], st["n_bad"], float(np.abs(got - ref)[unexplained].max()), st["scale"], int(ex.sum()))
+        if got.ndim >= 2 and np.asarray(explained).ndim == 1:
+            ex_rows = np.asarray(explained, dtype=bool)
+    else:
+        assert st["frac_bad"] <= max_frac, "%s: %.3g of elements outside tol (max err %.3g, scale %.3g)" % (name, st["frac_bad"], st["max_err"], st["scale"])
     assert st["max_bad_err"] <= outlier_rel * st["scale"], "%s: gate-flip outlier too large: %g (scale %g)" % (name, st["max_bad_err"], st["scale"])
     if rel_l2 is not None and st["scale"] > 1e-30:
         # a single flipped (pixel, Gaussian) pair moves one element by up to ~alpha: allow the L2 mass of the permitted outliers
@@ -58,7 +97,10 @@ def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l
         assert st["rel_l2"] <= allow, "%s: relative L2 error %.3g > %.3g" % (name, st["rel_l2"], allow)
     if row_tol is not None and "_row_rel" in st:
         for rt, rf in row_tol:          # (relative row error, fraction of the non-zero rows that may exceed it)
-            frac = float((st["_row_rel"] > rt).mean())
+            over = st["_row_rel"] > rt
+            if ex_rows is not None:     # rows of Gaussians a flipped pixel feeds are accounted for by constraint 1
+                over = over & ~ex_rows[st["_row_nz"]]
+            frac = float(over.mean())
             assert frac <= max(rf, 2.0 / st["rows"]), "%s: %.3g of the rows are off by more than %g of their own norm (p99 %.3g, max %.3g)" % (
                 name, frac, rt, st["row_rel_p99"], st["row_rel_max"])
     return st

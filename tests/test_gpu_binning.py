@@ -147,6 +147,20 @@ def test_chunk_table_overflow_falls_back_to_the_device_wide_sort(monkeypatch):
     assert _stats()["bucket_binning"] == 1
 
 
+def test_chunk_table_overflow_without_speculation_still_renders(monkeypatch):
+    """ADGS_NO_SPECULATION=1 (documented in INTEGRATION.md) with a full chunk table: cell_scan raises the device-side overflow word also
+    when nothing was enqueued against a capacity; the fallback must clear it before it launches the blend (round-3 advisor finding: the
+    blend returned early for every tile -- a silently blank image and zero gradients)."""
+    monkeypatch.setenv("ADGS_MAX_CHUNKS", "3")
+    monkeypatch.setenv("ADGS_NO_SPECULATION", "1")
+    sc = synthetic.make_scene(30000, 400, 300, 300.0, seed=50, n_objects=2)
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 50))
+    assert _stats()["bucket_binning"] == 0
+    monkeypatch.delenv("ADGS_MAX_CHUNKS")
+    compare(sc, grads=synthetic.make_upstream_grads(sc, 50))
+    assert _stats()["bucket_binning"] == 1
+
+
 def test_c5_size_bucket_binning_equals_sort_binning_bit_for_bit(monkeypatch):
     """3 M Gaussians, 68 k pairs per cell (9 chunks per cell, 11 719 preprocess workgroups in the counts matrix): the library would pick
     the device-wide sort for this frame by itself; forced onto the bucket path, every forward output must still be bit-identical."""

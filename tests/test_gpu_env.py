@@ -117,7 +117,7 @@ def test_sparse_gradient_protocol_equals_the_dense_path(fused_zero):
             loss = loss + (e.grid_map ** 2).sum() * 1e-3          # a second gradient source: autograd hands over gg + other
         loss.backward()
         mg = e.optimizer.marked_gradient(e.grid_map)
-        own = e.grid_map.grad.data_ptr() == mg.live_ptr
+        own = mg.is_live(e.grid_map.grad)
         assert own == (it != 6), it
         adopted += own
         ref.grad = e.grid_map.grad.detach().clone()
@@ -139,3 +139,39 @@ def test_sparse_gradient_protocol_equals_the_dense_path(fused_zero):
         assert torch.equal(e.grid_map.detach(), ref.detach()), it
         assert torch.equal(st["exp_avg"], rst["exp_avg"]) and torch.equal(st["exp_avg_sq"], rst["exp_avg_sq"]), it
     assert adopted == 8 and float(st["exp_avg"].abs().max()) > 0
+
+
+def test_in_place_accumulation_into_the_marked_buffer_is_handled_densely():
+    """Round-3 advisor finding: with grad mode off autograd accumulates IN PLACE (`p.grad += new` for a second backward before the
+    step), so a non-marking source writes into unmarked tiles of the producer's buffer while its address still matches.  The optimizer
+    must see that (version counter) and scan the gradient densely: the regulariser's share reaches every texel, the step equals a plain
+    dense FusedAdam on the same gradient, and the buffer that comes back later is all zero (no residue in recycled tiles)."""
+    from adgs import env
+    from adgs.optim import FusedAdam
+    e = env.EnvironmentMap(512, 3, sparse_grad=True)
+    with torch.no_grad():
+        e.grid_map.copy_(torch.randn(e.grid_map.shape, generator=torch.Generator().manual_seed(2)).cuda() * 0.3)
+    e.training_setup(types.SimpleNamespace(env_lr=1e-2))
+    ref = torch.nn.Parameter(e.grid_map.detach().clone())
+    ref_opt = FusedAdam([{"params": [ref], "lr": 1e-2}], lr=0.0, eps=1e-15)
+    cam = _env_cam(0.3, 0.05, 0)
+    w = torch.randn(3, 400, 640, generator=torch.Generator().manual_seed(6)).cuda()
+    mg = e.optimizer.marked_gradient(e.grid_map)
+    for it in range(4):
+        (e.get_image_background(cam) * w).sum().backward()
+        ptr = e.grid_map.grad.data_ptr()
+        assert mg.is_live(e.grid_map.grad)
+        if it == 1:
+            ((e.grid_map ** 2).sum() * 1e-3).backward()          # a second backward: AccumulateGrad adds into p.grad in place
+            assert e.grid_map.grad.data_ptr() == ptr              # same address ...
+            assert not mg.is_live(e.grid_map.grad)                # ... but no longer the buffer that was issued
+            assert float((e.grid_map.grad != 0).float().mean()) > 0.99      # the regulariser reaches texels no camera ray marks
+        ref.grad = e.grid_map.grad.detach().clone()
+        e.optimizer.step(zero_grad=True)
+        ref_opt.step(zero_grad=True)
+        assert torch.equal(e.grid_map.detach(), ref.detach()), it
+        buf = mg.buffer
+        assert (buf is None) == (it == 1)                          # the touched buffer is not recycled
+        if buf is not None:
+            assert float(buf.abs().max()) == 0.0
+        del buf

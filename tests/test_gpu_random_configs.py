@@ -51,17 +51,19 @@ def test_v2_matches_classic_and_oracle_on_random_configs(seed):
                 os.environ[k] = v
     ref = run_oracle(sc, grads=g, **opts)
     assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
+    # an element outside 1e-4 passes only where the oracle's gate margins explain it (a pixel whose walk came within float32 rounding
+    # error of a gate; a Gaussian such a pixel feeds): tests/parity.py.  The same masks describe v2 ~ classic: two float32 evaluations
+    # of one frame.
+    ex = ref["explained"]
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a, b = v2[k].detach().cpu().numpy(), cl[k].detach().cpu().numpy()
-        frac = max(2e-5, 3.5 / max(a.size, 1))            # images of a few thousand pixels: 2e-5 rounds to zero -- allow ONE pixel's gate flip
-        assert_close(k + " v2~classic", a, b, max_frac=frac)
-        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), max_frac=frac)
+        assert_close(k + " v2~classic", a, b, explained=ex["pixel"])
+        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"])
     for k, gv in v2["grads"].items():
         if gv is None:
             continue
         a, b = gv.cpu().numpy(), cl["grads"][k].cpu().numpy()
-        # one flipped alpha gate moves the gradient rows of the Gaussian it belongs to and of the ones behind it on that pixel
-        assert_close("grad " + k + " v2~classic", a, b, max_frac=max(2e-4, 6.5 / max(a.size, 1)))
+        assert_close("grad " + k + " v2~classic", a, b, explained=ex["gauss"])
 
 
 def _large_case(seed):
@@ -95,20 +97,20 @@ def test_v2_matches_classic_and_oracle_on_large_random_configs(seed):
                 os.environ[k] = v
     ref = run_oracle(sc, grads=g, **opts)
     assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
+    ex = ref["explained"]
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a = v2[k].detach().cpu().numpy()
-        assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), max_frac=2e-5)
-        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), max_frac=2e-5)
+        assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), explained=ex["pixel"])
+        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"])
     names = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations",
                  flow="dL_dflow_points", sem="dL_dsemantic")
     for k, gv in v2["grads"].items():
         if gv is None:
             continue
         a = gv.cpu().numpy()
-        frac = max(2e-4, 4.5 / max(a.size, 1))          # one gate-flipped Gaussian moves all (<= 4) components of its row
-        assert_close("grad " + k + " v2~classic", a, cl["grads"][k].cpu().numpy(), max_frac=frac)
+        assert_close("grad " + k + " v2~classic", a, cl["grads"][k].cpu().numpy(), explained=ex["gauss"])
         if k in names:
-            assert_close("grad " + k + " v2~oracle", a, np.asarray(ref["grads"][names[k]]).reshape(a.shape), max_frac=frac)
+            assert_close("grad " + k + " v2~oracle", a, np.asarray(ref["grads"][names[k]]).reshape(a.shape), explained=ex["gauss"])
 
 
 def _cov3d(sc):
