@@ -58,6 +58,7 @@ SIGNATURES = {
     "adgs_envmap_backward_marked": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     # include/adgs_loss.h
     "adgs_l1_ssim_forward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_l1_ssim_means": (c_i, [c_p, ctypes.c_longlong, c_p, c_p]),
     "adgs_l1_ssim_backward": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_depth_loss_forward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_depth_loss_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -19,6 +19,49 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class _WorkArena:
+    """Zero-initialised work buffers of the loss kernels (include/adgs_loss.h) without a fill per call: the kernel that consumes a
+    buffer's slot rows leaves them zero, so a buffer only has to be zeroed when it is created.  One arena per (device, stream): N
+    slices handed out round-robin -- a training iteration uses ~9 (train.py:78-113), and with N = 64 a slice comes round again long
+    after its backward has been enqueued.  The scalars a backward reads live in the slice too: every slice carries a generation
+    number, and a backward whose slice has been handed out again in the meantime (more than N loss terms between a forward and its
+    backward) raises instead of reading another term's totals.  One arena per LAYOUT (the scalars of one layout lie inside the slot
+    rows of another: a slice must always be used with the same layout)."""
+    N = 64
+
+    def __init__(self, device, doubles):
+        self.buf = torch.zeros(self.N, doubles, dtype=torch.float64, device=device)
+        self.gen = [0] * self.N
+        self.next = 0
+
+    def take(self):
+        i = self.next
+        self.next = (i + 1) % self.N
+        self.gen[i] += 1
+        return self.buf[i], (self, i, self.gen[i])
+
+    @staticmethod
+    def check(token, what):
+        arena, i, gen = token
+        if arena.gen[i] != gen:
+            raise RuntimeError("%s: the work buffer of this loss term was handed out again before its backward ran (more than %d loss "
+                               "terms between a forward and its backward on one stream)" % (what, _WorkArena.N))
+
+
+_ARENAS = {}
+
+
+def _work(device, doubles):
+    """(zeroed work buffer of `doubles` doubles for one loss term, token for _WorkArena.check in the backward)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, doubles)
+    a = _ARENAS.get(key)
+    if a is None:
+        if len(_ARENAS) > 48:
+            _ARENAS.clear()
+        a = _ARENAS[key] = _WorkArena(device, doubles)
+    return a.take()
+
+
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, gt):
@@ -31,14 +74,15 @@ class _L1SSIM(torch.autograd.Function):
         planes = img.numel() // (H * W) if H * W else 0
         n = img.numel()
         need = ctx.needs_input_grad[0]
-        sums = torch.zeros(SLOTS, 2, dtype=torch.float64, device=img.device)      # spread atomics (include/adgs_loss.h)
+        sums, _ = _work(img.device, 2 * SLOTS)                     # spread atomics (include/adgs_loss.h); consumed by adgs_l1_ssim_means below
         maps = [torch.empty_like(img) for _ in range(3)] if need else [None] * 3
+        means = torch.empty(2, dtype=torch.float32, device=img.device) if n else torch.zeros(2, dtype=torch.float32, device=img.device)
         if n:
             with torch.cuda.device(img.device):
                 _lib.check(_lib.lib().adgs_l1_ssim_forward(planes, H, W, img.data_ptr(), ref.data_ptr(), sums.data_ptr(),
                                                            *[m.data_ptr() if m is not None else None for m in maps], _stream(img.device)),
                            "adgs_l1_ssim_forward")
-        means = (sums.sum(0) / max(n, 1)).float()
+                _lib.check(_lib.lib().adgs_l1_ssim_means(sums.data_ptr(), n, means.data_ptr(), _stream(img.device)), "adgs_l1_ssim_means")
         if need:
             ctx.save_for_backward(img, ref, *maps)
         ctx.dims = (planes, H, W)
@@ -96,8 +140,8 @@ class _DepthLoss(torch.autograd.Function):
         m = None if mask is None else mask.contiguous().float()
         if p.shape != g.shape or (m is not None and m.shape != p.shape):
             raise ValueError("get_depth_loss: prediction, target and mask must have the same shape")
-        work = torch.zeros(DEPTH_WORK_DOUBLES, dtype=torch.float64, device=p.device)
-        out = torch.zeros(1, dtype=torch.float32, device=p.device)
+        work, ctx.token = _work(p.device, DEPTH_WORK_DOUBLES)
+        out = torch.empty(1, dtype=torch.float32, device=p.device) if p.numel() else torch.zeros(1, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().adgs_depth_loss_forward(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else None,
                                                           work.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_depth_loss_forward")
@@ -107,6 +151,7 @@ class _DepthLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         p, g, work, *rest = ctx.saved_tensors
+        _WorkArena.check(ctx.token, "get_depth_loss")
         m = rest[0] if rest else None
         out = torch.empty_like(p)
         gl = g_loss.reshape(1).float().contiguous()
@@ -138,8 +183,8 @@ class _FlowLoss(torch.autograd.Function):
         if f.shape != (3, H, W) or fl.shape[0] != 2 or vis.shape != (H, W) or (op is not None and op.numel() != H * W):
             raise ValueError("get_flow_loss: expected img_flow [3,H,W], flow [2,H,W], flow_vis [H,W], img_opacity [H,W]")
         cam = [(ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()]) for t, n in ((K, 9), (R, 9), (T, 3))]
-        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=f.device)
-        out = torch.zeros(1, dtype=torch.float32, device=f.device)
+        work, ctx.token = _work(f.device, AUX_WORK_DOUBLES)
+        out = torch.empty(1, dtype=torch.float32, device=f.device) if H * W else torch.zeros(1, dtype=torch.float32, device=f.device)
         with torch.cuda.device(f.device):
             _lib.check(_lib.lib().adgs_flow_loss_forward(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
                                                          cam[0], cam[1], cam[2], float(dist), work.data_ptr(), out.data_ptr(), _stream(f.device)),
@@ -151,6 +196,7 @@ class _FlowLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         f, fl, vis, work, *rest = ctx.saved_tensors
+        _WorkArena.check(ctx.token, "get_flow_loss")
         op = rest[0] if rest else None
         H, W = fl.shape[1], fl.shape[2]
         g_f = torch.empty_like(f)
@@ -180,8 +226,8 @@ class _BceClip(torch.autograd.Function):
         p, t = pred.contiguous().float(), target.contiguous().float()
         if p.numel() != t.numel():
             raise ValueError("bce_clip_loss: prediction and target must have the same number of elements")
-        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=p.device)
-        out = torch.zeros(1, dtype=torch.float32, device=p.device)
+        work, _ = _work(p.device, AUX_WORK_DOUBLES)
+        out = torch.empty(1, dtype=torch.float32, device=p.device) if p.numel() else torch.zeros(1, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().adgs_bce_clip_forward(p.numel(), p.data_ptr(), t.data_ptr(), float(lo), float(hi), int(bool(invert)),
                                                         int(bool(positive_target)), work.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_bce_clip_forward")
@@ -228,8 +274,8 @@ class _GroupVar(torch.autograd.Function):
         N = xs.shape[0]
         D = xs.numel() // max(N, 1)
         G, K = ix.shape
-        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=xs.device)
-        out = torch.zeros(1, dtype=torch.float32, device=xs.device)
+        work, _ = _work(xs.device, AUX_WORK_DOUBLES)
+        out = torch.empty(1, dtype=torch.float32, device=xs.device) if (G and D) else torch.zeros(1, dtype=torch.float32, device=xs.device)
         if G and D:
             with torch.cuda.device(xs.device):
                 _lib.check(_lib.lib().adgs_group_var_forward(N, G, K, D, int(inner), xs.data_ptr(), ix.data_ptr(), work.data_ptr(), out.data_ptr(),
@@ -269,8 +315,8 @@ class _SigmaLoss(torch.autograd.Function):
         if log_sigma.dim() != 2 or log_sigma.shape[1] != 2:
             raise ValueError("gs_time_sigma must be [N, 2]")
         ls = log_sigma.contiguous().float()
-        work = torch.zeros(AUX_WORK_DOUBLES, dtype=torch.float64, device=ls.device)
-        out = torch.zeros(1, dtype=torch.float32, device=ls.device)
+        work, _ = _work(ls.device, AUX_WORK_DOUBLES)
+        out = torch.empty(1, dtype=torch.float32, device=ls.device) if ls.shape[0] else torch.zeros(1, dtype=torch.float32, device=ls.device)
         if ls.shape[0]:
             with torch.cuda.device(ls.device):
                 _lib.check(_lib.lib().adgs_sigma_loss_forward(ls.shape[0], ls.data_ptr(), float(frame_gap), work.data_ptr(), out.data_ptr(),

@@ -75,7 +75,7 @@ struct BinState {
 
 // ---- v2 (coarse-binned) state ----
 struct GeomStateV2 {
-	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; FilterRec* rects; uint4* dupinfo;
+	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; uint4* dupinfo;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
 	// bucket binning (binning.hip): ONE block of counters the host zeroes with a single memset -- pair counts / cursors per cell,
 	// the fine-tile total slots, the device-side (pairs, chunks, overflow) words -- then the cell starts and the chunk table
@@ -91,7 +91,6 @@ struct GeomStateV2 {
 		g.chunks = c.take<uint4>(MAX_CHUNKS);
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
-		g.rects = c.take<FilterRec>(P);
 		g.dupinfo = c.take<uint4>(P);
 		g.clamped = c.take<uint8_t>(P);
 		g.cells_touched = c.take<uint32_t>(P + 1);
@@ -180,9 +179,15 @@ static bool use_v2(int D_S) {
 // Re-measured in round 3 with bucket binning (the cells' lists are sorted inside the CUs: more, smaller cells cost little): C2 cell edge
 // 8 / 6 / 5 / 4 / 3: binning 73 / 66 / 60 / 56 / 51 us, forward 138 / 131 / 128 / 126 / 127 us; C1 as graph replays 10 380 / 10 790 / - / 10 980
 // frames/s; C3 12 / 10 / 8: 857 / 860 / 826 frames/s.  Small tile grids therefore aim at ~110 cells.
-static int v2_cell_tiles(size_t ntiles16) {
+// Coarse-cell edge in tiles: 12 for large tile grids, ~110 cells per image for small ones (EXPERIMENTS.md), ADGS_CELL_TILES overrides.
+// The cell lists carry one mask bit per tile row and per tile column of a cell (the blend forward's rectangle test); in a sorted
+// (not bucket-binned) frame these 2 x edge bits share the upper key word with the cell index: the edge shrinks until they fit.
+static int v2_cell_tiles(int gx, int gy) {
+	const size_t ntiles16 = (size_t)gx * gy;
 	const int small = std::min(8, std::max(3, (int)std::lround(std::sqrt((double)ntiles16 / 110.0))));
-	return std::max(1, env_int("ADGS_CELL_TILES", ntiles16 >= 4096 ? 12 : small));
+	int c = std::max(1, env_int("ADGS_CELL_TILES", ntiles16 >= 4096 ? 12 : small));
+	while (c > 1 && 2 * c + (int)higher_msb((uint32_t)(((gx + c - 1) / c) * ((gy + c - 1) / c))) > 32) c--;
+	return c;
 }
 static int v2_pixels_per_lane(size_t ntiles16) {
 	const int e = env_int("ADGS_V2_PPL", 0);
@@ -401,7 +406,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (ntiles * 4 * (2 * (size_t)POOL_BLOCK + 1) > 0xffffffffull) { set_error("image too large: chunk slots are 32-bit"); return -1; }      // 4: wave tiles per 16x16 tile at most
 
 	if (use_v2(D_S)) {
-		const int cell_tiles = v2_cell_tiles(ntiles);
+		const int cell_tiles = v2_cell_tiles(gx, gy);
 		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
 		const size_t ncells = (size_t)cgx * cgy;
 		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs) unless the cell grid has more than MAX_CELLS cells,
@@ -440,7 +445,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.focal_y = height / (2.0f * tan_fovy); pa.focal_x = width / (2.0f * tan_fovx);
 		pa.inv_depth = inv_depth;
 		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = nullptr; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;     // cov3D: recomputed by the backward
-		pa.rects = geom.rects; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
+		pa.v2 = 1; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
 		pa.bucket_count = nullptr;
@@ -499,7 +504,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const int bit = (int)higher_msb((uint32_t)ncells);
 		BinStateV2 bin;
 		// rectangle-coverage masks in the key bits above (cell | depth): one bit per tile row and per tile column of a cell
-		const int mask_shift = (2 * cell_tiles + bit <= 32 && env_int("ADGS_KEY_MASKS", 1) != 0) ? 32 + bit : -1;
+		const int mask_shift = 32 + bit;          // 2 * cell_tiles + bit <= 32: v2_cell_tiles
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
 			if (buckets) {
@@ -544,7 +549,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		};
 		auto launch_blend = [&]() -> int {      // on the binning state `bin` of the last enqueue_binning
 			RenderV2FwdArgs ra;
-			ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.rects = geom.rects; ra.splats = geom.splats;
+			ra.cell_ranges = img.cell_ranges; ra.cell_list = bin.list; ra.splats = geom.splats;
 			ra.cell_keys = bin.keys; ra.mask_shift = mask_shift; ra.cell_entries = buckets ? bin.entries : nullptr;
 			ra.W = width; ra.H = height; ra.gx = gx; ra.gy = wgy; ra.ppl = ppl; ra.cell_tiles = cell_tiles; ra.cgx = cgx;
 			ra.has_color = (colors_precomp != nullptr) || (shs != nullptr) || (sh_src != nullptr);
@@ -640,7 +645,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.focal_x = width / (2.0f * tan_fovx);
 	pa.inv_depth = inv_depth;
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
-	pa.rects = nullptr; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
+	pa.v2 = 0; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
 	pa.bucket_count = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
@@ -712,7 +717,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	FrameCfg cfg;
 	const FrameKey fkey{ img_buffer, geom_buffer, width, height, P };
-	if (!lookup_frame(fkey, &cfg)) { cfg.v2 = use_v2(D_S) ? 1 : 0; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }      // foreign buffers: today's environment
+	if (!lookup_frame(fkey, &cfg)) { cfg.v2 = use_v2(D_S) ? 1 : 0; cfg.cell_tiles = v2_cell_tiles(gx, gy); cfg.ppl = v2_pixels_per_lane(ntiles); }      // foreign buffers: today's environment
 	if (cfg.v2) {
 		const int cell_tiles = cfg.cell_tiles;
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
@@ -957,7 +962,7 @@ bool v2_image_view(const char* img_buffer, int width, int height, V2ImageView* v
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	FrameCfg cfg;
-	if (!lookup_frame_by_image(img_buffer, width, height, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(ntiles); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	if (!lookup_frame_by_image(img_buffer, width, height, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(gx, gy); cfg.ppl = v2_pixels_per_lane(ntiles); }
 	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
 	v->ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 	v->wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));

@@ -29,7 +29,7 @@ __device__ unsigned long long g_probe[16];
 
 #ifdef ADGS_PHASE_TIMING
 // forward [0..15]: [0] key-stream scan, [1] filter-record test, [2] Splat gather + staging, [3] blend loop, [4] whole wave, [5] waves,
-// [6] cycles waiting for the scan's loads, [7] scan super-rounds, [8] cycles waiting for filter records, [9] filter rounds
+// [6] round-trip cycles of the scan's loads (issue -> landed), [7] scan super-rounds, [8] round-trip cycles of the filter-record gathers, [9] filter rounds
 // backward [16..31]: [16] chunk header wait, [17] id + Splat gather, [18] entry loop, [19] of it: reduction + atomic, [20] whole wave, [21] waves,
 // [22] chunks, [23] entries, [24] prologue (pixel state loads)
 __device__ unsigned long long g_phase[32];
@@ -37,17 +37,18 @@ __device__ unsigned long long g_phase[32];
 #define PT(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PT_ACC(slot, a, b) t_acc[slot] += (b) - (a)
 #define PT_ADD(slot, v) t_acc[slot] += (v)
-// a timed wait for the loads that produced the listed registers
-#define PT_WAIT_VM8(slot, cnt, r0, r1, r2, r3, r4, r5, r6, r7) do { PT(t_w0_); \
+// round trip of the loads that produced the listed registers: from `t_begin` (a PT() taken BEFORE the loads were issued -- the compiler
+// puts its own s_waitcnt for the asm's operands in front of the asm, so a timer started here would start after the wait) until they landed
+#define PT_WAIT_VM8(slot, cnt, t_begin, r0, r1, r2, r3, r4, r5, r6, r7) do { \
 	asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) :: "memory"); \
-	PT(t_w1_); t_acc[slot] += t_w1_ - t_w0_; t_acc[cnt] += 1ull; } while (0)
+	PT(t_w1_); t_acc[slot] += t_w1_ - (t_begin); t_acc[cnt] += 1ull; } while (0)
 #define PT_FLUSH(base, n, lane) do { if ((lane) == 0) { for (int i_ = 0; i_ < (n); i_++) atomicAdd(&g_phase[(base) + i_], t_acc[i_]); } } while (0)
 #else
 #define PT_DECL(n)
 #define PT(var)
 #define PT_ACC(slot, a, b)
 #define PT_ADD(slot, v)
-#define PT_WAIT_VM8(slot, cnt, r0, r1, r2, r3, r4, r5, r6, r7)
+#define PT_WAIT_VM8(slot, cnt, t_begin, r0, r1, r2, r3, r4, r5, r6, r7)
 #define PT_FLUSH(base, n, lane)
 #endif
 

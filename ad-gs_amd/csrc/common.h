@@ -24,20 +24,14 @@ struct __attribute__((aligned(64))) Splat {
 	float dval;              // blended depth value: z or 1/(z+1e-7) (forward.cu:374-375)
 	float fx, fy, fz;        // flow point (world position at the other time)
 	float sem0;              // first semantic channel
-	float zview;             // raw view-space depth
+	float aux;               // default pipeline: tau = 2 ln(255 opacity) + slack, the bound of the tile test (alpha >= 1/255 <=> d^T Q d <= tau);
+	                         // stage-by-stage ("classic") pipeline: the raw view-space depth (the key of duplicate_keys)
 	float lean;             // 1.0: neither `power > 0` nor the 0.99 clamp can fire for this Gaussian (preprocess.hip); else 0.0
 };
 static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 
-// What the v2 tile filter needs to decide "can this Gaussian reach alpha >= 1/255 on that tile":
-// half a cache line per Gaussian.
-struct __attribute__((aligned(32))) FilterRec {
-	float x, y;              // pixel-space mean
-	float ca, cb, cc;        // conic
-	float tau;               // 2 ln(255 opacity) + slack: alpha >= 1/255  <=>  d^T Q d <= tau
-	uint32_t rmin, rmax;     // tile rectangle (reference rect shrunk by the opacity-aware bound): x | y << 16
-};
-static_assert(sizeof(FilterRec) == 32, "FilterRec must be 32 bytes");
+// (Until round 3 a 32-byte `FilterRec` per Gaussian -- mean, conic, tau, tile rectangle -- fed the v2 tile filter; the filter now reads the
+// Splat line itself, and the rectangle travels as row / column masks in the cell lists: render_v2.hip.)
 
 void set_error(const std::string& msg);
 

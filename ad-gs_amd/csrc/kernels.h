@@ -16,8 +16,8 @@ struct PreprocessArgs {
 	int inv_depth;
 	// outputs
 	int* radii; Splat* splats; float* cov3D; uint8_t* clamped; uint32_t* tiles_touched;
-	// v2 (coarse-binned) extras; rects == nullptr selects the classic behaviour
-	FilterRec* rects;                // per-Gaussian tile-filter record (rectangle possibly empty)
+	// v2 (coarse-binned) extras; v2 == 0 selects the classic behaviour
+	int v2;
 	uint32_t* fine_touched;          // #fine tiles covered per Gaussian (its sum bounds the chunk pool)
 	uint4* dupinfo;                  // (shrunk rect min, max, depth bits, -) per Gaussian: the binning kernel's only input
 	int cell_tiles, cgx, cgy;        // coarse cell = cell_tiles x cell_tiles fine tiles
@@ -133,8 +133,8 @@ int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets,
 	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, int mask_shift, hipStream_t stream);
 
 struct RenderV2FwdArgs {
-	const uint2* cell_ranges; const uint32_t* cell_list; const FilterRec* rects; const Splat* splats;
-	const uint64_t* cell_keys; int mask_shift;   // sorted keys with the rectangle-coverage masks at bit mask_shift (-1: keys carry no masks)
+	const uint2* cell_ranges; const uint32_t* cell_list; const Splat* splats;
+	const uint64_t* cell_keys; int mask_shift;   // sorted keys with the rectangle-coverage masks at bit mask_shift (sorted frames; api.hip picks a cell size whose masks fit)
 	const uint2* cell_entries;                   // bucket binning: (id, mask) per list entry (then cell_keys / cell_list == nullptr)
 	int W, H, gx, gy, cell_tiles, cgx;      // gy: rows of WAVE tiles (16 x 4*ppl pixels), not of 16x16 tiles
 	int ppl;                                // pixels per lane: 4 or 2 (v2_pixels_per_lane)

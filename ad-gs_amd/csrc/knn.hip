@@ -126,9 +126,10 @@ __device__ __forceinline__ void update3(float rx, float ry, float rz, float px, 
 }
 
 __global__ void __launch_bounds__(KT) knn_meandist_kernel(int P, int nboxes, const float4* __restrict__ sorted, const uint32_t* __restrict__ ids,
-	const MinMax* __restrict__ boxes, float* __restrict__ dists) {
+	const MinMax* __restrict__ boxes, float* __restrict__ dists, unsigned long long* __restrict__ staged_total) {
 	__shared__ float4 s_pts[BOX];
 	const int tid = threadIdx.x;
+	uint32_t staged = 0;                      // candidate boxes this workgroup scanned (bench.py: boxes visited per query box)
 	float qx[QPT], qy[QPT], qz[QPT], best[QPT][3], reject[QPT];
 	int qi[QPT];
 #pragma unroll
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(KT) knn_meandist_kernel(int P, int nboxes, con
 		if (!__syncthreads_or(any_need)) continue;
 		const int b0 = b * BOX;
 		const int cnt = min(BOX, P - b0);
+		staged++;
 		for (int k = tid; k < cnt; k += KT) s_pts[k] = sorted[b0 + k];
 		__syncthreads();
 		if (__any(any_need)) {
@@ -183,6 +185,7 @@ __global__ void __launch_bounds__(KT) knn_meandist_kernel(int P, int nboxes, con
 	for (int k = 0; k < QPT; k++) {
 		if (qi[k] < P) dists[ids[qi[k]]] = (best[k][0] + best[k][1] + best[k][2]) / 3.0f;
 	}
+	if (tid == 0) atomicAdd(staged_total, (unsigned long long)staged);
 }
 
 struct KnnWs {
@@ -219,7 +222,7 @@ int knn_run(int P, const float* points, float* meanDists, char* workspace, hipSt
 	hipLaunchKernelGGL(knn_boxes_kernel, dim3(nboxes), dim3(KT), 0, stream, P, (const float4*)w.sorted, w.boxes);
 	ADGS_HIP_CHECK(hipGetLastError());
 	hipLaunchKernelGGL(knn_meandist_kernel, dim3(nboxes), dim3(KT), 0, stream, P, nboxes, (const float4*)w.sorted, (const uint32_t*)w.ids_sorted,
-		(const MinMax*)w.boxes, meanDists);
+		(const MinMax*)w.boxes, meanDists, reinterpret_cast<unsigned long long*>(w.mm + 6));      // words 6..7 of the workspace: boxes scanned, summed over the query boxes
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

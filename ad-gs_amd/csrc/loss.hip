@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(256) depth_solve_kernel(double* __restrict__ w
 #pragma unroll
 	for (int q = 0; q < 5; q++) {
 		v[q] = work[(size_t)threadIdx.x * 8 + q];
+		work[(size_t)threadIdx.x * 8 + q] = 0.0;      // consumed (see aux_finish_kernel)
 #pragma unroll
 		for (int off = WAVE / 2; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, WAVE);
 		if ((threadIdx.x & (WAVE - 1)) == 0) s[q][threadIdx.x / WAVE] = v[q];
@@ -282,6 +283,7 @@ __global__ void __launch_bounds__(256) depth_finish_kernel(double* __restrict__ 
 #pragma unroll
 	for (int q = 0; q < 3; q++) {
 		v[q] = work[(size_t)threadIdx.x * 8 + 5 + q];
+		work[(size_t)threadIdx.x * 8 + 5 + q] = 0.0;
 #pragma unroll
 		for (int off = WAVE / 2; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, WAVE);
 		if ((threadIdx.x & (WAVE - 1)) == 0) s[q][threadIdx.x / WAVE] = v[q];
@@ -358,6 +360,7 @@ __global__ void __launch_bounds__(256) flow_loss_sum_kernel(int H, int W, const 
 __global__ void __launch_bounds__(256) aux_finish_kernel(double* __restrict__ work, float* __restrict__ loss) {
 	__shared__ double s[2][256 / WAVE];
 	double a = work[(size_t)threadIdx.x * 2], b = work[(size_t)threadIdx.x * 2 + 1];
+	work[(size_t)threadIdx.x * 2] = 0.0; work[(size_t)threadIdx.x * 2 + 1] = 0.0;      // consumed: the slot region is zero again for the next call on this buffer (include/adgs_loss.h)
 #pragma unroll
 	for (int off = WAVE / 2; off > 0; off >>= 1) { a += __shfl_xor(a, off, WAVE); b += __shfl_xor(b, off, WAVE); }
 	if ((threadIdx.x & (WAVE - 1)) == 0) { s[0][threadIdx.x / WAVE] = a; s[1][threadIdx.x / WAVE] = b; }
@@ -522,6 +525,31 @@ extern "C" int adgs_l1_ssim_forward(int planes, int H, int W, const float* image
 	static const Window win = make_window();
 	const dim3 grid((W + TSX - 1) / TSX, (H + TSY - 1) / TSY, planes);
 	hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(LT), 0, (hipStream_t)stream, H, W, image, gt, win, sums, d_mu1, d_e11, d_e12);
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+// means of the two sums of adgs_l1_ssim_forward: out2 = (sum |image - gt|, sum ssim_map) / n; the slot rows are consumed (zero afterwards)
+namespace {
+__global__ void __launch_bounds__(256) l1_ssim_finish_kernel(double* __restrict__ sums, double inv_n, float* __restrict__ out2) {
+	__shared__ double s[2][256 / WAVE];
+	double a = sums[(size_t)threadIdx.x * 2], b = sums[(size_t)threadIdx.x * 2 + 1];
+	sums[(size_t)threadIdx.x * 2] = 0.0; sums[(size_t)threadIdx.x * 2 + 1] = 0.0;
+#pragma unroll
+	for (int off = WAVE / 2; off > 0; off >>= 1) { a += __shfl_xor(a, off, WAVE); b += __shfl_xor(b, off, WAVE); }
+	if ((threadIdx.x & (WAVE - 1)) == 0) { s[0][threadIdx.x / WAVE] = a; s[1][threadIdx.x / WAVE] = b; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double ta = 0, tb = 0;
+		for (int w = 0; w < 256 / WAVE; w++) { ta += s[0][w]; tb += s[1][w]; }
+		out2[0] = (float)(ta * inv_n); out2[1] = (float)(tb * inv_n);
+	}
+}
+}
+extern "C" int adgs_l1_ssim_means(double* sums, long long n, float* out2, void* stream) {
+	if (!sums || !out2) { set_error("adgs_l1_ssim_means: NULL pointer"); return -1; }
+	static_assert(ADGS_LOSS_SLOTS == 256, "one thread per slot row");
+	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, 1.0 / (double)std::max<long long>(n, 1), out2);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

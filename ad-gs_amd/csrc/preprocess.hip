@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		}
 	}
 	if (STAGED || a.bucket_count) __syncthreads();
-	if (a.rects && !a.bucket_count && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
+	if (a.v2 && !a.bucket_count && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
 	PreOut o = { 0u, 0u };
 	if (idx < a.P) o = preprocess_one<STAGED>(a, idx, s_sh, s_cell);
 	if (a.bucket_count) {
@@ -141,11 +141,11 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	const PreOut none = { 0u, 0u };
 	if (idx == 0) {       // sentinels: the exclusive scans over P + 1 entries leave the totals at [P]
 		a.tiles_touched[a.P] = 0;
-		if (a.rects) a.fine_touched[a.P] = 0;
+		if (a.v2) a.fine_touched[a.P] = 0;
 	}
 	a.radii[idx] = 0;
 	a.tiles_touched[idx] = 0;
-	if (a.rects) { a.dupinfo[idx] = make_uint4(0u, 0u, 0u, 0u); a.fine_touched[idx] = 0; }      // culled: no cells
+	if (a.v2) { a.dupinfo[idx] = make_uint4(0u, 0u, 0u, 0u); a.fine_touched[idx] = 0; }      // culled: no cells
 
 	// raw scene geometry: Gaussians idx < Ns read position / log-scale / raw rotation / opacity logit from the raw tensors
 	const bool rs = a.sh_src.scene_xyz != nullptr && idx < a.sh_src.Ns;
@@ -248,7 +248,10 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	else if (a.flow_points) { s.fx = a.flow_points[3 * (size_t)idx]; s.fy = a.flow_points[3 * (size_t)idx + 1]; s.fz = a.flow_points[3 * (size_t)idx + 2]; }
 	else { s.fx = 0.f; s.fy = 0.f; s.fz = 0.f; }
 	s.sem0 = (a.semantic && a.D_S > 0) ? a.semantic[(size_t)idx * a.D_S] : 0.f;
-	s.zview = vz;
+	// alpha = opacity * exp(-0.5 d^T Q d) >= 1/255  <=>  d^T Q d <= tau = 2 ln(255 opacity); +0.02: a 1 % slack on alpha that dominates
+	// every fp32 rounding in the per-pixel test (the blend forward's tile test and the rectangle shrink below use it)
+	const float tau = 2.f * logf(255.f * s.opacity) + 0.02f;
+	s.aux = a.v2 ? tau : vz;
 	// "lean" Gaussians (render_v2.hip, eval_pixel<true>): opacity <= 0.99 and a conic that is positive definite with a relative margin of
 	// 1e-4 on its determinant.  For these neither `power > 0` (forward.cu:345-346) nor the 0.99 clamp (forward.cu:353) can fire for any pixel
 	// offset: the quadratic form is >= 5e-5 (A dx^2 + C dy^2) while an fp32 evaluation of it in any order is off by < 1e-6 of that sum, and
@@ -260,7 +263,7 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	dst[0] = make_float4(s.x, s.y, s.ca, s.cb);
 	dst[1] = make_float4(s.cc, s.opacity, s.r, s.g);
 	dst[2] = make_float4(s.b, s.dval, s.fx, s.fy);
-	dst[3] = make_float4(s.fz, s.sem0, s.zview, s.lean);
+	dst[3] = make_float4(s.fz, s.sem0, s.aux, s.lean);
 	a.clamped[idx] = clamp_bits;
 	a.radii[idx] = (int)my_radius;
 	if (a.gacc) {     // the blend backward accumulates into this 64-B line (rows of culled Gaussians are never read)
@@ -268,7 +271,7 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 		g[0] = z; g[1] = z; g[2] = z; g[3] = z;
 	}
-	if (!a.rects) {
+	if (!a.v2) {
 		a.tiles_touched[idx] = (maxy - miny) * (maxx - minx);
 		return none;
 	}
@@ -278,7 +281,6 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	// (cov = Q^-1).  A 1% slack on alpha (+0.02 on tau) and 1e-3 relative + 0.01 px on the extents
 	// dominate every fp32 rounding in the per-pixel test, so no contributing pixel is ever lost.
 	uint32_t sminx = 0, sminy = 0, smaxx = 0, smaxy = 0;
-	const float tau = 2.f * logf(255.f * s.opacity) + 0.02f;
 	if (tau > 0.f) {
 		const float ex = sqrtf(tau * cxx) * 1.001f + 0.01f, ey = sqrtf(tau * cyy) * 1.001f + 0.01f;
 		// tile t covers pixel centres [16t, 16t+15]
@@ -288,14 +290,6 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 		const int ix0 = max((int)minx, tminx), ix1 = min((int)maxx, tmaxx);
 		const int iy0 = max((int)miny, tminy), iy1 = min((int)maxy, tmaxy);
 		if (ix1 > ix0 && iy1 > iy0) { sminx = (uint32_t)ix0; smaxx = (uint32_t)ix1; sminy = (uint32_t)iy0; smaxy = (uint32_t)iy1; }
-	}
-	{
-		FilterRec fr;
-		fr.x = pix; fr.y = piy; fr.ca = conx; fr.cb = cony; fr.cc = conz; fr.tau = tau;
-		fr.rmin = sminx | (sminy << 16); fr.rmax = smaxx | (smaxy << 16);
-		float4* d = reinterpret_cast<float4*>(a.rects + idx);
-		d[0] = make_float4(fr.x, fr.y, fr.ca, fr.cb);
-		d[1] = make_float4(fr.cc, fr.tau, __uint_as_float(fr.rmin), __uint_as_float(fr.rmax));
 	}
 	uint32_t ncell = 0;
 	const uint32_t nfine = (smaxx - sminx) * (smaxy - sminy);
@@ -331,7 +325,7 @@ __global__ void __launch_bounds__(256) duplicate_keys_kernel(int P, const Splat*
 	if (r > 0) {
 		uint32_t off = offsets[idx];       // exclusive scan: start slot of this Gaussian
 		const float2 xy = *reinterpret_cast<const float2*>(&splats[idx].x);
-		const uint32_t dbits = __float_as_uint(splats[idx].zview);
+		const uint32_t dbits = __float_as_uint(splats[idx].aux);      // classic pipeline: the view-space depth
 		uint32_t minx, miny, maxx, maxy;
 		tile_rect(xy.x, xy.y, r, gx, gy, minx, miny, maxx, maxy);
 		for (uint32_t y = miny; y < maxy; y++)
@@ -362,7 +356,7 @@ __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const uint4
 		for (uint32_t x = c0x; x <= c1x; x++) {
 			uint64_t key = (uint64_t)(y * cgx + x);
 			key <<= 32; key |= dbits;
-			if (mask_shift >= 0) {
+			{
 				// The key bits above (cell | depth) are not sorted on but travel with the key: they carry which tile rows and tile
 				// columns OF THIS CELL the Gaussian's rectangle covers, so that the blend forward can run the rectangle test on the
 				// sorted key stream alone (8 sequential bytes per candidate) and gathers the 32-byte filter record only for

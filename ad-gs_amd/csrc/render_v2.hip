@@ -51,21 +51,25 @@ constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
 #define ADGS_SETPRIO 1             // 0: no s_setprio around the memory phases (A/B builds)
 #endif
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ADGS_BWD_PF2
+#define ADGS_BWD_PF2 1             // 0: the backward gathers a chunk's Splat lines when it reaches the chunk (A/B builds)
+#endif
+#ifndef ADGS_FWD_DMA
+#define ADGS_FWD_DMA 1             // 0: the forward loads the key stream into registers at the moment it needs it (A/B builds)
+#endif
 #ifndef ADGS_KO
 #define ADGS_KO 0                  // knock-out experiment builds (WRONG results, timing only): 1 no atomic, 2 no LDS reduction, 4 no strip bodies (backward), 8 no channel FMAs (forward)
 #endif
 
-// Can Gaussian `f` reach alpha >= 1/255 on any pixel centre of tile (tx,ty)?  Exact minimum of the
-// quadratic form d^T Q d over the tile's pixel-centre rectangle [16tx,16tx+15]x[16ty,16ty+15]
-// (a lower bound of the minimum over its integer pixels), compared with tau (which carries the slack).
-__device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float4 f1, uint32_t tx, uint32_t ty16, uint32_t row0, int rows) {
-	const uint32_t rmin = __float_as_uint(f1.z), rmax = __float_as_uint(f1.w);
-	const uint32_t minx = rmin & 0xFFFFu, miny = rmin >> 16, maxx = rmax & 0xFFFFu, maxy = rmax >> 16;
-	if (!(tx >= minx && tx < maxx && ty16 >= miny && ty16 < maxy)) return false;
-	const float A = f0.z, B = f0.w, C = f1.x, tau = f1.y;
+// Can the Gaussian of Splat line (q0 = x y ca cb, cc, tau) reach alpha >= 1/255 on any pixel centre of the wave's tile (column tx, pixel rows
+// row0 .. row0 + rows - 1)?  Exact minimum of the quadratic form d^T Q d over the tile's pixel-centre rectangle (a lower bound of the
+// minimum over its integer pixels), compared with tau (which carries the slack).  The tile lies inside the Gaussian's tile rectangle:
+// the list's row / column masks said so.
+__device__ __forceinline__ bool tile_may_contribute(const float4 q0, float C, float tau, uint32_t tx, uint32_t row0, int rows) {
+	const float A = q0.z, B = q0.w;
 	// rectangle relative to the mean: d = pixel - mean (the form is symmetric in the sign of d)
-	const float x0 = (float)(tx * TILE_X) - f0.x, x1 = x0 + (float)(TILE_X - 1);
-	const float y0 = (float)row0 - f0.y, y1 = y0 + (float)(rows - 1);      // the wave's own rows (a 16x16 tile or a half of one)
+	const float x0 = (float)(tx * TILE_X) - q0.x, x1 = x0 + (float)(TILE_X - 1);
+	const float y0 = (float)row0 - q0.y, y1 = y0 + (float)(rows - 1);      // the wave's own rows (a 16x16 tile or a half of one)
 	if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;      // mean inside the tile
 	// minimum over the four edges: fix one coordinate, clamp the unconstrained minimiser of the other
 	// (any point of an edge bounds its minimum from above and the form is flat at the minimiser, so the
@@ -85,8 +89,10 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 f0, const float
 }
 
 // Measured on gfx950 and NOT used: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 issue at half the rate of their scalar
-// counterparts -- a SIMD already retires a wave64 v_fma_f32 in 2 cycles -- and cost operand shuffles; this file is built
-// with -fno-slp-vectorize so the compiler does not pack either), and branch-free predicated per-pixel code (the
+// counterparts -- a SIMD already retires a wave64 v_fma_f32 in 2 cycles -- ; this file is built with -fno-slp-vectorize so the
+// compiler does not pack either.  Re-measured in round 4 with clean code -- the channel accumulations as v_pk_fma_f32 on the Splat
+// line's natural pairs, op_sel broadcast, no register moves, 12 instead of 16 / 20 instead of 27 vector instructions per strip --:
+// forward 0.234 -> 0.248 ms, backward 0.339 -> 0.343 ms, EXPERIMENTS.md), and branch-free predicated per-pixel code (the
 // wave-uniform per-strip branches below skip ~22 % of the strip work).
 
 // Per-entry, per-lane part of the Gaussian evaluation (the lane's 4 pixels share the column x):
@@ -140,10 +146,20 @@ __device__ __forceinline__ uint64_t eval_entry_fwd(const EntryGeom& eg, const fl
 template <int PPL>
 __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(RenderV2FwdArgs a) {
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
-	__shared__ float4 s_splat[(WAVE + 1) * 4];
-	__shared__ uint32_t s_queue[2 * WAVE];
-	constexpr int SCAN_ROUNDS = 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;      // ring: < 64 waiting + one super-round of 256, power of two
+	__shared__ float4 s_splat[WAVE * 4];
+	__shared__ uint32_t s_pub[2 * WAVE];         // live ids waiting to leave as a full chunk
+	// key-stream scan: SCAN_ROUNDS x 64 list entries per step; ring: < 64 waiting + one step's survivors, power of two.  With the
+	// staged key stream (below) a step is half a staged block: 4096 + 512 + 1024 + 2048 bytes of LDS = 21 workgroups per CU.
+	constexpr int SCAN_ROUNDS = ADGS_FWD_DMA ? 2 : 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
 	__shared__ uint32_t s_cand[CAND_RING];
+	// The key stream of a cell is SEQUENTIAL and the tile's position in it is known long before the entries are needed: the next
+	// block of KEY_BLOCK (id, mask) entries is copied global -> LDS by the DMA path of the load unit (global_load_lds_dwordx4: no
+	// registers, two instructions per block) as soon as the previous block has been scanned, i.e. it flies under the filter round, the
+	// Splat gather and the whole blend loop of the batch.  Until round 3 the scan loaded 256 entries into registers when it needed
+	// them: ~10 exposed round trips per tile at several microseconds each under load (tools/blend_phase_timing.py) -- a third of a
+	// wave's life.  Bucket-binned frames only (cell_entries); the device-wide-sort fallback keeps the register path.
+	constexpr int KEY_BLOCK = 4 * WAVE;
+	__shared__ __attribute__((aligned(16))) uint2 s_keys[ADGS_FWD_DMA ? KEY_BLOCK : 2];
 	const int lane = threadIdx.x;
 	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
 	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
@@ -191,16 +207,58 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		T[k] = 1.f;
 		C0[k] = C1[k] = C2[k] = Dp[k] = F0[k] = F1[k] = F2[k] = S0[k] = 0.f;
 	}
-	uint32_t pos = range.x, qhead = 0, qcount = 0, consumed = 0, prev_chunk = NO_CHUNK;
-	uint32_t blk_next = tile * POOL_BLOCK, blk_left = POOL_BLOCK, batches = 0;      // chunk slots: the tile's own block first (kernels.h)
+	uint32_t pos = range.x, consumed = 0, prev_chunk = NO_CHUNK;
+	uint32_t blk_next = tile * POOL_BLOCK, blk_left = POOL_BLOCK;      // chunk slots: the tile's own block first (kernels.h)
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 	// stage-1 state: candidates whose rectangle holds this tile (ring buffer), the prefetched next batch of the key stream
 	uint32_t chead = 0, ccount = 0;
-	const bool masks = a.cell_entries != nullptr || a.mask_shift >= 0;
+	const bool staged = ADGS_FWD_DMA && a.cell_entries != nullptr;
+	uint32_t bpos = range.x, bhalf = 2;           // the staged block covers list positions [bpos, bpos + KEY_BLOCK); bhalf: its next unscanned half (2: none left)
+	auto stage_block = [&](uint32_t p) {          // wave-uniform p < range.y
+		// lane l copies entries p + 2l, p + 2l + 1 (16 bytes); lanes past the end of the list re-read its last entry (the word behind a
+		// list is inside the binning buffer: BinStateV2::carve_buckets), the scan ignores positions >= range.y
+		// Written as inline assembly, not __builtin_amdgcn_global_load_lds: the compiler cannot tell which LDS array a DMA writes and
+		// puts s_waitcnt vmcnt(0) in front of EVERY later LDS read (the queue read that precedes the Splat gather, the blend loop's
+		// rows) -- the round trip would be exposed again, once per batch.  Unknown to the compiler, the two copies only ever make its
+		// own vmcnt waits conservative (memory operations complete in order); the scan waits for them itself (vmcnt(0) below).
+		const uint32_t last = range.y - 1u;
+		const uint2* g0 = a.cell_entries + min(p + 2u * lane, last);
+		const uint2* g1 = a.cell_entries + min(p + (uint32_t)(KEY_BLOCK / 2) + 2u * lane, last);
+		const uint32_t l0 = (uint32_t)(uintptr_t)s_keys, l1 = l0 + (uint32_t)(KEY_BLOCK / 2 * sizeof(uint2));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is a reserved register: named as clobbered on purpose (the DMA's LDS base travels in it)
+		asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, off\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, off"
+			:: "v"(g0), "v"(g1), "s"(l0), "s"(l1) : "memory", "m0");
+#pragma clang diagnostic pop
+		bpos = p; bhalf = 0;
+	};
+	if (staged && range.x < range.y) stage_block(range.x);
 	const int row_bit = (int)(ty16 % a.cell_tiles), col_bit = a.cell_tiles + (int)(tx % a.cell_tiles);
 	// a candidate = (Gaussian id, rectangle-coverage mask): one 8-byte entry (bucket binning) or the list id + the bits above
 	// (cell | depth) of its sort key
 	PT_DECL(10); PT(t_wave0); TL_DECL; PROBE_DECL;
+
+	// Chunk publication (the backward's replay list): live entries collect in s_pub and leave as FULL chunks of 64 -- a batch of the direct
+	// refill holds ~45 entries, and every chunk boundary is a gather round trip for the backward.  Chunk slots: the tile's own block
+	// first; a new block of POOL_BLOCK slots is drawn from the shared cursor when the block is used up -- before the blend loop of the
+	// batch that may need it, so that the atomic's round trip hides behind the loop.
+	uint32_t pub_n = 0, pre_block = 0; bool pre_drawn = false;
+	auto flush_chunk = [&](uint32_t cnt) {       // wave-uniform cnt in [1, 64]: the first cnt ids of s_pub become a chunk, the rest moves down
+		if (blk_left == 0) {
+			if (!pre_drawn) { uint32_t nb = 0; if (lane == 0) nb = atomicAdd(a.pool_cursor, (uint32_t)POOL_BLOCK); pre_block = nb; }
+			blk_next = gridDim.x * (uint32_t)POOL_BLOCK + __shfl(pre_block, 0, WAVE); blk_left = POOL_BLOCK; pre_drawn = false;
+		}
+		const uint32_t chunk = blk_next;
+		blk_next++; blk_left--;
+		uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
+		const uint32_t mine = s_pub[lane], behind = s_pub[WAVE + lane];
+		if ((uint32_t)lane < cnt) c[lane] = mine;
+		if (lane == 0) { c[CHUNK_PREV] = prev_chunk; c[CHUNK_COUNT] = cnt; }
+		prev_chunk = chunk;
+		s_pub[lane] = behind;                     // (a partial chunk is the tile's last: what moves down then is never read)
+		pub_n -= cnt;
+	};
+	uint32_t entries_in = 0;                     // entries handed to the blend loop (statistics)
 
 	while (true) {
 		bool mine_done = true;
@@ -208,111 +266,108 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		for (int k = 0; k < PPL; k++) mine_done = mine_done && (pyf[k] == PIXEL_DONE);
 		const bool all_done = !wave_any(!mine_done);
 		if (all_done) break;
-		// The memory phases (refill, gather) are a few dozen instructions between long waits; under the SIMD's oldest-first arbitration a
-		// young wave in such a phase starves behind older waves that are in their blend loops (tools/blend_phase_timing.py: 10 000 cycles
-		// "waiting" per filter round, 750 of them for the load).  Raised priority lets it issue its loads at once; the blend loops, which
-		// only need throughput, fill the rest.
+		// The memory phases (refill, gather) are a few dozen instructions between long waits: raised priority lets the wave issue its loads
+		// at once when it returns from one; the blend loops of the other waves, which only need throughput, fill the rest.
 		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(2);
-		// ---- refill the survivor queue from the cell's depth-sorted list (stable compaction), in two stages.
-		// Stage 1 scans the sorted KEY stream: the key bits above (cell | depth) say which tile rows and columns of the cell the
-		// Gaussian's rectangle covers (duplicate_cells), so the rectangle test costs 8 sequential, prefetched bytes and two
-		// shifts per candidate -- at C3 a tile scans ~2100 candidates to blend ~180 entries.  Only candidates whose rectangle
-		// holds the tile go on to stage 2, 64 at a time: gather of the 32-byte filter record + the exact ellipse test.
-		while (qcount < WAVE && (pos < range.y || ccount > 0)) {
-			PT(t_s1a);
-			// A super-round = SCAN_ROUNDS x 64 candidates with all their loads in flight before the first is looked at: one exposed
-			// memory round trip per 256 candidates.  (One round of 64 with the next round prefetched still waited ~a full round
-			// trip per round -- a round is ~30 instructions --, and the key-stream scan was 52 % of a wave's life at C3:
-			// tools/blend_phase_timing.py.)  The ring holds a whole super-round on top of a stage-2 batch.
-			while (ccount < WAVE && pos < range.y) {
-				uint32_t key[SCAN_ROUNDS], id[SCAN_ROUNDS];
-				// UNCONDITIONAL loads at clamped indices, the bucket / sort distinction outside the unrolled loop: a load inside a
-				// divergent `if (e < end)` is followed by s_waitcnt vmcnt(0) at the end of its block (its value is copied into the
-				// merged register there), which serialises the round trips again -- the one-round prefetch this replaces never
-				// overlapped anything for that reason.
-				const uint32_t last = range.y - 1u;
-				if (a.cell_entries) {
-					uint2 v[SCAN_ROUNDS];
+		// ---- refill.  Stage 1 scans the cell's depth-sorted list: every entry carries which tile rows and columns of the cell the
+		// Gaussian's rectangle covers (cell_scatter / duplicate_cells), so the rectangle test costs 8 sequential bytes and two shifts per
+		// candidate -- at C3 a tile scans ~2400 candidates to find ~250.  Stage 2 gathers the 64-byte Splat line of up to 64 of them,
+		// runs the exact ellipse-against-tile test on it and keeps the survivors' lines, compacted in order: ONE scattered line per
+		// candidate.  (Until round 3: a 32-byte filter record per candidate, then the Splat line of every survivor -- 478 instead of
+		// 253 scattered lines per tile and one more dependent round trip per batch.  The chip serves ~58 G scattered 64-byte lines per
+		// second whatever the occupancy -- tools/microbench/gather_latency.hip -- : the forward's 7.5 M lines per frame were 130 us.)
+		PT(t_s1a);
+		while (ccount < WAVE && pos < range.y) {
+			uint32_t key[SCAN_ROUNDS], id[SCAN_ROUNDS];
+			if (staged) {
+				// half a staged block per step (pos == bpos + bhalf * KEY_BLOCK / 2)
+				PT(t_l0);
+				if (bhalf == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the block has landed (issued a batch ago: no wait in steady state)
 #pragma unroll
-					for (int r = 0; r < SCAN_ROUNDS; r++) v[r] = a.cell_entries[min(pos + r * WAVE + lane, last)];
-#pragma unroll
-					for (int r = 0; r < SCAN_ROUNDS; r++) { id[r] = v[r].x; key[r] = v[r].y; }
-				} else {
-					unsigned long long kk[SCAN_ROUNDS];
-#pragma unroll
-					for (int r = 0; r < SCAN_ROUNDS; r++) {
-						const uint32_t e = min(pos + r * WAVE + lane, last);
-						id[r] = a.cell_list[e];
-						kk[r] = a.mask_shift >= 0 ? a.cell_keys[e] : 0ull;
-					}
-#pragma unroll
-					for (int r = 0; r < SCAN_ROUNDS; r++) key[r] = a.mask_shift >= 0 ? (uint32_t)(kk[r] >> a.mask_shift) : 0u;
+				for (int r = 0; r < SCAN_ROUNDS; r++) { const uint2 v = s_keys[bhalf * (KEY_BLOCK / 2) + r * WAVE + lane]; id[r] = v.x; key[r] = v.y; }
+				PT_WAIT_VM8(6, 7, t_l0, key[0], key[1], id[0], id[1], key[0], key[1], id[0], id[1]);
+				bhalf++;
+				if (bhalf == 2 && bpos + KEY_BLOCK < range.y) {
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // every lane has its entries: the block may be overwritten
+					stage_block(bpos + KEY_BLOCK);
 				}
-				PT_WAIT_VM8(6, 7, key[0], key[1], key[2], key[3], id[0], id[1], id[2], id[3]);
+			} else {
+			// UNCONDITIONAL loads at clamped indices, the bucket / sort distinction outside the unrolled loop: a load inside a
+			// divergent `if (e < end)` is followed by s_waitcnt vmcnt(0) at the end of its block (its value is copied into the
+			// merged register there), which serialises the round trips again -- the one-round prefetch this replaces never
+			// overlapped anything for that reason.
+			const uint32_t last = range.y - 1u;
+			PT(t_l0);
+			if (a.cell_entries) {
+				uint2 v[SCAN_ROUNDS];
+#pragma unroll
+				for (int r = 0; r < SCAN_ROUNDS; r++) v[r] = a.cell_entries[min(pos + r * WAVE + lane, last)];
+#pragma unroll
+				for (int r = 0; r < SCAN_ROUNDS; r++) { id[r] = v[r].x; key[r] = v[r].y; }
+			} else {
+				unsigned long long kk[SCAN_ROUNDS];
 #pragma unroll
 				for (int r = 0; r < SCAN_ROUNDS; r++) {
-					const bool have = pos + r * WAVE + lane < range.y;
-					const bool rp = have && (!masks || (((key[r] >> row_bit) & (key[r] >> col_bit)) & 1u));
-					const uint64_t m = __ballot(rp);
-					if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (CAND_RING - 1)] = id[r];
-					ccount += __popcll(m);
+					const uint32_t e = min(pos + r * WAVE + lane, last);
+					id[r] = a.cell_list[e];
+					kk[r] = a.cell_keys[e];
 				}
-				pos += SCAN_ROUNDS * WAVE;
+#pragma unroll
+				for (int r = 0; r < SCAN_ROUNDS; r++) key[r] = (uint32_t)(kk[r] >> a.mask_shift);
 			}
-			PT(t_s1b); PT_ACC(0, t_s1a, t_s1b);
-			const uint32_t nc = min(ccount, (uint32_t)WAVE);
-			if (nc == 0) break;
-			__syncthreads();
-			bool pass = false; uint32_t id = 0;
-			if ((uint32_t)lane < nc) {
-				id = s_cand[(chead + lane) & (CAND_RING - 1)];
-				const float4* fr = reinterpret_cast<const float4*>(a.rects + id);
-				float4 f0 = fr[0], f1 = fr[1];
-				PT_WAIT_VM8(8, 9, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w);
-				// both halves of the record are requested together (otherwise the compiler sinks the first
-				// load behind the rectangle test and the survivors pay a third dependent memory round trip)
-				asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f1.z), "+v"(f1.w));
-				pass = tile_may_contribute(f0, f1, tx, ty16, ty * ROWS, ROWS);
+			PT_WAIT_VM8(6, 7, t_l0, key[0], key[1], key[SCAN_ROUNDS - 1], key[SCAN_ROUNDS - 2], id[0], id[1], id[SCAN_ROUNDS - 1], id[SCAN_ROUNDS - 2]);
 			}
-			chead = (chead + nc) & (CAND_RING - 1); ccount -= nc;
-			const uint64_t m = __ballot(pass);
-			if (pass) s_queue[(qhead + qcount + __popcll(m & lt_mask)) & (2 * WAVE - 1)] = id;
-			qcount += __popcll(m);
-			PT(t_s2b); PT_ACC(1, t_s1b, t_s2b);
+#pragma unroll
+			for (int r = 0; r < SCAN_ROUNDS; r++) {
+				const bool have = pos + r * WAVE + lane < range.y;
+				const bool rp = have && (((key[r] >> row_bit) & (key[r] >> col_bit)) & 1u);
+				const uint64_t m = __ballot(rp);
+				if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (CAND_RING - 1)] = id[r];
+				ccount += __popcll(m);
+			}
+			pos += SCAN_ROUNDS * WAVE;
 		}
-		const uint32_t n = min(qcount, (uint32_t)WAVE);
-		if (n == 0) break;
+		PT(t_s1b); PT_ACC(0, t_s1a, t_s1b);
+		const uint32_t nc = min(ccount, (uint32_t)WAVE);
+		if (nc == 0) break;
+		__syncthreads();
+		// lane l's candidate lands in row l of s_splat whether it passes or not: the blend loop walks the set bits of the pass mask (no
+		// compaction -- sixteen registers of gathered line per lane next to the blend accumulators cost a wave per SIMD)
+		bool pass = false, my_lean = false; uint32_t myid = 0;
+		if ((uint32_t)lane < nc) {
+			myid = s_cand[(chead + lane) & (CAND_RING - 1)];
+			PT(t_f0);
+			const float4* src = reinterpret_cast<const float4*>(a.splats + myid);
+			float4 g0 = src[0], g1 = src[1];
+			const float4 g2 = src[2], g3 = src[3];
+			PT_WAIT_VM8(8, 9, t_f0, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w);
+			s_splat[lane * 4 + 2] = g2; s_splat[lane * 4 + 3] = g3;
+			s_splat[lane * 4 + 0] = g0; s_splat[lane * 4 + 1] = g1;
+			pass = tile_may_contribute(g0, g1.x, g3.z, tx, ty * ROWS, ROWS);      // g3.z: tau (Splat::aux)
+			my_lean = ADGS_LEAN && pass && g3.w != 0.f;
+		}
+		chead = (chead + nc) & (CAND_RING - 1); ccount -= nc;
+		const uint64_t pm = __ballot(pass);                                     // bit j: row j of s_splat is an entry of this batch
+		const uint64_t lean_m = __builtin_amdgcn_ballot_w64(my_lean);           // bit j: entry j takes the lean evaluation
+		const uint32_t n = (uint32_t)__popcll(pm);
+		PT(t_s2b); PT_ACC(1, t_s1b, t_s2b);
+		if (n == 0) continue;
 		PT(t_g0);
 		__syncthreads();
-		uint32_t myid = 0;
-		bool my_lean = false;
-		if ((uint32_t)lane < n) {
-			myid = s_queue[(qhead + lane) & (2 * WAVE - 1)];
-			const float4* src = reinterpret_cast<const float4*>(a.splats + myid);
-			const float4 s3 = src[3];
-			s_splat[lane * 4 + 0] = src[0];
-			s_splat[lane * 4 + 1] = src[1];
-			s_splat[lane * 4 + 2] = src[2];
-			s_splat[lane * 4 + 3] = s3;
-			my_lean = ADGS_LEAN && s3.w != 0.f;
+		entries_in += n;
+		if (blk_left == 0 && !pre_drawn && pub_n + n >= (uint32_t)WAVE) {      // this batch may complete a chunk and the block is used up
+			uint32_t nb = 0;
+			if (lane == 0) nb = atomicAdd(a.pool_cursor, (uint32_t)POOL_BLOCK);
+			pre_block = nb; pre_drawn = true;
 		}
-		const uint64_t lean_m = __builtin_amdgcn_ballot_w64(my_lean);      // bit j: entry j of this batch takes the lean evaluation
-		qhead = (qhead + n) & (2 * WAVE - 1); qcount -= n;
-		// the chunk slot of this batch: the next one of the tile's current block; a new block of POOL_BLOCK slots is drawn from the
-		// shared cursor only when the block is used up -- now, so that the atomic's round trip hides behind the blend loop (a
-		// batch without a live entry gives its slot back)
-		batches++;
-		uint32_t new_block = 0;
-		const bool draw = blk_left == 0;                 // wave-uniform
-		if (draw && lane == 0) new_block = atomicAdd(a.pool_cursor, (uint32_t)POOL_BLOCK);
-		__syncthreads();
 		// ---- blend.  `live` collects the entries at least one pixel evaluates as contributing: only those are published for
 		// the backward replay (at C3 22 % of the entries that pass the tile test are blended by no pixel -- the test is a bound
 		// over the tile rectangle, and pixels saturate), and positions (n_contrib) count live entries only.
 		uint64_t live = 0ull;
 		PT(t_b0); PT_ACC(2, t_g0, t_b0);
 		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
-		for (uint32_t j = 0; j < n; j++) {
+		for (uint64_t todo = pm; todo != 0ull; todo &= todo - 1ull) {
+			const uint32_t j = (uint32_t)__builtin_ctzll(todo);
 			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
 			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
@@ -346,20 +401,15 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			}
 		}
 		PT(t_b1); PT_ACC(3, t_b0, t_b1);
-		// ---- publish the live entries of this batch, in order, as one chunk of the backward's replay list
+		// ---- the live entries of this batch join the pending chunk, in order
 		const uint32_t nlive = (uint32_t)__popcll(live);
-		if (draw) { blk_next = gridDim.x * (uint32_t)POOL_BLOCK + __shfl(new_block, 0, WAVE); blk_left = POOL_BLOCK; }
-		if (nlive > 0) {
-			const uint32_t chunk = blk_next;
-			blk_next++; blk_left--;
-			uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
-			if (lane == 0) { c[CHUNK_PREV] = prev_chunk; c[CHUNK_COUNT] = nlive; }
-			if ((live >> lane) & 1ull) c[__popcll(live & lt_mask)] = myid;
-			prev_chunk = chunk;
-			consumed += nlive;
-		}
+		if ((live >> lane) & 1ull) s_pub[pub_n + (uint32_t)__popcll(live & lt_mask)] = myid;
+		pub_n += nlive; consumed += nlive;
+		if (pub_n >= (uint32_t)WAVE) flush_chunk(WAVE);
 	}
-	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = batches; }
+	if (pub_n > 0) flush_chunk(pub_n);
+
+	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = entries_in; }
 	TL_STORE(lane, a.tile_scanned, a.tile_batches, tile);      // timeline build: the wave's life instead of the statistics
 	PROBE_FLUSH(0, lane);
 	{ PT(t_wave1); PT_ACC(4, t_wave0, t_wave1); PT_ADD(5, 1ull); PT_FLUSH(0, 10, lane); }
@@ -561,14 +611,27 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 #endif
 		PT(t_p1); PT_ACC(8, t_wave0, t_p1);
 	}
-	// The replay list is a chain of chunks ([64 ids, prev, count]).  Ids and link words of a chunk are two independent vector loads, and
-	// those of the NEXT chunk are requested before the current chunk's entry loop, so that at a chunk boundary only the Splat gather is
-	// an exposed round trip (until round 3: header -> ids -> gather, three dependent ones per 64 entries).
-	uint32_t my_id = 0, link = 0;                 // lane j: id of entry j; lanes 0 / 1: prev chunk / entry count
+	// The replay list is a chain of chunks ([64 ids, prev, count]), walked from the tile's last chunk to its first.  Ids and link words of a
+	// chunk are two independent vector loads.  The walk is pipelined two chunks deep: while chunk c is replayed, the Splat lines of chunk
+	// c - 1 are in flight into registers (its ids arrived while c + 1 was replayed) and the ids of chunk c - 2 are requested -- at a
+	// chunk boundary nothing but a wait for loads that landed long ago and four LDS stores is left.  (Until round 3: header -> ids ->
+	// gather, three dependent round trips per 64 entries; a gather of 64 scattered lines is ~6 us under load.)
+	uint32_t my_id = 0, link = 0;                 // current chunk -- lane j: id of entry j; lanes 0 / 1: prev chunk / entry count
+	uint32_t nx_id = 0, nx_link = 0;              // the chunk behind it in the walk (`prev`)
+	float4 nx0, nx1, nx2, nx3;                    // ... and this lane's Splat line of it
+	nx0 = nx1 = nx2 = nx3 = make_float4(0.f, 0.f, 0.f, 0.f);
+	auto request_rows = [&](uint32_t id, int cnt, float4& r0, float4& r1, float4& r2, float4& r3) {
+		if (lane < cnt) {
+			const float4* src = reinterpret_cast<const float4*>(a.splats + id);
+			r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+			if (!FULL && a.sem_src) r3.y = a.sem_src[(size_t)id * a.sem_stride];      // an extra semantic channel's replay
+		}
+	};
 	if (chunk != NO_CHUNK) {
 		const uint32_t* c = a.pool + (size_t)chunk * CHUNK_WORDS;
 		my_id = c[lane]; link = c[CHUNK_PREV + (lane & 1)];
 	}
+	bool rows_ready = false;                      // nx0 .. nx3 hold the CURRENT chunk's lines (requested one chunk ago)
 	while (chunk != NO_CHUNK) {
 		PT(t_c0);
 		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(2);      // a chunk boundary is a dozen instructions between two waits: do not starve behind the older waves' entry loops
@@ -580,23 +643,33 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 		PT(t_c1); PT_ACC(0, t_c0, t_c1); PT_ADD(6, 1ull);
 		base -= n;
 		const uint32_t cur_id = my_id;
-		if (prev != NO_CHUNK) {
-			const uint32_t* cn = a.pool + (size_t)prev * CHUNK_WORDS;
-			my_id = cn[lane]; link = cn[CHUNK_PREV + (lane & 1)];
+		float4 c0, c1, c2, c3;
+		if (ADGS_BWD_PF2 && rows_ready) { c0 = nx0; c1 = nx1; c2 = nx2; c3 = nx3; }
+		else {
+			// the tile's first chunk: its lines now, the next chunk's ids at the same time
+			if (prev != NO_CHUNK) { const uint32_t* cn = a.pool + (size_t)prev * CHUNK_WORDS; nx_id = cn[lane]; nx_link = cn[CHUNK_PREV + (lane & 1)]; }
+			c0 = c1 = c2 = c3 = make_float4(0.f, 0.f, 0.f, 0.f);
+			request_rows(cur_id, n, c0, c1, c2, c3);
 		}
-		if (base < max_contrib) {
+		{
 			__syncthreads();
 			bool my_lean = false;
 			if (lane < n) {
-				const float4* src = reinterpret_cast<const float4*>(a.splats + cur_id);
-				s_splat[lane * 4 + 0] = src[0];
-				s_splat[lane * 4 + 1] = src[1];
-				s_splat[lane * 4 + 2] = src[2];
-				float4 q3s = src[3];
-				my_lean = ADGS_LEAN && q3s.w != 0.f;
-				if (!FULL && a.sem_src) q3s.y = a.sem_src[(size_t)cur_id * a.sem_stride];      // an extra semantic channel's replay
-				s_splat[lane * 4 + 3] = q3s;
+				s_splat[lane * 4 + 0] = c0; s_splat[lane * 4 + 1] = c1; s_splat[lane * 4 + 2] = c2; s_splat[lane * 4 + 3] = c3;
+				my_lean = ADGS_LEAN && c3.w != 0.f;
 			}
+			// the chunk behind this one: its lines fly while this chunk is replayed; the ids of the one behind that follow
+			uint32_t nn_id = 0, nn_link = 0;
+			if (prev != NO_CHUNK) {
+				if (ADGS_BWD_PF2) {
+					const uint32_t pprev = (uint32_t)__builtin_amdgcn_readlane((int)nx_link, 0);
+					request_rows(nx_id, __builtin_amdgcn_readlane((int)nx_link, 1), nx0, nx1, nx2, nx3);
+					if (pprev != NO_CHUNK) { const uint32_t* cp = a.pool + (size_t)pprev * CHUNK_WORDS; nn_id = cp[lane]; nn_link = cp[CHUNK_PREV + (lane & 1)]; }
+					rows_ready = true;
+				}
+			}
+			my_id = nx_id; link = nx_link; nx_id = nn_id; nx_link = nn_link;
+			if (!ADGS_BWD_PF2) rows_ready = false;
 			// bit j: entry j takes the lean evaluation -- its Gaussian allows it and its position lies before every pixel's last contributor
 			// (contributor = base + j < min_contrib: the position test holds for all pixels)
 			const int n_before = min_contrib - base;
@@ -604,9 +677,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 			__syncthreads();
 			if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
 			PT(t_g1); PT_ACC(1, t_c1, t_g1);
-			for (int j = n - 1; j >= 0; j--) {
+			// entries at or behind every pixel's last contributor are not replayed: the loop starts below them
+			const int j_first = min(n - 1, max_contrib - base - 1);
+			for (int j = j_first; j >= 0; j--) {
 				const int contributor = base + j;
-				if (contributor >= max_contrib) continue;
 				PT_ADD(7, 1ull);
 				const float4 q0 = s_splat[j * 4 + 0], q1 = s_splat[j * 4 + 1];
 				const float dx = q0.x - pxf;

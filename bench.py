@@ -83,9 +83,12 @@ def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None, bucket=False)
 
 # ------------------------------------------------------------------ scenes
 def build_scene(config, variant="default"):
-    """BASELINE.json config scene, or one of two C3-sized stress variants for the scene-sensitivity lines:
-    'translucent' (opacity x 0.05 + 0.01: no pixel saturates, every tile walks its whole list) and 'sky' (the upper 40 % of the
-    image is empty; the Gaussians that were there lie on the road plane y = +1.5 m instead: long lists around the horizon)."""
+    """BASELINE.json config scene, or one of three C3-sized stress variants for the scene-sensitivity lines:
+    'translucent' (opacity x 0.05 + 0.01: no pixel saturates, every tile walks its whole list), 'sky' (the upper 40 % of the
+    image is empty; the Gaussians that were there lie on the road plane y = +1.5 m instead: long lists around the horizon) and
+    'street' (a driving-scene layout with NON-UNIFORM depth complexity: a road plane, two facades seen at grazing angles that pile
+    up towards the vanishing point, semi-transparent Gaussians, empty sky -- the p99 / median of the per-tile list lengths is
+    printed with the line: `entries_per_tile`)."""
     import torch
     from adgs import synthetic
     sc = synthetic.make_config_scene(config)
@@ -100,6 +103,25 @@ def build_scene(config, variant="default"):
         n = int(up.sum())
         xyz[up, 1] = 1.5 + 0.05 * torch.randn(n, generator=g)    # the road plane, 1.5 m below the camera (y points down)
         sc["means3D"] = xyz.contiguous()
+        sc["flow_points"] = (xyz + 0.05 * torch.randn(xyz.shape, generator=g)).float().contiguous()
+    elif variant == "street":
+        g = torch.Generator().manual_seed(78)
+        xyz = sc["means3D"].clone()
+        scene = ~sc["obj_mask"]
+        n = int(scene.sum())
+        z = torch.rand(n, generator=g) ** 0.7 * 88.0 + 2.0                       # denser far away: the vanishing point collects them
+        kind = torch.rand(n, generator=g)
+        x = (torch.rand(n, generator=g) * 2 - 1) * 7.5
+        y = 1.5 + 0.04 * torch.randn(n, generator=g)                             # road plane, 1.5 m below the camera (y points down)
+        wall = kind > 0.45                                                       # 55 %: the two facades at x = -8 / +8 m, 0 .. 14 m high
+        side = torch.where(torch.rand(n, generator=g) > 0.5, 1.0, -1.0)
+        x = torch.where(wall, side * (8.0 + 0.05 * torch.randn(n, generator=g)), x)
+        y = torch.where(wall, 1.5 - torch.rand(n, generator=g) * 14.0, y)
+        xyz[scene] = torch.stack([x, y, z], 1)
+        sc["means3D"] = xyz.contiguous()
+        op = sc["opacities"].clone()
+        op[scene] = torch.sigmoid(1.2 * torch.randn(n, 1, generator=g) - 1.6)    # mostly semi-transparent: saturation takes many entries where they pile up
+        sc["opacities"] = op.contiguous()
         sc["flow_points"] = (xyz + 0.05 * torch.randn(xyz.shape, generator=g)).float().contiguous()
     elif variant != "default":
         raise ValueError(variant)
@@ -284,8 +306,7 @@ def graphed_steps(frames, ups):
 
 # ------------------------------------------------------------------ scene statistics
 def frame_work_figures(frame, settings, use_fs, device, with_ref=True, full=False):
-    """(E, R, E_pub, scanned) -- with `full` also (V, Rc, fine_pairs) of that forward: E = (tile, Gaussian) entries the v2 forward hands to the blend loop (64 x the chunks it published: an
-    upper bound within #tiles x 63), R = the reference's num_rendered for the same frame (one extra forward in classic mode),
+    """(E, R, E_pub, scanned) -- with `full` also (V, Rc, fine_pairs) of that forward: E = (tile, Gaussian) entries the v2 forward hands to the blend loop (counted by the kernel), R = the reference's num_rendered for the same frame (one extra forward in classic mode),
     E_pub = the entries at least one pixel blends (what the backward replays), scanned = candidates of the cell lists that the
     tiles' walks went through."""
     import ctypes
@@ -324,8 +345,8 @@ def frame_work_figures(frame, settings, use_fs, device, with_ref=True, full=Fals
                 else:
                     os.environ["ADGS_RASTER_MODE"] = old
     if full:
-        return chunks * 64, r_ref, published, scanned, int((out[4] > 0).sum().item()), fstats["num_rendered"], fstats["fine_pairs"]
-    return chunks * 64, r_ref, published, scanned
+        return chunks, r_ref, published, scanned, int((out[4] > 0).sum().item()), fstats["num_rendered"], fstats["fine_pairs"]
+    return chunks, r_ref, published, scanned
 
 
 def library_stamp():
@@ -433,6 +454,58 @@ def parity_vs_oracle(hip_outs, oracle_fwd):
 
 
 # ------------------------------------------------------------------ timing helpers
+def knn_measure(device, sizes=((1_000_000, "C3"), (3_000_000, "C5")), cpu_points=1_000_000, with_cpu=True):
+    """simple-knn (R11, KNN/simple_knn.cu:185-221, called once at scene/gaussian_model.py:277): adgs_knn_dist2 on the positions of the
+    C3 / C5 scenes.  Algorithmic bytes P (12 + 16 + 4): the points read, their Morton-ordered float4 copy, the distances written.
+    CPU baseline: oracle/knn_oracle.cpp, the line-by-line restatement of the same box-pruned search (O(P x boxes) box tests plus the
+    points of the boxes that survive them), OpenMP over the host's threads, on the first workload's cloud (`cpu_points` of it)."""
+    import ctypes as _ct
+    import gc
+    import torch
+    from adgs import _lib as _l, synthetic as _syn
+    from simple_knn._C import distCUDA2
+    out = []
+    lib = _l.lib()
+    for P, cfg_name in sizes:
+        sc = _syn.make_config_scene(cfg_name)
+        pts = sc["means3D"][:P].to(device).contiguous()
+        P = int(pts.shape[0])
+        for _ in range(2):
+            distCUDA2(pts)
+        torch.cuda.synchronize()
+        ws = torch.empty((int(lib.adgs_knn_workspace_bytes(P)),), dtype=torch.uint8, device=device)
+        res = torch.empty((P,), dtype=torch.float32, device=device)
+        stream = _ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        n = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            _l.check(lib.adgs_knn_dist2(P, pts.data_ptr(), res.data_ptr(), ws.data_ptr(), stream), "adgs_knn_dist2")
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        staged = int(ws[24:32].view(torch.int64).item())
+        nboxes = (P + 1023) // 1024
+        ab = P * (12 + 16 + 4)
+        r = {"workload": "%s positions" % cfg_name, "points": P, "ms": round(ms, 3), "points_per_s": round(P / (ms * 1e-3)), "alg_bytes": ab,
+             "GB/s_algorithmic": round(ab / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+             "boxes": nboxes, "boxes_scanned_per_query_box": round(staged / max(nboxes, 1), 1),
+             "candidate_points_scanned_per_query": round(staged / max(nboxes, 1) * 1024)}
+        out.append(r)
+        del ws, res, pts
+        gc.collect(); torch.cuda.empty_cache()
+    if with_cpu:
+        from oracle import oracle as _o
+        sc = _syn.make_config_scene(sizes[0][1])
+        sub = sc["means3D"][torch.randperm(sc["means3D"].shape[0], generator=torch.Generator().manual_seed(0))[:cpu_points]].numpy()
+        t0 = time.perf_counter()
+        _o.knn_dist2(sub)
+        dt = time.perf_counter() - t0
+        out.append({"cpu_baseline": {"points": int(sub.shape[0]), "ms": round(dt * 1e3, 1), "points_per_s": round(sub.shape[0] / dt), "cores": _o.num_threads(),
+                                     "kind": "port", "sample": "oracle/knn_oracle.cpp (the reference's box-pruned search restated; cost grows ~quadratically: P/1024 box tests per "
+                                     "point) on %d of the %s positions" % (sub.shape[0], sizes[0][1])}})
+    return out
+
+
 def percentile(xs, q):
     xs = sorted(xs)
     if not xs:
@@ -1020,8 +1093,12 @@ def main():
                 except Exception as exc:
                     result["train_iteration"] = "failed: %r" % (exc,)
                 gc.collect(); torch.cuda.empty_cache()
+                try:
+                    result["knn_dist2"] = knn_measure(device, with_cpu=not args.no_cpu_baseline)
+                except Exception as exc:
+                    result["knn_dist2"] = "failed: %r" % (exc,)
                 sens = []
-                for variant in ("translucent", "sky"):
+                for variant in ("translucent", "sky", "street"):
                     a = quick_measure("C3", 40, device, use_fs, variant=variant, with_stats=True)[0]
                     b = quick_measure("C3", 6, device, use_fs, variant=variant, mode="classic", warm=3)[0]
                     a["classic_frames_per_s"] = b["frames_per_s"]

@@ -18,13 +18,20 @@
 extern "C" {
 #endif
 
-/* sums: ADGS_LOSS_SLOTS x 2 device doubles, zero-initialised by the caller.  Workgroup b adds its partial sums
+/* Work buffers of this header (`sums`, `work`): their SLOT rows must be zero when a forward is enqueued; the kernel that consumes the
+ * rows (adgs_l1_ssim_means, the finish kernels inside the other forwards) leaves them zero again, so ONE zero-initialised buffer per
+ * concurrent loss term serves every iteration without a fill (the scalars behind the rows -- totals the backward reads -- are
+ * overwritten by every forward: a buffer may be reused once its backward has been enqueued, stream order).
+ *
+ * sums: ADGS_LOSS_SLOTS x 2 device doubles, zero on entry.  Workgroup b adds its partial sums
  * (sum |image - gt|, sum ssim_map) into row b % ADGS_LOSS_SLOTS -- atomics on ONE address would serialise in the L2;
- * the caller adds the rows up and divides by planes*H*W for the two means.
+ * adgs_l1_ssim_means (or the caller) adds the rows up and divides by planes*H*W for the two means.
  * d_mu1 / d_e11 / d_e12: planes*H*W floats each, or all NULL for a forward without backward. */
 #define ADGS_LOSS_SLOTS 256
 int adgs_l1_ssim_forward(int planes, int H, int W, const float* image, const float* gt, double* sums,
 	float* d_mu1, float* d_e11, float* d_e12, void* stream);
+/* out2[0] = mean |image - gt| (utils/loss_utils.py:20-21), out2[1] = mean ssim_map (:37-68), n = planes*H*W; consumes `sums` (zero afterwards). */
+int adgs_l1_ssim_means(double* sums, long long n, float* out2, void* stream);
 
 /* dL_dimage = g_l1[0] * sign(image - gt) / n + g_ssim[0] * d(mean ssim)/d(image),  n = planes*H*W.
  * g_l1 / g_ssim are DEVICE scalars (the upstream gradients of the two means; NULL = 0): no host round trip. */
@@ -36,7 +43,7 @@ int adgs_l1_ssim_backward(int planes, int H, int W, const float* image, const fl
  * utils/depth_utils.py:3-45 (closed-form least squares for scale s and shift t of the prediction, then
  * sum(|s p + t - g| m) / sum(m)), differentiable through s and t like the reference's autograd, with the
  * reference's `det == 0 -> (0, 0)` case decided on the device (the reference synchronises for it).
- * work: ADGS_DEPTH_WORK_DOUBLES device doubles, zero-initialised by the caller, kept for the backward.
+ * work: ADGS_DEPTH_WORK_DOUBLES device doubles (256 x 8 slot rows, zero on entry and on return; 16 scalars), kept for the backward.
  * mask may be NULL (all ones).  loss: one device float.
  */
 #define ADGS_DEPTH_WORK_DOUBLES (256 * 8 + 16)
@@ -52,7 +59,7 @@ int adgs_depth_loss_backward(int n, const float* prediction, const float* target
  * K, R, T: HOST pointers to the 3x3 / 3x3 / 3 camera of the flow target (row-major).  Per selected pixel
  *   p = K (R f + T); (u, v) = p.xy / max(p.z, dist); loss += (|u - flow_x| / W + |v - flow_y| / H) * opacity * [p.z > dist]
  * and loss = sum / #selected, 0 when nothing is selected -- decided on the device (the reference's nonzero() synchronises).
- * work: ADGS_AUX_WORK_DOUBLES device doubles, zero-initialised by the caller, kept for the backward.
+ * work: ADGS_AUX_WORK_DOUBLES device doubles (256 x 2 slot rows, zero on entry and on return; 2 scalars), kept for the backward.
  */
 #define ADGS_AUX_WORK_DOUBLES (256 * 2 + 2)
 int adgs_flow_loss_forward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,

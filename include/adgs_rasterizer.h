@@ -191,7 +191,9 @@ int adgs_mark_visible(int P, const float* means3D, const float* viewmatrix, cons
 
 /* SimpleKNN::knn (KNN/simple_knn.h:17-20, simple_knn.cu:185-221): mean squared
  * distance to the 3 nearest other points.  `workspace` must hold
- * adgs_knn_workspace_bytes(P) bytes of device memory. */
+ * adgs_knn_workspace_bytes(P) bytes of device memory.  After the call, the 64-bit word at byte 24 of the workspace
+ * holds the number of candidate boxes (1024 Morton-sorted points each, KNN/simple_knn.cu:12) the search scanned, summed over
+ * the ceil(P / 1024) query boxes (a statistic for bench.py; device memory). */
 size_t adgs_knn_workspace_bytes(int P);
 int adgs_knn_dist2(int P, const float* points, float* meanDists, char* workspace, void* stream);
 

@@ -246,7 +246,7 @@ def test_regulariser_indices_follow_fancy_indexing_and_never_leave_the_tensor():
     pos = idx.clone(); pos[3, 2] = 49; pos[7, 0] = 0
     a = loss.reg_loss(x, neg); ga, = torch.autograd.grad(a, x)
     b = loss.reg_loss(x, pos); gb, = torch.autograd.grad(b, x)
-    assert torch.equal(a, b) and torch.equal(ga, gb)
+    assert torch.equal(a, b) and torch.allclose(ga, gb, rtol=1e-5, atol=1e-7)       # the gradient rows are float atomics: same sums, any order
     ref = x[pos].var(dim=1).sum(-1).mean()
     assert abs(float(a) - float(ref)) <= 1e-5 * abs(float(ref))
     for bad_value in (50, -51, 10 ** 12):
