@@ -19,7 +19,23 @@
 namespace adgs {
 
 static thread_local std::string g_last_error;
-static adgs_frame_stats g_stats = { 0, 0, 0, 0, 0, 0 };   // process-wide (autograd runs backward on its own thread)
+// What a forward remembers for its caller and for the next forward -- per (host thread, device), like the mailbox: two threads (or one thread
+// on two GPUs) rendering at the same time do not see each other's statistics or capacity hints.  Only the forward touches it (autograd runs the
+// backward on a thread of its own: the backward keys what it needs by the state buffers, remember_frame / lookup_frame).  The stage profiler
+// (adgs_profile_*) stays process-wide on purpose: it collects the events of both directions.
+struct FrameContext {
+	adgs_frame_stats stats;
+	size_t hint_cells, hint_fine;          // speculative binning capacities (v2 forward): previous frames' counts + 25 %
+	unsigned hint_max_cell_chunks;         // chunks of the fullest cell of the last bucket-binned frame
+	long long reruns;                      // forwards whose capacity was too small (binning + blend enqueued twice)
+};
+static FrameContext* frame_context() {
+	constexpr int MAX_DEV = 64;
+	static thread_local FrameContext ctx[MAX_DEV] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+	return &ctx[dev];
+}
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 // rasterizer_impl.cu:35-50 (next-highest bit of the MSB)
@@ -218,9 +234,6 @@ StageTimer::~StageTimer() {
 
 // pinned host word for the one device->host read-back of num_rendered
 // (the reference does a blocking cudaMemcpy, rasterizer_impl.cu:288)
-static std::atomic<size_t> g_hint_cells{0}, g_hint_fine{0};      // speculative binning capacities (v2 forward)
-static std::atomic<unsigned> g_hint_max_cell_chunks{0};            // chunks of the fullest cell of the last bucket-binned frame
-static std::atomic<long long> g_reruns{0};                       // forwards whose capacity was too small (binning + blend enqueued twice)
 static uint32_t* pinned_word() {
 	static thread_local uint32_t* p = nullptr;
 	if (!p) { if (hipHostMalloc((void**)&p, 1024, hipHostMallocDefault) != hipSuccess) p = nullptr; }
@@ -321,7 +334,7 @@ using namespace adgs;
 
 extern "C" const char* adgs_last_error(void) { return g_last_error.c_str(); }
 
-extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = g_stats; }
+extern "C" void adgs_get_frame_stats(adgs_frame_stats* out) { if (out) *out = frame_context()->stats; }
 
 // Totals the device published for the calling thread's most recent v2 forward on the current device, and whether they fitted the
 // capacity that forward (eager or captured in a HIP graph) was enqueued against.  Reads host memory only; meaningful once the
@@ -337,7 +350,7 @@ extern "C" int adgs_get_frame_status(adgs_frame_status* out) {
 	out->capacity_pairs = mb->host->cap_cells == 0xffffffffu ? (int64_t)mb->host->r_cells : (int64_t)mb->host->cap_cells;
 	out->capacity_fine_pairs = mb->host->cap_fine == ~0ull ? (int64_t)mb->host->r_fine : (int64_t)mb->host->cap_fine;
 	out->overflow = (int32_t)mb->host->overflow; out->overflow_count = (int64_t)mb->host->overflow_count;
-	out->eager_reruns = (int64_t)g_reruns.load();
+	out->eager_reruns = (int64_t)frame_context()->reruns;
 	out->unrepaired_overflow_count = (int64_t)mb->host->overflow_count - (int64_t)mb->repaired;
 	return 0;
 }
@@ -397,6 +410,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	int inv_depth, int* radii, int debug, void* stream_) {
 	(void)prefiltered;   // the reference only uses it to trap on an impossible cull (auxiliary.h:156-160)
 	hipStream_t stream = (hipStream_t)stream_;
+	FrameContext* fc = frame_context();
 	if (P <= 0) return 0;
 	if (D_S > MAX_SEMANTIC) { set_error("D_S exceeds 32 semantic channels"); return -1; }
 	if (!means3D || !opacities || (!cov3D_precomp && (!scales || !rotations)) || !radii) { set_error("missing required input pointer"); return -1; }
@@ -418,8 +432,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const char* binning_env = getenv("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
-			(binning_mode == "bucket" || (g_hint_cells.load() <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells &&
-			                              g_hint_max_cell_chunks.load() <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));      // ... or ONE cell held more than 16 chunks
+			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells &&
+			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));      // ... or ONE cell held more than 16 chunks
 		size_t gb = 0, ib = 0;
 		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] exists for bucket binning only
 		GeomStateV2::carve(nullptr, P, &gb, count_cells);
@@ -458,6 +472,16 @@ static int raster_forward_impl(const ShSource* sh_src,
 			pa.bucket_count = geom.counts; pa.fine_total = geom.bucket_fine_total();
 		}
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream, zero_words, zero_words ? n_zero : 0) != 0) return -1; }
+		if (const int evict_mb = env_int("ADGS_DBG_EVICT_MB", 0)) {
+			// measurement hook (tools/stage_cache_experiment.py): a fill of `evict_mb` MiB between the sh0 kernel and the preprocess pushes what
+			// the previous kernels wrote (deformed parameters, sh0) out of the 256 MiB Infinity Cache -- the state rocprofv3's serialised,
+			// instrumented dispatches leave the preprocess in, and the reason its kernel-trace duration exceeds the HIP-event bracket of the
+			// undisturbed frame
+			static thread_local void* scratch = nullptr; static thread_local size_t scratch_bytes = 0;
+			const size_t want = (size_t)evict_mb << 20;
+			if (scratch_bytes < want) { if (scratch) (void)hipFree(scratch); scratch = nullptr; scratch_bytes = 0; if (hipMalloc(&scratch, want) == hipSuccess) scratch_bytes = want; }
+			if (scratch) ADGS_HIP_CHECK(hipMemsetAsync(scratch, 0, want, stream));
+		}
 		{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		// The two totals (coarse (cell, Gaussian) pairs; fine-tile bound of the chunk pool) size the binning buffer.  Instead of
@@ -477,8 +501,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const bool capturing = cap_status == hipStreamCaptureStatusActive;
 		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
 		const bool speculate = capturing || (env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99);
-		const size_t cap_cells = std::min<size_t>(std::max<size_t>(g_hint_cells.load(), (size_t)P + 4096), 0x7fffffffu);
-		const size_t cap_fine = std::max<size_t>(g_hint_fine.load(), (size_t)8 * P + 4096);
+		const size_t cap_cells = std::min<size_t>(std::max<size_t>(fc->hint_cells, (size_t)P + 4096), 0x7fffffffu);
+		const size_t cap_fine = std::max<size_t>(fc->hint_fine, (size_t)8 * P + 4096);
 		mb->cap_cells = cap_cells; mb->cap_fine = cap_fine;
 		uint32_t* overflow_flag = geom.d_counts() + 3;         // written by cell_scan / publish_counts in every frame
 		if (buckets) {
@@ -578,8 +602,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 		}
 		if (capturing) {
 			// nothing of this frame can be read back inside a capture: the totals stay in the mailbox for adgs_get_frame_status()
-			g_stats.num_rendered = (int64_t)cap_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = buckets ? 32 : 32 + bit;
-			g_stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8; g_stats.reserved = buckets ? 1 : 0; g_stats.fine_pairs = (int64_t)cap_fine;
+			fc->stats.num_rendered = (int64_t)cap_cells; fc->stats.tiles = (int32_t)ntiles; fc->stats.sort_bits = buckets ? 32 : 32 + bit;
+			fc->stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8; fc->stats.reserved = buckets ? 1 : 0; fc->stats.fine_pairs = (int64_t)cap_fine;
 			return (int)cap_cells;
 		}
 		if (wait_mailbox(mb, seq, stream) != 0) return -1;
@@ -591,7 +615,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (mb->host->overflow) mb->repaired++;      // an eager frame that did not fit is enqueued again below, before this call returns
 		const bool chunk_table_full = buckets && mb->host->oversize;
 		if (!speculate || chunk_table_full || R_cells > cap_cells || R_fine > cap_fine) {
-			if (speculate) g_reruns.fetch_add(1);
+			if (speculate) fc->reruns++;
 			// the re-run fits by construction; the device word can also be set without speculation (cell_scan raises it when the chunk
 			// table is full), and a blend launched with it set renders nothing
 			ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream));
@@ -609,17 +633,17 @@ static int raster_forward_impl(const ShSource* sh_src,
 		}
 		{	// capacity hints for the next frame: 25% head-room over this frame, slow decay of older peaks
 			const size_t want_c = R_cells + R_cells / 4 + 4096, want_f = R_fine + R_fine / 4 + 4096;
-			const size_t old_c = g_hint_cells.load(), old_f = g_hint_fine.load();
-			g_hint_cells.store(std::max(want_c, old_c - old_c / 16));
-			g_hint_fine.store(std::max(want_f, old_f - old_f / 16));
+			const size_t old_c = fc->hint_cells, old_f = fc->hint_fine;
+			fc->hint_cells = std::max(want_c, old_c - old_c / 16);
+			fc->hint_fine = std::max(want_f, old_f - old_f / 16);
 			// the fullest cell of a bucket-binned frame; a sorted frame does not report one: the old figure decays, so that a scene
 			// with a persistent hot cell re-tries the bucket path once in a few dozen frames instead of every other frame
-			const unsigned old_m = g_hint_max_cell_chunks.load();
-			g_hint_max_cell_chunks.store(std::max(buckets ? mb->host->max_cell_chunks : 0u, old_m - std::max(1u, old_m / 16) * (old_m ? 1u : 0u)));
+			const unsigned old_m = fc->hint_max_cell_chunks;
+			fc->hint_max_cell_chunks = std::max(buckets ? mb->host->max_cell_chunks : 0u, old_m - std::max(1u, old_m / 16) * (old_m ? 1u : 0u));
 		}
-		g_stats.num_rendered = (int64_t)R_cells; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = buckets ? 32 : 32 + bit;
-		g_stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
-		g_stats.reserved = buckets ? 1 : 0; g_stats.fine_pairs = (int64_t)R_fine;       // reserved: 1 = bucket binning (the sort passes stay inside the CUs)
+		fc->stats.num_rendered = (int64_t)R_cells; fc->stats.tiles = (int32_t)ntiles; fc->stats.sort_bits = buckets ? 32 : 32 + bit;
+		fc->stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
+		fc->stats.reserved = buckets ? 1 : 0; fc->stats.fine_pairs = (int64_t)R_fine;       // reserved: 1 = bucket binning (the sort passes stay inside the CUs)
 		return (int)R_cells;
 	}
 
@@ -694,8 +718,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 	{ StageTimer t(ST_RENDER_FWD, stream); if (launch_render_fwd(ra, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 
-	g_stats.num_rendered = num_rendered; g_stats.tiles = (int32_t)ntiles; g_stats.sort_bits = 32 + bit; g_stats.sort_passes = (32 + bit + 7) / 8;
-	g_stats.fine_pairs = num_rendered;
+	fc->stats.num_rendered = num_rendered; fc->stats.tiles = (int32_t)ntiles; fc->stats.sort_bits = 32 + bit; fc->stats.sort_passes = (32 + bit + 7) / 8;
+	fc->stats.fine_pairs = num_rendered;
 	return num_rendered;
 }
 
@@ -1038,7 +1062,8 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 	}
 }
 extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
-	g_hint_cells.store((size_t)std::max(0ll, pairs)); g_hint_fine.store((size_t)std::max(0ll, fine_pairs)); g_hint_max_cell_chunks.store(0u);
+	FrameContext* fc = frame_context();
+	fc->hint_cells = (size_t)std::max(0ll, pairs); fc->hint_fine = (size_t)std::max(0ll, fine_pairs); fc->hint_max_cell_chunks = 0u;
 }
 extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
 extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {

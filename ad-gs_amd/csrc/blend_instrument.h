@@ -1,8 +1,8 @@
 // Experiment-build instrumentation of the v2 blend kernels (render_v2.hip).  The shipping library defines none of these macros: every
 // hook below expands to nothing.  One macro family per experiment (make -C ad-gs_amd/csrc variant TAG=<tag> DEFS=-D<macro>):
 //   ADGS_PROBE         tools/blend_probe.py       per wave: shader cycles (s_memtime), 100 MHz ticks (s_memrealtime), (pixel, entry) pair counts
-//   ADGS_PHASE_TIMING  tools/blend_phase_timing.py  per wave: shader cycles in the phases of the forward (key-stream scan, filter-record test,
-//                      Splat gather, blend loop) and of the backward (chunk header, id + Splat gather, entry loop, of it the reduction tail)
+//   ADGS_PHASE_TIMING  tools/blend_phase_timing.py  per wave: shader cycles in the phases of the forward (key-stream scan, Splat gather +
+//                      tile test, batch set-up, blend loop) and of the backward (chunk header, id + Splat gather, entry loop, of it the reduction tail)
 //   ADGS_TIMELINE      tools/wave_timeline.py     per tile: start / end of its wave in 100 MHz ticks
 #pragma once
 #include <hip/hip_runtime.h>
@@ -28,8 +28,8 @@ __device__ unsigned long long g_probe[16];
 #endif
 
 #ifdef ADGS_PHASE_TIMING
-// forward [0..15]: [0] key-stream scan, [1] filter-record test, [2] Splat gather + staging, [3] blend loop, [4] whole wave, [5] waves,
-// [6] round-trip cycles of the scan's loads (issue -> landed), [7] scan super-rounds, [8] round-trip cycles of the filter-record gathers, [9] filter rounds
+// forward [0..15]: [0] key-stream scan, [1] Splat gather + tile test, [2] batch set-up (barrier, pool block draw), [3] blend loop, [4] whole wave,
+// [5] waves, [6] round-trip cycles of the scan's loads (issue -> landed), [7] scan steps, [8] round-trip cycles of the Splat gathers, [9] gather rounds
 // backward [16..31]: [16] chunk header wait, [17] id + Splat gather, [18] entry loop, [19] of it: reduction + atomic, [20] whole wave, [21] waves,
 // [22] chunks, [23] entries, [24] prologue (pixel state loads)
 __device__ unsigned long long g_phase[32];

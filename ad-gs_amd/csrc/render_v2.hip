@@ -541,6 +541,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	// its registers allowed)
 	__shared__ float4 s_splat[WAVE * 4];
 	__shared__ __attribute__((aligned(16))) float s_red[RED_ROWS * RED_STRIDE];
+#ifdef ADGS_BWD_LDS_PAD
+	__shared__ float s_pad[ADGS_BWD_LDS_PAD / 4];      // occupancy experiment: what would a second Splat buffer cost?
+	if (a.W < 0) s_pad[threadIdx.x] = 1.f;
+#endif
 	const int lane = threadIdx.x;
 	const uint32_t tile = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;

@@ -36,13 +36,13 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, densify_every=10)}
 
 
 # VALU issue peak: a SIMD-32 retires one wave64 fp32 instruction per 2 cycles (MI355X_MICROARCH.md: 0.5 per SIMD and cycle), scaled by the
 # SUSTAINED shader clock under the blend kernels' load over the nominal 2.4 GHz -- measured with s_memtime against s_memrealtime inside
-# both kernels (tools/blend_probe.py, profiles/r03/blend_probe_c3.json: 2.35 - 2.36 GHz) and under pure VALU loops
+# both kernels (tools/blend_probe.py, profiles/r04/blend_probe_c3.json: 2.35 - 2.36 GHz) and under pure VALU loops
 # (tools/microbench/valu_rates.hip, profiles/r03/valu_rates.txt: 2.24 - 2.43 GHz).  The clock does not sag: round 2's "0.36" was a
 # wall-time figure of a microbenchmark whose one-wave workgroups the dispatcher does not spread evenly over the SIMDs.
 VALU_PEAK_PER_SIMD_CYCLE = 0.5 * 2.35 / 2.4
@@ -73,7 +73,7 @@ def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None, bucket=False)
     binning = ({"scan": 16384 * 4 * 3, "duplicate_keys": P * 16 + Rc * 12, "radix_sort": Rc * 20, "tile_ranges": 0} if bucket else
                {"scan": P * 12, "duplicate_keys": V * (8 + 4) + Rc * 12, "radix_sort": passes * Rc * 24 + Rc * 8, "tile_ranges": Rc * 8})
     return {
-        "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 32 + 24 + 1 + 64),
+        "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 24 + 1 + 64),      # Splat line, binning words, clamp byte, zeroed accumulator line (no filter record since round 4)
         **binning,
         "render_fwd": E * (4 + 64 + 4) + out,
         "render_bwd": (E if E_pub is None else E_pub) * (4 + 64 + 56) + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),
@@ -362,7 +362,7 @@ def library_stamp():
 
 def committed_pmc(stage, config, measured_case):
     """HBM traffic / VALU issue rate of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's build
-    (profiles/r03/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
+    (profiles/r04/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
     the case they were measured on (C3, flow+semantic, default pipeline); absent files leave `traffic` null; counters collected on
     another build of the library are flagged (`counters_stale`)."""
     if config != "C3" or not measured_case:
@@ -376,7 +376,7 @@ def committed_pmc(stage, config, measured_case):
         for k, v in tr.items():
             if kname and kname in k:
                 out["traffic"] = v["hbm_bytes_per_launch"]
-                out["traffic_source"] = ("profiles/r03/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
+                out["traffic_source"] = ("profiles/r04/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
                                          "FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, per launch)")
                 break
         pmf = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))
@@ -384,14 +384,56 @@ def committed_pmc(stage, config, measured_case):
         if pm:
             out["valu_insts_per_simd_cycle"] = pm.get("valu_insts_per_simd_cycle")
             out["valu_issue_frac_of_peak"] = None if pm.get("valu_insts_per_simd_cycle") is None else round(pm["valu_insts_per_simd_cycle"] / VALU_PEAK_PER_SIMD_CYCLE, 3)
-            out["valu_note"] = ("the blend kernels are bound by fp32 VALU issue and per-wave latency, not by HBM (SURVEY.md 8(d)): wave64 VALU instructions "
-                                "per SIMD and cycle (rocprofv3 --pmc, profiles/r03/pmc_blend_kernels.json) against the datasheet issue rate 0.5 x the "
-                                "sustained shader clock measured inside the kernels over the nominal 2.4 GHz = %.3f (tools/blend_probe.py)" % VALU_PEAK_PER_SIMD_CYCLE)
+            out["wave_state_shares"] = pm.get("wave_state_shares")
+            out["waves_per_simd_mean"] = pm.get("waves_per_simd_mean")
+            out["valu_note"] = ("the blend kernels are far from the HBM roof by construction (SURVEY.md 8(d)): wave64 VALU instructions per SIMD and cycle "
+                                "(rocprofv3 --pmc, profiles/r04/pmc_blend_kernels.json; normalisation: tools/pmc_blend.py) against the full-rate fp32 issue rate "
+                                "0.5 x the sustained shader clock over the nominal 2.4 GHz = %.3f -- a ceiling the kernels' instruction mixes cannot reach (half-rate "
+                                "compares / selects, quarter-rate exp / rcp: tools/isa_mix.py, tools/microbench/issue_hazards.hip); wave_state_shares: where the "
+                                "resident waves' cycles go (issuing / parked at s_waitcnt / ready but not issued)" % VALU_PEAK_PER_SIMD_CYCLE)
         built = tr.get("_library_sha256_16") if isinstance(tr, dict) else None
         if out and (built is None or built != stamp):
             out["counters_stale"] = "the committed counter files were collected on library build %s, this run loaded %s" % (built, stamp)
     except (OSError, ValueError, KeyError, AttributeError):
         pass
+    return out
+
+
+# stage of the bench line -> (kernels of the stage, "f" / "b": launched once per forward / per backward)
+STAGE_KERNELS = {"preprocess_fwd": (("sh0_rows_kernel", "sh0_kernel", "preprocess_fwd_kernel"), "f"), "render_fwd": (("render_fwd_v2_kernel",), "f"),
+                 "render_bwd": (("render_bwd_v2_kernel", "tile_order_kernel"), "b"),
+                 "preprocess_bwd": (("preprocess_bwd_kernel", "deform_lin_param_grad_kernel"), "b"),      # + the SH-deformation gradient rows of the raw-SH path (launched by the raster backward)
+                 "deform_fwd": (("deform_fwd_kernel",), "f"), "deform_bwd": (("deform_bwd_kernel",), "b"),
+                 "scan": (("cell_colscan_kernel", "cell_scan_kernel"), "f"), "duplicate_keys": (("cell_scatter_kernel",), "f"),
+                 "radix_sort": (("chunk_sort_kernel",), "f"), "tile_ranges": (("chunk_merge_kernel",), "f")}
+
+
+def committed_kernel_stats():
+    """Per-stage kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this round (profiles/r04/kernel_stats.csv):
+    total duration of the stage's kernels over the number of forwards / backwards in the profiled run (= the calls of the blend kernel of that
+    direction).  Empty when the file is absent."""
+    import csv
+    path = os.path.join(PROFILE_DIR, "kernel_stats.csv")
+    out = {}
+    try:
+        rows = list(csv.DictReader(open(path)))
+        calls = {"f": 0, "b": 0}
+        for r in rows:
+            if "render_fwd_v2_kernel<4>" in r["Name"]:
+                calls["f"] = int(r["Calls"])
+            if "render_bwd_v2_kernel<4, true>" in r["Name"]:
+                calls["b"] = int(r["Calls"])
+        for stage, (pats, d) in STAGE_KERNELS.items():
+            if not calls[d]:
+                continue
+            ns, names = 0.0, []
+            for r in rows:
+                if any(p in r["Name"] for p in pats):
+                    ns += float(r["TotalDurationNs"]); names.append(r["Name"].replace("void ", "").replace("adgs::", "").replace("(anonymous namespace)::", "").split("(")[0])
+            if ns > 0:
+                out[stage] = {"ms": round(ns / calls[d] * 1e-6, 4), "kernels": sorted(set(names))}
+    except (OSError, ValueError, KeyError):
+        return {}
     return out
 
 
@@ -840,7 +882,7 @@ def main():
     # reading the stage events back, a garbage collection), then the remaining plain warm-up steps, then the timed region at once:
     # a GPU left idle for the milliseconds that set-up takes runs its next step up to 1 ms slower (clocks), which is 3.5 % of a
     # 20-step run when it lands inside it.
-    stages_all, dom, gpu_idle = None, None, None
+    stages_all, dom, gpu_idle, stage_step_ms = None, None, None, None
     n_prof = min(4, args.warmup // 2)
     if n_prof > 0:
         sync()
@@ -857,6 +899,7 @@ def main():
         stages_all = wprof.collect()
         prof_step_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(n_prof)) / n_prof
         per_step = {k: v[0] * v[1] / n_prof for k, v in stages_all.items()}
+        stage_step_ms = {k: (round(v, 4), stages_all[k][1] // n_prof) for k, v in per_step.items() if stages_all[k][1] > 0}
         gpu_idle = {"profiled_step_ms": round(prof_step_ms, 4), "sum_of_stage_ms": round(sum(per_step.values()), 4),
                     "gpu_not_in_adgs_kernels_ms": round(prof_step_ms - sum(per_step.values()), 4),
                     "note": "from %d warm-up steps with every stage bracketed by HIP events (each bracket adds a bubble: an upper bound)" % n_prof}
@@ -1038,12 +1081,32 @@ def main():
                 roof["pixel_entry_evals_per_s"] = round((config["published_entries"] if dom == "render_bwd" else config["blended_entries"]) * 256 / (dom_ms * 1e-3), 1)
             result["config"] = config
             result["roofline"] = roof
-            result["stages_ms"] = {k: round(v[0], 4) for k, v in stages_all.items() if v[1] > 0}    # all stages timed: from the last warm-up steps
-            # every stage against the HBM roofline (algorithmic bytes of DESIGN.md section 5 / its HIP-event time in the last warm-up
-            # steps): the streaming stages sit at 45-70 % of the 8 TB/s peak, the two blend stages are VALU-bound (see "roofline")
-            result["stage_rooflines"] = {k: {"alg_bytes": int(ab.get(k, 0)), "GB/s": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9, 1),
-                                             "frac_of_8TBs": round(ab.get(k, 0) / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                         for k, v in stages_all.items() if v[0] > 0 and k in ab}
+            # ms per STEP of every stage (HIP events, all stages timed: from the last warm-up steps).  A stage can hold several launches per
+            # step (preprocess_fwd: the sh0 kernel and the preprocess kernel); until round 3 this field held the mean per LAUNCH, i.e. half
+            # of that stage's time -- the "83 us bracket around a 111 us kernel" of VERDICT r3 was the mean of 52 us and 107 us.
+            if stage_step_ms is None:
+                stage_step_ms = {k: (round(v[0] * v[1] / max(args.steps, 1), 4), v[1] // max(args.steps, 1)) for k, v in stages_all.items() if v[1] > 0}
+            result["stages_ms"] = {k: v[0] for k, v in stage_step_ms.items()}
+            result["stage_launches_per_step"] = {k: v[1] for k, v in stage_step_ms.items()}
+            # every stage against the HBM roofline: algorithmic bytes per step over the stage's HIP-event time per step,
+            # cross-checked against the rocprofv3 kernel-trace averages of the committed profile of this build where one exists
+            # (tools/stage_cache_experiment.py explains the few percent by which the serialised, profiled run is slower)
+            kstats = committed_kernel_stats()
+            result["stage_rooflines"] = {}
+            ab_stage = dict(ab)
+            if isinstance(frame, DeformFrame) and frame.model.raw_sh:
+                # the stage holds the sh0 kernel too (coefficient 0 = dc + f_shs(t) from the raw tensors): dc in, deformation rows in, [N,3] out;
+                # in the frame total these bytes are part of `deformation` (deform_bytes_per_frame), here they belong to the stage's time
+                m = frame.model
+                ab_stage["preprocess_fwd"] += 4 * (m.shs_deform_param_scene.numel() + m.shs_deform_param_obj.numel()) + Pn * 24
+            for k, (ms, _) in stage_step_ms.items():
+                if ms > 0 and k in ab:
+                    r = {"alg_bytes": int(ab_stage.get(k, 0)), "ms_per_step": ms, "GB/s": round(ab_stage.get(k, 0) / (ms * 1e-3) / 1e9, 1),
+                         "frac_of_8TBs": round(ab_stage.get(k, 0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    if k in kstats:
+                        r["rocprof_ms_per_step"] = kstats[k]["ms"]; r["rocprof_kernels"] = kstats[k]["kernels"]
+                        r["rocprof_frac_of_8TBs"] = round(ab_stage.get(k, 0) / (kstats[k]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    result["stage_rooflines"][k] = r
         else:
             result["config"] = config
         secondary = world == 1 and not force_coll and not args.no_secondary and args.config == "C3" and not iteration_mode

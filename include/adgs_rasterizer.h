@@ -218,15 +218,15 @@ void adgs_get_frame_stats(adgs_frame_stats* out);
  * or re-enqueued: after a replay and a stream synchronisation the caller must check `overflow` (this frame) or
  * `unrepaired_overflow_count` (replayed frames that did not fit, since the mailbox exists; `overflow_count` also counts eager
  * frames, which repaired themselves); on overflow the captured frame's outputs are a defined EMPTY render (background, opacity 0,
- * no gradients), and an eager frame (which raises the capacity hints) followed by a new capture repairs it.  Single context per process: the hints and
- * statistics are process-wide, the mailbox is per (host thread, device). */
+ * no gradients), and an eager frame (which raises the capacity hints) followed by a new capture repairs it.  Statistics, capacity hints and the mailbox are kept per
+ * (host thread, device): threads (or devices) rendering at the same time do not disturb each other; only the stage profiler below is process-wide. */
 typedef struct adgs_frame_status {
 	int64_t pairs;                 /* (cell, Gaussian) pairs of the frame */
 	int64_t fine_pairs;            /* bound of the blended (tile, Gaussian) entries */
 	int64_t capacity_pairs;        /* what the frame's launches were enqueued against (a replay: what its capture was enqueued against) */
 	int64_t capacity_fine_pairs;
 	int64_t overflow_count;        /* frames that did not fit, since the mailbox exists */
-	int64_t eager_reruns;          /* eager forwards that were enqueued twice, process-wide */
+	int64_t eager_reruns;          /* eager forwards of this thread on this device that were enqueued twice */
 	int32_t overflow;              /* 1: this frame did not fit its capacity */
 	int32_t reserved;
 	int64_t unrepaired_overflow_count;      /* overflow_count minus the eager frames this library re-enqueued itself: overflows of graph replays */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the waves of the two blend kernels spend their time (experiment build: `make -C ad-gs_amd/csrc variant TAG=timing
 DEFS=-DADGS_PHASE_TIMING`, then `ADGS_LIB=ad-gs_amd/lib/libadgs_hip_timing.so python tools/blend_phase_timing.py C3`): shader-clock
-cycles per wave in the forward's key-stream scan, filter-record test, Splat gather and blend loop, and in the backward's chunk-header
+cycles per wave in the forward's key-stream scan, Splat gather + tile test, batch set-up (barrier, pool block draw) and blend loop, and in the backward's chunk-header
 wait, id + Splat gather, entry loop (of it: reduction + atomic).  One JSON object."""
 import ctypes
 import json
@@ -47,13 +47,13 @@ res = {"config": name, "frames": N}
 waves = max(v[5], 1)
 tot = v[4] / waves
 f = {"waves_per_launch": v[5] // N, "cycles_per_wave": round(tot)}
-for i, n in enumerate(["key_stream_scan", "filter_record_test", "splat_gather_staging", "blend_loop"]):
+for i, n in enumerate(["key_stream_scan", "splat_gather_and_tile_test", "batch_setup", "blend_loop"]):
     f[n] = {"cycles_per_wave": round(v[i] / waves), "share": round(v[i] / waves / tot, 4)}
 f["rest_prologue_publish_epilogue_share"] = round(1.0 - sum(v[0:4]) / waves / tot, 4)
 f["scan_super_rounds_per_wave"] = round(v[7] / waves, 2)
 f["cycles_waiting_per_scan_super_round"] = round(v[6] / max(v[7], 1))
-f["filter_rounds_per_wave"] = round(v[9] / waves, 2)
-f["cycles_waiting_per_filter_round"] = round(v[8] / max(v[9], 1))
+f["gather_rounds_per_wave"] = round(v[9] / waves, 2)
+f["cycles_waiting_per_gather_round"] = round(v[8] / max(v[9], 1))
 res["render_fwd_v2"] = f
 b = v[16:32]
 waves = max(b[5], 1)

@@ -36,4 +36,6 @@ ADGS_LIB=$L/libadgs_hip_timing.so python tools/blend_phase_timing.py C3 20 > $o/
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/issue_hazards.hip -o /tmp/issue_hazards 2>/dev/null && /tmp/issue_hazards > $o/issue_hazards.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates > $o/valu_rates.txt 2>&1
 python tools/microbench/hbm_rates.py > $o/hbm_rates.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/gather_latency.hip -o /tmp/gather_latency 2>/dev/null && /tmp/gather_latency > $o/gather_latency.txt 2>&1
+python tools/stage_cache_experiment.py C3 > $o/stage_cache_experiment.json 2> $o/sce.err
 tail -3 $o/stats.log | cut -c1-300; head -24 $o/traffic.txt; cat $o/blend.txt; head -14 $o/kernel_stats.csv | cut -c1-160

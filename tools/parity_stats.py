@@ -54,11 +54,16 @@ def main():
         for name, a, b32, b64 in tensors:
             b32 = np.asarray(b32).reshape(a.shape); b64 = np.asarray(b64).reshape(a.shape)
             row = {}
-            for tag, x, y in (("hip_vs_f64", a, b64), ("f32_vs_f64", b32, b64), ("hip_vs_f32", a, b32)):
+            for tag, x, y, ex in (("hip_vs_f64", a, b64, o64["explained"]), ("f32_vs_f64", b32, b64, o64["explained"]), ("hip_vs_f32", a, b32, o32["explained"])):
                 st = parity.error_stats(x, y)
-                st.pop("_row_rel", None)
+                # elements outside 1e-4 that the oracle's gate margins do NOT explain (tests/parity.py: the tests allow none)
+                mask = parity._broadcast_mask(ex["gauss"] if name.startswith("grad_") else ex["pixel"], x.shape, name)
+                st["n_unexplained"] = int((st["_bad"] & ~mask).sum())
+                st["n_flagged"] = int(mask.sum())
+                for k in ("_row_rel", "_bad", "_row_nz"):
+                    st.pop(k, None)
                 row[tag] = st
-                print("  " + parity.fmt_stats(name + " " + tag, st), flush=True)
+                print("  " + parity.fmt_stats(name + " " + tag, st) + " n_bad=%d n_unexplained=%d flagged=%d" % (st["n_bad"], st["n_unexplained"], st["n_flagged"]), flush=True)
             out[name] = row
         res[cfg] = out
     if args.out:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-tile work distribution of one forward frame of a BASELINE config: blended (published) entries and scanned candidates per
 16x16 tile -- mean, percentiles, maximum -- i.e. how long the longest one-wave tile walk is against the average (the blend
-kernels are one wave per tile: the longest tile bounds the kernel time from below).   python tools/tile_histogram.py C3 [C5]"""
+kernels are one wave per tile: the longest tile bounds the kernel time from below).   python tools/tile_histogram.py C3 [C5] [C3:street]
+(config[:variant], the variants of bench.build_scene)"""
 import ctypes
 import json
 import os
@@ -19,8 +20,9 @@ from diff_gaussian_rasterization import _C
 
 out = {}
 for name in sys.argv[1:] or ["C3"]:
-    cfg = synthetic.CONFIGS[name]
-    sc = bench.build_scene(name)
+    config, _, variant = name.partition(":")
+    cfg = synthetic.CONFIGS[config]
+    sc = bench.build_scene(config, variant or "default")
     cam = synthetic.make_camera(cfg["W"], cfg["H"], cfg["focal"])
     dev = torch.device("cuda", 0)
     frame = bench.make_frame(sc, cfg, cam, dev, True)
