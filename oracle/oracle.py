@@ -137,7 +137,10 @@ class RasterOracle:
         gauss = np.full((self.P,), 1e30, self.real)
         if self.P != 0:
             getattr(lib(), "adgs_oracle_gate_margins_" + self.suf)(self._h, _ptr(pix), _ptr(gauss))
-        return dict(pixel=pix, gauss=gauss)
+        cond = np.zeros((self.H, self.W), self.real)
+        if self.P != 0:
+            getattr(lib(), "adgs_oracle_pixel_conditioning_" + self.suf)(self._h, _ptr(cond))
+        return dict(pixel=pix, gauss=gauss, cond=cond)
 
     def state(self):
         """Internal buffers (geometry / binning / image state) for white-box tests."""

@@ -522,6 +522,41 @@ struct Oracle {
 		}
 	}
 
+	// Conditioning of the blend per pixel (test infrastructure, with gate_margins): sum over the contributing entries of
+	// alpha_k T_k (1 + S_k), S as above.  power = -(0.5 A dx^2 + 0.5 C dy^2) - B dx dy is a sum of terms of magnitude S: a float32
+	// evaluation is off by ~u S absolutely (u = 6e-8), which is a RELATIVE error u S of alpha = op exp(power) -- for needle-thin or
+	// image-filling Gaussians S reaches 1e3 .. 1e4 and two correct float32 evaluations (another operation order, exp2 of a pre-scaled
+	// conic) differ by 1e-4 of alpha with no gate involved.  First order, a unit-scale blended output moves by at most
+	// sum_k alpha_k T_k (relative error of alpha_k) (1 + what the entries behind lose), i.e. by ~2 u cond.
+	void pixel_conditioning(real* cond /*H*W*/) {
+#pragma omp parallel for schedule(dynamic, 1)
+		for (int tile = 0; tile < gx * gy; tile++) {
+			int tx = tile % gx, ty = tile / gx;
+			uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+			for (int ly = 0; ly < BLOCK_Y; ly++) for (int lx = 0; lx < BLOCK_X; lx++) {
+				int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+				if (!(px < W && py < H)) continue;
+				real pixfx = (real)px, pixfy = (real)py, T = 1, c = 0;
+				for (uint32_t k = r0; k < r1; k++) {
+					uint32_t g = point_list[k];
+					real dx = means2D[2 * g] - pixfx, dy = means2D[2 * g + 1] - pixfy;
+					const real* co = &conic_opacity[4 * (size_t)g];
+					real ta = (real)0.5 * co[0] * dx * dx, tc = (real)0.5 * co[2] * dy * dy, tb = co[1] * dx * dy;
+					real S = std::abs(ta) + std::abs(tc) + std::abs(tb);
+					real power = -(ta + tc) - tb;
+					if (power > 0) continue;
+					real alpha = std::min(fc<real>(0.99f), co[3] * std::exp(power));
+					if (alpha < fc<real>(1.0f / 255.0f)) continue;
+					real test_T = T * (1 - alpha);
+					if (test_T < fc<real>(0.0001f)) break;
+					c += alpha * T * (1 + S);
+					T = test_T;
+				}
+				cond[(size_t)W * py + px] = c;
+			}
+		}
+	}
+
 	// ------------------------------------------------------------------ backward
 	// backward.cu:417-646 (renderCUDA).  The reference scatters with fp32
 	// atomicAdd in an unspecified order; this restatement accumulates every
@@ -891,6 +926,7 @@ extern "C" void adgs_oracle_mark_visible_##SUF(void* h, int P, const float* mean
 	((Oracle<real>*)h)->markVisible(P, means, view, proj, present); } \
 extern "C" int adgs_oracle_num_rendered_##SUF(void* h) { return ((Oracle<real>*)h)->R; } \
 extern "C" void adgs_oracle_gate_margins_##SUF(void* h, real* pix_margin, real* gauss_margin) { ((Oracle<real>*)h)->gate_margins(pix_margin, gauss_margin); } \
+extern "C" void adgs_oracle_pixel_conditioning_##SUF(void* h, real* cond) { ((Oracle<real>*)h)->pixel_conditioning(cond); } \
 extern "C" void adgs_oracle_get_state_##SUF(void* h, real* means2D, real* depths, real* cov3D, real* rgb, real* conic_opacity, \
 	uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_list, uint64_t* keys, uint32_t* ranges, uint32_t* n_contrib) { \
 	Oracle<real>* o = (Oracle<real>*)h; \

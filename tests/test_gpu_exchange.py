@@ -14,10 +14,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def close(name, a, b, tol=TOL, atol_frac=1e-2):
+def close(name, a, b, tol=TOL, atol_frac=1e-2, noise=None):
+    """|a - b| <= tol |b| + tol atol_frac max|b| (+ 4 x `noise`, the measured run-to-run spread of the SAME path per element: the
+    rasterizer's fp32 atomics land in hardware order, which shows on sums whose terms nearly cancel)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     scale = max(np.abs(b).max(), 1e-30)
-    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * atol_frac * scale, err_msg=name)
+    if noise is None:
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol * atol_frac * scale, err_msg=name)
+        return
+    bad = np.abs(a - b) > tol * np.abs(b) + tol * atol_frac * scale + 4.0 * np.asarray(noise, np.float64)
+    assert not bad.any(), "%s: %d element(s) differ by more than the tolerance plus 4x the run-to-run spread of the conventional path (max %.3g, scale %.3g)" % (
+        name, int(bad.sum()), float(np.abs(a - b)[bad].max()), scale)
 
 
 @pytest.mark.parametrize("Ns,No,M,C,D,row0_mode,n", [(700, 301, 16, 12, 3, "scene", 3), (700, 301, 16, 12, 2, "none", 2), (0, 513, 16, 12, 3, "scene", 1),
@@ -166,11 +173,14 @@ def _factored_vs_conventional(oa, sh_degree, factor_xyz, P, times, scene_seed, m
 
     a, b = run(False), run(True)
     assert set(a) == set(b)
+    # fuzz: the objects may be masked out at a random time stamp (all-zero gradients on both sides).  Two runs of ONE path differ by
+    # the order of the rasterizer's fp32 atomics, which shows on near-cancelling sums (seed 7000: one scale gradient, 6e-4 relative):
+    # the conventional path runs twice and every element gets 4x its own measured spread on top of the 1e-4 budget -- a deviation
+    # that the same code does not show against itself is a failure
+    a2 = run(False) if fuzz else None
     for k in a:
-        # fuzz: the objects may be masked out at a random time stamp (all-zero gradients on both sides), and the two runs differ by the
-        # order of the rasterizer's fp32 atomics, which shows on near-cancelling elements -> absolute part at 0.3 of the 1e-4 budget
         assert fuzz or np.abs(a[k]).max() > 0, k
-        close(k, b[k], a[k], atol_frac=0.3 if fuzz else 1e-2)
+        close(k, b[k], a[k], atol_frac=0.3 if fuzz else 1e-2, noise=np.abs(a[k] - a2[k]) if fuzz else None)
 
 
 def test_rgb_factor_equals_oracle_masked_colour_gradient():

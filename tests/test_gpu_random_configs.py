@@ -211,9 +211,14 @@ def test_adversarial_scenes_match_classic_and_oracle(seed):
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a = v2[k].detach().cpu().numpy()
         assert np.isfinite(a).all(), k
-        frac = max(1e-3, 6.5 / max(a.size, 1))      # 5 % of these Gaussians sit exactly ON the 1/255 gate: a handful of pixels flips (seen: 12 of 53 k, 3e-4 of the scale)
-        assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), max_frac=frac)
-        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), max_frac=frac)
+        # 5 % of these Gaussians sit exactly ON the 1/255 gate: pixels flip between any two float32 evaluations (seed 7042: 0.2 % of the
+        # colour elements between the two HIP pipelines).  A deviation passes only where the oracle has a gate within GATE_EPS of its
+        # threshold for a Gaussian that feeds the pixel (tests/parity.py)
+        # ... and needles / image-filling Gaussians make alpha itself ill-conditioned (|power| is the small difference of terms of
+        # magnitude 1e3 .. 1e4): the tolerance grows by the first-order bound of that effect per pixel (parity.py: COND_K, `slack`)
+        ex = ref["explained"]
+        assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), explained=ex["pixel"], slack=ex["slack"])
+        assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"], slack=ex["slack"])
     names = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations",
                  flow="dL_dflow_points", sem="dL_dsemantic")
     # Gradients: needles, image-filling and unnormalised Gaussians make dL/drotation (and a few dL/dmean) ill-conditioned -- the fp32
