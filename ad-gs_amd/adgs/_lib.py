@@ -153,7 +153,7 @@ def frame_stats():
     st = FrameStats()
     lib().adgs_get_frame_stats(ctypes.byref(st))
     return dict(num_rendered=int(st.num_rendered), tiles=int(st.tiles), sort_bits=int(st.sort_bits), sort_passes=int(st.sort_passes),
-                fine_pairs=int(st.fine_pairs), bucket_binning=int(st.reserved != 0), depth_slabs=int(st.reserved))
+                fine_pairs=int(st.fine_pairs), bucket_binning=int(st.reserved))
 
 
 def frame_status():

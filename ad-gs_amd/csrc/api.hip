@@ -26,38 +26,9 @@ static thread_local std::string g_last_error;
 struct FrameContext {
 	adgs_frame_stats stats;
 	size_t hint_cells, hint_fine;          // speculative binning capacities (v2 forward): previous frames' counts + 25 %
-	unsigned hint_max_cell_chunks;         // chunks of the fullest (cell, slab) list of the last bucket-binned frame
+	unsigned hint_max_cell_chunks;         // chunks of the fullest cell of the last bucket-binned frame
 	long long reruns;                      // forwards whose capacity was too small (binning + blend enqueued twice)
-	SlabMap slabs;                         // depth slabs of the bucket binning (kernels.h): the bounds the next frame is enqueued with
-	unsigned hint_slabs;                   // slab count of the frame hint_max_cell_chunks comes from
 };
-// Depth-slab bounds.  The depth bits of visible Gaussians lie in [bits(0.2), bits(inf)): the near cull of the preprocess (forward.cu:198-202
-// in the reference) is 0.2.  The population of the slabs under the current bounds is a piecewise-constant estimate of the depth density of
-// the (cell, Gaussian) pairs; the new bounds are the k / n quantiles of that estimate -- a few frames of one scene converge to even slabs,
-// and a frame rendered with stale bounds is exactly as correct as any other (slab_of is monotone for any bounds).
-static void slab_rebalance(SlabMap* m, const uint32_t* total, uint32_t new_n) {
-	const double LO = 1045220557.0 /* bits(0.2f) */, HI = 1176256512.0 /* bits(1e4f): everything beyond shares the last slab */;
-	const uint32_t n = std::max(1u, std::min(m->n, (uint32_t)MAX_SLABS));
-	double edge[MAX_SLABS + 1], cdf[MAX_SLABS + 1];
-	edge[0] = LO; cdf[0] = 0.0;
-	for (uint32_t i = 0; i + 1 < n; i++) edge[i + 1] = std::min(std::max((double)m->bound[i], edge[i]), HI);
-	edge[n] = HI;
-	for (uint32_t i = 0; i < n; i++) cdf[i + 1] = cdf[i] + (total ? (double)total[i] : 1.0);
-	if (cdf[n] <= 0.0) for (uint32_t i = 0; i < n; i++) cdf[i + 1] = (double)(i + 1);
-	new_n = std::max(1u, std::min(new_n, (uint32_t)MAX_SLABS));
-	SlabMap out; out.n = new_n;
-	uint32_t seg = 0;
-	for (uint32_t k = 1; k < new_n; k++) {
-		const double t = cdf[n] * k / new_n;
-		while (seg + 1 < n && cdf[seg + 1] < t) seg++;
-		const double w = cdf[seg + 1] - cdf[seg];
-		const double b = w > 0.0 ? edge[seg] + (edge[seg + 1] - edge[seg]) * (t - cdf[seg]) / w : edge[seg + 1];
-		const uint32_t prev = k > 1 ? out.bound[k - 2] : 0u;
-		out.bound[k - 1] = std::max(prev, (uint32_t)std::min(std::max(b, LO), HI));
-	}
-	for (uint32_t k = new_n; k < (uint32_t)MAX_SLABS; k++) out.bound[k - 1] = 0xFFFFFFFFu;
-	*m = out;
-}
 static FrameContext* frame_context() {
 	constexpr int MAX_DEV = 64;
 	static thread_local FrameContext ctx[MAX_DEV] = {};
@@ -452,31 +423,19 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const int cell_tiles = v2_cell_tiles(gx, gy);
 		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
 		const size_t ncells = (size_t)cgx * cgy;
-		// Binning: bucket binning (binning.hip: per-(cell, depth slab) lists sorted inside the CUs) unless the cell grid has more than
-		// MAX_CELLS cells, the lists of the previous frames averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of 8192 pairs, ONE list held
-		// more than ADGS_BUCKET_MAX_CELL_CHUNKS (16) -- a list of k chunks pays k - 1 rank searches per entry in the merge, each against a
-		// whole staged chunk; crossover against the device-wide sort at about 4 -- or ADGS_BINNING=sort asks for the device-wide radix
-		// sort of (cell | depth) keys.  Until round 4 a list was a whole cell and C5 (3 M Gaussians, 9 chunks per cell, 28 in the fullest)
-		// took the sort; a merge over sampled windows of the other chunks, linear in k, was built in round 3 and was slower at both sizes
-		// (EXPERIMENTS.md).  Depth slabs (kernels.h: SlabMap) remove most of the merge instead: as many slabs as bring the average list to
-		// half a sort chunk, within the MAX_CELLS virtual cells one cell_scan workgroup handles.  C1 / C2: 1 (nothing changes); C3: 6;
-		// C5: 14.  ADGS_SLABS=n: forced.
+		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs) unless the cell grid has more than MAX_CELLS cells,
+		// the previous frames averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of 8192 pairs per cell, or ADGS_BINNING=sort asks
+		// for the device-wide radix sort of (cell | depth) keys.  (A cell of k chunks pays k - 1 rank searches per entry in the merge,
+		// each against a whole staged chunk; measured crossover against the device-wide sort at about 4 chunks per cell -- C5's 3 M
+		// Gaussians, 9 chunks per cell, take the sort.  A merge over sampled WINDOWS of the other chunks -- linear in k -- was built
+		// and measured in round 3: bit-identical, but slower at both sizes; EXPERIMENTS.md.)
 		const char* binning_env = getenv("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
-		const size_t max_slabs = std::max<size_t>(1, std::min<size_t>(MAX_SLABS, (size_t)MAX_CELLS / std::max<size_t>(ncells, 1)));
-		uint32_t nslab = (uint32_t)std::min<size_t>(std::max<size_t>((fc->hint_cells + ncells * (GS_NMAX / 2) - 1) / (ncells * (GS_NMAX / 2)), 1), max_slabs);
-		if (const int forced = env_int("ADGS_SLABS", 0)) nslab = (uint32_t)std::min<size_t>(std::max(forced, 1), max_slabs);
-		// the fullest list of the last bucket-binned frame, rescaled to this frame's slab count (the first frame of a scene runs with one slab)
-		const unsigned hint_list_chunks = (fc->hint_max_cell_chunks * std::max(1u, fc->hint_slabs) + nslab - 1) / nslab;
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
-			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells * nslab &&
-			                              hint_list_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));
-		if (!buckets) nslab = 1;
-		else if (fc->slabs.n != nslab) slab_rebalance(&fc->slabs, nullptr, nslab);      // first frame / other size: same density estimate, other count
-		const SlabMap slabs = fc->slabs;
-		const size_t nvcells = ncells * nslab;
+			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells &&
+			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));      // ... or ONE cell held more than 16 chunks
 		size_t gb = 0, ib = 0;
-		const size_t count_cells = buckets ? nvcells : 0;      // the counts matrix [ceil(P / 256)][cells x slabs] exists for bucket binning only
+		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] exists for bucket binning only
 		GeomStateV2::carve(nullptr, P, &gb, count_cells);
 		char* gch = geometryBuffer(geometryUser, gb);
 		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
@@ -503,7 +462,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.v2 = 1; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
-		pa.bucket_count = nullptr; pa.slabs = slabs; pa.nvcells = (int)nvcells;
+		pa.bucket_count = nullptr;
 		// bucket binning accumulates the fine-tile total and a few device words: zeroed by the sh0 kernel on the raw-SH path (one
 		// launch less), by a memset otherwise
 		uint32_t* zero_words = nullptr; const int n_zero = 2 * SCAN_AUX_SLOTS + 8;
@@ -548,9 +507,9 @@ static int raster_forward_impl(const ShSource* sh_src,
 		uint32_t* overflow_flag = geom.d_counts() + 3;         // written by cell_scan / publish_counts in every frame
 		if (buckets) {
 			StageTimer t(ST_SCAN, stream);
-			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)nvcells, geom.cell_count(), stream) != 0) return -1;
+			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
 			CellScanArgs sa;
-			sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)nvcells; sa.nslab = (int)nslab;
+			sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
 			sa.chunks = geom.chunks; sa.max_chunks = (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))); sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
 			sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
 			sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
@@ -580,12 +539,12 @@ static int raster_forward_impl(const ShSource* sh_src,
 				if (cells == 0) { ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream)); return 0; }     // cell_ranges: all (0, 0) from bucket_scan
 				const uint32_t cap = (uint32_t)std::min<size_t>(cells, 0xffffffffu);
 				{ StageTimer t(ST_DUPLICATE, stream);
-				  if (launch_cell_scatter(P, geom.dupinfo, geom.cell_start, geom.counts, bin.rec_unsorted, cap, cell_tiles, cgx, (int)nvcells, slabs, bin.pool_cursor, stream) != 0) return -1; }
+				  if (launch_cell_scatter(P, geom.dupinfo, geom.cell_start, geom.counts, bin.rec_unsorted, cap, cell_tiles, cgx, (int)ncells, bin.pool_cursor, stream) != 0) return -1; }
 				ADGS_LAUNCH_CHECK(debug, stream);
 				ChunkSortArgs ga;
 				ga.chunks = geom.chunks; ga.d_counts = geom.d_counts(); ga.rec_u = bin.rec_unsorted; ga.key_s = bin.key_stage; ga.mask_s = bin.mask_stage;
 				ga.ent_f = bin.entries; ga.cap = cap;
-				const size_t grid = BinStateV2::max_chunks(cells, nvcells);
+				const size_t grid = BinStateV2::max_chunks(cells, ncells);
 				{ StageTimer t(ST_SORT, stream); if (launch_chunk_sort(ga, (uint32_t)grid, stream) != 0) return -1; }
 				{ StageTimer t(ST_RANGES, stream); if (launch_chunk_merge(ga, (uint32_t)grid, stream) != 0) return -1; }      // "tile_ranges" slot: the merge of multi-chunk cells
 				ADGS_LAUNCH_CHECK(debug, stream);
@@ -644,7 +603,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (capturing) {
 			// nothing of this frame can be read back inside a capture: the totals stay in the mailbox for adgs_get_frame_status()
 			fc->stats.num_rendered = (int64_t)cap_cells; fc->stats.tiles = (int32_t)ntiles; fc->stats.sort_bits = buckets ? 32 : 32 + bit;
-			fc->stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8; fc->stats.reserved = buckets ? (int32_t)nslab : 0; fc->stats.fine_pairs = (int64_t)cap_fine;
+			fc->stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8; fc->stats.reserved = buckets ? 1 : 0; fc->stats.fine_pairs = (int64_t)cap_fine;
 			return (int)cap_cells;
 		}
 		if (wait_mailbox(mb, seq, stream) != 0) return -1;
@@ -679,13 +638,12 @@ static int raster_forward_impl(const ShSource* sh_src,
 			fc->hint_fine = std::max(want_f, old_f - old_f / 16);
 			// the fullest cell of a bucket-binned frame; a sorted frame does not report one: the old figure decays, so that a scene
 			// with a persistent hot cell re-tries the bucket path once in a few dozen frames instead of every other frame
-			if (buckets && fc->hint_slabs != nslab) { fc->hint_max_cell_chunks = 0u; fc->hint_slabs = nslab; }      // lists of another granularity: the old peak says nothing
-			fc->hint_max_cell_chunks = std::max(buckets ? mb->host->max_cell_chunks : 0u, fc->hint_max_cell_chunks - std::max(1u, fc->hint_max_cell_chunks / 16) * (fc->hint_max_cell_chunks ? 1u : 0u));
-			if (buckets && nslab > 1) { uint32_t tot[MAX_SLABS]; for (int k = 0; k < MAX_SLABS; k++) tot[k] = mb->host->slab_total[k]; slab_rebalance(&fc->slabs, tot, nslab); }
+			const unsigned old_m = fc->hint_max_cell_chunks;
+			fc->hint_max_cell_chunks = std::max(buckets ? mb->host->max_cell_chunks : 0u, old_m - std::max(1u, old_m / 16) * (old_m ? 1u : 0u));
 		}
 		fc->stats.num_rendered = (int64_t)R_cells; fc->stats.tiles = (int32_t)ntiles; fc->stats.sort_bits = buckets ? 32 : 32 + bit;
 		fc->stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
-		fc->stats.reserved = buckets ? (int32_t)nslab : 0; fc->stats.fine_pairs = (int64_t)R_fine;       // reserved: depth slabs of the bucket binning (>= 1; the sort passes stay inside the CUs), 0 = device-wide sort
+		fc->stats.reserved = buckets ? 1 : 0; fc->stats.fine_pairs = (int64_t)R_fine;       // reserved: 1 = bucket binning (the sort passes stay inside the CUs)
 		return (int)R_cells;
 	}
 
@@ -1106,7 +1064,6 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
 	FrameContext* fc = frame_context();
 	fc->hint_cells = (size_t)std::max(0ll, pairs); fc->hint_fine = (size_t)std::max(0ll, fine_pairs); fc->hint_max_cell_chunks = 0u;
-	fc->hint_slabs = 0u; memset(&fc->slabs, 0, sizeof(fc->slabs));      // the depth-slab bounds start over from the default guess
 }
 extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
 extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {

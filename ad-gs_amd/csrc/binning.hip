@@ -100,21 +100,12 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 		if ((c & (WAVE - 1)) == 0) atomicMax(&s_maxch, m);
 	}
 	__syncthreads();
-	__shared__ uint32_t s_slab[MAX_SLABS];
-	if (c < MAX_SLABS) s_slab[c] = 0u;
-	__syncthreads();
 	if (c < a.ncells) {
 		a.cell_start[c] = start;
-		// a coarse cell's list = its depth slabs back to back: the first slab opens the range, the last one closes it
-		const int slab = c % a.nslab;
-		uint32_t* range = reinterpret_cast<uint32_t*>(a.cell_ranges + c / a.nslab);
-		if (slab == 0) range[0] = start;
-		if (slab == a.nslab - 1) range[1] = start + n;
-		if (n) atomicAdd(s_slab + slab, n);
+		a.cell_ranges[c] = make_uint2(start, start + n);
 		for (uint32_t q = 0; q < nch; q++)
 			if (g0 + q < a.max_chunks) a.chunks[g0 + q] = make_uint4(start + q * GS_NMAX, min(start + (q + 1) * GS_NMAX, start + n), start, start + n);
 	}
-	__syncthreads();
 	if (c == 0) {
 		a.cell_start[a.ncells] = total;
 		const uint32_t over = nchunks_total > a.max_chunks ? 1u : 0u;
@@ -126,14 +117,13 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 		a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit; a.box->max_cell_chunks = s_maxch;
 		if (nofit) a.box->overflow_count = a.box->overflow_count + 1u;
 		a.box->cap_cells = a.cap_cells; a.box->cap_fine = a.cap_fine;
-		for (int k = 0; k < MAX_SLABS; k++) a.box->slab_total[k] = s_slab[k];
 		__threadfence_system();
 		a.box->seq = a.seq;                       // published last: the host spins on it
 	}
 }
 
 __global__ void __launch_bounds__(256) cell_scatter_kernel(int P, const uint4* __restrict__ dupinfo, const uint32_t* __restrict__ cell_start,
-	const uint32_t* __restrict__ counts, uint4* __restrict__ rec_u, uint32_t cap, int cell_tiles, int cgx, int ncells, SlabMap slabs, uint32_t* __restrict__ pool_cursor) {      // ncells: virtual cells
+	const uint32_t* __restrict__ counts, uint4* __restrict__ rec_u, uint32_t cap, int cell_tiles, int cgx, int ncells, uint32_t* __restrict__ pool_cursor) {
 	__shared__ uint32_t s_cnt[MAX_CELLS];
 	__shared__ uint32_t s_base[MAX_CELLS];
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,10 +136,9 @@ __global__ void __launch_bounds__(256) cell_scatter_kernel(int P, const uint4* _
 	const uint32_t minx = d.x & 0xFFFFu, miny = d.x >> 16, maxx = d.y & 0xFFFFu, maxy = d.y >> 16;
 	if (maxx <= minx || maxy <= miny) return;
 	const uint32_t c0x = minx / cell_tiles, c1x = (maxx - 1) / cell_tiles, c0y = miny / cell_tiles, c1y = (maxy - 1) / cell_tiles;
-	const uint32_t sl = slab_of(slabs, d.z);         // the slab the preprocess counted this Gaussian into (same bounds, same bits)
 	for (uint32_t y = c0y; y <= c1y; y++)
 		for (uint32_t x = c0x; x <= c1x; x++) {
-			const uint32_t c = (y * cgx + x) * slabs.n + sl;
+			const uint32_t c = y * cgx + x;
 			const uint32_t pos = s_base[c] + atomicAdd(s_cnt + c, 1u);
 			// which tile rows / columns OF THIS CELL the Gaussian's rectangle covers: the blend forward runs its rectangle test on
 			// these 4 bytes and gathers the 32-byte filter record only for candidates that pass it
@@ -367,9 +356,9 @@ int launch_cell_colscan(uint32_t* counts, int nblocks, int ncells, uint32_t* cel
 	return 0;
 }
 int launch_cell_scatter(int P, const uint4* dupinfo, const uint32_t* cell_start, const uint32_t* counts, uint4* rec_u, uint32_t cap,
-	int cell_tiles, int cgx, int nvcells, const SlabMap& slabs, uint32_t* pool_cursor, hipStream_t stream) {
+	int cell_tiles, int cgx, int ncells, uint32_t* pool_cursor, hipStream_t stream) {
 	if (P == 0) return 0;
-	hipLaunchKernelGGL(cell_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, dupinfo, cell_start, counts, rec_u, cap, cell_tiles, cgx, nvcells, slabs, pool_cursor);
+	hipLaunchKernelGGL(cell_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, dupinfo, cell_start, counts, rec_u, cap, cell_tiles, cgx, ncells, pool_cursor);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -5,19 +5,6 @@
 
 namespace adgs {
 
-// Depth slabs of the bucket binning.  A coarse cell's list is only ever read front to back, so it may be built as the concatenation of
-// n independently sorted depth ranges ("slabs"): the binning counts, scatters and sorts (cell, slab) pairs -- "virtual cells", slabs of a
-// cell adjacent in memory, nearest first -- and a cell of 70 k candidates (C5) becomes 14 lists that fit one sort chunk each instead of
-// nine chunks that have to be merged pairwise.  slab(z) = #{ i : z >= bound[i] } is monotone in the depth bits for ANY bounds: the
-// bounds (the previous frames' population quantiles, api.hip) decide how even the slabs are, never what the lists contain.
-constexpr int MAX_SLABS = 16;
-struct SlabMap { uint32_t n; uint32_t bound[MAX_SLABS - 1]; };      // unused bounds: 0xFFFFFFFF (above the bits of every finite depth)
-__host__ __device__ __forceinline__ uint32_t slab_of(const SlabMap& m, uint32_t zbits) {
-	uint32_t s = 0;
-#pragma unroll
-	for (int i = 0; i < MAX_SLABS - 1; i++) s += zbits >= m.bound[i] ? 1u : 0u;
-	return s;
-}
 struct PreprocessArgs {
 	int P, D, M, D_S;
 	const float* means3D; const float* scales; float scale_modifier; const float* rotations;
@@ -42,7 +29,6 @@ struct PreprocessArgs {
 	// coarse cells it covers -- bucket_count[workgroup][cell], every entry written -- and fine_total is accumulated here (the host
 	// zeroed it)
 	uint32_t* bucket_count;
-	SlabMap slabs; int nvcells;      // depth slabs of the bucket binning: bucket_count[workgroup][cell * slabs.n + slab], nvcells = cells * slabs.n
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
@@ -117,15 +103,13 @@ constexpr int GS_NMAX = 8192;           // entries one chunk_sort workgroup sort
 constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
 // overflow: the totals exceed the capacity the frame's launches were enqueued against; overflow_count: such frames since the mailbox exists
-struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest (cell, slab) list's chunks
-	uint32_t cap_cells; unsigned long long cap_fine;         // the capacity THIS frame was enqueued against, as its kernels saw it (a graph replay reports its capture's)
-	uint32_t slab_total[MAX_SLABS]; };                       // bucket binning: pairs per depth slab, summed over the cells (the host re-balances the next frame's bounds)
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest cell's chunks
+	uint32_t cap_cells; unsigned long long cap_fine; };      // the capacity THIS frame was enqueued against, as its kernels saw it (a graph replay reports its capture's)
 struct CellScanArgs {
 	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
 	uint32_t* cell_start;               // [ncells + 1]
-	uint2* cell_ranges; int ncells;     // ncells: VIRTUAL cells (cell * nslab + slab); cell_ranges: one range per coarse cell = its slabs back to back
-	int nslab;
-	uint4* chunks; uint32_t max_chunks; // sort chunks: (start, end, list start, list end) in list positions; list = one (cell, slab)
+	uint2* cell_ranges; int ncells;
+	uint4* chunks; uint32_t max_chunks; // sort chunks: (start, end, cell start, cell end) in list positions
 	uint32_t* d_counts;                 // [0] pairs, [1] chunks, [2] overflow flag (more chunks than the table holds)
 	const unsigned long long* fine_total;
 	Mailbox* box; uint32_t seq;
@@ -134,7 +118,7 @@ struct CellScanArgs {
 int launch_cell_scan(const CellScanArgs& a, hipStream_t stream);
 int launch_cell_colscan(uint32_t* counts, int nblocks, int ncells, uint32_t* cell_count, hipStream_t stream);
 int launch_cell_scatter(int P, const uint4* dupinfo, const uint32_t* cell_start, const uint32_t* counts, uint4* rec_u, uint32_t cap,
-	int cell_tiles, int cgx, int nvcells, const SlabMap& slabs, uint32_t* pool_cursor, hipStream_t stream);
+	int cell_tiles, int cgx, int ncells, uint32_t* pool_cursor, hipStream_t stream);
 struct ChunkSortArgs {
 	const uint4* chunks; const uint32_t* d_counts;
 	const uint4* rec_u;                 // unsorted (cell-grouped) records (depth bits, id, mask, -)

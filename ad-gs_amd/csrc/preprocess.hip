@@ -95,9 +95,9 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	extern __shared__ float s_sh[];
-	__shared__ uint32_t s_cell[MAX_CELLS];     // bucket binning: this workgroup's (cell, Gaussian) pair count per (coarse cell, depth slab)
+	__shared__ uint32_t s_cell[MAX_CELLS];     // bucket binning: this workgroup's (cell, Gaussian) pair count per coarse cell
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a.bucket_count) for (int c = threadIdx.x; c < a.nvcells; c += 256) s_cell[c] = 0u;
+	if (a.bucket_count) for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) s_cell[c] = 0u;
 	if (STAGED) {
 		const int tid = threadIdx.x, base = blockIdx.x * 256, nvalid = min(256, a.P - base);
 		if (a.sh_src.scene_dc) {
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		for (int off = WAVE / 2; off > 0; off >>= 1) nf += __shfl_xor(nf, off, WAVE);
 		if ((threadIdx.x & (WAVE - 1)) == 0) s_red[threadIdx.x / WAVE] = nf;
 		__syncthreads();
-		for (int c = threadIdx.x; c < a.nvcells; c += 256) a.bucket_count[(size_t)blockIdx.x * a.nvcells + c] = s_cell[c];
+		for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) a.bucket_count[(size_t)blockIdx.x * (a.cgx * a.cgy) + c] = s_cell[c];
 		if (threadIdx.x == 0) {
 			uint32_t n = 0;
 #pragma unroll
@@ -296,10 +296,9 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	if (nfine) {
 		const uint32_t c0x = sminx / a.cell_tiles, c1x = (smaxx - 1) / a.cell_tiles, c0y = sminy / a.cell_tiles, c1y = (smaxy - 1) / a.cell_tiles;
 		ncell = (c1x - c0x + 1) * (c1y - c0y + 1);
-		if (a.bucket_count) {       // bucket binning: count this Gaussian into its depth slab of every coarse cell it covers
-			const uint32_t sl = slab_of(a.slabs, __float_as_uint(vz));
+		if (a.bucket_count) {       // bucket binning: count this Gaussian into every coarse cell it covers
 			for (uint32_t y = c0y; y <= c1y; y++)
-				for (uint32_t x = c0x; x <= c1x; x++) atomicAdd(s_cell + (y * a.cgx + x) * a.slabs.n + sl, 1u);
+				for (uint32_t x = c0x; x <= c1x; x++) atomicAdd(s_cell + y * a.cgx + x, 1u);
 		}
 	}
 	a.dupinfo[idx] = make_uint4(sminx | (sminy << 16), smaxx | (smaxy << 16), __float_as_uint(vz), 0u);   // all the binning kernel needs, 16 B

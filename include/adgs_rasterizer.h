@@ -204,7 +204,7 @@ typedef struct adgs_frame_stats {
 	int32_t tiles;
 	int32_t sort_bits;
 	int32_t sort_passes;
-	int32_t reserved;         /* v2: 0 = device-wide radix sort binning; n >= 1 = bucket binning with n depth slabs per coarse cell */
+	int32_t reserved;
 	int64_t fine_pairs;       /* v2: sum over Gaussians of the fine tiles of their shrunk rectangle (bound of the blended pairs) */
 } adgs_frame_stats;
 void adgs_get_frame_stats(adgs_frame_stats* out);

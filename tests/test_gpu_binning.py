@@ -25,11 +25,6 @@ def _force_bucket_binning(monkeypatch, request):
     monkeypatch.setenv("ADGS_BINNING", "bucket")
     if "c5_size" not in request.node.name:
         monkeypatch.setenv("ADGS_CELL_TILES", "8")
-    # Depth slabs (round 4: a cell's list is built as n independently sorted depth ranges, n chosen from the previous frames' pair count)
-    # would cut the many-chunk cells these tests build into single-chunk lists: the tests written for the chunk MERGE pin one slab, the
-    # slab tests below choose their own count
-    if "slab" not in request.node.name:
-        monkeypatch.setenv("ADGS_SLABS", "1")
 
 
 def test_default_is_bucket_binning_and_equals_sort_binning_bit_for_bit(monkeypatch):
@@ -167,9 +162,8 @@ def test_chunk_table_overflow_without_speculation_still_renders(monkeypatch):
 
 
 def test_c5_size_bucket_binning_equals_sort_binning_bit_for_bit(monkeypatch):
-    """3 M Gaussians, 68 k pairs per cell (9 chunks per cell, 11 719 preprocess workgroups in the counts matrix), ONE depth slab: until
-    round 4 the library picked the device-wide sort for this frame by itself; forced onto the bucket path with every cell a single list
-    (the k - 1 rank searches of the merge at k = 6 .. 28), every forward output must still be bit-identical."""
+    """3 M Gaussians, 68 k pairs per cell (9 chunks per cell, 11 719 preprocess workgroups in the counts matrix): the library would pick
+    the device-wide sort for this frame by itself; forced onto the bucket path, every forward output must still be bit-identical."""
     import os
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -189,67 +183,3 @@ def test_c5_size_bucket_binning_equals_sort_binning_bit_for_bit(monkeypatch):
         assert _stats()["num_rendered"] > 4_000_000
     for a, b in zip(outs["bucket"], outs["sort"]):
         assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("slabs", [2, 5, 16])
-def test_depth_slabs_equal_sort_binning_bit_for_bit(monkeypatch, slabs):
-    """n depth slabs per coarse cell (kernels.h: SlabMap): the cell's list is the concatenation of n independently sorted depth ranges.
-    Forward outputs bit-identical to the device-wide sort for every n, from the first frame (bounds: the default log-uniform guess)
-    through the frames whose bounds the host has re-balanced from the previous frame's slab populations."""
-    sc = synthetic.make_scene(60000, 640, 400, 620.0, seed=41, n_objects=3)
-    g = synthetic.make_upstream_grads(sc, 41)
-    monkeypatch.setenv("ADGS_BINNING", "sort")
-    ref = run_hip(sc, grads=g)
-    monkeypatch.setenv("ADGS_BINNING", "bucket")
-    monkeypatch.setenv("ADGS_SLABS", str(slabs))
-    _lib.lib().adgs_test_set_capacity_hints(0, 0)
-    for frame in range(4):
-        a = run_hip(sc, grads=g)
-        st = _stats()
-        assert st["bucket_binning"] == 1 and st["depth_slabs"] == min(slabs, 1024 // 15), (frame, st)      # 640 x 400 at 8-tile cells: 5 x 3 cells
-        for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic", "radii"):
-            assert torch.equal(a[k], ref[k]), (frame, k)
-        for k, v in a["grads"].items():
-            if v is not None:
-                # same lists, same blend order: the only difference between two runs is the order of the backward's float atomics
-                assert torch.allclose(v, ref["grads"][k], rtol=1e-3, atol=1e-4 * float(ref["grads"][k].abs().max())), (frame, k)
-
-
-@pytest.mark.parametrize("levels,P", [(8, 20000), (1, 6000)])
-def test_depth_slabs_with_exact_depth_ties(levels, P, monkeypatch):
-    """A few distinct depths only: every slab bound falls between (or on) long runs of equal keys; equal depths share a slab, where the
-    index order of the reference's stable sort decides."""
-    monkeypatch.setenv("ADGS_SLABS", "7")
-    sc = synthetic.make_scene(P, 320, 200, 300.0, seed=42, scale_mult=0.01)
-    z = sc["means3D"][:, 2]
-    vis = z > 0.5
-    q = torch.linspace(3.0, 40.0, levels)
-    znew = q[torch.randint(0, levels, (P,), generator=torch.Generator().manual_seed(1))]
-    sc["means3D"][vis, 0] *= (znew / z)[vis]
-    sc["means3D"][vis, 1] *= (znew / z)[vis]
-    sc["means3D"][vis, 2] = znew[vis]
-    sc["flow_points"] = sc["means3D"].clone()
-    sc["opacities"] = (sc["opacities"] * 0.5 + 0.3).contiguous()
-    for _ in range(3):                                     # the bounds move onto the populated depths from frame to frame
-        compare(sc, grads=synthetic.make_upstream_grads(sc, 42))
-        assert _stats()["depth_slabs"] == 7
-
-
-def test_depth_slab_count_follows_the_pair_count(monkeypatch):
-    """The library's own choice (no ADGS_SLABS): one slab while nothing is known about the scene, then as many as bring the average
-    (cell, slab) list to half a sort chunk; a many-chunk cell that sent the next frames to the device-wide sort until round 3 stays on
-    the bucket path.  Same images in every frame."""
-    _lib.lib().adgs_test_set_capacity_hints(0, 0)
-    monkeypatch.delenv("ADGS_BINNING")
-    sc = synthetic.make_scene(45000, 128, 128, 120.0, seed=48, scale_mult=0.003, near_frac=0.0)      # one cell, ~40 000 entries
-    sc["opacities"] = (sc["opacities"] * 0.08 + 0.01).contiguous()
-    first = run_hip(sc)
-    assert _stats()["bucket_binning"] == 1 and _stats()["depth_slabs"] == 1 and _stats()["num_rendered"] > 3 * 8192
-    seen = []
-    for _ in range(4):
-        a = run_hip(sc)
-        seen.append(_stats()["depth_slabs"])
-        for k in ("color", "depth", "img_opacity"):
-            assert torch.equal(a[k], first[k]), k
-    assert all(n >= 10 for n in seen), seen               # ~50 000 pairs (with head-room) over one cell: 13 slabs of half a chunk
-    _lib.lib().adgs_test_set_capacity_hints(0, 0)
