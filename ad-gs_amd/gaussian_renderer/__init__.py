@@ -108,7 +108,7 @@ def render(viewpoint_camera, pc, env_map, pipe, scaling_modifier=1.0, override_c
 
     rasterizer = GaussianRasterizer(raster_settings=_camera_settings(viewpoint_camera, pc, pipe, scaling_modifier, device))
     pkg, flow_points = _deformed_state(pc, viewpoint_camera.time, flow_pkg, full_rows=override_color is not None)
-    semantic = pc.get_obj_mask.float()[..., None] if render_objmask else None
+    semantic = (pc.obj_mask_float if hasattr(pc, "obj_mask_float") else pc.get_obj_mask.float()[..., None]) if render_objmask else None
     # the environment-map background first: on the raw-SH path the blend epilogue composites it (`render = C + T * background`,
     # gaussian_renderer/__init__.py:93-94) and the blend backward returns dL/dbackground = T * dL/drender -- no element-wise pass
     background = env_map.get_image_background(viewpoint_camera) if env_map is not None else None

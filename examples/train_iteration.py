@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
 OPT = types.SimpleNamespace(lambda_dssim=0.2, lambda_l1=1.0, lambda_depth=0.1, lambda_flow=0.1, lambda_obj=0.1, lambda_sky=0.05, lambda_sigma=0.01,
                             lambda_reg=0.5, lambda_sigma_reg=0.5, near_num=8, near_idx_reset_interval=10, densification_interval=200,
                             densify_scene_grad_threshold=None, densify_obj_grad_threshold=None, env_lr=1e-2)
-STAGES = ("render", "losses", "backward", "densify_stats", "near_idx_or_densify", "adam_gaussians", "adam_env_map")
+STAGES = ("regularisers", "render", "losses", "backward", "densify_stats", "near_idx_or_densify", "adam_gaussians", "adam_env_map")
 
 
 def build(config, env_res, device, n_cameras=16):
@@ -85,7 +85,7 @@ class StageClock:
         if self.on:
             e = self.torch.cuda.Event(enable_timing=True)
             e.record()
-            self.marks.append((name, e))
+            self.marks.append((name, e, time.perf_counter()))
 
     def end_iteration(self):
         if self.on:
@@ -95,8 +95,18 @@ class StageClock:
     def summary(self):
         tot = {}
         for marks in self.iters:
-            for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            for (_, a, _ta), (name, b, _tb) in zip(marks[:-1], marks[1:]):
                 tot[name] = tot.get(name, 0.0) + a.elapsed_time(b)
+        n = max(len(self.iters), 1)
+        return {k: round(v / n, 4) for k, v in tot.items()}
+
+    def host_summary(self):
+        """Host time between the same marks (time.perf_counter: what the Python side of a stage costs, enqueue included; where it
+        exceeds the device figure the GPU waits for the host)."""
+        tot = {}
+        for marks in self.iters:
+            for (_, _a, ta), (name, _b, tb) in zip(marks[:-1], marks[1:]):
+                tot[name] = tot.get(name, 0.0) + (tb - ta) * 1e3
         n = max(len(self.iters), 1)
         return {k: round(v / n, 4) for k, v in tot.items()}
 
@@ -118,6 +128,15 @@ def iteration(it, model, cams, env_map, clock, state):
     cam = cams[it % len(cams)]                                               # train.py:55-61
     flow_pkg = cam.flow[0]                                                   # :66-71
     clock.mark("start")
+    # The three regularisers (train.py:101-110) do not depend on the render: they are evaluated FIRST.  Same terms, same sum -- but their
+    # launches (and the Python around them) now run while the GPU is still busy with the previous iteration's Adam, and autograd, which
+    # runs the nodes created last first, back-propagates them LAST, under the rasterizer's long backward kernels, instead of between
+    # the render and the image losses where the GPU has nothing queued (the rasterizer's forward returns when the device has published
+    # the frame's pair count: the host is at most one blend kernel ahead at that point).
+    reg_loss = loss.reg_loss(model.xyz_deform_param, model.obj_near_idx)     # :101-103
+    sigma_loss = loss.sigma_loss(model.gs_time_sigma, model.frame_gap)       # :105-107
+    reg_sigma_loss = loss.reg_sigma_loss(model.gs_time_sigma, model.obj_near_idx)      # :108-110
+    clock.mark("regularisers")
     pkg = render(cam, model, env_map, pipe, flow_pkg=flow_pkg, render_objmask=opt.lambda_obj > 0.0)      # :73
     image = pkg["render"]
     clock.mark("render")
@@ -127,9 +146,6 @@ def iteration(it, model, cams, env_map, clock, state):
     flow_loss = loss.get_flow_loss(pkg["img_flow"], flow_pkg, pkg["img_opacity"], dist=model.scene_extent * 1e-3)      # :88-89
     obj_loss = loss.obj_loss(pkg["img_semantic"], cam.semantic)              # :91-94
     sky_loss = loss.sky_loss(pkg["img_opacity"], cam.sky)                    # :96-99
-    reg_loss = loss.reg_loss(model.xyz_deform_param, model.obj_near_idx)     # :101-103
-    sigma_loss = loss.sigma_loss(model.gs_time_sigma, model.frame_gap)       # :105-107
-    reg_sigma_loss = loss.reg_sigma_loss(model.gs_time_sigma, model.obj_near_idx)      # :108-110
     # :112-115 -- the reference's chain of python scalar products and sums is ~40 launches of 2 - 4 us; same total in three
     total = loss.weighted_total([((1.0 - opt.lambda_dssim) * opt.lambda_l1, Ll1), (opt.lambda_dssim, dssim), (opt.lambda_depth, depth_loss),
                                  (opt.lambda_flow, flow_loss), (opt.lambda_sky, sky_loss), (opt.lambda_obj, obj_loss), (opt.lambda_sigma, sigma_loss),
@@ -189,7 +205,7 @@ def run(config="C3", iters=60, env_res=8192, cameras=16, warm=12, device=None, s
                         "+ backward + densification statistics + fused Adam (Gaussians, environment map); set_obj_near_idx every %d and "
                         "densify_and_prune every %d iterations; %d cameras" % (config, env_res, OPT.near_idx_reset_interval, OPT.densification_interval, len(cams)),
             "iterations": iters, "ms_per_iteration": round(dt * 1e3, 4), "iterations_per_s": round(1.0 / dt, 2),
-            "stage_ms": clock.summary(), "densify_calls": state.get("densified", 0), "points_end": int(model.get_pts_num),
+            "stage_ms": clock.summary(), "host_stage_ms": clock.host_summary(), "densify_calls": state.get("densified", 0), "points_end": int(model.get_pts_num),
             "loss_first_last": [round(float(first), 6), round(float(last), 6)],
             "note": "stage_ms: HIP events on the launch stream, mean per iteration (near_idx_or_densify is amortised over the iterations)"}
 
