@@ -171,6 +171,24 @@ def get_depth_loss(pred, gt, mask=None):
 AUX_WORK_DOUBLES = 256 * 2 + 2           # ADGS_AUX_WORK_DOUBLES
 
 
+_HOST_FLOATS = {}
+
+
+def _host_floats(t, n):
+    """The n floats of a small camera tensor as a ctypes array (kernel arguments by value).  The reference keeps K / R / T on the GPU
+    (train.py:68-71): reading them back is a stream synchronisation per iteration, so the values are cached per tensor (storage address
+    and version counter: an in-place update of the camera invalidates the entry)."""
+    if not t.is_cuda:
+        return (ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()])
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+    c = _HOST_FLOATS.get(key)
+    if c is None:
+        if len(_HOST_FLOATS) > 4096:
+            _HOST_FLOATS.clear()
+        c = _HOST_FLOATS[key] = (ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()])
+    return c
+
+
 class _FlowLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img_flow, img_opacity, flow, flow_vis, K, R, T, dist):
@@ -182,7 +200,7 @@ class _FlowLoss(torch.autograd.Function):
         H, W = fl.shape[1], fl.shape[2]
         if f.shape != (3, H, W) or fl.shape[0] != 2 or vis.shape != (H, W) or (op is not None and op.numel() != H * W):
             raise ValueError("get_flow_loss: expected img_flow [3,H,W], flow [2,H,W], flow_vis [H,W], img_opacity [H,W]")
-        cam = [(ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()]) for t, n in ((K, 9), (R, 9), (T, 3))]
+        cam = [_host_floats(t, n) for t, n in ((K, 9), (R, 9), (T, 3))]
         work, ctx.token = _work(f.device, AUX_WORK_DOUBLES)
         out = torch.empty(1, dtype=torch.float32, device=f.device) if H * W else torch.zeros(1, dtype=torch.float32, device=f.device)
         with torch.cuda.device(f.device):

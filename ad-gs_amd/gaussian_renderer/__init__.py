@@ -16,12 +16,20 @@ import torch
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
 
+_BLACK = {}
+
+
 def _camera_settings(cam, pc, pipe, scale_modifier, device):
-    """Everything the rasterizer needs to know about the view (the background colour is black: the sky comes from env_map)."""
-    on = lambda t: t.to(device)
+    """Everything the rasterizer needs to know about the view (the background colour is black: the sky comes from env_map).
+    The reference's Camera keeps its matrices on the GPU (scene/cameras.py:77-80); a camera object that holds host tensors costs
+    three blocking uploads per render here -- each one a stream synchronisation."""
+    on = lambda t: t if t.device == device else t.to(device)
+    black = _BLACK.get(device)
+    if black is None:
+        black = _BLACK[device] = torch.zeros(3, dtype=torch.float32, device=device)
     return GaussianRasterizationSettings(
         int(cam.image_height), int(cam.image_width), math.tan(0.5 * cam.FoVx), math.tan(0.5 * cam.FoVy),
-        torch.zeros(3, dtype=torch.float32, device=device), scale_modifier, on(cam.world_view_transform), on(cam.full_proj_transform),
+        black, scale_modifier, on(cam.world_view_transform), on(cam.full_proj_transform),
         pc.active_sh_degree, on(cam.camera_center), False, pipe.inv_depth, pipe.debug)
 
 

@@ -61,6 +61,9 @@ def build(config, env_res, device, n_cameras=16):
         cam = synthetic.camera_to_z_up(cam)
         c = synthetic.camera_object(cam, time=t)
         c.cam_id = len(cams)
+        # scene/cameras.py:77-80: the reference's Camera holds its matrices on the GPU
+        for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(c, name, getattr(c, name).to(device))
         # per-camera supervision (scene/cameras.py: original_image, depth, semantic, sky, flow packages)
         c.original_image = torch.rand(3, H, W, generator=g).to(device)
         c.depth = (torch.rand(H, W, generator=g) * 0.5 + 0.01).to(device)                  # monocular inverse depth
