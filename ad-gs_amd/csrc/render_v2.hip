@@ -57,9 +57,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADGS_FWD_DMA
 #define ADGS_FWD_DMA 1             // 0: the forward loads the key stream into registers at the moment it needs it (A/B builds)
 #endif
-#ifndef ADGS_KO
-#define ADGS_KO 0                  // knock-out experiment builds (WRONG results, timing only): 1 no atomic, 2 no LDS reduction, 4 no strip bodies (backward), 8 no channel FMAs (forward)
-#endif
 
 // Can the Gaussian of Splat line (q0 = x y ca cb, cc, tau) reach alpha >= 1/255 on any pixel centre of the wave's tile (column tx, pixel rows
 // row0 .. row0 + rows - 1)?  Exact minimum of the quadratic form d^T Q d over the tile's pixel-centre rectangle (a lower bound of the
@@ -391,11 +388,9 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				const bool up = __builtin_amdgcn_inverse_ballot_w64(actm[k] & ~stopm);
 				pyf[k] = stop ? PIXEL_DONE : pyf[k];
 				const float w = up ? alpha[k] * T[k] : 0.f;   // pixels that do not blend this entry add exactly 0
-				if (!(ADGS_KO & 8)) {
 				C0[k] = fmaf(q1.z, w, C0[k]); C1[k] = fmaf(q1.w, w, C1[k]); C2[k] = fmaf(q2.x, w, C2[k]);
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
 				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
-				} else C0[k] += w;
 				T[k] = up ? test_T : T[k];
 				last_contrib[k] = up ? position : last_contrib[k];
 			}
@@ -541,10 +536,6 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	// its registers allowed)
 	__shared__ float4 s_splat[WAVE * 4];
 	__shared__ __attribute__((aligned(16))) float s_red[RED_ROWS * RED_STRIDE];
-#ifdef ADGS_BWD_LDS_PAD
-	__shared__ float s_pad[ADGS_BWD_LDS_PAD / 4];      // occupancy experiment: what would a second Splat buffer cost?
-	if (a.W < 0) s_pad[threadIdx.x] = 1.f;
-#endif
 	const int lane = threadIdx.x;
 	const uint32_t tile = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
@@ -714,13 +705,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	bwd_strip<true>(v, be, bp, act ? alpha[k] : 0.f, act ? G[k] : 0.f, dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
 #define ADGS_BWD_ACCK(k) if (__builtin_amdgcn_inverse_ballot_w64(actm[k])) { ADGS_BWD_PIXEL(k); \
 	bwd_strip<false>(v, be, bp, alpha[k], G[k], dy[k], T[k], Bsum[k], do_color, do_flow, do_sem, do_depth, do_opacity); }
-				if (ADGS_KO & 4) { v.op = alpha[0] + alpha[PPL - 1]; v.my = G[0]; v.cc = dy[0]; v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = q2.x + q3.x; }
-				else {
 				if (actm[0] != 0ull) { ADGS_BWD_INITK(0) }
 				else v.op = v.my = v.cc = v.c0 = v.c1 = v.c2 = v.d = v.f0 = v.f1 = v.f2 = v.s = 0.f;
 #pragma unroll
 				for (int k = 1; k < PPL; k++) { ADGS_BWD_ACCK(k) }
-				}
 				bwd_finish_moments(v, dx);
 #undef ADGS_BWD_PIXEL
 #undef ADGS_BWD_INITK
@@ -728,12 +716,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				// 14 wave sums through LDS (slot k of the 64-byte gradient line ends up in the quad of lanes 4k .. 4k+3) -> one atomic
 				// instruction on one 64-byte line.  Absent channels stay exactly 0.
 				PT(t_r0);
-				const float out = (ADGS_KO & 2) ? (((v.op + v.mx) + (v.my + v.ca)) + ((v.cb + v.cc) + (v.c0 + v.c1))) + (((v.c2 + v.d) + (v.f0 + v.f1)) + (v.f2 + v.s))
-					: wave_sum14_lds(s_red, red, lane, v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
+				const float out = wave_sum14_lds(s_red, red, lane, v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
 				if (!FULL && a.sem_dst) {
 					if (writer && (slot < 6 || slot == GACC_USED - 1)) atomicAdd(slot == GACC_USED - 1 ? a.sem_dst + (size_t)gid * a.sem_stride : a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
-				} else if (ADGS_KO & 1) { if (out == 123.456f) a.gacc[(size_t)gid * GACC_STRIDE + slot] = out; }
-				else if (writer) atomicAdd(a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
+				} else if (writer) atomicAdd(a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
 				PT(t_r1); PT_ACC(3, t_r0, t_r1);
 			}
 			PT(t_e1); PT_ACC(2, t_g1, t_e1);
