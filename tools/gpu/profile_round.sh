@@ -18,6 +18,8 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $o/grbm -o grbm -- $B > $
 rocprofv3 -L > $o/counters_available.txt 2>&1
 unset ADGS_BENCH_SKIP_STATS
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/ti -o ti -- python3 $R/examples/train_iteration.py --config C3 --iters 100 --json > $o/train_iteration.log 2>&1
+# where the GPU idles inside an iteration: the same trace, previous kernel's end -> next kernel's start (tools/iteration_gaps.py)
+python3 $R/tools/iteration_gaps.py $(find $o/ti -name "*kernel_trace.csv" | head -1) > $o/train_iteration_gaps.json 2> $o/gaps.err
 cd $R
 python tools/pmc_traffic.py $(find $o/fetch -name "*counter_collection.csv" | head -1) $(find $o/write -name "*counter_collection.csv" | head -1) $o/hbm_traffic_per_kernel.json $o/hbm_traffic_per_frame.json > $o/traffic.txt 2>&1
 python tools/pmc_blend.py $o/pmc_blend_kernels.json $(find $o/sq $o/sq2 $o/sq3 $o/grbm -name "*counter_collection.csv") > $o/blend.txt 2>&1
