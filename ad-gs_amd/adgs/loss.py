@@ -393,3 +393,96 @@ def weighted_total(terms):
         w = _WEIGHTS[key] = torch.tensor(key[0], dtype=torch.float32, device=ref.device)
     ts = [t if torch.is_tensor(t) else torch.tensor(float(t), dtype=torch.float32, device=ref.device) for _, t in terms]
     return _WeightedSum.apply(w, *ts)
+
+
+# ---------------------------------------------------------------- the image terms of train.py:78-99 as ONE autograd node
+class _ImageLosses(torch.autograd.Function):
+    """L1, SSIM, depth loss, flow loss, object BCE, sky BCE -- the same kernels, the same work buffers as the six functions above, behind
+    one autograd node: six Python-level Function calls forward and six backward (each ~30 us of host time around a 5 - 90 us kernel)
+    become two, so the short kernels of this section no longer wait for the host between them (tools/iteration_gaps.py: ~100 us of
+    idle GPU per iteration in front of the rasterizer's backward).  Output: a [6] tensor (Ll1, ssim, depth, flow, obj, sky)."""
+
+    @staticmethod
+    def forward(ctx, image, depth, img_flow, img_opacity, img_semantic, gt_image, gt_depth, flow, flow_vis, cam, dist, gt_semantic, gt_sky):
+        dev = image.device
+        if not image.is_cuda:
+            raise RuntimeError("image_losses: tensors must be on a HIP device; there is no CPU path")
+        L = _lib.lib()
+        st = _stream(dev)
+        f32 = lambda t: t.contiguous().float()
+        img, ref = f32(image), f32(gt_image)
+        H, W = img.shape[-2:]
+        if img.shape != ref.shape or img.dim() != 3:
+            raise ValueError("image_losses: image and gt_image must be [C, H, W]")
+        npix = H * W
+        dep, gdep = f32(depth).reshape(H, W), f32(gt_depth).reshape(H, W)
+        fl_img, op = f32(img_flow), f32(img_opacity).reshape(H, W)
+        fl, vis = f32(flow), f32(flow_vis)
+        sem = f32(img_semantic[0] if img_semantic.dim() == 3 else img_semantic).reshape(H, W)
+        gsem, gsky = f32(gt_semantic).reshape(H, W), f32(gt_sky).reshape(H, W)
+        if fl_img.shape != (3, H, W) or fl.shape != (2, H, W) or vis.shape != (H, W):
+            raise ValueError("image_losses: expected img_flow [3,H,W], flow [2,H,W], flow_vis [H,W]")
+        terms = torch.empty(6, dtype=torch.float32, device=dev)
+        maps = [torch.empty_like(img) for _ in range(3)]
+        sums, _ = _work(dev, 2 * SLOTS)
+        w_depth, tok_depth = _work(dev, DEPTH_WORK_DOUBLES)
+        w_flow, tok_flow = _work(dev, AUX_WORK_DOUBLES)
+        w_obj, _ = _work(dev, AUX_WORK_DOUBLES)
+        w_sky, _ = _work(dev, AUX_WORK_DOUBLES)
+        p0 = terms.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.adgs_l1_ssim_forward(img.shape[0], H, W, img.data_ptr(), ref.data_ptr(), sums.data_ptr(), *[m.data_ptr() for m in maps], st), "adgs_l1_ssim_forward")
+            _lib.check(L.adgs_l1_ssim_means(sums.data_ptr(), img.numel(), p0, st), "adgs_l1_ssim_means")
+            _lib.check(L.adgs_depth_loss_forward(npix, dep.data_ptr(), gdep.data_ptr(), None, w_depth.data_ptr(), p0 + 8, st), "adgs_depth_loss_forward")
+            _lib.check(L.adgs_flow_loss_forward(H, W, fl_img.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr(), cam[0], cam[1], cam[2], float(dist),
+                                                w_flow.data_ptr(), p0 + 12, st), "adgs_flow_loss_forward")
+            _lib.check(L.adgs_bce_clip_forward(npix, sem.data_ptr(), gsem.data_ptr(), 1e-3, 1.0 - 1e-3, 0, 1, w_obj.data_ptr(), p0 + 16, st), "adgs_bce_clip_forward")
+            _lib.check(L.adgs_bce_clip_forward(npix, op.data_ptr(), gsky.data_ptr(), 1e-3, 1.0 - 1e-3, 1, 0, w_sky.data_ptr(), p0 + 20, st), "adgs_bce_clip_forward")
+        ctx.save_for_backward(img, ref, *maps, dep, gdep, w_depth, fl_img, fl, vis, op, w_flow, sem, gsem, gsky)
+        ctx.tokens, ctx.cam, ctx.dist = (tok_depth, tok_flow), cam, float(dist)
+        ctx.shapes = (image.shape, depth.shape, img_flow.shape, img_opacity.shape, img_semantic.shape)
+        return terms
+
+    @staticmethod
+    def backward(ctx, g):
+        (img, ref, d_mu1, d_e11, d_e12, dep, gdep, w_depth, fl_img, fl, vis, op, w_flow, sem, gsem, gsky) = ctx.saved_tensors
+        _WorkArena.check(ctx.tokens[0], "image_losses (depth)")
+        _WorkArena.check(ctx.tokens[1], "image_losses (flow)")
+        dev = img.device
+        L = _lib.lib()
+        st = _stream(dev)
+        H, W = img.shape[-2:]
+        npix = H * W
+        g = g.contiguous().float()
+        p0 = g.data_ptr()
+        g_img, g_dep, g_fl = torch.empty_like(img), torch.empty_like(dep), torch.empty_like(fl_img)
+        g_op, g_op2, g_sem = torch.empty_like(op), torch.empty_like(op), torch.empty_like(sem)
+        with torch.cuda.device(dev):
+            _lib.check(L.adgs_l1_ssim_backward(img.shape[0], H, W, img.data_ptr(), ref.data_ptr(), d_mu1.data_ptr(), d_e11.data_ptr(), d_e12.data_ptr(),
+                                               p0, p0 + 4, g_img.data_ptr(), st), "adgs_l1_ssim_backward")
+            _lib.check(L.adgs_depth_loss_backward(npix, dep.data_ptr(), gdep.data_ptr(), None, w_depth.data_ptr(), p0 + 8, g_dep.data_ptr(), st), "adgs_depth_loss_backward")
+            _lib.check(L.adgs_flow_loss_backward(H, W, fl_img.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr(), ctx.cam[0], ctx.cam[1], ctx.cam[2], ctx.dist,
+                                                 w_flow.data_ptr(), p0 + 12, g_fl.data_ptr(), g_op.data_ptr(), st), "adgs_flow_loss_backward")
+            _lib.check(L.adgs_bce_clip_backward(npix, sem.data_ptr(), gsem.data_ptr(), 1e-3, 1.0 - 1e-3, 0, 1, p0 + 16, g_sem.data_ptr(), st), "adgs_bce_clip_backward")
+            _lib.check(L.adgs_bce_clip_backward(npix, op.data_ptr(), gsky.data_ptr(), 1e-3, 1.0 - 1e-3, 1, 0, p0 + 20, g_op2.data_ptr(), st), "adgs_bce_clip_backward")
+        g_op.add_(g_op2)                               # img_opacity feeds the flow loss and the sky loss
+        s_img, s_dep, s_fl, s_op, s_sem = ctx.shapes
+        if len(s_sem) == 3:                            # [D_S, H, W]: only channel 0 enters the object loss (train.py:95-98)
+            full = torch.zeros(s_sem, dtype=torch.float32, device=dev) if s_sem[0] > 1 else None
+            g_sem_out = g_sem.reshape(1, H, W) if full is None else full
+            if full is not None:
+                full[0].copy_(g_sem)
+        else:
+            g_sem_out = g_sem.reshape(s_sem)
+        return (g_img.reshape(s_img), g_dep.reshape(s_dep), g_fl.reshape(s_fl), g_op.reshape(s_op), g_sem_out) + (None,) * 8
+
+
+def image_losses(image, gt_image, depth, gt_depth, img_flow, flow_pkg, img_opacity, img_semantic, gt_semantic, gt_sky, dist=1e-3):
+    """The six image terms of a training iteration in one autograd node: returns (Ll1, ssim, depth_loss, flow_loss, obj_loss, sky_loss) --
+    bit for bit what l1_ssim, get_depth_loss (no mask), get_flow_loss, obj_loss and sky_loss return for the same arguments
+    (utils/loss_utils.py:20-106, train.py:78-99; flow_pkg = (_, K, R, T, flow, flow_vis) as in train.py:68-71)."""
+    _, K, R, T, flow, flow_vis = flow_pkg
+    cam = tuple(_host_floats(t, n) for t, n in ((K, 9), (R, 9), (T, 3)))
+    terms = _ImageLosses.apply(image, depth, img_flow, img_opacity, img_semantic, gt_image.detach(), gt_depth.detach(), flow.detach(), flow_vis.detach(),
+                               cam, float(dist), gt_semantic.detach(), gt_sky.detach())
+    return tuple(terms.unbind(0))

@@ -31,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
 OPT = types.SimpleNamespace(lambda_dssim=0.2, lambda_l1=1.0, lambda_depth=0.1, lambda_flow=0.1, lambda_obj=0.1, lambda_sky=0.05, lambda_sigma=0.01,
                             lambda_reg=0.5, lambda_sigma_reg=0.5, near_num=8, near_idx_reset_interval=10, densification_interval=200,
                             densify_scene_grad_threshold=None, densify_obj_grad_threshold=None, env_lr=1e-2)
+FUSED_IMAGE_LOSSES = os.environ.get("ADGS_FUSED_IMAGE_LOSSES", "1") != "0"
 STAGES = ("regularisers", "render", "losses", "backward", "densify_stats", "near_idx_or_densify", "adam_gaussians", "adam_env_map")
 
 
@@ -143,12 +144,19 @@ def iteration(it, model, cams, env_map, clock, state):
     pkg = render(cam, model, env_map, pipe, flow_pkg=flow_pkg, render_objmask=opt.lambda_obj > 0.0)      # :73
     image = pkg["render"]
     clock.mark("render")
-    Ll1, s = loss.l1_ssim(image, cam.original_image)                         # :78-80 (one fused kernel for both)
-    dssim = 1.0 - s
-    depth_loss = loss.get_depth_loss(pkg["depth"], cam.depth)                # :83-86
-    flow_loss = loss.get_flow_loss(pkg["img_flow"], flow_pkg, pkg["img_opacity"], dist=model.scene_extent * 1e-3)      # :88-89
-    obj_loss = loss.obj_loss(pkg["img_semantic"], cam.semantic)              # :91-94
-    sky_loss = loss.sky_loss(pkg["img_opacity"], cam.sky)                    # :96-99
+    if FUSED_IMAGE_LOSSES:
+        # :78-99 as one autograd node (adgs.loss.image_losses: the same six kernels and values, two Python-level calls instead of twelve)
+        Ll1, s, depth_loss, flow_loss, obj_loss, sky_loss = loss.image_losses(
+            image, cam.original_image, pkg["depth"], cam.depth, pkg["img_flow"], flow_pkg, pkg["img_opacity"], pkg["img_semantic"], cam.semantic, cam.sky,
+            dist=model.scene_extent * 1e-3)
+        dssim = 1.0 - s
+    else:
+        Ll1, s = loss.l1_ssim(image, cam.original_image)                         # :78-80 (one fused kernel for both)
+        dssim = 1.0 - s
+        depth_loss = loss.get_depth_loss(pkg["depth"], cam.depth)                # :83-86
+        flow_loss = loss.get_flow_loss(pkg["img_flow"], flow_pkg, pkg["img_opacity"], dist=model.scene_extent * 1e-3)      # :88-89
+        obj_loss = loss.obj_loss(pkg["img_semantic"], cam.semantic)              # :91-94
+        sky_loss = loss.sky_loss(pkg["img_opacity"], cam.sky)                    # :96-99
     # :112-115 -- the reference's chain of python scalar products and sums is ~40 launches of 2 - 4 us; same total in three
     total = loss.weighted_total([((1.0 - opt.lambda_dssim) * opt.lambda_l1, Ll1), (opt.lambda_dssim, dssim), (opt.lambda_depth, depth_loss),
                                  (opt.lambda_flow, flow_loss), (opt.lambda_sky, sky_loss), (opt.lambda_obj, obj_loss), (opt.lambda_sigma, sigma_loss),

@@ -256,3 +256,41 @@ def test_regulariser_indices_follow_fancy_indexing_and_never_leave_the_tensor():
         gv, = torch.autograd.grad(v, x)
         torch.cuda.synchronize()
         assert torch.isnan(v) and bool((guard == 7.0).all()) and gv.shape == x.shape
+
+
+@pytest.mark.parametrize("H,W,D_S", [(97, 131, 1), (64, 80, 3)])
+def test_image_losses_node_equals_the_six_functions(H, W, D_S):
+    """adgs.loss.image_losses (one autograd node for train.py:78-99) against l1_ssim / get_depth_loss / get_flow_loss / obj_loss / sky_loss
+    on the same inputs: the same kernels, so the same values bit for bit; the gradients of every input equal (img_opacity receives the
+    sum of the flow and the sky term either way)."""
+    from adgs import loss
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    dev = "cuda"
+    r = lambda *s: torch.rand(*s, generator=g)
+    gt_img, gt_depth, gt_sem, gt_sky = r(3, H, W).to(dev), (r(H, W) * 0.5 + 0.01).to(dev), (r(H, W) > 0.8).float().to(dev), (r(H, W) > 0.7).float().to(dev)
+    K = torch.tensor([[90.0, 0.0, W / 2.0], [0.0, 90.0, H / 2.0], [0.0, 0.0, 1.0]])
+    R, T = torch.eye(3), torch.tensor([0.05, -0.02, 0.1])
+    flow_pkg = (0.4, K, R, T, torch.stack([r(H, W) * (W - 1), r(H, W) * (H - 1)]).to(dev), (r(H, W) > 0.3).float().to(dev))
+    base = dict(image=r(3, H, W), depth=r(H, W) * 0.4 + 0.05, img_flow=torch.cat([r(2, H, W) * 4 - 2, r(1, H, W) * 5 + 1]), img_opacity=r(H, W) * 0.98 + 0.01,
+                img_semantic=r(D_S, H, W))
+    w = torch.tensor([0.8, 0.2, 0.1, 0.1, 0.1, 0.05], device=dev)
+
+    def run(fused):
+        x = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        if fused:
+            terms = loss.image_losses(x["image"], gt_img, x["depth"], gt_depth, x["img_flow"], flow_pkg, x["img_opacity"], x["img_semantic"], gt_sem, gt_sky, dist=0.02)
+        else:
+            l1, s = loss.l1_ssim(x["image"], gt_img)
+            terms = (l1, s, loss.get_depth_loss(x["depth"], gt_depth), loss.get_flow_loss(x["img_flow"], flow_pkg, x["img_opacity"], dist=0.02),
+                     loss.obj_loss(x["img_semantic"], gt_sem), loss.sky_loss(x["img_opacity"], gt_sky))
+        total = (torch.stack([t.reshape(()) for t in terms]) * w).sum()
+        total.backward()
+        return [t.detach().clone() for t in terms], {k: v.grad.detach().clone() for k, v in x.items()}
+
+    ta, ga = run(False)
+    tb, gb = run(True)
+    for a, b in zip(ta, tb):
+        assert torch.equal(a, b), (a, b)
+    for k in ga:
+        assert gb[k].shape == ga[k].shape, k
+        assert torch.allclose(gb[k], ga[k], rtol=1e-6, atol=1e-9 + 1e-6 * float(ga[k].abs().max())), k
