@@ -109,11 +109,11 @@ def build_scene(config, variant="default"):
         xyz = sc["means3D"].clone()
         scene = ~sc["obj_mask"]
         n = int(scene.sum())
-        z = torch.rand(n, generator=g) ** 0.7 * 88.0 + 2.0                       # denser far away: the vanishing point collects them
+        z = torch.rand(n, generator=g) ** 0.6 * 88.0 + 2.0                       # denser far away: the vanishing point collects them
         kind = torch.rand(n, generator=g)
         x = (torch.rand(n, generator=g) * 2 - 1) * 7.5
         y = 1.5 + 0.04 * torch.randn(n, generator=g)                             # road plane, 1.5 m below the camera (y points down)
-        wall = kind > 0.45                                                       # 55 %: the two facades at x = -8 / +8 m, 0 .. 14 m high
+        wall = kind > 0.35                                                       # 65 %: the two facades at x = -8 / +8 m, 0 .. 14 m high
         side = torch.where(torch.rand(n, generator=g) > 0.5, 1.0, -1.0)
         x = torch.where(wall, side * (8.0 + 0.05 * torch.randn(n, generator=g)), x)
         y = torch.where(wall, 1.5 - torch.rand(n, generator=g) * 14.0, y)
