@@ -35,10 +35,16 @@ __device__ __forceinline__ bool has_lin(const adgs_func_eval& f) { return (f.n_t
 // stride: the later one-row-per-thread accesses are bank-conflict free).  Scene members (gi < Ns)
 // live in `scene`, object members in `obj`; a nullptr side is skipped.  One thread per float,
 // consecutive threads on consecutive addresses; the (row, column) pair advances without divisions.
-template <bool TO_LDS, typename PtrT>
+// U4: 16-byte transfers in flight per thread on the contiguous path -- a batch is one memory round trip for the whole workgroup, so a
+// caller whose registers are idle while it stages (the preprocess kernels: 12 quads per thread for 45-float SH rows) asks for all of them at once.
+// `between`: called exactly once, after the loads of the first batch have been issued and before their LDS stores -- the place for a
+// caller's own loads that should share that round trip.
+struct StageNoOp { __device__ __forceinline__ void operator()() const {} };
+template <bool TO_LDS, int U4 = 4, typename PtrT, typename Between = StageNoOp>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, int L, int gi0, int count, int Ns, PtrT scene, PtrT obj,
-	int tid, int nthreads) {
+	int tid, int nthreads, Between between = Between()) {
 	constexpr int U = 8;                      // transfers in flight per thread: all loads of a batch are issued before the first store
+	bool called = false;
 	const int total = count * L;
 	int e_begin = 0;
 	// fast path, block entirely on one side of the scene|object boundary: its rows are one contiguous slab,
@@ -46,9 +52,8 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 	const bool all_scene = gi0 + count <= Ns, all_obj = gi0 >= Ns;
 	if (all_scene || all_obj) {
 		PtrT slab = all_scene ? (scene ? scene + (size_t)gi0 * L : nullptr) : (obj ? obj + (size_t)(gi0 - Ns) * L : nullptr);
-		if (!slab) return;
+		if (!slab) { between(); return; }
 		if ((reinterpret_cast<uintptr_t>(slab) & 15) == 0 && L >= 4) {
-			constexpr int U4 = 4;
 			const int total4 = total >> 2;
 			int e = 4 * tid;
 			int g = e / L, c = e - g * L;
@@ -65,6 +70,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 					c += dr; g += dq;
 					if (c >= L) { c -= L; g++; }
 				}
+				if (!called) { between(); called = true; }
 #pragma unroll
 				for (int u = 0; u < U4; u++) {
 					if (!in[u]) continue;
@@ -78,6 +84,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 			e_begin = total4 << 2;            // at most three tail elements go through the generic loop
 		}
 	}
+	if (!called) { between(); called = true; }
 	if (!scene && !obj) return;
 	int g = (e_begin + tid) / L, c = (e_begin + tid) - g * L;
 	const int dq = nthreads / L, dr = nthreads - dq * L;

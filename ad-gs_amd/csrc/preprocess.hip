@@ -16,6 +16,9 @@
 #include "geom.h"
 #include <cstdlib>
 
+#ifndef ADGS_PRE_STAGE_U4
+#define ADGS_PRE_STAGE_U4 12
+#endif
 namespace adgs {
 
 namespace {
@@ -89,8 +92,41 @@ constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
 
 struct PreOut { uint32_t nfine; uint32_t zbits; };     // per Gaussian: fine tiles covered, view-space depth bits (0: not visible)
 
+// Per-Gaussian inputs of the staged kernel, requested up front.  Read where the reference reads them they form a chain of dependent
+// round trips behind the staging barrier -- position -> (near cull) -> scale / rotation / opacity -> coefficient 0 -> flow point, semantic:
+// four trips of 3 - 5 us under load per workgroup, five workgroup rounds per CU.  Loaded unconditionally (clamped index, the culled
+// Gaussians included) right after the SH rows have been requested, all of them ride on the staging round trip.  Same values, same
+// arithmetic: only the loads move.
+struct PreIn { alignas(16) float q[4]; float p[3], s[3], op, sh0[3], f[3], sem; };
+__device__ __forceinline__ PreIn load_pre_in(const PreprocessArgs& a, const int idx) {
+	PreIn in;
+	const size_t i = (size_t)min(idx, a.P - 1);
+	const bool rs = a.sh_src.scene_xyz != nullptr && (int)i < a.sh_src.Ns;
+	const float* pos = rs ? a.sh_src.scene_xyz : a.means3D;
+	in.p[0] = pos[3 * i]; in.p[1] = pos[3 * i + 1]; in.p[2] = pos[3 * i + 2];
+	in.s[0] = in.s[1] = in.s[2] = 0.f; in.q[0] = in.q[1] = in.q[2] = in.q[3] = 0.f;
+	if (!a.cov3D_precomp) {
+		const float* sc = rs ? a.sh_src.scene_scaling : a.scales;
+		const float* rt = rs ? a.sh_src.scene_rotation : a.rotations;
+		in.s[0] = sc[3 * i]; in.s[1] = sc[3 * i + 1]; in.s[2] = sc[3 * i + 2];
+		const float4 r = *reinterpret_cast<const float4*>(rt + 4 * i);
+		in.q[0] = r.x; in.q[1] = r.y; in.q[2] = r.z; in.q[3] = r.w;
+	}
+	in.op = (rs ? a.sh_src.scene_opacity : a.opacities)[i];
+	in.sh0[0] = in.sh0[1] = in.sh0[2] = 0.f;
+	if (a.sh_src.scene_dc) { in.sh0[0] = a.sh0[3 * i]; in.sh0[1] = a.sh0[3 * i + 1]; in.sh0[2] = a.sh0[3 * i + 2]; }
+	in.f[0] = in.f[1] = in.f[2] = 0.f;
+	if (a.flow_points) {
+		// a scene Gaussian of the raw-scene path does not move (its flow point is its position) and its row of flow_points is never written
+		const float* fp = rs ? pos : a.flow_points;
+		in.f[0] = fp[3 * i]; in.f[1] = fp[3 * i + 1]; in.f[2] = fp[3 * i + 2];
+	}
+	in.sem = (a.semantic && a.D_S > 0) ? a.semantic[i * a.D_S] : 0.f;
+	return in;
+}
+
 template <bool STAGED>
-__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell);
+__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell, const PreIn& in);
 
 template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
@@ -98,11 +134,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	__shared__ uint32_t s_cell[MAX_CELLS];     // bucket binning: this workgroup's (cell, Gaussian) pair count per coarse cell
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a.bucket_count) for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) s_cell[c] = 0u;
+	PreIn in;
 	if (STAGED) {
 		const int tid = threadIdx.x, base = blockIdx.x * 256, nvalid = min(256, a.P - base);
 		if (a.sh_src.scene_dc) {
-			stage_rows<true>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, 256);
+			stage_rows<true, ADGS_PRE_STAGE_U4>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, 256, [&]() { in = load_pre_in(a, idx); });
 		} else {
+			in = load_pre_in(a, idx);
 			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
 			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += 256) {
 				const float4 v = src[q];
@@ -115,7 +153,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	if (STAGED || a.bucket_count) __syncthreads();
 	if (a.v2 && !a.bucket_count && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
 	PreOut o = { 0u, 0u };
-	if (idx < a.P) o = preprocess_one<STAGED>(a, idx, s_sh, s_cell);
+	if (idx < a.P) o = preprocess_one<STAGED>(a, idx, s_sh, s_cell, in);
 	if (a.bucket_count) {
 		// bucket binning (binning.hip): no scan pass runs.  The pair counts per coarse cell were summed in LDS (the Gaussians of an
 		// object are neighbours in index AND on the screen: global atomics serialise on a few hot cells) and go out as this
@@ -137,7 +175,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 }
 
 template <bool STAGED>
-__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell) {
+__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell, const PreIn& in) {
 	const PreOut none = { 0u, 0u };
 	if (idx == 0) {       // sentinels: the exclusive scans over P + 1 entries leave the totals at [P]
 		a.tiles_touched[a.P] = 0;
@@ -150,7 +188,7 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	// raw scene geometry: Gaussians idx < Ns read position / log-scale / raw rotation / opacity logit from the raw tensors
 	const bool rs = a.sh_src.scene_xyz != nullptr && idx < a.sh_src.Ns;
 	const float* pos = rs ? a.sh_src.scene_xyz : a.means3D;
-	const float px = pos[3 * (size_t)idx], py = pos[3 * (size_t)idx + 1], pz = pos[3 * (size_t)idx + 2];
+	const float px = STAGED ? in.p[0] : pos[3 * (size_t)idx], py = STAGED ? in.p[1] : pos[3 * (size_t)idx + 1], pz = STAGED ? in.p[2] : pos[3 * (size_t)idx + 2];
 	const float* V = a.view; const float* PJ = a.proj;
 	// near cull only (auxiliary.h:154)
 	const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
@@ -170,9 +208,13 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 		for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
 	} else {
 		if (rs) {
-			const SceneAct act = scene_activations(a.sh_src.scene_scaling, a.sh_src.scene_rotation, a.sh_src.scene_opacity, (size_t)idx);
+			// (the staged kernel hands scene_activations its prefetched row: index 0 of a one-row "tensor")
+			const SceneAct act = STAGED ? scene_activations(in.s, in.q, &in.op, (size_t)0)
+			                            : scene_activations(a.sh_src.scene_scaling, a.sh_src.scene_rotation, a.sh_src.scene_opacity, (size_t)idx);
 			cov3d_from_values(act.s[0], act.s[1], act.s[2], a.scale_modifier, act.q[0], act.q[1], act.q[2], act.q[3], c3);
 			opacity_in = act.op;
+		} else if (STAGED) {
+			cov3d_from_scale_rot(in.s, a.scale_modifier, in.q, c3);
 		} else {
 			cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
 		}
@@ -211,7 +253,7 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	if ((maxx - minx) * (maxy - miny) == 0) return none;
 
 	Splat s;
-	s.x = pix; s.y = piy; s.ca = conx; s.cb = cony; s.cc = conz; s.opacity = rs ? opacity_in : a.opacities[idx];
+	s.x = pix; s.y = piy; s.ca = conx; s.cb = cony; s.cc = conz; s.opacity = rs ? opacity_in : (STAGED ? in.op : a.opacities[idx]);
 	uint8_t clamp_bits = 0;
 	if (a.colors_precomp) {
 		s.r = a.colors_precomp[3 * (size_t)idx]; s.g = a.colors_precomp[3 * (size_t)idx + 1]; s.b = a.colors_precomp[3 * (size_t)idx + 2];
@@ -224,7 +266,8 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 			// dc + f_shs(t) || rest, straight from the raw scene/object tensors
 			const bool is_obj = idx >= a.sh_src.Ns;
 			const size_t m = is_obj ? idx - a.sh_src.Ns : idx;
-			sh0[0] = a.sh0[3 * (size_t)idx]; sh0[1] = a.sh0[3 * (size_t)idx + 1]; sh0[2] = a.sh0[3 * (size_t)idx + 2];
+			if (STAGED) { sh0[0] = in.sh0[0]; sh0[1] = in.sh0[1]; sh0[2] = in.sh0[2]; }
+			else { sh0[0] = a.sh0[3 * (size_t)idx]; sh0[1] = a.sh0[3 * (size_t)idx + 1]; sh0[2] = a.sh0[3 * (size_t)idx + 2]; }
 			if (STAGED) sh = s_sh + threadIdx.x * SH_ROW_REST - 3;
 			else sh = (is_obj ? a.sh_src.obj_rest : a.sh_src.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
 		} else {
@@ -245,9 +288,10 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	}
 	s.dval = a.inv_depth ? (1.0f / (vz + 0.0000001f)) : vz;
 	if (a.flow_points && rs) { s.fx = px; s.fy = py; s.fz = pz; }       // a scene Gaussian does not move: its flow point is its position
+	else if (a.flow_points && STAGED) { s.fx = in.f[0]; s.fy = in.f[1]; s.fz = in.f[2]; }
 	else if (a.flow_points) { s.fx = a.flow_points[3 * (size_t)idx]; s.fy = a.flow_points[3 * (size_t)idx + 1]; s.fz = a.flow_points[3 * (size_t)idx + 2]; }
 	else { s.fx = 0.f; s.fy = 0.f; s.fz = 0.f; }
-	s.sem0 = (a.semantic && a.D_S > 0) ? a.semantic[(size_t)idx * a.D_S] : 0.f;
+	s.sem0 = STAGED ? in.sem : ((a.semantic && a.D_S > 0) ? a.semantic[(size_t)idx * a.D_S] : 0.f);
 	// alpha = opacity * exp(-0.5 d^T Q d) >= 1/255  <=>  d^T Q d <= tau = 2 ln(255 opacity); +0.02: a 1 % slack on alpha that dominates
 	// every fp32 rounding in the per-pixel test (the blend forward's tile test and the rectangle shrink below use it)
 	const float tau = 2.f * logf(255.f * s.opacity) + 0.02f;

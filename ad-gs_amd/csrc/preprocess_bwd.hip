@@ -16,6 +16,9 @@
 #include "func_eval.h"
 #include <cstdlib>
 
+#ifndef ADGS_PREB_STAGE_U4
+#define ADGS_PREB_STAGE_U4 12
+#endif
 namespace adgs {
 namespace {
 
@@ -44,6 +47,31 @@ __device__ __forceinline__ M3 m3t(const M3& a) {
 constexpr int BW_THREADS = 256;
 constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
 
+// Per-Gaussian inputs of the staged v2 kernel, requested with the SH rows (preprocess.hip: PreIn -- the same reasoning: radii -> (visible?)
+// -> position / scale / rotation / opacity / accumulator line / Splat line -> clamp bits are dependent round trips behind the staging
+// barrier otherwise).  Loaded unconditionally at a clamped index; only the v2 raw-SH path (gacc != nullptr, no cov3D) uses them.
+struct PreBIn { alignas(16) float q[4]; float4 u0, u1, u2, u3, s0, s1; float p[3], s[3], op; int radius; uint8_t clamped; };
+__device__ __forceinline__ PreBIn load_preb_in(const PreprocessBwdArgs& a, const int idx) {
+	PreBIn in;
+	const size_t i = (size_t)min(idx, a.P - 1);
+	const bool rs = a.sh_src.scene_xyz != nullptr && (int)i < a.sh_src.Ns;
+	in.radius = a.radii[i];
+	const float* pos = rs ? a.sh_src.scene_xyz : a.means3D;
+	in.p[0] = pos[3 * i]; in.p[1] = pos[3 * i + 1]; in.p[2] = pos[3 * i + 2];
+	const float* sc = rs ? a.sh_src.scene_scaling : a.scales;
+	const float* rt = rs ? a.sh_src.scene_rotation : a.rotations;
+	in.s[0] = sc[3 * i]; in.s[1] = sc[3 * i + 1]; in.s[2] = sc[3 * i + 2];
+	const float4 r = *reinterpret_cast<const float4*>(rt + 4 * i);
+	in.q[0] = r.x; in.q[1] = r.y; in.q[2] = r.z; in.q[3] = r.w;
+	in.op = rs ? a.sh_src.scene_opacity[i] : 0.f;
+	const float4* ga = reinterpret_cast<const float4*>(a.gacc + i * GACC_STRIDE);
+	in.u0 = ga[0]; in.u1 = ga[1]; in.u2 = ga[2]; in.u3 = ga[3];
+	const float4* sp = reinterpret_cast<const float4*>(a.splats + i);
+	in.s0 = sp[0]; in.s1 = sp[1];
+	in.clamped = a.clamped[i];
+	return in;
+}
+
 template <bool STAGED>
 __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBwdArgs a) {
 	extern __shared__ float s_sh[];
@@ -52,9 +80,13 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	const int idx = base + tid;
 	const bool raw = a.sh_src.scene_dc != nullptr;
 	const int nvalid = min(BW_THREADS, a.P - base);
+	// prefetched inputs: the staged v2 path that recomputes cov3D from scales / rotations (what the raw-SH frames run)
+	const bool pf = STAGED && raw && a.gacc != nullptr && a.cov3D == nullptr && a.scales != nullptr && a.rotations != nullptr;      // kernel-uniform
+	PreBIn in;
 	if (STAGED) {
 		if (raw) {
-			stage_rows<true>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, BW_THREADS);
+			stage_rows<true, ADGS_PREB_STAGE_U4>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, BW_THREADS,
+				[&]() { if (pf) in = load_preb_in(a, idx); });
 		} else {
 			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
 			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
@@ -67,7 +99,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		__syncthreads();
 	}
 	const bool valid = idx < a.P;
-	const bool vis = valid && (a.radii[idx] > 0);
+	const bool vis = valid && ((pf ? in.radius : a.radii[idx]) > 0);
 	// raw scene geometry (preprocess.hip): position / log-scale / raw rotation / opacity logit of Gaussians idx < Ns come from the raw
 	// tensors, and their gradients -- chain rule through exp / normalize / sigmoid included -- go to the raw tensors' gradients
 	const bool rs = a.sh_src.scene_xyz != nullptr && idx < a.sh_src.Ns;
@@ -113,9 +145,10 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	if (vis) {
 	const float* V = a.view; const float* PJ = a.proj;
 	const float* pos = rs ? a.sh_src.scene_xyz : a.means3D;
-	const float mx = pos[3 * (size_t)idx], my = pos[3 * (size_t)idx + 1], mz = pos[3 * (size_t)idx + 2];
+	const float mx = pf ? in.p[0] : pos[3 * (size_t)idx], my = pf ? in.p[1] : pos[3 * (size_t)idx + 1], mz = pf ? in.p[2] : pos[3 * (size_t)idx + 2];
 	SceneAct act;
-	if (rs) act = scene_activations(a.sh_src.scene_scaling, a.sh_src.scene_rotation, a.sh_src.scene_opacity, (size_t)idx);
+	if (rs) act = pf ? scene_activations(in.s, in.q, &in.op, (size_t)0)
+	                 : scene_activations(a.sh_src.scene_scaling, a.sh_src.scene_rotation, a.sh_src.scene_opacity, (size_t)idx);
 	float gflow[3] = { 0.f, 0.f, 0.f };      // raw scene row: the flow point IS the position, its gradient joins the position's
 
 	// per-Gaussian sums of the blend backward: classic = separate ABI arrays filled by atomics,
@@ -123,12 +156,12 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	float dcon_x, dcon_y, dcon_z, g2x, g2y, gd, gcol[3];
 	if (a.gacc) {
 		const float4* ga = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GACC_STRIDE);
-		const float4 u0 = ga[0], u1 = ga[1], u2 = ga[2], u3 = ga[3];
+		const float4 u0 = pf ? in.u0 : ga[0], u1 = pf ? in.u1 : ga[1], u2 = pf ? in.u2 : ga[2], u3 = pf ? in.u3 : ga[3];
 		// (the line stays as it is: api.hip zeroes the accumulator again before a second backward over the same forward)
 		// u0 = (S0, Sx, Sy, Sxx), u1 = (Sxy, Syy, c0, c1): raw moment sums of L = G*dL/dalpha (render_v2.hip);
 		// the per-Gaussian factors of backward.cu:626-643 are applied here, once per Gaussian
 		const float4* sp = reinterpret_cast<const float4*>(a.splats + idx);
-		const float4 s0 = sp[0], s1 = sp[1];               // x y ca cb | cc op r g
+		const float4 s0 = pf ? in.s0 : sp[0], s1 = pf ? in.s1 : sp[1];               // x y ca cb | cc op r g
 		const float op = s1.y, qa = s0.z, qb = s0.w, qc = s1.x;
 		g2x = -op * (qa * u0.y + qb * u0.z) * (float)(0.5 * a.W);
 		g2y = -op * (qc * u0.z + qb * u0.y) * (float)(0.5 * a.H);
@@ -157,6 +190,8 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		for (int i = 0; i < 6; i++) c3[i] = a.cov3D[6 * (size_t)idx + i];
 	} else if (rs) {
 		cov3d_from_values(act.s[0], act.s[1], act.s[2], a.scale_modifier, act.q[0], act.q[1], act.q[2], act.q[3], c3);
+	} else if (pf) {
+		cov3d_from_scale_rot(in.s, a.scale_modifier, in.q, c3);
 	} else {                  // v2 without cov3D_precomp: recomputed instead of stored by the forward (24 B written + read per Gaussian)
 		cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, c3);
 	}
@@ -270,7 +305,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			dsh = a.dL_dsh + (size_t)idx * a.M * 3;
 			dsh0 = dsh;
 		}
-		const uint8_t cl = a.clamped[idx];
+		const uint8_t cl = pf ? in.clamped : a.clamped[idx];
 		float g[3];
 #pragma unroll
 		for (int c = 0; c < 3; c++) g[c] = ((cl >> c) & 1) ? 0.f : gcol[c];
@@ -336,8 +371,10 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	if (a.scales) {
 		float r, x, y, z;
 		if (rs) { r = act.q[0]; x = act.q[1]; y = act.q[2]; z = act.q[3]; }
+		else if (pf) { r = in.q[0]; x = in.q[1]; y = in.q[2]; z = in.q[3]; }
 		else { const float* q = a.rotations + 4 * (size_t)idx; r = q[0]; x = q[1]; y = q[2]; z = q[3]; }
-		const float sc0 = rs ? act.s[0] : a.scales[3 * (size_t)idx], sc1 = rs ? act.s[1] : a.scales[3 * (size_t)idx + 1], sc2 = rs ? act.s[2] : a.scales[3 * (size_t)idx + 2];
+		const float sc0 = rs ? act.s[0] : (pf ? in.s[0] : a.scales[3 * (size_t)idx]), sc1 = rs ? act.s[1] : (pf ? in.s[1] : a.scales[3 * (size_t)idx + 1]),
+			sc2 = rs ? act.s[2] : (pf ? in.s[2] : a.scales[3 * (size_t)idx + 2]);
 		M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
 		           { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
 		           { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } } };
