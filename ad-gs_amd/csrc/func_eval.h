@@ -40,7 +40,10 @@ __device__ __forceinline__ bool has_lin(const adgs_func_eval& f) { return (f.n_t
 // `between`: called exactly once, after the loads of the first batch have been issued and before their LDS stores -- the place for a
 // caller's own loads that should share that round trip.
 struct StageNoOp { __device__ __forceinline__ void operator()() const {} };
-template <bool TO_LDS, int U4 = 4, typename PtrT, typename Between = StageNoOp>
+#ifndef ADGS_STAGE_U4_DEFAULT
+#define ADGS_STAGE_U4_DEFAULT 4
+#endif
+template <bool TO_LDS, int U4 = ADGS_STAGE_U4_DEFAULT, typename PtrT, typename Between = StageNoOp>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, int L, int gi0, int count, int Ns, PtrT scene, PtrT obj,
 	int tid, int nthreads, Between between = Between()) {
 	constexpr int U = 8;                      // transfers in flight per thread: all loads of a batch are issued before the first store

@@ -57,6 +57,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ADGS_FWD_DMA
 #define ADGS_FWD_DMA 1             // 0: the forward loads the key stream into registers at the moment it needs it (A/B builds)
 #endif
+#ifndef ADGS_FWD_SCAN_ROUNDS
+#define ADGS_FWD_SCAN_ROUNDS 2     // staged scan: rounds of 64 list entries per step (1 or 2)
+#endif
+#ifndef ADGS_FWD_KEY_RING
+#define ADGS_FWD_KEY_RING 1        // staged key-stream blocks per wave (2 KiB of LDS each): a block is requested KEY_RING blocks before it is scanned (2 / 3: measured slower, see below)
+#endif
 
 // Can the Gaussian of Splat line (q0 = x y ca cb, cc, tau) reach alpha >= 1/255 on any pixel centre of the wave's tile (column tx, pixel rows
 // row0 .. row0 + rows - 1)?  Exact minimum of the quadratic form d^T Q d over the tile's pixel-centre rectangle (a lower bound of the
@@ -147,7 +153,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	__shared__ uint32_t s_pub[2 * WAVE];         // live ids waiting to leave as a full chunk
 	// key-stream scan: SCAN_ROUNDS x 64 list entries per step; ring: < 64 waiting + one step's survivors, power of two.  With the
 	// staged key stream (below) a step is half a staged block: 4096 + 512 + 1024 + 2048 bytes of LDS = 21 workgroups per CU.
-	constexpr int SCAN_ROUNDS = ADGS_FWD_DMA ? 2 : 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
+	constexpr int SCAN_ROUNDS = ADGS_FWD_DMA ? ADGS_FWD_SCAN_ROUNDS : 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
 	__shared__ uint32_t s_cand[CAND_RING];
 	// The key stream of a cell is SEQUENTIAL and the tile's position in it is known long before the entries are needed: the next
 	// block of KEY_BLOCK (id, mask) entries is copied global -> LDS by the DMA path of the load unit (global_load_lds_dwordx4: no
@@ -155,8 +161,8 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	// Splat gather and the whole blend loop of the batch.  Until round 3 the scan loaded 256 entries into registers when it needed
 	// them: ~10 exposed round trips per tile at several microseconds each under load (tools/blend_phase_timing.py) -- a third of a
 	// wave's life.  Bucket-binned frames only (cell_entries); the device-wide-sort fallback keeps the register path.
-	constexpr int KEY_BLOCK = 4 * WAVE;
-	__shared__ __attribute__((aligned(16))) uint2 s_keys[ADGS_FWD_DMA ? KEY_BLOCK : 2];
+	constexpr int KEY_BLOCK = 2 * SCAN_ROUNDS * WAVE, KEY_RING = ADGS_FWD_KEY_RING;      // a block = two scan steps; one DMA instruction copies 128 entries
+	__shared__ __attribute__((aligned(16))) uint2 s_keys[ADGS_FWD_DMA ? KEY_RING * KEY_BLOCK : 2];
 	const int lane = threadIdx.x;
 	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
 	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
@@ -210,8 +216,18 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	// stage-1 state: candidates whose rectangle holds this tile (ring buffer), the prefetched next batch of the key stream
 	uint32_t chead = 0, ccount = 0;
 	const bool staged = ADGS_FWD_DMA && a.cell_entries != nullptr;
-	uint32_t bpos = range.x, bhalf = 2;           // the staged block covers list positions [bpos, bpos + KEY_BLOCK); bhalf: its next unscanned half (2: none left)
-	auto stage_block = [&](uint32_t p) {          // wave-uniform p < range.y
+	// The staged blocks form a ring: block j of the cell's list (positions range.x + j KEY_BLOCK ...) lives in slot j % KEY_RING and is
+	// requested as soon as that slot is free, i.e. KEY_RING blocks before the scan reaches it.  With ONE slot (the default) a block is
+	// requested when the previous one is exhausted: the scan of a batch needs ~2.4 blocks and most of them are waited for at full latency
+	// (6 us; 41 % of a wave's life, tools/blend_phase_timing.py) -- but two slots (9.5 KiB of LDS: 16 instead of 21 waves per CU) make the
+	// kernel 20 us SLOWER and three 60 us (0.229 -> 0.250 -> 0.290 ms at C3): the waits are covered by the other waves of the SIMD, and a
+	// resident wave is worth more to this kernel than a shorter wave.  bpos / bslot / bhalf: the block being
+	// scanned, its slot, its next unscanned half; issued: end of the requested part of the list; landed: end of the part KNOWN to have
+	// arrived -- memory operations complete in order, so everything requested before a wait for younger loads (the Splat gather of a
+	// batch) or before an explicit vmcnt(0) is there, and a block is only waited for when it is not (a blanket vmcnt(0) per block also
+	// waits for the acknowledgement of the chunk stores the blend loop has just issued).
+	uint32_t bpos = range.x, bslot = 0, bhalf = 0, issued = range.x, landed = range.x;
+	auto stage_block = [&](uint32_t p, uint32_t slot) {          // wave-uniform p < range.y
 		// lane l copies entries p + 2l, p + 2l + 1 (16 bytes); lanes past the end of the list re-read its last entry (the word behind a
 		// list is inside the binning buffer: BinStateV2::carve_buckets), the scan ignores positions >= range.y
 		// Written as inline assembly, not __builtin_amdgcn_global_load_lds: the compiler cannot tell which LDS array a DMA writes and
@@ -221,15 +237,21 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		const uint32_t last = range.y - 1u;
 		const uint2* g0 = a.cell_entries + min(p + 2u * lane, last);
 		const uint2* g1 = a.cell_entries + min(p + (uint32_t)(KEY_BLOCK / 2) + 2u * lane, last);
-		const uint32_t l0 = (uint32_t)(uintptr_t)s_keys, l1 = l0 + (uint32_t)(KEY_BLOCK / 2 * sizeof(uint2));
+		const uint32_t l0 = (uint32_t)(uintptr_t)s_keys + slot * (uint32_t)(KEY_BLOCK * sizeof(uint2)), l1 = l0 + (uint32_t)(KEY_BLOCK / 2 * sizeof(uint2));
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // m0 is a reserved register: named as clobbered on purpose (the DMA's LDS base travels in it)
-		asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, off\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, off"
-			:: "v"(g0), "v"(g1), "s"(l0), "s"(l1) : "memory", "m0");
+		if (KEY_BLOCK > 2 * WAVE)
+			asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, off\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, off"
+				:: "v"(g0), "v"(g1), "s"(l0), "s"(l1) : "memory", "m0");
+		else
+			asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g0), "s"(l0) : "memory", "m0");
 #pragma clang diagnostic pop
-		bpos = p; bhalf = 0;
+		issued = p + KEY_BLOCK;
 	};
-	if (staged && range.x < range.y) stage_block(range.x);
+	if (staged) {
+#pragma unroll
+		for (int j = 0; j < KEY_RING; j++) if (range.x + (uint32_t)(j * KEY_BLOCK) < range.y) stage_block(range.x + (uint32_t)(j * KEY_BLOCK), (uint32_t)j);
+	}
 	const int row_bit = (int)(ty16 % a.cell_tiles), col_bit = a.cell_tiles + (int)(tx % a.cell_tiles);
 	// a candidate = (Gaussian id, rectangle-coverage mask): one 8-byte entry (bucket binning) or the list id + the bits above
 	// (cell | depth) of its sort key
@@ -279,14 +301,17 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			if (staged) {
 				// half a staged block per step (pos == bpos + bhalf * KEY_BLOCK / 2)
 				PT(t_l0);
-				if (bhalf == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the block has landed (issued a batch ago: no wait in steady state)
+				if (bhalf == 0 && bpos >= landed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); landed = issued; }      // not known to have arrived: everything requested so far has now
 #pragma unroll
-				for (int r = 0; r < SCAN_ROUNDS; r++) { const uint2 v = s_keys[bhalf * (KEY_BLOCK / 2) + r * WAVE + lane]; id[r] = v.x; key[r] = v.y; }
+				for (int r = 0; r < SCAN_ROUNDS; r++) { const uint2 v = s_keys[bslot * KEY_BLOCK + bhalf * (KEY_BLOCK / 2) + r * WAVE + lane]; id[r] = v.x; key[r] = v.y; }
 				PT_WAIT_VM8(6, 7, t_l0, key[0], key[1], id[0], id[1], key[0], key[1], id[0], id[1]);
 				bhalf++;
-				if (bhalf == 2 && bpos + KEY_BLOCK < range.y) {
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // every lane has its entries: the block may be overwritten
-					stage_block(bpos + KEY_BLOCK);
+				if (bhalf == 2) {
+					if (issued < range.y) {
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every lane has its entries: the slot may be overwritten
+						stage_block(issued, bslot);                                // block j + KEY_RING takes the slot of block j
+					}
+					bpos += KEY_BLOCK; bhalf = 0; bslot = bslot + 1 == (uint32_t)KEY_RING ? 0u : bslot + 1;
 				}
 			} else {
 			// UNCONDITIONAL loads at clamped indices, the bucket / sort distinction outside the unrolled loop: a load inside a
@@ -343,6 +368,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			pass = tile_may_contribute(g0, g1.x, g3.z, tx, ty * ROWS, ROWS);      // g3.z: tau (Splat::aux)
 			my_lean = ADGS_LEAN && pass && g3.w != 0.f;
 		}
+		landed = issued;          // the gather's lines (nc >= 1 lanes took part) are younger than every block requested so far: those have arrived
 		chead = (chead + nc) & (CAND_RING - 1); ccount -= nc;
 		const uint64_t pm = __ballot(pass);                                     // bit j: row j of s_splat is an entry of this batch
 		const uint64_t lean_m = __builtin_amdgcn_ballot_w64(my_lean);           // bit j: entry j takes the lean evaluation

@@ -14,7 +14,8 @@ import json
 try:
     d = json.loads(open("$o/bench_$v.json").read().strip().splitlines()[-1])
     s = d["stages_ms"]
-    print("%-10s %7.1f fwd %.4f bwd %.4f pre %.4f pbwd %.4f step median %.4f" % ("$v", d["value"], s["render_fwd"], s["render_bwd"], s.get("preprocess_fwd", 0), s.get("preprocess_bwd", 0), d["config"]["step_ms_hip_events"]["median"]))
+    print("%-10s %7.1f fwd %.4f bwd %.4f pre %.4f pbwd %.4f dfwd %.4f dbwd %.4f bin %.4f step median %.4f" % ("$v", d["value"], s["render_fwd"], s["render_bwd"], s.get("preprocess_fwd", 0), s.get("preprocess_bwd", 0),
+          s.get("deform_fwd", 0), s.get("deform_bwd", 0), s.get("scan", 0) + s.get("duplicate_keys", 0) + s.get("radix_sort", 0) + s.get("tile_ranges", 0), d["config"]["step_ms_hip_events"]["median"]))
 except Exception as e:
     print("$v failed", e)
 PY
