@@ -982,7 +982,8 @@ constexpr size_t MAX_STAGING_LDS = 156 * 1024;
 // block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB; one-wave blocks may take up to
 // MAX_STAGING_LDS of the CU's 160 KiB (very long parameter rows: B-spline + polynomial + Fourier + quaternion parts together)
 static int pick_block(int row_floats, size_t* lds) {
-	for (int B = 256; B >= 64; B >>= 1) {
+	static const int max_block = []() { const char* e = getenv("ADGS_DEFORM_BLOCK"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128) ? v : 256; }();      // measurement knob
+	for (int B = max_block; B >= 64; B >>= 1) {
 		const size_t bytes = (size_t)B * row_floats * sizeof(float);
 		if (bytes <= 48 * 1024 || B == 64) { *lds = bytes; return B; }
 	}
