@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) cell_scatter_kernel(int P, const uint4* _
 			const uint32_t c = y * cgx + x;
 			const uint32_t pos = s_base[c] + atomicAdd(s_cnt + c, 1u);
 			// which tile rows / columns OF THIS CELL the Gaussian's rectangle covers: the blend forward runs its rectangle test on
-			// these 4 bytes and gathers the 32-byte filter record only for candidates that pass it
+			// these 4 bytes and gathers the Splat line only of candidates that pass it
 			const uint32_t ty0 = y * cell_tiles, tx0 = x * cell_tiles;
 			const uint32_t r0 = max(miny, ty0) - ty0, r1 = min(maxy, ty0 + cell_tiles) - ty0;      // [r0, r1) within the cell
 			const uint32_t q0 = max(minx, tx0) - tx0, q1 = min(maxx, tx0 + cell_tiles) - tx0;

@@ -403,8 +403,8 @@ __global__ void __launch_bounds__(256) duplicate_cells_kernel(int P, const uint4
 			{
 				// The key bits above (cell | depth) are not sorted on but travel with the key: they carry which tile rows and tile
 				// columns OF THIS CELL the Gaussian's rectangle covers, so that the blend forward can run the rectangle test on the
-				// sorted key stream alone (8 sequential bytes per candidate) and gathers the 32-byte filter record only for
-				// candidates that pass it.
+				// sorted key stream alone (8 sequential bytes per candidate) and gathers the Splat line only of candidates
+				// that pass it.
 				const uint32_t ty0 = y * cell_tiles, tx0 = x * cell_tiles;
 				const uint32_t r0 = max(miny, ty0) - ty0, r1 = min(maxy, ty0 + cell_tiles) - ty0;      // [r0, r1) within the cell
 				const uint32_t q0 = max(minx, tx0) - tx0, q1 = min(maxx, tx0 + cell_tiles) - tx0;
