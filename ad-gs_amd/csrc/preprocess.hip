@@ -140,13 +140,23 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 		if (a.sh_src.scene_dc) {
 			stage_rows<true, ADGS_PRE_STAGE_U4>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, 256, [&]() { in = load_pre_in(a, idx); });
 		} else {
-			in = load_pre_in(a, idx);
+			// materialised [P,16,3] SH tensor (the reference's own call path): 12 quads per thread, all requested before the first LDS
+			// store (one load -> store per iteration was twelve dependent round trips), the per-Gaussian inputs with them
 			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
-			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += 256) {
-				const float4 v = src[q];
-				const int g = q / (SH_ROW_FULL / 4), c = (q - g * (SH_ROW_FULL / 4)) * 4;
-				float* d = s_sh + g * SH_ROW_FULL_LDS + c;
-				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+			constexpr int NQ4 = SH_ROW_FULL / 4;
+			const int total4 = nvalid * NQ4;
+			float4 v[NQ4];
+#pragma unroll
+			for (int u = 0; u < NQ4; u++) v[u] = src[min(tid + u * 256, total4 - 1)];
+			in = load_pre_in(a, idx);
+#pragma unroll
+			for (int u = 0; u < NQ4; u++) {
+				const int q = tid + u * 256;
+				if (q < total4) {
+					const int g = q / NQ4, c = (q - g * NQ4) * 4;
+					float* d = s_sh + g * SH_ROW_FULL_LDS + c;
+					d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+				}
 			}
 		}
 	}

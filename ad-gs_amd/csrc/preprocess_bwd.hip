@@ -49,7 +49,7 @@ constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
 
 // Per-Gaussian inputs of the staged v2 kernel, requested with the SH rows (preprocess.hip: PreIn -- the same reasoning: radii -> (visible?)
 // -> position / scale / rotation / opacity / accumulator line / Splat line -> clamp bits are dependent round trips behind the staging
-// barrier otherwise).  Loaded unconditionally at a clamped index; only the v2 raw-SH path (gacc != nullptr, no cov3D) uses them.
+// barrier otherwise).  Loaded unconditionally at a clamped index; the staged v2 paths that recompute cov3D (gacc != nullptr, no cov3D) use them.
 struct PreBIn { alignas(16) float q[4]; float4 u0, u1, u2, u3, s0, s1; float p[3], s[3], op; int radius; uint8_t clamped; };
 __device__ __forceinline__ PreBIn load_preb_in(const PreprocessBwdArgs& a, const int idx) {
 	PreBIn in;
@@ -81,19 +81,29 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	const bool raw = a.sh_src.scene_dc != nullptr;
 	const int nvalid = min(BW_THREADS, a.P - base);
 	// prefetched inputs: the staged v2 path that recomputes cov3D from scales / rotations (what the raw-SH frames run)
-	const bool pf = STAGED && raw && a.gacc != nullptr && a.cov3D == nullptr && a.scales != nullptr && a.rotations != nullptr;      // kernel-uniform
+	const bool pf = STAGED && a.gacc != nullptr && a.cov3D == nullptr && a.scales != nullptr && a.rotations != nullptr;      // kernel-uniform
 	PreBIn in;
 	if (STAGED) {
 		if (raw) {
 			stage_rows<true, ADGS_PREB_STAGE_U4>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, BW_THREADS,
 				[&]() { if (pf) in = load_preb_in(a, idx); });
 		} else {
+			// materialised [P,16,3] SH tensor: all 12 quads of a thread requested before the first LDS store (preprocess.hip)
 			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)base * SH_ROW_FULL);
-			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
-				const float4 v = src[q];
-				const int g = q / (SH_ROW_FULL / 4), c = (q - g * (SH_ROW_FULL / 4)) * 4;
-				float* d = s_sh + g * SH_ROW_FULL_LDS + c;
-				d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+			constexpr int NQ4 = SH_ROW_FULL / 4;
+			const int total4 = nvalid * NQ4;
+			float4 v[NQ4];
+#pragma unroll
+			for (int u = 0; u < NQ4; u++) v[u] = src[min(tid + u * BW_THREADS, total4 - 1)];
+			if (pf) in = load_preb_in(a, idx);
+#pragma unroll
+			for (int u = 0; u < NQ4; u++) {
+				const int q = tid + u * BW_THREADS;
+				if (q < total4) {
+					const int g = q / NQ4, c = (q - g * NQ4) * 4;
+					float* d = s_sh + g * SH_ROW_FULL_LDS + c;
+					d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+				}
 			}
 		}
 		__syncthreads();
