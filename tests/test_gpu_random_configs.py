@@ -237,7 +237,14 @@ def test_adversarial_scenes_match_classic_and_oracle(seed):
         tol = 1e-4 * np.abs(r64) + 1e-4 * scale
         e_hip, e_o32 = np.abs(a - r64), np.abs(r32 - r64)
         rows = lambda e: e.reshape(e.shape[0], -1).max(1)                      # conditioning is a per-Gaussian property
-        bad = (rows(e_hip - tol) > 0) & (rows(e_hip) > 8.0 * rows(e_o32) + 1e-6 * scale)
+        # what a float32 evaluation of the row is off by: ONE float32 result is a single draw (it is accidentally exact on some ill-conditioned
+        # rows: seed 7032 fails 3 rows of 3000 that way), so the classic HIP pipeline -- another float32 evaluation order of the same
+        # algorithm, computed above -- is the second draw
+        e_f32 = rows(e_o32)
+        c = cl["grads"].get(k)
+        if c is not None:
+            e_f32 = np.maximum(e_f32, rows(np.abs(c.cpu().numpy().astype(np.float64) - r64)))
+        bad = (rows(e_hip - tol) > 0) & (rows(e_hip) > 8.0 * e_f32 + 1e-6 * scale)
         assert bad.sum() <= max(2, 5e-4 * bad.size), "grad %s: %d of %d rows miss float64 by more than 8x the fp32 oracle's own error (max %.3g, scale %.3g)" % (
             k, int(bad.sum()), bad.size, float(rows(e_hip)[bad].max()), scale)
         assert np.isfinite(a).all(), k
