@@ -64,6 +64,8 @@ SIGNATURES = {
     "adgs_depth_loss_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "adgs_flow_loss_forward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
     "adgs_flow_loss_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "adgs_flow_loss_forward_devcam": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "adgs_flow_loss_backward_devcam": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "adgs_bce_clip_forward": (c_i, [c_i, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p]),
     "adgs_bce_clip_backward": (c_i, [c_i, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p]),
     "adgs_group_var_forward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     "adgs_test_v2_cell_ranges": (ctypes.c_longlong, [c_p, c_i, c_i, c_p, ctypes.c_longlong, c_p]),
     "adgs_test_abi_sizeof": (ctypes.c_size_t, [c_i]),
     "adgs_test_set_capacity_hints": (None, [ctypes.c_longlong, ctypes.c_longlong]),
+    "adgs_test_env_reads": (ctypes.c_ulonglong, []),
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),
     "adgs_test_sort_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),

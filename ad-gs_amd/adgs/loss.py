@@ -171,22 +171,30 @@ def get_depth_loss(pred, gt, mask=None):
 AUX_WORK_DOUBLES = 256 * 2 + 2           # ADGS_AUX_WORK_DOUBLES
 
 
-_HOST_FLOATS = {}
+class _FlowCam:
+    """K, R, T of the flow target (flow_pkg[1:4], train.py:68-71) as kernel arguments.  Tensors on the render device are handed to the
+    `_devcam` entry points as device pointers (the kernels form K R and K T themselves): nothing is read back, and -- unlike a host-side
+    copy keyed by storage address, which the caching allocator re-issues to the next iteration's `a.cuda()` -- nothing can go stale.
+    CPU tensors go by value through the host entry points."""
 
+    def __init__(self, K, R, T, device):
+        ts = (K, R, T)
+        for t, n, name in zip(ts, (9, 9, 3), "KRT"):
+            if t.numel() != n:
+                raise ValueError("flow camera: %s must have %d elements" % (name, n))
+        self.on_device = all(t.is_cuda and t.device == device for t in ts)
+        if self.on_device:
+            self.keep = tuple(t.detach().contiguous().float() for t in ts)          # alive until the backward has been enqueued
+            self.args = tuple(t.data_ptr() for t in self.keep)
+        else:                                                                          # a tensor on another device is read back (correct, slow)
+            self.keep = None
+            self.args = tuple((ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()]) for t, n in zip(ts, (9, 9, 3)))
 
-def _host_floats(t, n):
-    """The n floats of a small camera tensor as a ctypes array (kernel arguments by value).  The reference keeps K / R / T on the GPU
-    (train.py:68-71): reading them back is a stream synchronisation per iteration, so the values are cached per tensor (storage address
-    and version counter: an in-place update of the camera invalidates the entry)."""
-    if not t.is_cuda:
-        return (ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()])
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
-    c = _HOST_FLOATS.get(key)
-    if c is None:
-        if len(_HOST_FLOATS) > 4096:
-            _HOST_FLOATS.clear()
-        c = _HOST_FLOATS[key] = (ctypes.c_float * n)(*[float(x) for x in t.detach().reshape(-1).tolist()])
-    return c
+    def forward_fn(self):
+        return _lib.lib().adgs_flow_loss_forward_devcam if self.on_device else _lib.lib().adgs_flow_loss_forward
+
+    def backward_fn(self):
+        return _lib.lib().adgs_flow_loss_backward_devcam if self.on_device else _lib.lib().adgs_flow_loss_backward
 
 
 class _FlowLoss(torch.autograd.Function):
@@ -200,12 +208,12 @@ class _FlowLoss(torch.autograd.Function):
         H, W = fl.shape[1], fl.shape[2]
         if f.shape != (3, H, W) or fl.shape[0] != 2 or vis.shape != (H, W) or (op is not None and op.numel() != H * W):
             raise ValueError("get_flow_loss: expected img_flow [3,H,W], flow [2,H,W], flow_vis [H,W], img_opacity [H,W]")
-        cam = [_host_floats(t, n) for t, n in ((K, 9), (R, 9), (T, 3))]
+        cam = _FlowCam(K, R, T, f.device)
         work, ctx.token = _work(f.device, AUX_WORK_DOUBLES)
         out = torch.empty(1, dtype=torch.float32, device=f.device) if H * W else torch.zeros(1, dtype=torch.float32, device=f.device)
         with torch.cuda.device(f.device):
-            _lib.check(_lib.lib().adgs_flow_loss_forward(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
-                                                         cam[0], cam[1], cam[2], float(dist), work.data_ptr(), out.data_ptr(), _stream(f.device)),
+            _lib.check(cam.forward_fn()(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
+                                        cam.args[0], cam.args[1], cam.args[2], float(dist), work.data_ptr(), out.data_ptr(), _stream(f.device)),
                        "adgs_flow_loss_forward")
         ctx.save_for_backward(f, fl, vis, work, *([op] if op is not None else []))
         ctx.cam, ctx.dist, ctx.op_shape = cam, float(dist), None if img_opacity is None else img_opacity.shape
@@ -221,9 +229,9 @@ class _FlowLoss(torch.autograd.Function):
         g_op = torch.empty(H, W, dtype=torch.float32, device=f.device) if op is not None else None
         gl = g_loss.reshape(1).float().contiguous()
         with torch.cuda.device(f.device):
-            _lib.check(_lib.lib().adgs_flow_loss_backward(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
-                                                          ctx.cam[0], ctx.cam[1], ctx.cam[2], ctx.dist, work.data_ptr(), gl.data_ptr(), g_f.data_ptr(),
-                                                          g_op.data_ptr() if g_op is not None else None, _stream(f.device)), "adgs_flow_loss_backward")
+            _lib.check(ctx.cam.backward_fn()(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
+                                             ctx.cam.args[0], ctx.cam.args[1], ctx.cam.args[2], ctx.dist, work.data_ptr(), gl.data_ptr(), g_f.data_ptr(),
+                                             g_op.data_ptr() if g_op is not None else None, _stream(f.device)), "adgs_flow_loss_backward")
         return g_f, (g_op.reshape(ctx.op_shape) if g_op is not None else None), None, None, None, None, None, None
 
 
@@ -281,6 +289,23 @@ def sky_loss(img_opacity, gt_sky):
 
 
 # ---------------------------------------------------------------- neighbourhood regularisers (train.py:104-113)
+def _validate_near_idx(idx, N):
+    """`param[obj_near_idx]` raises IndexError in the reference when an index lies outside [-N, N) (a stale obj_near_idx after a prune).
+    A kernel cannot raise, so every index tensor is checked ONCE per (tensor object, in-place version, N): one min/max read-back when
+    set_obj_near_idx / densify_and_prune installs a new tensor (every 10 iterations at most), none afterwards.  The record lives ON the
+    tensor object (an attribute: it dies with the object and cannot be inherited by another tensor at the same address).  Skipped under
+    stream capture (no read-back possible): there the kernels' own guards apply (NaN loss, no gradient for the affected groups)."""
+    if idx.numel() == 0 or torch.cuda.is_current_stream_capturing():
+        return
+    if getattr(idx, "_adgs_validated", None) == (idx._version, N):
+        return
+    lo, hi = (int(v) for v in torch.aminmax(idx))
+    if lo < -N or hi >= N:
+        raise IndexError("obj_near_idx: index %d is out of bounds for dimension 0 with size %d (a stale neighbour index after densify / prune? "
+                         "call set_obj_near_idx())" % (lo if lo < -N else hi, N))
+    idx._adgs_validated = (idx._version, N)
+
+
 class _GroupVar(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, inner):
@@ -288,6 +313,7 @@ class _GroupVar(torch.autograd.Function):
             raise RuntimeError("group variance loss: tensors must be on a HIP device; there is no CPU path")
         if idx.dim() != 2 or idx.dtype != torch.int64:
             raise ValueError("obj_near_idx must be an int64 [G, K] tensor")
+        _validate_near_idx(idx, x.shape[0])
         xs, ix = x.contiguous().float(), idx.contiguous()
         N = xs.shape[0]
         D = xs.numel() // max(N, 1)
@@ -434,8 +460,8 @@ class _ImageLosses(torch.autograd.Function):
             _lib.check(L.adgs_l1_ssim_forward(img.shape[0], H, W, img.data_ptr(), ref.data_ptr(), sums.data_ptr(), *[m.data_ptr() for m in maps], st), "adgs_l1_ssim_forward")
             _lib.check(L.adgs_l1_ssim_means(sums.data_ptr(), img.numel(), p0, st), "adgs_l1_ssim_means")
             _lib.check(L.adgs_depth_loss_forward(npix, dep.data_ptr(), gdep.data_ptr(), None, w_depth.data_ptr(), p0 + 8, st), "adgs_depth_loss_forward")
-            _lib.check(L.adgs_flow_loss_forward(H, W, fl_img.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr(), cam[0], cam[1], cam[2], float(dist),
-                                                w_flow.data_ptr(), p0 + 12, st), "adgs_flow_loss_forward")
+            _lib.check(cam.forward_fn()(H, W, fl_img.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr(), cam.args[0], cam.args[1], cam.args[2], float(dist),
+                                        w_flow.data_ptr(), p0 + 12, st), "adgs_flow_loss_forward")
             _lib.check(L.adgs_bce_clip_forward(npix, sem.data_ptr(), gsem.data_ptr(), 1e-3, 1.0 - 1e-3, 0, 1, w_obj.data_ptr(), p0 + 16, st), "adgs_bce_clip_forward")
             _lib.check(L.adgs_bce_clip_forward(npix, op.data_ptr(), gsky.data_ptr(), 1e-3, 1.0 - 1e-3, 1, 0, w_sky.data_ptr(), p0 + 20, st), "adgs_bce_clip_forward")
         ctx.save_for_backward(img, ref, *maps, dep, gdep, w_depth, fl_img, fl, vis, op, w_flow, sem, gsem, gsky)
@@ -461,8 +487,8 @@ class _ImageLosses(torch.autograd.Function):
             _lib.check(L.adgs_l1_ssim_backward(img.shape[0], H, W, img.data_ptr(), ref.data_ptr(), d_mu1.data_ptr(), d_e11.data_ptr(), d_e12.data_ptr(),
                                                p0, p0 + 4, g_img.data_ptr(), st), "adgs_l1_ssim_backward")
             _lib.check(L.adgs_depth_loss_backward(npix, dep.data_ptr(), gdep.data_ptr(), None, w_depth.data_ptr(), p0 + 8, g_dep.data_ptr(), st), "adgs_depth_loss_backward")
-            _lib.check(L.adgs_flow_loss_backward(H, W, fl_img.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr(), ctx.cam[0], ctx.cam[1], ctx.cam[2], ctx.dist,
-                                                 w_flow.data_ptr(), p0 + 12, g_fl.data_ptr(), g_op.data_ptr(), st), "adgs_flow_loss_backward")
+            _lib.check(ctx.cam.backward_fn()(H, W, fl_img.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr(), ctx.cam.args[0], ctx.cam.args[1], ctx.cam.args[2], ctx.dist,
+                                             w_flow.data_ptr(), p0 + 12, g_fl.data_ptr(), g_op.data_ptr(), st), "adgs_flow_loss_backward")
             _lib.check(L.adgs_bce_clip_backward(npix, sem.data_ptr(), gsem.data_ptr(), 1e-3, 1.0 - 1e-3, 0, 1, p0 + 16, g_sem.data_ptr(), st), "adgs_bce_clip_backward")
             _lib.check(L.adgs_bce_clip_backward(npix, op.data_ptr(), gsky.data_ptr(), 1e-3, 1.0 - 1e-3, 1, 0, p0 + 20, g_op2.data_ptr(), st), "adgs_bce_clip_backward")
         g_op.add_(g_op2)                               # img_opacity feeds the flow loss and the sky loss
@@ -482,7 +508,7 @@ def image_losses(image, gt_image, depth, gt_depth, img_flow, flow_pkg, img_opaci
     bit for bit what l1_ssim, get_depth_loss (no mask), get_flow_loss, obj_loss and sky_loss return for the same arguments
     (utils/loss_utils.py:20-106, train.py:78-99; flow_pkg = (_, K, R, T, flow, flow_vis) as in train.py:68-71)."""
     _, K, R, T, flow, flow_vis = flow_pkg
-    cam = tuple(_host_floats(t, n) for t, n in ((K, 9), (R, 9), (T, 3)))
+    cam = _FlowCam(K, R, T, image.device)
     terms = _ImageLosses.apply(image, depth, img_flow, img_opacity, img_semantic, gt_image.detach(), gt_depth.detach(), flow.detach(), flow_vis.detach(),
                                cam, float(dist), gt_semantic.detach(), gt_sky.detach())
     return tuple(terms.unbind(0))

@@ -65,10 +65,14 @@ struct GeomState {
 		return g;
 	}
 };
+// Both image states start with the same 64-byte header: word 0 is the frame's configuration (frame_cfg_word), written by the forward's
+// preprocess kernel -- whatever the layout behind it, a backward can read how its forward carved it.
+constexpr size_t IMG_HEADER_WORDS = 16;
 struct ImgState {
-	uint32_t* n_contrib; uint2* ranges;
+	uint32_t* header; uint32_t* n_contrib; uint2* ranges;
 	static ImgState carve(char* chunk, size_t npix, size_t ntiles, size_t* bytes) {
 		Carver c(chunk); ImgState s;
+		s.header = c.take<uint32_t>(IMG_HEADER_WORDS);
 		s.n_contrib = c.take<uint32_t>(npix);
 		s.ranges = c.take<uint2>(ntiles);
 		if (bytes) *bytes = c.size();
@@ -121,9 +125,10 @@ struct GeomStateV2 {
 	}
 };
 struct ImgStateV2 {
-	uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order; uint32_t* tile_scanned; uint32_t* tile_batches;
+	uint32_t* header; uint32_t* n_contrib; uint2* cell_ranges; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_order; uint32_t* tile_scanned; uint32_t* tile_batches;
 	static ImgStateV2 carve(char* chunk, size_t npix, size_t ntiles, size_t ncells, size_t* bytes) {
 		Carver c(chunk); ImgStateV2 s;
+		s.header = c.take<uint32_t>(IMG_HEADER_WORDS);
 		s.n_contrib = c.take<uint32_t>(npix);
 		s.cell_ranges = c.take<uint2>(ncells);
 		s.tile_last_chunk = c.take<uint32_t>(ntiles);
@@ -171,8 +176,12 @@ struct BinStateV2 {
 	}
 };
 
+// Every environment switch of the rasterizer is read through these two (and counted: adgs_test_env_reads -- the backward of a frame
+// must not read any: what the forward decided from the environment travels in the frame table, FrameCfg).
+static std::atomic<unsigned long long> g_env_reads{0};
+static const char* env_str(const char* name) { g_env_reads.fetch_add(1, std::memory_order_relaxed); return getenv(name); }
 static int env_int(const char* name, int dflt) {
-	const char* v = getenv(name);
+	const char* v = env_str(name);
 	return (v && *v) ? atoi(v) : dflt;
 }
 // "classic" reproduces the reference pipeline stage by stage (full (tile|depth) sort, num_rendered
@@ -180,8 +189,10 @@ static int env_int(const char* name, int dflt) {
 // and replays the published lists once more per extra channel (render_sem_fwd_v2 / render_bwd_v2 with sem_src; AD-GS uses 1 channel.
 // C3 with 4 / 32 channels: 2.6 / 14.6 ms per frame against 23.8 / 46.5 ms on the classic kernels).  ADGS_V2_MAX_SEMANTIC (default 32
 // = all) sends larger D_S to the classic kernels.
-static bool use_v2(int D_S) {
-	const char* m = getenv("ADGS_RASTER_MODE");
+// env = false: the built-in defaults (what a backward over foreign state buffers assumes; it never reads the environment).
+static bool use_v2(int D_S, bool env = true) {
+	if (!env) return D_S <= (int)MAX_SEMANTIC;
+	const char* m = env_str("ADGS_RASTER_MODE");
 	if (m && std::string(m) == "classic") return false;
 	return D_S <= std::min(env_int("ADGS_V2_MAX_SEMANTIC", 32), (int)MAX_SEMANTIC);
 }
@@ -198,18 +209,23 @@ static bool use_v2(int D_S) {
 // Coarse-cell edge in tiles: 12 for large tile grids, ~110 cells per image for small ones (EXPERIMENTS.md), ADGS_CELL_TILES overrides.
 // The cell lists carry one mask bit per tile row and per tile column of a cell (the blend forward's rectangle test); in a sorted
 // (not bucket-binned) frame these 2 x edge bits share the upper key word with the cell index: the edge shrinks until they fit.
-static int v2_cell_tiles(int gx, int gy) {
+static bool v2_keys_fit(int gx, int gy, int c) { return 2 * c + (int)higher_msb((uint32_t)(((gx + c - 1) / c) * ((gy + c - 1) / c))) <= 32; }
+// fit_keys: shrink the edge until the mask bits fit the sort key -- only a frame that takes the device-wide SORT needs that (bucket
+// binning carries separate (id, mask) entries); a bucket-binned frame keeps the edge it was asked for.
+static int v2_cell_tiles(int gx, int gy, bool fit_keys, bool env = true) {
 	const size_t ntiles16 = (size_t)gx * gy;
 	const int small = std::min(8, std::max(3, (int)std::lround(std::sqrt((double)ntiles16 / 110.0))));
-	int c = std::max(1, env_int("ADGS_CELL_TILES", ntiles16 >= 4096 ? 12 : small));
-	while (c > 1 && 2 * c + (int)higher_msb((uint32_t)(((gx + c - 1) / c) * ((gy + c - 1) / c))) > 32) c--;
+	const int dflt = ntiles16 >= 4096 ? 12 : small;
+	int c = std::max(1, env ? env_int("ADGS_CELL_TILES", dflt) : dflt);
+	while (fit_keys && c > 1 && !v2_keys_fit(gx, gy, c)) c--;
 	return c;
 }
-static int v2_pixels_per_lane(size_t ntiles16) {
-	const int e = env_int("ADGS_V2_PPL", 0);
+static int v2_pixels_per_lane(size_t ntiles16, bool env = true) {
+	const int e = env ? env_int("ADGS_V2_PPL", 0) : 0;
 	if (e == 1 || e == 2 || e == 4) return e;
 	return ntiles16 < 4096 ? 2 : 4;
 }
+
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py); Stage / StageTimer are declared in common.h ----
 static const char* const kStageNames[ST_COUNT] = { "preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
@@ -268,7 +284,19 @@ static MailboxRef* mailbox() {
 // device memory, so the key is host-side: the (image, geometry) buffer addresses autograd hands back TOGETHER WITH the frame's shape
 // (W, H, P).  A state that reaches the backward under another address (cloned / offloaded saved tensors) or another shape is "not
 // found": the backward then carves by today's environment and zeroes the accumulator lines itself -- it never trusts a stale entry.
-struct FrameCfg { int v2; int cell_tiles; int ppl; int backwards = 0; };      // backwards: how many backward passes have consumed this forward's accumulator lines
+// tile_order / sh_staging / timeline: the backward's own measurement knobs (ADGS_TILE_ORDER, ADGS_NO_SH_STAGING, ADGS_TIMELINE_BWD), read by the FORWARD
+struct FrameCfg { int v2; int cell_tiles; int ppl; int tile_order = 1; int sh_staging = 1; int timeline = 0; int backwards = 0; };      // backwards: how many backward passes have consumed this forward's accumulator lines
+// FrameCfg <-> the configuration word in the image state's header (kernels.h: PreprocessArgs::cfg_word)
+static uint32_t frame_cfg_word(const FrameCfg& c) {
+	return 0xAD600000u | ((uint32_t)(c.v2 & 1) << 19) | ((uint32_t)(c.tile_order & 1) << 18) | ((uint32_t)(c.sh_staging & 1) << 17) | ((uint32_t)(c.timeline & 1) << 16) |
+	       ((uint32_t)(c.ppl & 0xff) << 8) | (uint32_t)(c.cell_tiles & 0xff);
+}
+static bool frame_cfg_from_word(uint32_t w, FrameCfg* c) {
+	if ((w & 0xFFF00000u) != 0xAD600000u) return false;
+	*c = FrameCfg{ (int)((w >> 19) & 1u), (int)(w & 0xffu), (int)((w >> 8) & 0xffu) };
+	c->tile_order = (int)((w >> 18) & 1u); c->sh_staging = (int)((w >> 17) & 1u); c->timeline = (int)((w >> 16) & 1u);
+	return c->cell_tiles >= 1 && (c->ppl == 1 || c->ppl == 2 || c->ppl == 4);
+}
 struct FrameKey {
 	const void* img; const void* geom; int W, H, P;
 	bool operator==(const FrameKey& o) const { return img == o.img && geom == o.geom && W == o.W && H == o.H && P == o.P; }
@@ -420,20 +448,26 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (ntiles * 4 * (2 * (size_t)POOL_BLOCK + 1) > 0xffffffffull) { set_error("image too large: chunk slots are 32-bit"); return -1; }      // 4: wave tiles per 16x16 tile at most
 
 	if (use_v2(D_S)) {
-		const int cell_tiles = v2_cell_tiles(gx, gy);
-		const int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
-		const size_t ncells = (size_t)cgx * cgy;
+		// the cell edge as asked for; a frame that takes the sorted path shrinks it until the mask bits fit its keys (decided below)
+		int cell_tiles = v2_cell_tiles(gx, gy, false);
+		int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
+		size_t ncells = (size_t)cgx * cgy;
 		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs) unless the cell grid has more than MAX_CELLS cells,
 		// the previous frames averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of 8192 pairs per cell, or ADGS_BINNING=sort asks
 		// for the device-wide radix sort of (cell | depth) keys.  (A cell of k chunks pays k - 1 rank searches per entry in the merge,
 		// each against a whole staged chunk; measured crossover against the device-wide sort at about 4 chunks per cell -- C5's 3 M
 		// Gaussians, 9 chunks per cell, take the sort.  A merge over sampled WINDOWS of the other chunks -- linear in k -- was built
 		// and measured in round 3: bit-identical, but slower at both sizes; EXPERIMENTS.md.)
-		const char* binning_env = getenv("ADGS_BINNING");
+		const char* binning_env = env_str("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
 			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells &&
 			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));      // ... or ONE cell held more than 16 chunks
+		if (!buckets && !v2_keys_fit(gx, gy, cell_tiles)) {
+			cell_tiles = v2_cell_tiles(gx, gy, true);
+			cgx = (gx + cell_tiles - 1) / cell_tiles; cgy = (gy + cell_tiles - 1) / cell_tiles; ncells = (size_t)cgx * cgy;
+		}
+		const bool sort_fallback_fits = v2_keys_fit(gx, gy, cell_tiles);      // may this frame still fall back to the sort (chunk table full)?
 		size_t gb = 0, ib = 0;
 		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] exists for bucket binning only
 		GeomStateV2::carve(nullptr, P, &gb, count_cells);
@@ -446,7 +480,13 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
 		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, count_cells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
-		remember_frame(FrameKey{ ich, gch, width, height, P }, FrameCfg{ 1, cell_tiles, ppl });
+		uint32_t frame_word = 0;
+		{
+			FrameCfg fcfg{ 1, cell_tiles, ppl };
+			fcfg.tile_order = env_int("ADGS_TILE_ORDER", 1) != 0; fcfg.sh_staging = env_str("ADGS_NO_SH_STAGING") == nullptr; fcfg.timeline = env_int("ADGS_TIMELINE_BWD", 0) != 0;
+			remember_frame(FrameKey{ ich, gch, width, height, P }, fcfg);
+			frame_word = frame_cfg_word(fcfg);
+		}
 
 		PreprocessArgs pa;
 		pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -463,6 +503,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
 		pa.bucket_count = nullptr;
+		pa.cfg_word = img.header; pa.cfg_value = frame_word;
 		// bucket binning accumulates the fine-tile total and a few device words: zeroed by the sh0 kernel on the raw-SH path (one
 		// launch less), by a memset otherwise
 		uint32_t* zero_words = nullptr; const int n_zero = 2 * SCAN_AUX_SLOTS + 8;
@@ -622,6 +663,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 			if (chunk_table_full) {
 				// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
 				// per-Gaussian pair offsets first
+				if (!sort_fallback_fits) { set_error("frame exceeds the bucket chunk table and its cell edge does not fit the sort keys: set ADGS_BINNING=sort (or a smaller ADGS_CELL_TILES)"); return -1; }
 				buckets = false;
 				ADGS_HIP_CHECK(hipMemsetAsync(geom.fine_total, 0, SCAN_AUX_SLOTS * sizeof(unsigned long long), stream));
 				StageTimer t(ST_SCAN, stream);
@@ -655,7 +697,13 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (!gchunk || !ichunk) { set_error("buffer allocator returned NULL"); return -1; }
 	GeomState geom = GeomState::carve(gchunk, P, nullptr);
 	ImgState img = ImgState::carve(ichunk, npix, ntiles, nullptr);
-	remember_frame(FrameKey{ ichunk, gchunk, width, height, P }, FrameCfg{ 0, 1, 4 });
+	uint32_t frame_word = 0;
+	{
+		FrameCfg fcfg{ 0, 1, 4 };
+		fcfg.sh_staging = env_str("ADGS_NO_SH_STAGING") == nullptr;
+		remember_frame(FrameKey{ ichunk, gchunk, width, height, P }, fcfg);
+		frame_word = frame_cfg_word(fcfg);
+	}
 
 	PreprocessArgs pa;
 	pa.P = P; pa.D = D; pa.M = M; pa.D_S = D_S;
@@ -672,6 +720,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.v2 = 0; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
 	pa.bucket_count = nullptr;
+	pa.cfg_word = img.header; pa.cfg_value = frame_word;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
@@ -741,7 +790,18 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	FrameCfg cfg;
 	const FrameKey fkey{ img_buffer, geom_buffer, width, height, P };
-	if (!lookup_frame(fkey, &cfg)) { cfg.v2 = use_v2(D_S) ? 1 : 0; cfg.cell_tiles = v2_cell_tiles(gx, gy); cfg.ppl = v2_pixels_per_lane(ntiles); }      // foreign buffers: today's environment
+	if (!lookup_frame(fkey, &cfg)) {
+		// State buffers this library did not hand out at these addresses (cloned / offloaded saved tensors), or a forward that has
+		// dropped out of the frame table.  The backward never reads the environment: the forward's preprocess kernel wrote the frame's
+		// configuration into the header of the image state, and this rare path reads that word back (one blocking 4-byte copy).
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		(void)hipStreamIsCapturing(stream, &cs);
+		if (cs == hipStreamCaptureStatusActive) { set_error("backward over state buffers the captured forward did not allocate: their configuration cannot be read back inside a stream capture"); return -1; }
+		uint32_t word = 0;
+		ADGS_HIP_CHECK(hipMemcpyAsync(&word, img_buffer, sizeof(word), hipMemcpyDeviceToHost, stream));
+		ADGS_HIP_CHECK(hipStreamSynchronize(stream));
+		if (!frame_cfg_from_word(word, &cfg)) { set_error("backward: the image state buffer does not carry a forward's configuration word (not written by adgs_raster_forward?)"); return -1; }
+	}
 	if (cfg.v2) {
 		const int cell_tiles = cfg.cell_tiles;
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
@@ -766,10 +826,10 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		ra.do_opacity = grad_img_opacity != nullptr || (ra.bg_image != nullptr && ra.do_color);      // the per-pixel background's term rides on the opacity path
 		ra.gacc = geom.gacc;
 		ra.tile_order = nullptr;
-		ra.tl_start = env_int("ADGS_TIMELINE_BWD", 0) ? img.tile_scanned : nullptr; ra.tl_end = img.tile_batches;      // experiment build only
+		ra.tl_start = cfg.timeline ? img.tile_scanned : nullptr; ra.tl_end = img.tile_batches;      // experiment build only
 		{
 			StageTimer t(ST_RENDER_BWD, stream);
-			if (wtiles >= 2048 && env_int("ADGS_TILE_ORDER", 1) != 0) {      // fewer tiles than wave slots: nothing to balance
+			if (wtiles >= 2048 && cfg.tile_order) {      // fewer tiles than wave slots: nothing to balance
 				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream) != 0) return -1;
 				ra.tile_order = img.tile_order;
 			}
@@ -811,6 +871,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		if (sh_src) { pa.sh_src = *sh_src; if (sh_dst) pa.sh_dst = *sh_dst; }
 		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
 		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
+		pa.sh_staging = cfg.sh_staging;
 		{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		return 0;
@@ -854,6 +915,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); memset(&pa.sh_dst, 0, sizeof(pa.sh_dst));
 	pa.gacc = nullptr; pa.splats = nullptr; pa.W = width; pa.H = height; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
 	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;
+	pa.sh_staging = cfg.sh_staging;
 	{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 	return 0;
@@ -986,7 +1048,7 @@ bool v2_image_view(const char* img_buffer, int width, int height, V2ImageView* v
 	const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
 	const size_t ntiles = (size_t)gx * gy, npix = (size_t)width * height;
 	FrameCfg cfg;
-	if (!lookup_frame_by_image(img_buffer, width, height, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(gx, gy); cfg.ppl = v2_pixels_per_lane(ntiles); }
+	if (!lookup_frame_by_image(img_buffer, width, height, &cfg)) { cfg.v2 = 1; cfg.cell_tiles = v2_cell_tiles(gx, gy, true, false); cfg.ppl = v2_pixels_per_lane(ntiles, false); }      // test hooks over foreign buffers: the defaults
 	const int cell_tiles = cfg.cell_tiles, ppl = cfg.ppl;
 	v->ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
 	v->wtiles = (size_t)gx * ((height + 4 * ppl - 1) / (4 * ppl));
@@ -1050,6 +1112,7 @@ extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int
 }
 // sizeof of the structs that cross the ABI by pointer: lets a binding check its mirror (which: 0 adgs_sh_source, 1 adgs_sh_grads,
 // 2 adgs_frame_stats, 3 adgs_frame_status, 4 adgs_func_eval, 5 adgs_adam_group)
+extern "C" unsigned long long adgs_test_env_reads(void) { return g_env_reads.load(); }
 extern "C" size_t adgs_test_abi_sizeof(int which) {
 	switch (which) {
 	case 0: return sizeof(adgs_sh_source);

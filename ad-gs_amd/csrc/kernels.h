@@ -29,6 +29,9 @@ struct PreprocessArgs {
 	// coarse cells it covers -- bucket_count[workgroup][cell], every entry written -- and fine_total is accumulated here (the host
 	// zeroed it)
 	uint32_t* bucket_count;
+	// the frame's configuration word, written into the header of the image state (api.hip: frame_cfg_word): a backward that cannot find
+	// its forward in the host-side frame table (cloned / offloaded state buffers) reads it back instead of consulting the environment
+	uint32_t* cfg_word; uint32_t cfg_value;
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
@@ -83,6 +86,7 @@ struct PreprocessBwdArgs {
 	ShSource sh_src; ShGradDst sh_dst;   // raw-SH path: gradients go straight to the raw tensors' layout
 	float* out_mean2D; float* out_conic; float* out_opacity; float* out_color; float* out_depth; float* out_flow; float* out_sem;
 	int D_S;
+	int sh_staging;                  // 0: ADGS_NO_SH_STAGING was set when the FORWARD of this frame ran (api.hip: FrameCfg)
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
 

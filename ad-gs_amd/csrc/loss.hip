@@ -320,6 +320,23 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(int n, const float* __re
 // and one elementwise backward.  aux work layout (doubles): [slot][2] = (sum, count), then [2*AUX_SLOTS] = sum, [+1] = count.
 constexpr int AUX_SLOTS = 256;
 struct FlowCam { float M[9]; float KT[3]; float dist; };          // M = K R, KT = K T (3x3 row-major products formed on the host in fp32)
+// The camera of the flow target as DEVICE pointers (the reference keeps K / R / T on the GPU, train.py:68-71): nothing is read back
+// and nothing is cached on the host.  K == nullptr: the by-value FlowCam is used.
+struct FlowCamDev { const float* K; const float* R; const float* T; };
+// the same products, in the same order and without contraction, as make_flow_cam forms on the host: both entry points agree bit for bit
+__device__ __forceinline__ FlowCam flow_cam_load(const FlowCam& host, const FlowCamDev& d) {
+	if (!d.K) return host;
+	FlowCam c;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+#pragma unroll
+		for (int j = 0; j < 3; j++)
+			c.M[3 * i + j] = __fadd_rn(__fadd_rn(__fmul_rn(d.K[3 * i], d.R[j]), __fmul_rn(d.K[3 * i + 1], d.R[3 + j])), __fmul_rn(d.K[3 * i + 2], d.R[6 + j]));
+		c.KT[i] = __fadd_rn(__fadd_rn(__fmul_rn(d.K[3 * i], d.T[0]), __fmul_rn(d.K[3 * i + 1], d.T[1])), __fmul_rn(d.K[3 * i + 2], d.T[2]));
+	}
+	c.dist = host.dist;
+	return c;
+}
 
 struct FlowPix { bool sel; float w, u, v, z, px, py; bool front; };
 __device__ __forceinline__ FlowPix flow_pixel(int i, int HW, int W, int H, const float* __restrict__ f, const float* __restrict__ fl,
@@ -340,8 +357,9 @@ __device__ __forceinline__ FlowPix flow_pixel(int i, int HW, int W, int H, const
 	return r;
 }
 __global__ void __launch_bounds__(256) flow_loss_sum_kernel(int H, int W, const float* __restrict__ f, const float* __restrict__ fl,
-	const float* __restrict__ vis, const float* __restrict__ op, FlowCam c, double* __restrict__ work) {
+	const float* __restrict__ vis, const float* __restrict__ op, FlowCam c0, FlowCamDev cd, double* __restrict__ work) {
 	const int HW = H * W;
+	const FlowCam c = flow_cam_load(c0, cd);
 	double sum = 0, cnt = 0;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
 		const FlowPix p = flow_pixel(i, HW, W, H, f, fl, vis, op, c);
@@ -373,11 +391,12 @@ __global__ void __launch_bounds__(256) aux_finish_kernel(double* __restrict__ wo
 	}
 }
 __global__ void __launch_bounds__(256) flow_loss_bwd_kernel(int H, int W, const float* __restrict__ f, const float* __restrict__ fl,
-	const float* __restrict__ vis, const float* __restrict__ op, FlowCam c, const double* __restrict__ work, const float* __restrict__ g_loss,
+	const float* __restrict__ vis, const float* __restrict__ op, FlowCam c0, FlowCamDev cd, const double* __restrict__ work, const float* __restrict__ g_loss,
 	float* __restrict__ g_f, float* __restrict__ g_op) {
 	const int HW = H * W;
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= HW) return;
+	const FlowCam c = flow_cam_load(c0, cd);
 	const double n = work[2 * AUX_SLOTS + 1];
 	const FlowPix p = flow_pixel(i, HW, W, H, f, fl, vis, op, c);
 	float gx = 0.f, gy = 0.f, gz = 0.f, go = 0.f;
@@ -442,7 +461,9 @@ using namespace adgs;
 // the backward adds 2 (x - mean) / ((K - 1) denom) to the K rows with one atomic each (a Gaussian can sit in several groups).
 // Row indices follow the reference's fancy indexing (`param[obj_near_idx]`): a negative index counts from the end; anything outside
 // [-N, N) raises IndexError there.  A kernel cannot raise without a host round trip, so an out-of-range index (a stale obj_near_idx from
-// before a prune) makes the LOSS NaN -- loud, and no out-of-bounds access -- and its row receives no gradient.
+// before a prune) makes the LOSS NaN -- and no out-of-bounds access -- and the rows of the affected GROUP receive no gradient (a NaN mean would
+// otherwise reach every valid row of the group and, one Adam step later, the parameters and both moments for good).  The host wrapper
+// (adgs.loss._GroupVar) validates every new index tensor once and raises IndexError like the reference.
 constexpr int GV_MAXK = 32;
 __device__ __forceinline__ long long gv_row(long long i, int N) { if (i < 0) i += N; return (i < 0 || i >= N) ? -1 : i; }
 __global__ void __launch_bounds__(256) group_var_sum_kernel(int N, int G, int K, int D, const float* __restrict__ x, const long long* __restrict__ idx,
@@ -472,7 +493,10 @@ __global__ void __launch_bounds__(256) group_var_bwd_kernel(int N, int G, int K,
 	for (int k = 0; k < K; k++) { row[k] = gv_row(idx[(size_t)g * K + k], N); v[k] = row[k] < 0 ? __int_as_float(0x7fc00000) : x[(size_t)row[k] * D + d]; mean += v[k]; }
 	mean /= (float)K;
 	const float c = scale * g_loss[0];
-	for (int k = 0; k < K; k++) if (row[k] >= 0) atomicAdd(dx + (size_t)row[k] * D + d, c * (v[k] - mean));
+	bool valid = true;
+	for (int k = 0; k < K; k++) valid = valid && row[k] >= 0;
+	if (!valid) return;          // a group with an out-of-range index has no defined variance: its rows receive NO gradient (never NaN) -- the forward's loss is NaN
+	for (int k = 0; k < K; k++) atomicAdd(dx + (size_t)row[k] * D + d, c * (v[k] - mean));
 }
 __global__ void __launch_bounds__(256) sigma_loss_sum_kernel(int N, const float* __restrict__ ls, float gap, double* __restrict__ work) {
 	double sum = 0;
@@ -576,28 +600,51 @@ static FlowCam make_flow_cam(const float* K, const float* R, const float* T, flo
 	c.dist = dist;
 	return c;
 }
-extern "C" int adgs_flow_loss_forward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+static int flow_loss_forward_impl(const char* who, bool dev_cam, int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
 	const float* K, const float* R, const float* T, float dist, double* work, float* loss, void* stream_) {
 	if (H <= 0 || W <= 0) return 0;
-	if (!img_flow || !flow || !flow_vis || !K || !R || !T || !work || !loss) { set_error("adgs_flow_loss_forward: NULL pointer"); return -1; }
+	if (!img_flow || !flow || !flow_vis || !K || !R || !T || !work || !loss) { set_error(std::string(who) + ": NULL pointer"); return -1; }
 	hipStream_t stream = (hipStream_t)stream_;
 	const int n = H * W;
-	hipLaunchKernelGGL(flow_loss_sum_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, stream, H, W, img_flow, flow, flow_vis, img_opacity,
-		make_flow_cam(K, R, T, dist), work);
+	FlowCam c; FlowCamDev cd{nullptr, nullptr, nullptr};
+	if (dev_cam) { c = FlowCam{}; c.dist = dist; cd = FlowCamDev{K, R, T}; } else c = make_flow_cam(K, R, T, dist);
+	hipLaunchKernelGGL(flow_loss_sum_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, stream, H, W, img_flow, flow, flow_vis, img_opacity, c, cd, work);
 	hipLaunchKernelGGL(aux_finish_kernel, dim3(1), dim3(256), 0, stream, work, loss);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
-extern "C" int adgs_flow_loss_backward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+static int flow_loss_backward_impl(const char* who, bool dev_cam, int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
 	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
 	void* stream_) {
 	if (H <= 0 || W <= 0) return 0;
-	if (!img_flow || !flow || !flow_vis || !K || !R || !T || !work || !g_loss || !dL_dimg_flow) { set_error("adgs_flow_loss_backward: NULL pointer"); return -1; }
+	if (!img_flow || !flow || !flow_vis || !K || !R || !T || !work || !g_loss || !dL_dimg_flow) { set_error(std::string(who) + ": NULL pointer"); return -1; }
 	const int n = H * W;
+	FlowCam c; FlowCamDev cd{nullptr, nullptr, nullptr};
+	if (dev_cam) { c = FlowCam{}; c.dist = dist; cd = FlowCamDev{K, R, T}; } else c = make_flow_cam(K, R, T, dist);
 	hipLaunchKernelGGL(flow_loss_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, H, W, img_flow, flow, flow_vis, img_opacity,
-		make_flow_cam(K, R, T, dist), work, g_loss, dL_dimg_flow, dL_dimg_opacity);
+		c, cd, work, g_loss, dL_dimg_flow, dL_dimg_opacity);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
+}
+extern "C" int adgs_flow_loss_forward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, double* work, float* loss, void* stream) {
+	return flow_loss_forward_impl("adgs_flow_loss_forward", false, H, W, img_flow, flow, flow_vis, img_opacity, K, R, T, dist, work, loss, stream);
+}
+extern "C" int adgs_flow_loss_forward_devcam(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, double* work, float* loss, void* stream) {
+	return flow_loss_forward_impl("adgs_flow_loss_forward_devcam", true, H, W, img_flow, flow, flow_vis, img_opacity, K, R, T, dist, work, loss, stream);
+}
+extern "C" int adgs_flow_loss_backward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
+	void* stream) {
+	return flow_loss_backward_impl("adgs_flow_loss_backward", false, H, W, img_flow, flow, flow_vis, img_opacity, K, R, T, dist, work, g_loss, dL_dimg_flow,
+		dL_dimg_opacity, stream);
+}
+extern "C" int adgs_flow_loss_backward_devcam(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
+	void* stream) {
+	return flow_loss_backward_impl("adgs_flow_loss_backward_devcam", true, H, W, img_flow, flow, flow_vis, img_opacity, K, R, T, dist, work, g_loss, dL_dimg_flow,
+		dL_dimg_opacity, stream);
 }
 extern "C" int adgs_bce_clip_forward(int n, const float* pred, const float* target, float lo, float hi, int invert, int positive_target,
 	double* work, float* loss, void* stream_) {

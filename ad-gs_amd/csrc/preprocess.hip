@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	__shared__ uint32_t s_cell[MAX_CELLS];     // bucket binning: this workgroup's (cell, Gaussian) pair count per coarse cell
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a.bucket_count) for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) s_cell[c] = 0u;
+	if (idx == 0 && a.cfg_word) *a.cfg_word = a.cfg_value;
 	PreIn in;
 	if (STAGED) {
 		const int tid = threadIdx.x, base = blockIdx.x * 256, nvalid = min(256, a.P - base);

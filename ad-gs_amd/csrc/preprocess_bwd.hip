@@ -443,7 +443,7 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
 	if (a.P == 0) return 0;
 	const bool raw = a.sh_src.scene_dc != nullptr;
 	// the staged kernel needs 16 SH coefficients and, in the v2 (gacc) path, writes every row
-	const bool staged = a.M == 16 && (raw || a.shs) && a.gacc != nullptr && getenv("ADGS_NO_SH_STAGING") == nullptr;
+	const bool staged = a.M == 16 && (raw || a.shs) && a.gacc != nullptr && a.sh_staging != 0;
 	const unsigned grid = (unsigned)((a.P + BW_THREADS - 1) / BW_THREADS);
 	if (staged) {
 		const size_t lds = (size_t)BW_THREADS * (raw ? SH_ROW_REST : SH_ROW_FULL_LDS) * sizeof(float);

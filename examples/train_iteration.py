@@ -5,7 +5,8 @@
     -> L1 + SSIM, scale/shift-invariant depth loss, flow re-projection loss, object BCE, sky BCE (train.py:78-103)
     -> the three regularisers reg_loss / sigma_loss / reg_sigma_loss over obj_near_idx (train.py:104-113)
     -> backward -> densification statistics -> every `densification_interval` iterations densify_and_prune, otherwise every
-       `near_idx_reset_interval` iterations set_obj_near_idx (train.py:146-156) -> both Adam steps (train.py:163-167).
+       `near_idx_reset_interval` iterations set_obj_near_idx, every `opacity_reset_interval` iterations reset_opacity (train.py:146-158)
+       -> both Adam steps (train.py:163-167).
 
     python examples/train_iteration.py [--config C3] [--iters 60] [--env-res 8192] [--cameras 16] [--json]
 
@@ -30,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
 # arguments/__init__.py:104-133
 OPT = types.SimpleNamespace(lambda_dssim=0.2, lambda_l1=1.0, lambda_depth=0.1, lambda_flow=0.1, lambda_obj=0.1, lambda_sky=0.05, lambda_sigma=0.01,
                             lambda_reg=0.5, lambda_sigma_reg=0.5, near_num=8, near_idx_reset_interval=10, densification_interval=200,
-                            densify_scene_grad_threshold=None, densify_obj_grad_threshold=None, env_lr=1e-2)
+                            densify_scene_grad_threshold=None, densify_obj_grad_threshold=None, opacity_reset_interval=3000, min_opacity=0.005, env_lr=1e-2)
 FUSED_IMAGE_LOSSES = os.environ.get("ADGS_FUSED_IMAGE_LOSSES", "1") != "0"
 STAGES = ("regularisers", "render", "losses", "backward", "densify_stats", "near_idx_or_densify", "adam_gaussians", "adam_env_map")
 
@@ -173,10 +174,12 @@ def iteration(it, model, cams, env_map, clock, state):
         if n % opt.densification_interval == 0:                              # :152-153
             if state.get("thr") is None:
                 state["thr"] = densify_threshold(model)
-            model.densify_and_prune(state["thr"], state["thr"], 0.005, False)
+            model.densify_and_prune(state["thr"], state["thr"], opt.min_opacity, False)
             state["densified"] = state.get("densified", 0) + 1
         elif model.use_near_idx and n % opt.near_idx_reset_interval == 0:    # :154-155
             model.set_obj_near_idx()
+        if n % opt.opacity_reset_interval == 0:                              # :157-158
+            model.reset_opacity()
         clock.mark("near_idx_or_densify")
         model.optimizer.step(zero_grad=True)                                 # :163-167 (after a densification the new parameter tensors
         clock.mark("adam_gaussians")                                         #  carry no gradient: that step is skipped, as in the reference)

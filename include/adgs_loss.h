@@ -68,6 +68,14 @@ int adgs_flow_loss_forward(int H, int W, const float* img_flow, const float* flo
 int adgs_flow_loss_backward(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
 	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
 	void* stream);
+/* The same two entry points with K, R, T as DEVICE pointers (train.py:68-71 moves the flow package to the GPU every iteration:
+ * `flow_pkg = [a.cuda() ...]`): the kernels form K R and K T themselves, in the host's operation order (bit-identical results);
+ * nothing is read back and no host-side copy of the camera exists that could go stale. */
+int adgs_flow_loss_forward_devcam(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, double* work, float* loss, void* stream);
+int adgs_flow_loss_backward_devcam(int H, int W, const float* img_flow, const float* flow, const float* flow_vis, const float* img_opacity,
+	const float* K, const float* R, const float* T, float dist, const double* work, const float* g_loss, float* dL_dimg_flow, float* dL_dimg_opacity,
+	void* stream);
 
 /*
  * Clipped binary cross entropy (train.py:95-103): mean BCE of q against t, q = clip(pred, lo, hi) or, with invert,

@@ -34,6 +34,10 @@ long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height
  * 4 adgs_func_eval): a binding checks its mirror against it. */
 size_t adgs_test_abi_sizeof(int which);
 
+/* How many times the rasterizer has read an ADGS_* environment switch so far (process-wide).  The backward of a frame must not read any:
+ * what the forward decided from the environment travels with the frame (api.hip: FrameCfg); a test reads this before and after. */
+unsigned long long adgs_test_env_reads(void);
+
 /* Overwrites the process-wide capacity hints the next default-pipeline forward is enqueued against (pairs, fine pairs; the
  * forward still uses at least P + 4096 / 8 P + 4096): lets a test force the "frame does not fit its capacity" path. */
 void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs);

@@ -58,34 +58,48 @@ def _frame_vs_chain(config, max_frac_img=2e-5):
     frame = bench.DeformFrame(sc, GaussianRasterizer(settings), dev, True)      # exactly what bench.py times
     assert frame.model.raw_sh and frame.fused_flow
     up = synthetic.make_upstream_grads(sc, cfg["seed"])
-    outs = frame.forward()
-    torch.autograd.backward(outs, [d(up[k]) for k in ("color", "depth", "img_opacity", "flow", "semantic")])
-    torch.cuda.synchronize()
     m = frame.model
     raw = chain_ref.raw_numpy(m)
     ups = {k: up[k].numpy() for k in up}
     ref = chain_ref.run_chain(raw, m.order_args, m.use_time_mask, frame.t, frame.t + 0.05, {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in cam.items()},
-                              cfg["H"], cfg["W"], cfg["sh_degree"], ups, semantic=frame.sem.cpu().numpy())
+                              cfg["H"], cfg["W"], cfg["sh_degree"], ups, semantic=frame.sem.cpu().numpy(), strict=True)
+    ex = ref["explained"]
+    parity.assert_masked_coverage(ex, what=config)
+    outs = frame.forward()
+    keys = ("color", "depth", "img_opacity", "flow", "semantic")
+    torch.autograd.backward(outs, [d(up[k]) for k in keys], retain_graph=True)
+    torch.cuda.synchronize()
+    params = {name: getattr(m, chain_ref.attr_of(name)) for name in chain_ref.RAW_NAMES if name != "gs_time"}
+    unmasked = {name: (None if p.grad is None else p.grad.detach().clone()) for name, p in params.items()}
+    for p in params.values():
+        p.grad = None
+    masked_up = parity.mask_upstream({k: up[k] for k in keys}, ex["pixel"])
+    torch.autograd.backward(outs, [d(masked_up[k]) for k in keys])          # the strict pass: no gradient enters at the gate-flip pixels
+    torch.cuda.synchronize()
     n_rad = _check_radii(frame.last_radii.cpu().numpy(), ref["radii"])
-    report = ["%s: %d radii differ" % (config, n_rad)]
+    report = ["%s: %d radii differ; gate-flip mask: %.3g of the pixels, %.3g of the Gaussians" % (config, n_rad, ex["frac_pixel"], ex["frac_gauss"])]
     for name, got, want in zip(("color", "depth", "img_opacity", "img_flow", "img_semantic"), outs,
                                (ref["color"], ref["depth"], ref["img_opacity"], ref["img_flow"], ref["img_semantic"])):
         st = parity.assert_close(name, got.detach().cpu().numpy(), np.asarray(want).reshape(tuple(got.shape)), max_frac=max_frac_img)
         report.append(parity.fmt_stats(name, st))
     checked = 0
-    for name in chain_ref.RAW_NAMES:
-        if name == "gs_time":
-            continue
-        p = getattr(m, chain_ref.attr_of(name))
-        want = ref["raw_grads"][name]
+    for name, p in params.items():
+        want, want_s = ref["raw_grads"][name], ref["raw_grads_strict"][name]
         if p.numel() == 0:
             continue
         if want is None or not np.any(want):
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            assert unmasked[name] is None or float(unmasked[name].abs().max()) == 0.0, name
             continue
-        assert p.grad is not None, name
-        # small tensors: one gate-flipped Gaussian moves the components of its row
-        st = parity.assert_close("grad " + name, p.grad.cpu().numpy(), want, max_frac=max(2e-4, 4.5 / p.numel()))
+        assert p.grad is not None and unmasked[name] is not None, name
+        # THE gradient check: every element, no exemption (tests/parity.py).  n_rad Gaussians whose radius differs by one (the deformation's
+        # last bit, _check_radii) cover other tiles on the two sides: their rows and their tile neighbours' are the only permitted outliers
+        if n_rad == 0:
+            st = parity.assert_close("grad[strict] " + name, p.grad.cpu().numpy(), want_s, strict=True)
+        else:
+            st = parity.assert_close("grad[strict] " + name, p.grad.cpu().numpy(), want_s, max_frac=max(2e-5, 40.0 * n_rad / p.numel()))
+        report.append(parity.fmt_stats("grad[strict] " + name, st))
+        # sanity: the unmasked backward (flips included) -- small tensors: one gate-flipped Gaussian moves the components of its row
+        st = parity.assert_close("grad " + name, unmasked[name].cpu().numpy(), want, max_frac=max(2e-4, 4.5 / p.numel()))
         report.append(parity.fmt_stats("grad " + name, st))
         checked += 1
     print("\n".join(report))

@@ -141,6 +141,49 @@ def test_flow_loss_full_size_vs_oracle_and_bce_terms():
         sky_loss(torch.zeros(4, 4), torch.zeros(4, 4))
 
 
+def test_flow_camera_reallocated_every_iteration_is_never_stale():
+    """train.py:70 `flow_pkg = [a.cuda() ...]`: with the dataset on the CPU every iteration hands in FRESH GPU tensors for K / R / T,
+    and the caching allocator re-issues the same few addresses (version counter 0, same shape).  Each call must use the camera it was
+    given -- device camera and host camera agree bit for bit, forward and backward, standalone term and the fused image_losses node."""
+    from adgs import loss
+    from oracle import loss_oracle as lo
+    rng = np.random.default_rng(11)
+    H, W = 40, 56
+    pts = (rng.normal(size=(3, H, W)) * [[[3.0]], [[2.0]], [[6.0]]] + [[[0.0]], [[0.0]], [[8.0]]]).astype(np.float32)
+    flow = np.stack([rng.random((H, W)) * (W - 1), rng.random((H, W)) * (H - 1)]).astype(np.float32)
+    vis, op = (rng.random((H, W)) * 0.5 + 0.5).astype(np.float32), rng.random((H, W)).astype(np.float32)
+    d = lambda a: torch.tensor(a, device="cuda")
+    seen = set()
+    for it in range(6):
+        K = np.array([[300.0 + 37 * it, 0, W / 2], [0, 310.0 - 11 * it, H / 2], [0, 0, 1]], np.float32)
+        a = 0.1 * it
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+        T = np.array([0.2 - 0.1 * it, 0.05 * it, 0.1], np.float32)
+        Kd, Rd, Td = d(K), d(R), d(T)                         # fresh allocations, freed at the end of the iteration
+        seen.add((Kd.data_ptr(), Rd.data_ptr(), Td.data_ptr()))
+        want, g_f, g_o = lo.flow_loss(pts, flow, vis, op, K, R, T, 0.02)
+        res = []
+        for cam in ((Kd, Rd, Td), (torch.tensor(K), torch.tensor(R), torch.tensor(T))):
+            f, o = d(pts).requires_grad_(True), d(op).requires_grad_(True)
+            l = loss.get_flow_loss(f, (None,) + cam + (d(flow), d(vis)), o, dist=0.02)
+            l.backward()
+            np.testing.assert_allclose(float(l), want, rtol=1e-5, err_msg="iteration %d" % it)
+            np.testing.assert_allclose(f.grad.cpu().numpy(), g_f, rtol=1e-4, atol=1e-4 * np.abs(g_f).max())
+            np.testing.assert_allclose(o.grad.cpu().numpy(), g_o, rtol=1e-4, atol=1e-4 * np.abs(g_o).max())
+            res.append((l.detach().clone(), f.grad.clone(), o.grad.clone()))
+        for x, y in zip(*res):
+            assert torch.equal(x, y)                           # device camera == host camera, bit for bit
+        f = d(pts).requires_grad_(True)
+        z = lambda *s: torch.rand(*s, device="cuda")
+        terms = loss.image_losses(z(3, H, W), z(3, H, W), z(H, W), z(H, W), f, (None, Kd, Rd, Td, d(flow), d(vis)), d(op), z(1, H, W), z(H, W), z(H, W), dist=0.02)
+        assert torch.equal(terms[3], res[0][0])
+        terms[3].backward()
+        assert torch.equal(f.grad, res[0][1])
+        del Kd, Rd, Td
+    assert len({k for k, _, _ in seen}) < 6, "the allocator did not re-issue an address: the test does not exercise the stale-cache case"
+    assert not hasattr(loss, "_HOST_FLOATS")
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ADGS_TEST_SEED_BASE", "0")), int(os.environ.get("ADGS_TEST_SEED_BASE", "0")) + int(os.environ.get("ADGS_TEST_LOSS_SEEDS", "12"))))
 def test_random_image_shapes_vs_oracle(seed):
     """L1 + SSIM, the depth loss and the flow loss on random image shapes (smaller than the 11x11 window, one row / one column,
@@ -251,11 +294,32 @@ def test_regulariser_indices_follow_fancy_indexing_and_never_leave_the_tensor():
     assert abs(float(a) - float(ref)) <= 1e-5 * abs(float(ref))
     for bad_value in (50, -51, 10 ** 12):
         bad = idx.clone(); bad[5, 1] = bad_value
+        with pytest.raises(IndexError):                        # the wrapper validates every new index tensor once, like the reference's indexing
+            loss.reg_loss(x, bad)
+        # ... and below the wrapper (stream capture, other callers of the C ABI) the kernels guard themselves: NaN loss, nothing out of
+        # bounds, and NO gradient for the rows of the affected group -- a NaN there would poison the parameters and both Adam moments
+        import ctypes
+        from adgs import _lib
         guard = torch.full((64,), 7.0, device="cuda")          # memory next to the gradient: must stay untouched
-        v = loss.reg_loss(x, bad)
-        gv, = torch.autograd.grad(v, x)
+        xs = x.detach().contiguous()
+        work = torch.zeros(loss.AUX_WORK_DOUBLES, dtype=torch.float64, device="cuda")
+        out, gl, dx = torch.empty(1, device="cuda"), torch.ones(1, device="cuda"), torch.zeros_like(xs)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib().adgs_group_var_forward(50, 20, 8, 12, 4, xs.data_ptr(), bad.data_ptr(), work.data_ptr(), out.data_ptr(), st), "fwd")
+        _lib.check(_lib.lib().adgs_group_var_backward(50, 20, 8, 12, 4, xs.data_ptr(), bad.data_ptr(), gl.data_ptr(), dx.data_ptr(), st), "bwd")
         torch.cuda.synchronize()
-        assert torch.isnan(v) and bool((guard == 7.0).all()) and gv.shape == x.shape
+        assert torch.isnan(out[0]) and bool((guard == 7.0).all()) and bool(torch.isfinite(dx).all())
+        ok = idx.clone(); ok[5] = ok[4]                        # the same index with group 5 replaced: every other group's gradient is unchanged
+        dx_ok = torch.zeros_like(xs)
+        _lib.check(_lib.lib().adgs_group_var_backward(50, 20, 8, 12, 4, xs.data_ptr(), ok.data_ptr(), gl.data_ptr(), dx_ok.data_ptr(), st), "bwd")
+        only4 = idx[4:5].repeat(20, 1); dx4 = torch.zeros_like(xs)
+        _lib.check(_lib.lib().adgs_group_var_backward(50, 20, 8, 12, 4, xs.data_ptr(), only4.data_ptr(), gl.data_ptr(), dx4.data_ptr(), st), "bwd")
+        torch.cuda.synchronize()
+        assert torch.allclose(dx, dx_ok - dx4 / 20.0, rtol=1e-4, atol=1e-6)
+    loss.reg_loss(x, idx)                                      # a valid tensor is validated once ...
+    idx[0, 0] = 77                                             # ... and again after an in-place change (version counter)
+    with pytest.raises(IndexError):
+        loss.reg_loss(x, idx)
 
 
 @pytest.mark.parametrize("H,W,D_S", [(97, 131, 1), (64, 80, 3)])

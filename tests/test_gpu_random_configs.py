@@ -11,7 +11,26 @@ from adgs import synthetic
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from test_gpu_raster import assert_close, run_hip, run_oracle  # noqa: E402
+from test_gpu_raster import GRAD_PAIRS, assert_close, compare_strict_grads, run_hip, run_oracle  # noqa: E402
+from tests.parity import assert_masked_coverage  # noqa: E402
+
+
+def _both_pipelines(sc, g, opts, env, mask):
+    """The default (v2) and the classic pipeline on one scene, each with the strict second backward (upstream gradients zeroed at `mask`)."""
+    saved = {k: os.environ.get(k) for k in list(env) + ["ADGS_RASTER_MODE"]}
+    try:
+        os.environ.update(env)
+        os.environ.pop("ADGS_RASTER_MODE", None)
+        v2 = run_hip(sc, grads=g, strict_mask=mask, **opts)
+        os.environ["ADGS_RASTER_MODE"] = "classic"
+        cl = run_hip(sc, grads=g, strict_mask=mask, **opts)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return v2, cl
 
 pytestmark = pytest.mark.gpu
 
@@ -36,34 +55,24 @@ _BASE = int(os.environ.get("ADGS_TEST_SEED_BASE", "0"))
 def test_v2_matches_classic_and_oracle_on_random_configs(seed):
     sc, opts, env = _case(seed)
     g = synthetic.make_upstream_grads(sc, seed)
-    saved = {k: os.environ.get(k) for k in list(env) + ["ADGS_RASTER_MODE"]}
-    try:
-        os.environ.update(env)
-        os.environ.pop("ADGS_RASTER_MODE", None)
-        v2 = run_hip(sc, grads=g, **opts)
-        os.environ["ADGS_RASTER_MODE"] = "classic"
-        cl = run_hip(sc, grads=g, **opts)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    ref = run_oracle(sc, grads=g, **opts)
-    assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
-    # an element outside 1e-4 passes only where the oracle's gate margins explain it (a pixel whose walk came within float32 rounding
-    # error of a gate; a Gaussian such a pixel feeds): tests/parity.py.  The same masks describe v2 ~ classic: two float32 evaluations
-    # of one frame.
+    ref = run_oracle(sc, grads=g, strict=True, **opts)
     ex = ref["explained"]
+    assert_masked_coverage(ex, limit=0.08, what="seed %d" % seed)          # images of a few hundred pixels: one flagged tile corner is percents
+    v2, cl = _both_pipelines(sc, g, opts, env, ex["pixel"])
+    assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
+    # images: an element outside 1e-4 passes only in a pixel whose walk came within float32 rounding error of a gate (tests/parity.py).
+    # The same mask describes v2 ~ classic: two float32 evaluations of one frame.
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a, b = v2[k].detach().cpu().numpy(), cl[k].detach().cpu().numpy()
         assert_close(k + " v2~classic", a, b, explained=ex["pixel"])
         assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"])
-    for k, gv in v2["grads"].items():
+    # gradients: the strict pass (no gradient enters at the flagged pixels), every element, both pipelines against the oracle
+    compare_strict_grads(v2, ref, "v2~oracle ")
+    compare_strict_grads(cl, ref, "classic~oracle ")
+    for k, gv in v2["grads"].items():                                       # sanity: the unmasked backward, flips included
         if gv is None:
             continue
-        a, b = gv.cpu().numpy(), cl["grads"][k].cpu().numpy()
-        assert_close("grad " + k + " v2~classic", a, b, explained=ex["gauss"])
+        assert_close("grad " + k + " v2~classic", gv.cpu().numpy(), cl["grads"][k].cpu().numpy(), explained=ex["gauss"])
 
 
 def _large_case(seed):
@@ -82,29 +91,19 @@ def _large_case(seed):
 def test_v2_matches_classic_and_oracle_on_large_random_configs(seed):
     sc, opts, env = _large_case(seed)
     g = synthetic.make_upstream_grads(sc, seed)
-    saved = {k: os.environ.get(k) for k in list(env) + ["ADGS_RASTER_MODE"]}
-    try:
-        os.environ.update(env)
-        os.environ.pop("ADGS_RASTER_MODE", None)
-        v2 = run_hip(sc, grads=g, **opts)
-        os.environ["ADGS_RASTER_MODE"] = "classic"
-        cl = run_hip(sc, grads=g, **opts)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    ref = run_oracle(sc, grads=g, **opts)
-    assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
+    ref = run_oracle(sc, grads=g, strict=True, **opts)
     ex = ref["explained"]
+    assert_masked_coverage(ex, what="large seed %d" % seed)
+    v2, cl = _both_pipelines(sc, g, opts, env, ex["pixel"])
+    assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a = v2[k].detach().cpu().numpy()
         assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), explained=ex["pixel"])
         assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"])
-    names = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations",
-                 flow="dL_dflow_points", sem="dL_dsemantic")
-    for k, gv in v2["grads"].items():
+    compare_strict_grads(v2, ref, "v2~oracle ")
+    compare_strict_grads(cl, ref, "classic~oracle ")
+    names = dict(GRAD_PAIRS)
+    for k, gv in v2["grads"].items():                                       # sanity: the unmasked backward, flips included
         if gv is None:
             continue
         a = gv.cpu().numpy()
@@ -193,58 +192,52 @@ def test_adversarial_scenes_match_classic_and_oracle(seed):
     g = synthetic.make_upstream_grads(sc, seed)
     opts = dict(flow=bool(rng.randint(2)), sem=bool(rng.randint(2)), inv_depth=bool(rng.randint(2)), degree=int(rng.randint(0, 4)))
     env = dict(ADGS_CELL_TILES=str(int(rng.choice([1, 4, 8, 12]))), ADGS_V2_PPL=str(int(rng.choice([2, 4]))))
-    saved = {k: os.environ.get(k) for k in list(env) + ["ADGS_RASTER_MODE"]}
-    try:
-        os.environ.update(env)
-        os.environ.pop("ADGS_RASTER_MODE", None)
-        v2 = run_hip(sc, grads=g, **opts)
-        os.environ["ADGS_RASTER_MODE"] = "classic"
-        cl = run_hip(sc, grads=g, **opts)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    ref = run_oracle(sc, grads=g, **opts)
+    ref = run_oracle(sc, grads=g, strict=True, **opts)
+    ex = ref["explained"]
+    # 5 % of these Gaussians sit exactly ON the 1/255 gate and needles graze it along their whole length: the flagged share of the pixels is
+    # far above an ordinary frame's -- bounded all the same, and every unflagged pixel is held to the tolerance
+    assert_masked_coverage(ex, limit=0.5, what="adversarial seed %d" % seed)
+    v2, cl = _both_pipelines(sc, g, opts, env, ex["pixel"])
     assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a = v2[k].detach().cpu().numpy()
         assert np.isfinite(a).all(), k
-        # 5 % of these Gaussians sit exactly ON the 1/255 gate: pixels flip between any two float32 evaluations (seed 7042: 0.2 % of the
-        # colour elements between the two HIP pipelines).  A deviation passes only where the oracle has a gate within GATE_EPS of its
-        # threshold for a Gaussian that feeds the pixel (tests/parity.py)
-        # ... and needles / image-filling Gaussians make alpha itself ill-conditioned (|power| is the small difference of terms of
-        # magnitude 1e3 .. 1e4): the tolerance grows by the first-order bound of that effect per pixel (parity.py: COND_K, `slack`)
-        ex = ref["explained"]
+        # a deviation passes only where the oracle has a gate within GATE_EPS of its threshold for a Gaussian that feeds the pixel
+        # (tests/parity.py) ... and needles / image-filling Gaussians make alpha itself ill-conditioned (|power| is the small difference of
+        # terms of magnitude 1e3 .. 1e4): the tolerance grows by the first-order bound of that effect per pixel (parity.py: COND_K, `slack`)
         assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), explained=ex["pixel"], slack=ex["slack"])
         assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"], slack=ex["slack"])
-    names = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales", rotations="dL_drotations",
-                 flow="dL_dflow_points", sem="dL_dsemantic")
-    # Gradients: needles, image-filling and unnormalised Gaussians make dL/drotation (and a few dL/dmean) ill-conditioned -- the fp32
-    # CPU oracle itself then misses the float64 oracle by percents on those rows.  The HIP path is held to the float64 result with
-    # the usual tolerance on every element where the fp32 oracle meets it too, and to a few times the fp32 oracle's own error elsewhere.
-    ref64 = run_oracle(sc, grads=g, precision="f64", **opts)
+    names = dict(GRAD_PAIRS)
+    # Gradients (the STRICT backward: no gradient enters at the flagged pixels, so no flip is involved): needles, image-filling and
+    # unnormalised Gaussians make dL/drotation (and a few dL/dmean) ill-conditioned -- the fp32 CPU oracle itself then misses the float64
+    # oracle by percents on those rows.  The HIP path is held to the float64 result with the usual tolerance on every row where float32
+    # can meet it, and to a few times the float32 ORACLE's own error elsewhere.  The yardstick comes from the oracle alone (round-4 advisor:
+    # the repository's other pipeline shares preprocess_bwd with v2 and must not widen its tolerance): one float32 evaluation is a single
+    # draw (accidentally exact on some ill-conditioned rows: seed 7032), so the second draw is the float32 oracle on inputs moved by ONE
+    # float32 ulp -- what any float32 evaluation may legitimately mistake the inputs for.
+    ref64 = run_oracle(sc, grads=g, precision="f64", strict_mask=ex["pixel"], **opts)
     if not np.array_equal(np.asarray(ref64["radii"]), ref["radii"]):
         return                                              # a cull / radius decision that differs between fp32 and fp64: no common ground truth
-    for k, gv in v2["grads"].items():
+    prng = np.random.RandomState(77000 + seed)
+    sc_p = dict(sc)
+    for k in ("means3D", "scales", "rotations", "opacities"):
+        sgn = torch.tensor(prng.choice([-1.0, 1.0], size=tuple(sc[k].shape)).astype(np.float32))
+        sc_p[k] = (sc[k] * (1.0 + sgn * 2.0 ** -23)).float().contiguous()
+    refp = run_oracle(sc_p, grads=g, strict_mask=ex["pixel"], **opts)
+    same_cull = np.array_equal(refp["radii"], ref["radii"])
+    for k, gv in v2["grads_strict"].items():
         if gv is None or k not in names:
             continue
         a = gv.cpu().numpy().astype(np.float64)
-        r64 = np.asarray(ref64["grads"][names[k]], np.float64).reshape(a.shape)
-        r32 = np.asarray(ref["grads"][names[k]], np.float64).reshape(a.shape)
+        assert np.isfinite(a).all(), k
+        r64 = np.asarray(ref64["grads_strict"][names[k]], np.float64).reshape(a.shape)
+        r32 = np.asarray(ref["grads_strict"][names[k]], np.float64).reshape(a.shape)
         scale = max(np.abs(r64).max(), 1e-30)
         tol = 1e-4 * np.abs(r64) + 1e-4 * scale
-        e_hip, e_o32 = np.abs(a - r64), np.abs(r32 - r64)
         rows = lambda e: e.reshape(e.shape[0], -1).max(1)                      # conditioning is a per-Gaussian property
-        # what a float32 evaluation of the row is off by: ONE float32 result is a single draw (it is accidentally exact on some ill-conditioned
-        # rows: seed 7032 fails 3 rows of 3000 that way), so the classic HIP pipeline -- another float32 evaluation order of the same
-        # algorithm, computed above -- is the second draw
-        e_f32 = rows(e_o32)
-        c = cl["grads"].get(k)
-        if c is not None:
-            e_f32 = np.maximum(e_f32, rows(np.abs(c.cpu().numpy().astype(np.float64) - r64)))
+        e_hip, e_f32 = np.abs(a - r64), rows(np.abs(r32 - r64))
+        if same_cull:
+            e_f32 = np.maximum(e_f32, rows(np.abs(np.asarray(refp["grads_strict"][names[k]], np.float64).reshape(a.shape) - r64)))
         bad = (rows(e_hip - tol) > 0) & (rows(e_hip) > 8.0 * e_f32 + 1e-6 * scale)
         assert bad.sum() <= max(2, 5e-4 * bad.size), "grad %s: %d of %d rows miss float64 by more than 8x the fp32 oracle's own error (max %.3g, scale %.3g)" % (
             k, int(bad.sum()), bad.size, float(rows(e_hip)[bad].max()), scale)
-        assert np.isfinite(a).all(), k

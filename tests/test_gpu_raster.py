@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-from tests.parity import assert_close, explained_masks  # noqa: E402  (element-wise 1e-4 + relative L2 + per-row relative error; tests/parity.py)
+from tests.parity import assert_close, assert_masked_coverage, explained_masks, mask_upstream  # noqa: E402  (element-wise 1e-4 + relative L2 + per-row relative error; tests/parity.py)
 
 
 def dev(t):
@@ -31,7 +31,9 @@ def dev(t):
 
 
 def run_hip(sc, colors=None, cov3D=None, use_sh=True, flow=True, sem=True, inv_depth=True, scale_modifier=1.0, degree=None,
-            semantic=None, bg=None, grads=None, debug=False):
+            semantic=None, bg=None, grads=None, debug=False, strict_mask=None):
+    """strict_mask ([H, W] bool, the oracle's gate-flip pixels): a SECOND backward over the same forward state with the upstream gradients
+    zeroed there -> res["grads_strict"] (tests/parity.py: the strict gradient pass)."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     settings = GaussianRasterizationSettings(
         image_height=sc["H"], image_width=sc["W"], tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"],
@@ -51,19 +53,29 @@ def run_hip(sc, colors=None, cov3D=None, use_sh=True, flow=True, sem=True, inv_d
     color, radii, depth, img_opacity, img_flow, img_sem = out
     res = dict(color=color, radii=radii, depth=depth, img_opacity=img_opacity, img_flow=img_flow, img_semantic=img_sem)
     if grads is not None:
-        loss = (color * dev(grads["color"])).sum() + (depth * dev(grads["depth"])).sum() + (img_opacity * dev(grads["img_opacity"])).sum()
-        if flow:
-            loss = loss + (img_flow * dev(grads["flow"])).sum()
-        if sem:
-            loss = loss + (img_sem * dev(grads["semantic"])).sum()
-        loss.backward()
+        def total(g):
+            loss = (color * dev(g["color"])).sum() + (depth * dev(g["depth"])).sum() + (img_opacity * dev(g["img_opacity"])).sum()
+            if flow:
+                loss = loss + (img_flow * dev(g["flow"])).sum()
+            if sem:
+                loss = loss + (img_sem * dev(g["semantic"])).sum()
+            return loss
+        total(grads).backward(retain_graph=strict_mask is not None)
         res["grads"] = {k: (v.grad if v is not None else None) for k, v in L.items()}
+        if strict_mask is not None:
+            for v in L.values():
+                if v is not None:
+                    v.grad = None
+            total(mask_upstream(grads, strict_mask)).backward()
+            res["grads_strict"] = {k: (v.grad if v is not None else None) for k, v in L.items()}
     torch.cuda.synchronize()
     return res
 
 
 def run_oracle(sc, colors=None, cov3D=None, use_sh=True, flow=True, sem=True, inv_depth=True, scale_modifier=1.0, degree=None,
-               semantic=None, bg=None, grads=None, precision="f32"):
+               semantic=None, bg=None, grads=None, precision="f32", strict=False, strict_mask=None):
+    """strict: also out["grads_strict"], the backward with the upstream gradients zeroed at the gate-flip pixels (`strict_mask`, default
+    this run's own out["explained"]["pixel"])."""
     o = oracle.RasterOracle(precision)
     semt = (sc["semantic"] if semantic is None else semantic) if sem else None
     out = o.forward(sc["bg"] if bg is None else bg, sc["means3D"], colors, sc["opacities"],
@@ -75,26 +87,49 @@ def run_oracle(sc, colors=None, cov3D=None, use_sh=True, flow=True, sem=True, in
     if grads is not None:
         # unused outputs receive materialised ZERO grads from autograd
         H, W = sc["H"], sc["W"]
-        out["grads"] = o.backward(grads["color"], grads["depth"], grads["flow"] if flow else np.zeros((3, H, W), np.float32),
-                                  grads["semantic"] if sem else None, grads["img_opacity"])
+        back = lambda g: o.backward(g["color"], g["depth"], g["flow"] if flow else np.zeros((3, H, W), np.float32),
+                                    g["semantic"] if sem else None, g["img_opacity"])
+        out["grads"] = back(grads)
+        if strict or strict_mask is not None:
+            gm = mask_upstream({k: (v.numpy() if torch.is_tensor(v) else v) for k, v in grads.items()},
+                               out["explained"]["pixel"] if strict_mask is None else strict_mask)
+            out["grads_strict"] = back(gm)
     return out
 
 
-def compare(sc, **kw):
+GRAD_PAIRS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh"),
+              ("colors", "dL_dcolors"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"), ("cov3D", "dL_dcov3D"),
+              ("flow", "dL_dflow_points"), ("sem", "dL_dsemantic")]
+
+
+def compare_strict_grads(h, o, label=""):
+    """THE gradient parity check (tests/parity.py): the backward with the upstream gradients zeroed at the oracle's gate-flip pixels, on both
+    sides -- every element of every gradient tensor, no exemption."""
+    g, og = h["grads_strict"], o["grads_strict"]
+    n = 0
+    for hk, ok in GRAD_PAIRS:
+        if g.get(hk) is None:
+            continue
+        assert_close(label + "grad_" + hk, g[hk].cpu().numpy(), np.asarray(og[ok]).reshape(g[hk].shape), strict=True)
+        n += 1
+    return n
+
+
+def compare(sc, coverage=None, **kw):
     grads = kw.get("grads")
-    h = run_hip(sc, **kw)
-    kw.pop("debug", None)
-    o = run_oracle(sc, **kw)
-    np.testing.assert_array_equal(h["radii"].cpu().numpy(), o["radii"])
+    okw = dict(kw); okw.pop("debug", None)
+    o = run_oracle(sc, strict=grads is not None, **okw)
     ex = o["explained"]
+    assert_masked_coverage(ex, **({} if coverage is None else dict(limit=coverage)))
+    h = run_hip(sc, strict_mask=ex["pixel"] if grads is not None else None, **kw)
+    np.testing.assert_array_equal(h["radii"].cpu().numpy(), o["radii"])
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         assert_close(k, h[k].detach().cpu().numpy(), o[k], explained=ex["pixel"])
     if grads is not None:
+        assert compare_strict_grads(h, o) >= 1
+        # sanity only (bounds nothing for the rows a flagged pixel feeds -- most rows at full size): the unmasked backward, flips included
         g, og = h["grads"], o["grads"]
-        pairs = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh"),
-                 ("colors", "dL_dcolors"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"), ("cov3D", "dL_dcov3D"),
-                 ("flow", "dL_dflow_points"), ("sem", "dL_dsemantic")]
-        for hk, ok in pairs:
+        for hk, ok in GRAD_PAIRS:
             if g.get(hk) is None:
                 continue
             assert_close("grad_" + hk, g[hk].cpu().numpy(), og[ok].reshape(g[hk].shape), explained=ex["gauss"])
@@ -402,8 +437,12 @@ def test_backward_uses_the_forwards_configuration_not_the_environment(monkeypatc
     monkeypatch.setenv("ADGS_CELL_TILES", "3")
     monkeypatch.setenv("ADGS_V2_PPL", "4")
     monkeypatch.setenv("ADGS_RASTER_MODE", "classic")
+    monkeypatch.setenv("ADGS_TILE_ORDER", "0")
+    monkeypatch.setenv("ADGS_NO_SH_STAGING", "1")
+    reads = _lib.lib().adgs_test_env_reads()
     torch.autograd.backward([out[0], out[2], out[3], out[4], out[5]], [dev(g["color"]), dev(g["depth"]), dev(g["img_opacity"]), dev(g["flow"]), dev(g["semantic"])])
     torch.cuda.synchronize()
+    assert _lib.lib().adgs_test_env_reads() == reads, "the backward read the environment: the forward decides, the frame state carries it"
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         assert_close("grad_" + k, L[k].grad.cpu().numpy(), ref["grads"][k].cpu().numpy(), tol=2e-5, max_frac=1e-4, rel_l2=2e-5)      # two runs: the order of the float atomics differs
 
