@@ -3,6 +3,7 @@
 There is NO CPU fallback: if the library is missing or cannot be loaded this
 module raises, and every operator built on it raises with it.
 """
+import contextlib
 import ctypes
 import os
 
@@ -42,6 +43,7 @@ SIGNATURES = {
     "adgs_get_frame_stats": (None, [c_p]),
     "adgs_get_frame_status": (c_i, [c_p]),
     "adgs_raster_needs_zero_init": (c_i, [c_i]),
+    "adgs_raster_backward_needs_zero_init": (c_i, [c_p, c_p, c_i, c_i, c_i]),
     "adgs_profile_enable": (None, [c_i]),
     "adgs_profile_reserve": (c_i, [c_i]),
     "adgs_profile_num_stages": (c_i, []),
@@ -144,6 +146,16 @@ def lib():
 def last_error():
     msg = lib().adgs_last_error()
     return msg.decode("utf-8", "replace") if msg else ""
+
+
+_NULL_CTX = contextlib.nullcontext()
+
+
+def on_device(device):
+    """`with torch.cuda.device(device)` only when `device` is not already the current one (the context manager costs ~10 us per use and
+    every wrapper of the library needs the right device current while it launches)."""
+    import torch
+    return _NULL_CTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
 def check(code, what):

@@ -156,7 +156,7 @@ class _FuncEvalFn(torch.autograd.Function):
         lead, D = p.shape[:-2], p.shape[-2]
         N = int(np.prod(lead)) if len(lead) else 1
         out = torch.empty(*lead, D, dtype=torch.float32, device=p.device)
-        with torch.cuda.device(p.device):
+        with _lib.on_device(p.device):
             _lib.check(_lib.lib().adgs_func_eval_forward(N, D, p.data_ptr(), ctypes.byref(feval), out.data_ptr(), _stream(p.device)),
                        "adgs_func_eval_forward")
         ctx.save_for_backward(p)
@@ -168,7 +168,7 @@ class _FuncEvalFn(torch.autograd.Function):
         (p,) = ctx.saved_tensors
         gp = torch.zeros_like(p)
         g = g.contiguous().float()
-        with torch.cuda.device(p.device):
+        with _lib.on_device(p.device):
             _lib.check(_lib.lib().adgs_func_eval_backward(ctx.N, ctx.D, p.data_ptr(), ctypes.byref(ctx.feval), g.data_ptr(), gp.data_ptr(),
                                                           _stream(p.device)), "adgs_func_eval_backward")
         return gp, None
@@ -228,7 +228,7 @@ class _DeformPkgFn(torch.autograd.Function):
         o = DeformOutputs()
         for k, v in outs.items():
             setattr(o, k, _dp(v))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().adgs_deform_forward_flow(
                 ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]), ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]),
                 ctypes.byref(fe["xyz_flow"]) if flow_t is not None else None, ctypes.byref(fe["background_flow"]) if flow_t is not None else None,
@@ -293,7 +293,7 @@ class _DeformPkgFn(torch.autograd.Function):
                 grads[n] = g if g is not None else torch.empty_like(src)
             setattr(gs, n, _dp(grads[n]))
         fe = ctx.fe
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().adgs_deform_backward_flow(
                 ctypes.byref(p), ctypes.byref(fe["xyz"]), ctypes.byref(fe["rotation"]), ctypes.byref(fe["shs"]), ctypes.byref(fe["background"]),
                 ctypes.byref(fe["xyz_flow"]) if flow_t is not None else None, ctypes.byref(fe["background_flow"]) if flow_t is not None else None,

@@ -386,6 +386,13 @@ extern "C" int adgs_get_frame_status(adgs_frame_status* out) {
 // 1 if the caller must zero-fill the outputs of forward/backward for this D_S (the classic,
 // atomics-into-outputs pipeline; also the reference's contract), 0 if every element is written.
 extern "C" int adgs_raster_needs_zero_init(int D_S) { return use_v2(D_S) ? 0 : 1; }
+// The same question for the BACKWARD of a given forward: answered from the frame table (what that forward decided), never from the
+// environment; a state the table does not know is answered "zero-fill" (always safe).
+extern "C" int adgs_raster_backward_needs_zero_init(const char* geom_buffer, const char* img_buffer, int width, int height, int P) {
+	FrameCfg cfg;
+	if (!lookup_frame(FrameKey{ img_buffer, geom_buffer, width, height, P }, &cfg)) return 1;
+	return cfg.v2 ? 0 : 1;
+}
 
 extern "C" void adgs_profile_enable(int stage_mask) { g_prof_mask.store((unsigned)stage_mask); }
 // Pre-creates event objects so that a measurement loop never calls hipEventCreate (a driver call that can block).

@@ -36,6 +36,10 @@ constexpr float PIXEL_DONE = 3.0e38f;      // row coordinate of a pixel that tak
 // pixels per lane: 4 (one wave = one 16x16 tile) or, for small images that would leave the chip idle, 2 (one wave = a 16x8
 // half tile: twice the waves, a shorter dependent chain per wave); PPL is a template parameter of both blend kernels
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
+#ifndef ADGS_SPLAT_ROW
+#define ADGS_SPLAT_ROW 5           // float4 quads between two gathered Splat rows in LDS (4: dense, the round-4 layout; A/B builds)
+#endif
+constexpr int SPLAT_ROW = ADGS_SPLAT_ROW;
 
 // The exponent is kept in log2 units (entry_geom scales the conic by log2 e once per entry): G = 2^pw is ONE v_exp_f32 per pixel
 // (~1 ulp), not v_mul + v_exp.  ADGS_PRECISE_EXP: libm's exp2f (parity experiments: the share of gate flips the fast exp owns).
@@ -149,12 +153,22 @@ __device__ __forceinline__ uint64_t eval_entry_fwd(const EntryGeom& eg, const fl
 template <int PPL>
 __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(RenderV2FwdArgs a) {
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
-	__shared__ float4 s_splat[WAVE * 4];
+	// Gathered Splat lines, one ROW per candidate.  Rows are SPLAT_ROW = 5 quads apart (80 bytes), not 4: lane l stores its line with four
+	// ds_write_b128 at l * 64 bytes otherwise, and the sixteen lanes of a pass land on four bank quads (round 4: SQ_LDS_BANK_CONFLICT = 23 % of
+	// the kernel's LDS-active cycles); at 80 bytes the sixteen start banks 20 l mod 64 are all different.  The fifth quad of the 64 rows is
+	// exactly the 256-entry candidate ring (s_cand): the kernel's LDS footprint stays 7680 bytes = 21 workgroups per CU.
 	__shared__ uint32_t s_pub[2 * WAVE];         // live ids waiting to leave as a full chunk
 	// key-stream scan: SCAN_ROUNDS x 64 list entries per step; ring: < 64 waiting + one step's survivors, power of two.  With the
 	// staged key stream (below) a step is half a staged block: 4096 + 512 + 1024 + 2048 bytes of LDS = 21 workgroups per CU.
 	constexpr int SCAN_ROUNDS = ADGS_FWD_DMA ? ADGS_FWD_SCAN_ROUNDS : 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
-	__shared__ uint32_t s_cand[CAND_RING];
+	constexpr bool CAND_IN_PAD = CAND_RING == 4 * WAVE && SPLAT_ROW == 5;        // the ring lives in the rows' pad quads (else: behind the rows)
+	constexpr int SPLAT_BYTES = WAVE * SPLAT_ROW * (int)sizeof(float4);
+	__shared__ __attribute__((aligned(16))) unsigned char s_rows[SPLAT_BYTES + (CAND_IN_PAD ? 0 : CAND_RING * (int)sizeof(uint32_t))];
+	float4* const s_splat = reinterpret_cast<float4*>(s_rows);
+	uint32_t* const s_cand_own = reinterpret_cast<uint32_t*>(s_rows + SPLAT_BYTES);
+	auto cand = [&](uint32_t i) -> uint32_t& {
+		return CAND_IN_PAD ? reinterpret_cast<uint32_t*>(s_splat)[(i >> 2) * (4 * SPLAT_ROW) + 16 + (i & 3u)] : s_cand_own[i];
+	};
 	// The key stream of a cell is SEQUENTIAL and the tile's position in it is known long before the entries are needed: the next
 	// block of KEY_BLOCK (id, mask) entries is copied global -> LDS by the DMA path of the load unit (global_load_lds_dwordx4: no
 	// registers, two instructions per block) as soon as the previous block has been scanned, i.e. it flies under the filter round, the
@@ -344,7 +358,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 				const bool have = pos + r * WAVE + lane < range.y;
 				const bool rp = have && (((key[r] >> row_bit) & (key[r] >> col_bit)) & 1u);
 				const uint64_t m = __ballot(rp);
-				if (rp) s_cand[(chead + ccount + __popcll(m & lt_mask)) & (CAND_RING - 1)] = id[r];
+				if (rp) cand((chead + ccount + __popcll(m & lt_mask)) & (CAND_RING - 1)) = id[r];
 				ccount += __popcll(m);
 			}
 			pos += SCAN_ROUNDS * WAVE;
@@ -357,14 +371,14 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		// compaction -- sixteen registers of gathered line per lane next to the blend accumulators cost a wave per SIMD)
 		bool pass = false, my_lean = false; uint32_t myid = 0;
 		if ((uint32_t)lane < nc) {
-			myid = s_cand[(chead + lane) & (CAND_RING - 1)];
+			myid = cand((chead + lane) & (CAND_RING - 1));
 			PT(t_f0);
 			const float4* src = reinterpret_cast<const float4*>(a.splats + myid);
 			float4 g0 = src[0], g1 = src[1];
 			const float4 g2 = src[2], g3 = src[3];
 			PT_WAIT_VM8(8, 9, t_f0, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w);
-			s_splat[lane * 4 + 2] = g2; s_splat[lane * 4 + 3] = g3;
-			s_splat[lane * 4 + 0] = g0; s_splat[lane * 4 + 1] = g1;
+			s_splat[lane * SPLAT_ROW + 2] = g2; s_splat[lane * SPLAT_ROW + 3] = g3;
+			s_splat[lane * SPLAT_ROW + 0] = g0; s_splat[lane * SPLAT_ROW + 1] = g1;
 			pass = tile_may_contribute(g0, g1.x, g3.z, tx, ty * ROWS, ROWS);      // g3.z: tau (Splat::aux)
 			my_lean = ADGS_LEAN && pass && g3.w != 0.f;
 		}
@@ -391,8 +405,8 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
 		for (uint64_t todo = pm; todo != 0ull; todo &= todo - 1ull) {
 			const uint32_t j = (uint32_t)__builtin_ctzll(todo);
-			const float4 q0 = s_splat[j * 4 + 0];      // x y ca cb
-			const float4 q1 = s_splat[j * 4 + 1];      // cc op r g
+			const float4 q0 = s_splat[j * SPLAT_ROW + 0];      // x y ca cb
+			const float4 q1 = s_splat[j * SPLAT_ROW + 1];      // cc op r g
 			const EntryGeom eg = entry_geom(q0, q1, q0.x - pxf);
 			PROBE_EVAL();
 			float alpha[PPL]; uint64_t actm[PPL];
@@ -403,8 +417,8 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
 			asm volatile("" : "+v"(position));        // one copy into a vector register per entry (else: one v_mov per strip)
 			live |= 1ull << j;
-			const float4 q2 = s_splat[j * 4 + 2];      // b dval fx fy
-			const float4 q3 = s_splat[j * 4 + 3];      // fz sem0 zview lean
+			const float4 q2 = s_splat[j * SPLAT_ROW + 2];      // b dval fx fy
+			const float4 q3 = s_splat[j * SPLAT_ROW + 3];      // fz sem0 zview lean
 #pragma unroll
 			for (int k = 0; k < PPL; k++) {
 				if (actm[k] == 0ull) continue;           // wave-uniform: a 16x4 pixel strip the entry does not reach costs nothing
@@ -560,7 +574,10 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
 	// 4096 + 3584 bytes: 21 one-wave workgroups per CU (8768 bytes until round 3 capped the kernel at 18 = 4.5 waves per SIMD whatever
 	// its registers allowed)
-	__shared__ float4 s_splat[WAVE * 4];
+	// rows 80 bytes apart: conflict-free ds_write_b128 (see the forward) where the registers cap the kernel at 16 workgroups per CU anyway
+	// (PPL = 4: 5120 + 3584 bytes = 18 per CU); the half-tile kernels (88 registers: 20 per CU) keep the dense 7680-byte layout
+	constexpr int BROW = PPL == 4 ? SPLAT_ROW : 4;
+	__shared__ float4 s_splat[WAVE * BROW];
 	__shared__ __attribute__((aligned(16))) float s_red[RED_ROWS * RED_STRIDE];
 	const int lane = threadIdx.x;
 	const uint32_t tile = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
@@ -676,7 +693,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 			__syncthreads();
 			bool my_lean = false;
 			if (lane < n) {
-				s_splat[lane * 4 + 0] = c0; s_splat[lane * 4 + 1] = c1; s_splat[lane * 4 + 2] = c2; s_splat[lane * 4 + 3] = c3;
+				s_splat[lane * BROW + 0] = c0; s_splat[lane * BROW + 1] = c1; s_splat[lane * BROW + 2] = c2; s_splat[lane * BROW + 3] = c3;
 				my_lean = ADGS_LEAN && c3.w != 0.f;
 			}
 			// the chunk behind this one: its lines fly while this chunk is replayed; the ids of the one behind that follow
@@ -703,7 +720,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 			for (int j = j_first; j >= 0; j--) {
 				const int contributor = base + j;
 				PT_ADD(7, 1ull);
-				const float4 q0 = s_splat[j * 4 + 0], q1 = s_splat[j * 4 + 1];
+				const float4 q0 = s_splat[j * BROW + 0], q1 = s_splat[j * BROW + 1];
 				const float dx = q0.x - pxf;
 				const EntryGeom eg = entry_geom(q0, q1, dx);
 				// the entry's Gaussian: a scalar from the id register (lane j holds entry j), early -- its only use is the atomic's address
@@ -713,8 +730,8 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				const uint64_t any_m = ((lean_m >> j) & 1ull) ? eval_entry_bwd<true, PPL>(eg, pyf0, contributor, last_contributor, alpha, G, dy, actm)
 				                            : eval_entry_bwd<false, PPL>(eg, pyf0, contributor, last_contributor, alpha, G, dy, actm);
 				if (any_m == 0ull) continue;
-				const float4 q2 = s_splat[j * 4 + 2];
-				const float4 q3 = s_splat[j * 4 + 3];
+				const float4 q2 = s_splat[j * BROW + 2];
+				const float4 q3 = s_splat[j * BROW + 3];
 				PROBE_LIVE(actm, PPL);
 				// geometric part: with L = G * dL/dalpha per pixel, the reference's six sums are linear in
 				//   S0 = sum L, Sx = sum L dx, Sy = sum L dy, Sxx = sum L dx^2, Sxy = sum L dx dy, Syy = sum L dy^2

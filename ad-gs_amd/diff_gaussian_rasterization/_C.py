@@ -5,6 +5,7 @@ rasterize_points.cu:35-275), implemented over the C ABI of libadgs_hip.so.
 Tensors must live on a HIP ("cuda") device; there is no CPU path.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -34,19 +35,35 @@ def _prep(t, device, name, dtype=torch.float32):
 
 
 class _Buffer:
-    """Byte buffer grown through the C allocator callback (the reference's resizeFunctional,
-    rasterize_points.cu:27-33)."""
+    """Byte buffer grown through the C allocator callback (the reference's resizeFunctional, rasterize_points.cu:27-33).
+
+    ONE ctypes callback serves every buffer of the process: creating a CFUNCTYPE thunk costs ~10 us, and a forward needs three buffers.
+    The library hands the callback the `user` pointer it was given next to it (include/adgs_rasterizer.h: adgs_alloc_fn) -- here a slot
+    number of a per-thread table of the tensors being grown (the callback runs synchronously inside the forward call, on its thread)."""
+    _tls = threading.local()
 
     def __init__(self, device):
-        t = torch.empty(0, dtype=torch.uint8, device=device)
-        self.t = t
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+        slots = getattr(_Buffer._tls, "slots", None)
+        if slots is None:
+            slots = _Buffer._tls.slots = {}
+        self.user = (max(slots) + 1) if slots else 1
+        slots[self.user] = self.t             # the table holds the tensor, not self: no reference cycle (0.4 GB of frame state at C3)
+        self.cb = _ALLOC_CB
 
-        # the callback closes over the tensor, NOT over self: self -> cb -> closure -> self would be a reference cycle that
-        # keeps every frame's buffers (0.4 GB at C3) alive until the cyclic garbage collector runs
-        def cb(_user, nbytes):
-            t.resize_(int(nbytes))
-            return t.data_ptr()
-        self.cb = _lib.ALLOC_FN(cb)
+    def release(self):
+        """The forward call is over: the slot is free (the tensor lives on in the caller's hands)."""
+        _Buffer._tls.slots.pop(self.user, None)
+
+
+def _alloc(user, nbytes):
+    t = _Buffer._tls.slots[user]
+    t.resize_(int(nbytes))
+    return t.data_ptr()
+
+
+_ALLOC_CB = _lib.ALLOC_FN(_alloc)
+_on = _lib.on_device
 
 
 def _stream_ptr(device):
@@ -88,13 +105,20 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             (semantic, "semantic"), (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"),
             (cov3D_precomp, "cov3D_precomp"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"))]
         bg_, m3_, sh_, col_, fl_, sem_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
-        with torch.cuda.device(dev):
-            rendered = _lib.check(lib.adgs_raster_forward(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, D_S, _ptr(bg_), W, H,
-                _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
-                _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic), int(bool(inv_depth)),
-                _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward")
+        try:
+            with _on(dev):
+                rendered = _lib.check(lib.adgs_raster_forward(
+                    geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, D_S, _ptr(bg_), W, H,
+                    _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
+                    _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                    _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic), int(bool(inv_depth)),
+                    _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward")
+        finally:
+            for b in (geom, binning, img):
+                b.release()
+    else:
+        for b in (geom, binning, img):
+            b.release()
     return rendered, out_color, out_depth, img_opacity, radii, geom.t, binning.t, img.t, img_flow, img_semantic
 
 
@@ -113,7 +137,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         assert D_S <= SEMANTIC_CHANNELS
     if flow_points.size(0) != 0:
         assert flow_points.size(1) == FLOW_CHANNELS
-    lazy = P != 0 and lib.adgs_raster_needs_zero_init(D_S) == 0
+    # the FORWARD of this state decided the pipeline (frame table of the library): its backward never looks at the environment
+    lazy = P != 0 and lib.adgs_raster_backward_needs_zero_init(_ptr(geomBuffer), _ptr(imageBuffer), W, H, P) == 0
     z = lambda written, *shape: (torch.empty if (lazy and written) else torch.zeros)(shape, dtype=torch.float32, device=dev)
     has_sr = scales.size(0) != 0
     has_flow = flow_points.size(0) != 0 and dL_dout_flow is not None and dL_dout_flow.numel() != 0
@@ -131,7 +156,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             (grad_img_opacity, "grad_img_opacity"), (img_opacity, "img_opacity"))]
         bg_, m3_, sh_, col_, fl_, sem_, sc_, rot_, cov_, view_, proj_, cam_, gc_, gd_, gf_, gs_, go_, io_ = keep
         radii_ = _prep(radii, dev, "radii", torch.int32)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.adgs_raster_backward(
                 P, int(degree), M, int(R), D_S, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_),
                 _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_),
@@ -153,7 +178,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     present = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P != 0:
         m3, view, proj = (_prep(t, dev, n) for t, n in ((means3D, "means3D"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix")))
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.adgs_mark_visible(P, _ptr(m3), _ptr(view), _ptr(proj), _ptr(present), _stream_ptr(dev)), "adgs_mark_visible")
     return present
 
@@ -233,12 +258,19 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
                                               (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"), (viewmatrix, "viewmatrix"),
                                               (projmatrix, "projmatrix"), (campos, "campos"))]
         bg_, m3_, fl_, sem_, op_, sc_, rot_, view_, proj_, cam_ = keep
-        with torch.cuda.device(dev):
-            rendered = _lib.check(lib.adgs_raster_forward_rawsh(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src),
-                _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_),
-                float(tan_fovx), float(tan_fovy), _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic),
-                int(bool(inv_depth)), _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward_rawsh")
+        try:
+            with _on(dev):
+                rendered = _lib.check(lib.adgs_raster_forward_rawsh(
+                    geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src),
+                    _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_),
+                    float(tan_fovx), float(tan_fovy), _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic),
+                    int(bool(inv_depth)), _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward_rawsh")
+        finally:
+            for b in (geom, binning, img):
+                b.release()
+    else:
+        for b in (geom, binning, img):
+            b.release()
     return rendered, out_color, out_depth, img_opacity, radii, geom.t, binning.t, img.t, img_flow, img_semantic
 
 
@@ -300,7 +332,7 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
             (dL_dout_semantic, "dL_dout_semantic"), (grad_img_opacity, "grad_img_opacity"), (img_opacity, "img_opacity"))]
         bg_, m3_, fl_, sem_, sc_, rot_, view_, proj_, cam_, gc_, gd_, gf_, gs_, go_, io_ = keep
         radii_ = _prep(radii, dev, "radii", torch.int32)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.adgs_raster_backward_rawsh(
                 P, int(degree), M, int(R), D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src), _ptr(fl_), _ptr(sem_), _ptr(sc_),
                 float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), _ptr(radii_),

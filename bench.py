@@ -48,6 +48,10 @@ ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, den
 VALU_PEAK_PER_SIMD_CYCLE = 0.5 * 2.35 / 2.4
 
 
+KNN_FLOPS_PER_PAIR = 8
+VALU_FP32_PEAK_TFLOPS = 157.3
+
+
 def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     """Algorithmic bytes per launch of every stage of the reference-order ("classic") pipeline."""
     pay = 12 + 4 + 12 * F + 4 * D_S
@@ -399,6 +403,50 @@ def committed_pmc(stage, config, measured_case):
     return out
 
 
+def measure_traffic_in_run(stage, argv_config, timeout_s=170):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child processes of this same script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section; FETCH_SIZE counts
+    128-byte requests at 64 bytes on gfx950: x 2; both in KiB), a handful of steps each, the program itself after `--`.  Returns
+    {traffic, traffic_source, ...} or {} when rocprofv3 is not on the box, ADGS_BENCH_PMC=0, or a pass fails (the caller then replays
+    the committed counters and says so)."""
+    import csv, shutil, tempfile
+    kname = {"render_bwd": "render_bwd_v2_kernel", "render_fwd": "render_fwd_v2_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
+             "preprocess_fwd": "preprocess_fwd_kernel"}.get(stage)
+    exe = shutil.which("rocprofv3")
+    if not exe or not kname or os.environ.get("ADGS_BENCH_PMC", "1") == "0":
+        return {}
+    out, vals = {}, {}
+    t0 = time.perf_counter()
+    env = dict(os.environ, ADGS_BENCH_PMC="0", ADGS_BENCH_SKIP_STATS="1", ADGS_BENCH_SETTLE="0", TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="adgs_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "4",
+                   "--warmup", "2", "--config", argv_config, "--no-cpu-baseline", "--no-secondary"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            tot, n = 0.0, 0
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root, f))):
+                            if kname in r.get("Kernel_Name", "") and r.get("Counter_Name", counter) == counter:
+                                tot += float(r["Counter_Value"]); n += 1
+            if n == 0:
+                return {}
+            vals[counter] = (tot / n, n)
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError):
+            return {}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * vals["FETCH_SIZE"][0] * 1024, vals["WRITE_SIZE"][0] * 1024
+    out["traffic"] = int(rd + wr)
+    out["traffic_read_bytes"], out["traffic_write_bytes"] = int(rd), int(wr)
+    out["traffic_measured_in_run"] = True
+    out["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes of this script, %d + %d launches of %s; KiB, "
+                             "FETCH_SIZE x 2 on gfx950 per MI355X_MICROARCH.md), %.0f s" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1], kname, time.perf_counter() - t0))
+    return out
+
+
 # stage of the bench line -> (kernels of the stage, "f" / "b": launched once per forward / per backward)
 STAGE_KERNELS = {"preprocess_fwd": (("sh0_rows_kernel", "sh0_kernel", "preprocess_fwd_kernel"), "f"), "render_fwd": (("render_fwd_v2_kernel",), "f"),
                  "render_bwd": (("render_bwd_v2_kernel", "tile_order_kernel"), "b"),
@@ -452,9 +500,32 @@ def committed_frame_traffic(config, measured_case, fps_per_gpu):
 
 
 # ------------------------------------------------------------------ CPU baseline / parity
-def cpu_baseline(sc, cam, cfg, use_fs, up, threads=None):
+def cpu_deformation_seconds(model, t, t_flow):
+    """The frame's deformation stage on the CPU (BASELINE.md section 2 times the frame WITH it): oracle/deform_oracle.py -- the NumPy
+    restatement of get_deformed_pkg / get_deformed_xyz (scene/gaussian_model.py:173-231, utils/func_utils.py:121-173), single thread --
+    on the raw parameters of the benchmarked model, at the camera time and at the flow time.  Forward only: the chain rule through the
+    deformation exists on the CPU as float64 torch autograd in the tests, not as an oracle (stated in the sample text)."""
+    import numpy as np
+    from oracle import deform_oracle as do
+    names = {"scene_xyz": "_scene_xyz", "obj_xyz": "_obj_xyz", "scene_shs_dc": "_scene_shs_dc", "obj_shs_dc": "_obj_shs_dc", "scene_shs_rest": "_scene_shs_rest",
+             "obj_shs_rest": "_obj_shs_rest", "scene_scaling": "_scene_scaling", "obj_scaling": "_obj_scaling", "scene_rotation": "_scene_rotation",
+             "obj_rotation": "_obj_rotation", "scene_opacity": "_scene_opacity", "obj_opacity": "_obj_opacity", "xyz_deform_param": "xyz_deform_param",
+             "rotation_deform_param": "rotation_deform_param", "shs_deform_param_scene": "shs_deform_param_scene", "shs_deform_param_obj": "shs_deform_param_obj",
+             "background_deform_param": "background_deform_param", "gs_time_sigma": "gs_time_sigma", "gs_time": "gs_time"}
+    raw = {k: getattr(model, a).detach().cpu().numpy().astype(np.float32) for k, a in names.items()}
+    raw["order_args"], raw["use_time_mask"] = model.order_args, model.use_time_mask
+    t0 = time.perf_counter()
+    do.get_deformed_pkg(raw, t)
+    if t_flow is not None:
+        obj = raw["obj_xyz"] + do.get_func_result(t_flow, raw["xyz_deform_param"], model.order_args["xyz"])
+        _ = np.concatenate([raw["scene_xyz"], np.asarray(obj, np.float32)], 0) + do.get_func_result(t_flow, raw["background_deform_param"], model.order_args["background"])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(sc, cam, cfg, use_fs, up, threads=None, deform_s=None):
     """The CPU oracle (oracle/, a port of the reference kernels -- the reference has no CPU path) timed on this host's cores
-    for ONE frame of the same workload."""
+    for ONE frame of the same workload; deform_s: seconds of the frame's deformation stage on the CPU (cpu_deformation_seconds), part
+    of the frame where the configuration has one."""
     import numpy as np
     from oracle import oracle
     H, W = cfg["H"], cfg["W"]
@@ -475,9 +546,11 @@ def cpu_baseline(sc, cam, cfg, use_fs, up, threads=None):
     finally:
         if threads is not None:
             oracle.set_num_threads(all_threads)
-    base = {"value": round(1.0 / (t2 - t0), 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 full frame (rasterizer fwd %.3f s + bwd %.3f s; the O(N) deformation is not included) of the same scene "
-                      "and camera, %s, g++ -O3 -fno-fast-math -ffp-contract=off" % (t1 - t0, t2 - t1, "OpenMP over Gaussians/tiles" if cores > 1 else "single thread")}
+    total = (t2 - t0) + (deform_s or 0.0)
+    base = {"value": round(1.0 / total, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 full frame (%srasterizer fwd %.3f s + bwd %.3f s) of the same scene and camera, %s, g++ -O3 -fno-fast-math -ffp-contract=off" % (
+                ("deformation forward at the camera and the flow time %.3f s [NumPy, one thread; its O(N) backward is not part of the oracle] + " % deform_s)
+                if deform_s is not None else "", t1 - t0, t2 - t1, "OpenMP over Gaussians/tiles" if cores > 1 else "single thread")}
     return base, fwd
 
 
@@ -532,6 +605,15 @@ def knn_measure(device, sizes=((1_000_000, "C3"), (3_000_000, "C5")), cpu_points
              "GB/s_algorithmic": round(ab / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
              "boxes": nboxes, "boxes_scanned_per_query_box": round(staged / max(nboxes, 1), 1),
              "candidate_points_scanned_per_query": round(staged / max(nboxes, 1) * 1024)}
+        # which roof: not HBM (the cloud is read ~twice: 0.0002 of 8 TB/s) -- the distance arithmetic of the box scan on the fp32 vector
+        # pipes.  KNN_FLOPS_PER_PAIR per (query, candidate) pair: 3 subtractions, 1 multiply + 2 fused multiply-adds (5 flops), and the
+        # three compare / select steps of the 3-best insertion counted as one flop each.
+        pairs = float(P) * r["candidate_points_scanned_per_query"]
+        tflops = pairs * KNN_FLOPS_PER_PAIR / (ms * 1e-3) / 1e12
+        r["roofline"] = {"bound": "valu", "achieved": round(tflops, 2), "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_FP32_PEAK_TFLOPS, 4),
+                         "point_pairs_per_s": round(pairs / (ms * 1e-3)), "flops_per_pair": KNN_FLOPS_PER_PAIR,
+                         "note": "fp32 vector peak of MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 64 lanes x 2 flops x 2.4 GHz); compares and selects issue at "
+                                 "half rate (profiles/r04/issue_hazards.txt), so ~0.6 of the peak is what this mix could reach"}
         out.append(r)
         del ws, res, pts
         gc.collect(); torch.cuda.empty_cache()
@@ -1077,6 +1159,12 @@ def main():
                     "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4),
                     "launches_timed": int((stages_all if use_graph else stages)[dom][1]), "timing": roof_timing}
             roof.update(committed_pmc(dom, args.config, use_fs and v2))
+            if world == 1 and not force_coll and not iteration_mode and not use_graph and args.config == "C3" and use_fs and v2:
+                live = measure_traffic_in_run(dom, args.config)
+                if live:
+                    roof.update(live)
+                else:
+                    roof["traffic_measured_in_run"] = False      # rocprofv3 absent / ADGS_BENCH_PMC=0 / a pass failed: `traffic` is the committed replay
             if v2 and dom in ("render_fwd", "render_bwd"):
                 roof["pixel_entry_evals_per_s"] = round((config["published_entries"] if dom == "render_bwd" else config["blended_entries"]) * 256 / (dom_ms * 1e-3), 1)
             result["config"] = config
@@ -1178,7 +1266,8 @@ def main():
             else:
                 sc_cpu = sc
             try:
-                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, canonical_cam, cfg, use_fs, up)
+                deform_s = cpu_deformation_seconds(frame.model, frame.t, frame.t + 0.05 if use_fs else None) if isinstance(frame, DeformFrame) else None
+                result["cpu_baseline"], oracle_fwd = cpu_baseline(sc_cpu, canonical_cam, cfg, use_fs, up, deform_s=deform_s)
                 result["parity"] = parity_vs_oracle(outs, oracle_fwd)
             except Exception as exc:                     # e.g. the oracle library could not be built on this host
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (exc,)}

@@ -183,6 +183,9 @@ int adgs_raster_backward_rawsh(
  * must stay zero-filled when the corresponding input is absent: out_color (no shs/colours),
  * img_flow / dL_dflow (no flow_points), dL_dscale / dL_drot (cov3D_precomp given). */
 int adgs_raster_needs_zero_init(int D_S);
+/* ... and for the backward of a given forward (its state buffers, shape and point count): what THAT forward's pipeline needs, from the
+ * library's frame table -- the backward never consults the environment.  Unknown state: 1 (zero-fill is always safe). */
+int adgs_raster_backward_needs_zero_init(const char* geom_buffer, const char* img_buffer, int width, int height, int P);
 
 /* CudaRasterizer::Rasterizer::markVisible (RAST/cuda_rasterizer/rasterizer.h:24-29,
  * rasterizer_impl.cu:141-153).  `present` is a bool (1 byte) array of length P. */

@@ -168,7 +168,7 @@ def test_thirty_iterations_follow_the_cpu_reference_trajectory():
             assert pos[0] == len(draws), "the HIP side asked for %d of the reference's %d random draws" % (pos[0], len(draws))
     finally:
         ti.OPT.densification_interval, ti.OPT.near_idx_reset_interval, ti.OPT.opacity_reset_interval, ti.OPT.min_opacity = saved
-        print("\\n".join(report))
+        print("\n".join(report))
     torch.cuda.synchronize()
     assert state.get("densified") == 2 and (model.get_scene_pts_num, model.get_obj_pts_num) == (ref.n_scene, ref.n_obj) == plan[max(plan)]["points"]
     assert model.get_pts_num != cfg["P"]
@@ -198,4 +198,4 @@ def test_thirty_iterations_follow_the_cpu_reference_trajectory():
     assert np.array_equal(model.denom.cpu().numpy() > 0, ref.st["denom"] > 0) or float(((model.denom.cpu().numpy() > 0) != (ref.st["denom"] > 0)).mean()) < 1e-3
     lines.append("%-18s rel L2 %.2e" % ("xyz_gradient_accum", _rel_l2(acc, want)))
     assert _rel_l2(acc, want) <= 1e-3, lines[-1]
-    print("\\n".join(lines))
+    print("\n".join(lines))

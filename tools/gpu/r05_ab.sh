@@ -1,0 +1,21 @@
+#!/bin/bash
+# A/B of library builds and split modes on one box: bash tools/gpu/r05_ab.sh <tag> ; 200-step C3 eager runs, interleaved twice
+R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/r05_ab_$1; mkdir -p $o; cd $R
+run() { # name, env...
+  name=$1; shift
+  env "$@" timeout 300 python bench.py --steps 200 --warmup 30 --no-secondary --no-cpu-baseline > $o/$name.json 2> $o/$name.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open("$o/$name.json").read().strip().splitlines()[-1]); c = d["config"]; st = d.get("stages_ms") or {}
+    print("%-22s value %7.1f median %.4f  fwd %.4f bwd %.4f pre %.4f scan %.4f dup %.4f side %s" % ("$name", d["value"], c["step_ms_hip_events"]["median"], st.get("render_fwd", 0), st.get("render_bwd", 0), st.get("preprocess_fwd", 0), st.get("scan", 0), st.get("duplicate_keys", 0), st.get("sh_color_side_stream")))
+except Exception as e:
+    print("$name failed", e)
+PY
+}
+for rep in 1 2; do
+run base_split0_$rep ADGS_SPLIT_SH=0
+run row4_split0_$rep ADGS_SPLIT_SH=0 ADGS_LIB=$R/ad-gs_amd/lib/libadgs_hip_row4.so
+run split1_$rep ADGS_SPLIT_SH=1
+run split2_$rep ADGS_SPLIT_SH=2
+done

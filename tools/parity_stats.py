@@ -40,15 +40,31 @@ def main():
         sc = synthetic.make_config_scene(cfg)
         g = synthetic.make_upstream_grads(sc, synthetic.CONFIGS[cfg]["seed"])
         t0 = time.time()
-        h = run_hip(sc, grads=g)
-        t1 = time.time()
-        o32 = run_oracle(sc, grads=g, precision="f32")
-        t2 = time.time()
+        o32 = run_oracle(sc, grads=g, precision="f32", strict=True)
+        d32 = time.time() - t0
+        ex = o32["explained"]
+        t0 = time.time()
+        h = run_hip(sc, grads=g, strict_mask=ex["pixel"])
+        dh = time.time() - t0
+        t0 = time.time()
         o64 = run_oracle(sc, grads=g, precision="f64")
-        t3 = time.time()
-        print("%s: hip %.1fs, oracle f32 %.1fs, oracle f64 %.1fs; radii equal: %s" % (cfg, t1 - t0, t2 - t1, t3 - t2,
+        d64 = time.time() - t0
+        print("%s: hip %.1fs, oracle f32 (two backward passes) %.1fs, oracle f64 %.1fs; radii equal: %s" % (cfg, dh, d32, d64,
               np.array_equal(h["radii"].cpu().numpy(), o32["radii"])), flush=True)
-        out = {}
+        out = {"gate_flip_mask": {"GATE_EPS": parity.GATE_EPS, "frac_pixels_flagged": ex["frac_pixel"], "frac_gaussians_fed_by_a_flagged_pixel": ex["frac_gauss"]}}
+        print("  gate-flip mask (GATE_EPS %.1e): %.4f of the pixels flagged, %.4f of the Gaussians fed by a flagged pixel" % (parity.GATE_EPS, ex["frac_pixel"], ex["frac_gauss"]), flush=True)
+        # the strict pass (tests/parity.py): upstream gradients zeroed at the flagged pixels on both sides -- no exemption applies
+        strict = {}
+        for hk, ok in pairs:
+            if h["grads_strict"].get(hk) is None:
+                continue
+            a = h["grads_strict"][hk].cpu().numpy()
+            st = parity.error_stats(a, np.asarray(o32["grads_strict"][ok]).reshape(a.shape))
+            for k in ("_row_rel", "_bad", "_row_nz"):
+                st.pop(k, None)
+            strict["grad_" + hk] = st
+            print("  " + parity.fmt_stats("strict grad_" + hk + " hip_vs_f32", st) + " n_bad=%d (allowed: 0)" % st["n_bad"], flush=True)
+        out["strict_gradient_pass"] = strict
         tensors = [(k, h[k].detach().cpu().numpy(), o32[k], o64[k]) for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic")]
         tensors += [("grad_" + hk, h["grads"][hk].cpu().numpy(), o32["grads"][ok], o64["grads"][ok]) for hk, ok in pairs if h["grads"].get(hk) is not None]
         for name, a, b32, b64 in tensors:
