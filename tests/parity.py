@@ -25,6 +25,12 @@ one flagged pixel.  A per-Gaussian exemption therefore exempts nearly every grad
     to constraint 1 with NO exemption, constraint 2 with a fixed allowance and constraint 3 over all rows; 98.85 % of C3's pixels
     still carry their gradient.  The unmasked gradients (flips included) are additionally checked with the per-Gaussian mask as a
     sanity check only (`explained=` on a [P, ...] tensor): it bounds nothing for the flagged rows and the tests say so.
+    A tensor that fails the strict pass is re-examined row by row (assert_rows_conditioned): some gradient rows are small differences
+    of large terms -- the rotation gradient of a nearly isotropic Gaussian -- and the float32 ORACLE itself misses the float64 oracle by
+    more than 1e-4 there; such a row passes iff the HIP result is within 8 x the float32 oracle's own deviation from float64 (two
+    draws of it: on the inputs, and on inputs moved by one float32 ulp), every other row must meet the tolerance against float64.
+    Seen on 3 of 25 large random configurations of a fuzz sweep (1 - 4 elements of 10^5, all rotation / scale gradients, 1.2 - 7 x
+    the element tolerance); C1 / C2 / C3 / C5 at full size pass the strict pass outright.
 
 Without a mask (HIP-vs-HIP comparisons of tensors no oracle pass describes) the round-1..3 rule applies: at most a `max_frac`
 fraction of bounded outliers.
@@ -180,6 +186,30 @@ def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l
             assert frac <= max(rf, 2.0 / st["rows"]), "%s: %.3g of the rows are off by more than %g of their own norm (p99 %.3g, max %.3g)" % (
                 name, frac, rt, st["row_rel_p99"], st["row_rel_max"])
     return st
+
+
+def assert_rows_conditioned(name, got, f32_draws, exact, tol=TOL, factor=8.0, allowed=0, context=""):
+    """The fallback of the strict gradient pass for ILL-CONDITIONED rows.  Some gradient rows are small differences of large terms (the
+    rotation gradient of a nearly isotropic Gaussian, needles, image-filling Gaussians): a float32 evaluation of the reference algorithm
+    -- the float32 oracle itself -- then misses the exact (float64) result by more than 1e-4 on them.  `got` is held to the exact result
+    within the usual tolerance on every row where float32 can meet it, and to `factor` x the float32 ORACLE's own deviation elsewhere.
+    The yardstick comes from the oracle alone: `f32_draws` = its float32 run on the inputs and on inputs moved by one float32 ulp (one
+    draw can be accidentally exact on an ill-conditioned row), `exact` = its float64 run.  Rows, because conditioning is a property of the
+    Gaussian.  Returns the number of rows that needed the yardstick."""
+    got = np.asarray(got, np.float64)
+    exact = np.asarray(exact, np.float64).reshape(got.shape)
+    scale = max(float(np.abs(exact).max()), 1e-30)
+    bound = tol * np.abs(exact) + tol * scale
+    rows = lambda e: e.reshape(e.shape[0], -1).max(1)
+    e_got = np.abs(got - exact)
+    yard = np.zeros(got.shape[0])
+    for d in f32_draws:
+        yard = np.maximum(yard, rows(np.abs(np.asarray(d, np.float64).reshape(got.shape) - exact)))
+    outside = rows(e_got - bound) > 0
+    bad = outside & (rows(e_got) > factor * yard + 1e-6 * scale)
+    assert int(bad.sum()) <= allowed, "%s: %d of %d rows miss the float64 oracle by more than %gx the float32 oracle's own error (max %.3g, scale %.3g)%s" % (
+        name, int(bad.sum()), bad.size, float(rows(e_got)[bad].max()), factor, scale, ("; strict pass said: " + context) if context else "")
+    return int(outside.sum())
 
 
 def fmt_stats(name, st):

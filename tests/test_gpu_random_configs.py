@@ -11,7 +11,7 @@ from adgs import synthetic
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from test_gpu_raster import GRAD_PAIRS, assert_close, compare_strict_grads, run_hip, run_oracle  # noqa: E402
+from test_gpu_raster import GRAD_PAIRS, assert_close, compare_strict_grads, conditioning_draws, run_hip, run_oracle  # noqa: E402
 from tests.parity import assert_masked_coverage  # noqa: E402
 
 
@@ -33,6 +33,17 @@ def _both_pipelines(sc, g, opts, env, mask):
     return v2, cl
 
 pytestmark = pytest.mark.gpu
+
+
+def _cached(fn):
+    """fn() evaluated at most once (the conditioning draws of a case: two more oracle runs, only needed when a strict comparison fails)."""
+    box = []
+
+    def get():
+        if not box:
+            box.append(fn())
+        return box[0]
+    return get
 
 
 def _case(seed):
@@ -67,8 +78,9 @@ def test_v2_matches_classic_and_oracle_on_random_configs(seed):
         assert_close(k + " v2~classic", a, b, explained=ex["pixel"])
         assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"])
     # gradients: the strict pass (no gradient enters at the flagged pixels), every element, both pipelines against the oracle
-    compare_strict_grads(v2, ref, "v2~oracle ")
-    compare_strict_grads(cl, ref, "classic~oracle ")
+    draws = _cached(lambda: conditioning_draws(sc, g, ex["pixel"], seed=seed, **opts))
+    compare_strict_grads(v2, ref, "v2~oracle ", draws=draws)
+    compare_strict_grads(cl, ref, "classic~oracle ", draws=draws)
     for k, gv in v2["grads"].items():                                       # sanity: the unmasked backward, flips included
         if gv is None:
             continue
@@ -100,8 +112,9 @@ def test_v2_matches_classic_and_oracle_on_large_random_configs(seed):
         a = v2[k].detach().cpu().numpy()
         assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), explained=ex["pixel"])
         assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"])
-    compare_strict_grads(v2, ref, "v2~oracle ")
-    compare_strict_grads(cl, ref, "classic~oracle ")
+    draws = _cached(lambda: conditioning_draws(sc, g, ex["pixel"], seed=seed, **opts))
+    compare_strict_grads(v2, ref, "v2~oracle ", draws=draws)
+    compare_strict_grads(cl, ref, "classic~oracle ", draws=draws)
     names = dict(GRAD_PAIRS)
     for k, gv in v2["grads"].items():                                       # sanity: the unmasked backward, flips included
         if gv is None:
@@ -194,10 +207,15 @@ def test_adversarial_scenes_match_classic_and_oracle(seed):
     env = dict(ADGS_CELL_TILES=str(int(rng.choice([1, 4, 8, 12]))), ADGS_V2_PPL=str(int(rng.choice([2, 4]))))
     ref = run_oracle(sc, grads=g, strict=True, **opts)
     ex = ref["explained"]
-    # 5 % of these Gaussians sit exactly ON the 1/255 gate and needles graze it along their whole length: the flagged share of the pixels is
-    # far above an ordinary frame's -- bounded all the same, and every unflagged pixel is held to the tolerance
-    assert_masked_coverage(ex, limit=0.5, what="adversarial seed %d" % seed)
-    v2, cl = _both_pipelines(sc, g, opts, env, ex["pixel"])
+    # 5 % of these Gaussians sit exactly ON the 1/255 gate, and image-filling / needle Gaussians have |power| as the small difference of
+    # terms of magnitude S = 1e3 .. 1e4: the band around their gate contour in which a float32 evaluation may flip is (1 + S) x wider and
+    # can cover most of the image.  Where the gate-flip mask leaves at least half of the pixels their gradient the STRICT pass runs (no
+    # gradient enters at the flagged pixels, so no flip is involved); where it does not, gate decisions are ill-conditioned everywhere
+    # and the UNMASKED gradients are judged -- either way against the float64 oracle with the float32 oracle's own error as the yardstick.
+    strict = ex["frac_pixel"] <= 0.5
+    mask = ex["pixel"] if strict else np.zeros_like(ex["pixel"])
+    key = "grads_strict"
+    v2, cl = _both_pipelines(sc, g, opts, env, mask)
     assert torch.equal(v2["radii"], cl["radii"]) and np.array_equal(v2["radii"].cpu().numpy(), ref["radii"])
     for k in ("color", "depth", "img_opacity", "img_flow", "img_semantic"):
         a = v2[k].detach().cpu().numpy()
@@ -207,37 +225,24 @@ def test_adversarial_scenes_match_classic_and_oracle(seed):
         # terms of magnitude 1e3 .. 1e4): the tolerance grows by the first-order bound of that effect per pixel (parity.py: COND_K, `slack`)
         assert_close(k + " v2~classic", a, cl[k].detach().cpu().numpy(), explained=ex["pixel"], slack=ex["slack"])
         assert_close(k + " v2~oracle", a, np.asarray(ref[k]).reshape(a.shape), explained=ex["pixel"], slack=ex["slack"])
-    names = dict(GRAD_PAIRS)
-    # Gradients (the STRICT backward: no gradient enters at the flagged pixels, so no flip is involved): needles, image-filling and
-    # unnormalised Gaussians make dL/drotation (and a few dL/dmean) ill-conditioned -- the fp32 CPU oracle itself then misses the float64
-    # oracle by percents on those rows.  The HIP path is held to the float64 result with the usual tolerance on every row where float32
-    # can meet it, and to a few times the float32 ORACLE's own error elsewhere.  The yardstick comes from the oracle alone (round-4 advisor:
-    # the repository's other pipeline shares preprocess_bwd with v2 and must not widen its tolerance): one float32 evaluation is a single
-    # draw (accidentally exact on some ill-conditioned rows: seed 7032), so the second draw is the float32 oracle on inputs moved by ONE
-    # float32 ulp -- what any float32 evaluation may legitimately mistake the inputs for.
-    ref64 = run_oracle(sc, grads=g, precision="f64", strict_mask=ex["pixel"], **opts)
-    if not np.array_equal(np.asarray(ref64["radii"]), ref["radii"]):
+    # Gradients: needles, image-filling and unnormalised Gaussians make dL/drotation (and a few dL/dmean) ill-conditioned -- the fp32 CPU
+    # oracle itself then misses the float64 oracle by percents on those rows.  The HIP path is held to the float64 result with the usual
+    # tolerance on every row where float32 can meet it, and to 8 x the float32 ORACLE's own error elsewhere (tests/parity.py:
+    # assert_rows_conditioned).  The yardstick comes from the oracle alone (round-4 advisor: the repository's other pipeline shares
+    # preprocess_bwd with v2 and must not widen its tolerance): its float32 run on the inputs and on inputs moved by one float32 ulp.
+    from tests.parity import assert_rows_conditioned
+    if not strict:
+        ref = dict(ref, grads_strict=ref["grads"])            # mask empty: the "strict" backward of the HIP runs IS the unmasked one
+    exact, pert = conditioning_draws(sc, g, mask, seed=seed, **opts)
+    if not np.array_equal(np.asarray(exact["radii"]), ref["radii"]):
         return                                              # a cull / radius decision that differs between fp32 and fp64: no common ground truth
-    prng = np.random.RandomState(77000 + seed)
-    sc_p = dict(sc)
-    for k in ("means3D", "scales", "rotations", "opacities"):
-        sgn = torch.tensor(prng.choice([-1.0, 1.0], size=tuple(sc[k].shape)).astype(np.float32))
-        sc_p[k] = (sc[k] * (1.0 + sgn * 2.0 ** -23)).float().contiguous()
-    refp = run_oracle(sc_p, grads=g, strict_mask=ex["pixel"], **opts)
-    same_cull = np.array_equal(refp["radii"], ref["radii"])
-    for k, gv in v2["grads_strict"].items():
+    same_cull = np.array_equal(np.asarray(pert["radii"]), ref["radii"])
+    names = dict(GRAD_PAIRS)
+    for k, gv in v2[key].items():
         if gv is None or k not in names:
             continue
-        a = gv.cpu().numpy().astype(np.float64)
+        a = gv.cpu().numpy()
         assert np.isfinite(a).all(), k
-        r64 = np.asarray(ref64["grads_strict"][names[k]], np.float64).reshape(a.shape)
-        r32 = np.asarray(ref["grads_strict"][names[k]], np.float64).reshape(a.shape)
-        scale = max(np.abs(r64).max(), 1e-30)
-        tol = 1e-4 * np.abs(r64) + 1e-4 * scale
-        rows = lambda e: e.reshape(e.shape[0], -1).max(1)                      # conditioning is a per-Gaussian property
-        e_hip, e_f32 = np.abs(a - r64), rows(np.abs(r32 - r64))
-        if same_cull:
-            e_f32 = np.maximum(e_f32, rows(np.abs(np.asarray(refp["grads_strict"][names[k]], np.float64).reshape(a.shape) - r64)))
-        bad = (rows(e_hip - tol) > 0) & (rows(e_hip) > 8.0 * e_f32 + 1e-6 * scale)
-        assert bad.sum() <= max(2, 5e-4 * bad.size), "grad %s: %d of %d rows miss float64 by more than 8x the fp32 oracle's own error (max %.3g, scale %.3g)" % (
-            k, int(bad.sum()), bad.size, float(rows(e_hip)[bad].max()), scale)
+        f32 = [np.asarray(ref[key][names[k]]).reshape(a.shape)] + ([np.asarray(pert[key][names[k]]).reshape(a.shape)] if same_cull else [])
+        assert_rows_conditioned("grad " + k + (" [strict]" if strict else " [unmasked: the gate-flip mask covers %.0f %% of the pixels]" % (100 * ex["frac_pixel"])),
+                                a, f32, np.asarray(exact[key][names[k]]).reshape(a.shape), allowed=max(2, int(5e-4 * a.shape[0])))
