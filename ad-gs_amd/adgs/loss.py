@@ -7,6 +7,7 @@ names and signatures on top of it.  Images are [..., C, H, W] fp32 on a HIP devi
 There is no CPU fallback.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -19,47 +20,77 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class _Slice:
+    """Ownership of one slice of a _WorkArena (or of nothing: a fresh buffer).  The slot is free again when the token is dropped -- at once
+    for terms whose backward does not read the slice, with the autograd context for the terms whose backward does (depth, flow).  A token
+    dropped before done() (a launch failed between the sum kernel and the finish kernel that re-zeroes the slot rows) marks its slice
+    dirty: it is zero-filled before it is handed out again."""
+    __slots__ = ("arena", "i", "clean")
+
+    def __init__(self, arena, i):
+        self.arena, self.i, self.clean = arena, i, False
+
+    def done(self):
+        self.clean = True
+
+    def __del__(self):
+        a = self.arena
+        if a is not None:
+            if not self.clean:
+                a.dirty.add(self.i)
+            a.busy[self.i] = False
+
+
 class _WorkArena:
     """Zero-initialised work buffers of the loss kernels (include/adgs_loss.h) without a fill per call: the kernel that consumes a
-    buffer's slot rows leaves them zero, so a buffer only has to be zeroed when it is created.  One arena per (device, stream): N
-    slices handed out round-robin -- a training iteration uses ~9 (train.py:78-113), and with N = 64 a slice comes round again long
-    after its backward has been enqueued.  The scalars a backward reads live in the slice too: every slice carries a generation
-    number, and a backward whose slice has been handed out again in the meantime (more than N loss terms between a forward and its
-    backward) raises instead of reading another term's totals.  One arena per LAYOUT (the scalars of one layout lie inside the slot
-    rows of another: a slice must always be used with the same layout)."""
+    buffer's slot rows leaves them zero, so a buffer only has to be zeroed when it is created.  One arena per (device, stream, layout):
+    N slices; a slice is busy while its _Slice token lives (a training iteration holds two across its backward: depth and flow).  When
+    every slice is busy -- gradient accumulation over more terms than the ring holds -- or under stream capture (an arena created there
+    would have its zero fill baked into the graph) the caller gets a fresh zero-filled buffer instead.  take() is guarded by a lock (two
+    threads may share a stream)."""
     N = 64
 
     def __init__(self, device, doubles):
         self.buf = torch.zeros(self.N, doubles, dtype=torch.float64, device=device)
-        self.gen = [0] * self.N
+        self.busy = [False] * self.N
+        self.dirty = set()
         self.next = 0
+        self.lock = threading.Lock()
 
     def take(self):
-        i = self.next
-        self.next = (i + 1) % self.N
-        self.gen[i] += 1
-        return self.buf[i], (self, i, self.gen[i])
-
-    @staticmethod
-    def check(token, what):
-        arena, i, gen = token
-        if arena.gen[i] != gen:
-            raise RuntimeError("%s: the work buffer of this loss term was handed out again before its backward ran (more than %d loss "
-                               "terms between a forward and its backward on one stream)" % (what, _WorkArena.N))
+        with self.lock:
+            for k in range(self.N):
+                i = (self.next + k) % self.N
+                if not self.busy[i]:
+                    break
+            else:
+                return None
+            self.next = (i + 1) % self.N
+            self.busy[i] = True
+            spoiled = i in self.dirty
+            self.dirty.discard(i)
+        if spoiled:
+            self.buf[i].zero_()
+        return self.buf[i], _Slice(self, i)
 
 
 _ARENAS = {}
 
 
 def _work(device, doubles):
-    """(zeroed work buffer of `doubles` doubles for one loss term, token for _WorkArena.check in the backward)"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, doubles)
-    a = _ARENAS.get(key)
-    if a is None:
-        if len(_ARENAS) > 48:
-            _ARENAS.clear()
-        a = _ARENAS[key] = _WorkArena(device, doubles)
-    return a.take()
+    """(zeroed work buffer of `doubles` doubles for one loss term, its _Slice token: call done() after the term's launches)"""
+    if not torch.cuda.is_current_stream_capturing():
+        key = (device, torch.cuda.current_stream(device).cuda_stream, doubles)
+        a = _ARENAS.get(key)
+        if a is None:
+            if len(_ARENAS) > 48:
+                _ARENAS.clear()
+            a = _ARENAS[key] = _WorkArena(device, doubles)
+        got = a.take()
+        if got is not None:
+            return got
+    t = _Slice(None, -1)
+    return torch.zeros(doubles, dtype=torch.float64, device=device), t
 
 
 class _L1SSIM(torch.autograd.Function):
@@ -74,7 +105,7 @@ class _L1SSIM(torch.autograd.Function):
         planes = img.numel() // (H * W) if H * W else 0
         n = img.numel()
         need = ctx.needs_input_grad[0]
-        sums, _ = _work(img.device, 2 * SLOTS)                     # spread atomics (include/adgs_loss.h); consumed by adgs_l1_ssim_means below
+        sums, tok = _work(img.device, 2 * SLOTS)                   # spread atomics (include/adgs_loss.h); consumed by adgs_l1_ssim_means below
         maps = [torch.empty_like(img) for _ in range(3)] if need else [None] * 3
         means = torch.empty(2, dtype=torch.float32, device=img.device) if n else torch.zeros(2, dtype=torch.float32, device=img.device)
         if n:
@@ -83,6 +114,7 @@ class _L1SSIM(torch.autograd.Function):
                                                            *[m.data_ptr() if m is not None else None for m in maps], _stream(img.device)),
                            "adgs_l1_ssim_forward")
                 _lib.check(_lib.lib().adgs_l1_ssim_means(sums.data_ptr(), n, means.data_ptr(), _stream(img.device)), "adgs_l1_ssim_means")
+        tok.done()
         if need:
             ctx.save_for_backward(img, ref, *maps)
         ctx.dims = (planes, H, W)
@@ -145,13 +177,13 @@ class _DepthLoss(torch.autograd.Function):
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().adgs_depth_loss_forward(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else None,
                                                           work.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_depth_loss_forward")
+        ctx.token.done()
         ctx.save_for_backward(p, g, work, *([m] if m is not None else []))
         return out[0]
 
     @staticmethod
     def backward(ctx, g_loss):
         p, g, work, *rest = ctx.saved_tensors
-        _WorkArena.check(ctx.token, "get_depth_loss")
         m = rest[0] if rest else None
         out = torch.empty_like(p)
         gl = g_loss.reshape(1).float().contiguous()
@@ -215,6 +247,7 @@ class _FlowLoss(torch.autograd.Function):
             _lib.check(cam.forward_fn()(H, W, f.data_ptr(), fl.data_ptr(), vis.data_ptr(), op.data_ptr() if op is not None else None,
                                         cam.args[0], cam.args[1], cam.args[2], float(dist), work.data_ptr(), out.data_ptr(), _stream(f.device)),
                        "adgs_flow_loss_forward")
+        ctx.token.done()
         ctx.save_for_backward(f, fl, vis, work, *([op] if op is not None else []))
         ctx.cam, ctx.dist, ctx.op_shape = cam, float(dist), None if img_opacity is None else img_opacity.shape
         return out[0]
@@ -222,7 +255,6 @@ class _FlowLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         f, fl, vis, work, *rest = ctx.saved_tensors
-        _WorkArena.check(ctx.token, "get_flow_loss")
         op = rest[0] if rest else None
         H, W = fl.shape[1], fl.shape[2]
         g_f = torch.empty_like(f)
@@ -252,11 +284,12 @@ class _BceClip(torch.autograd.Function):
         p, t = pred.contiguous().float(), target.contiguous().float()
         if p.numel() != t.numel():
             raise ValueError("bce_clip_loss: prediction and target must have the same number of elements")
-        work, _ = _work(p.device, AUX_WORK_DOUBLES)
+        work, tok = _work(p.device, AUX_WORK_DOUBLES)
         out = torch.empty(1, dtype=torch.float32, device=p.device) if p.numel() else torch.zeros(1, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().adgs_bce_clip_forward(p.numel(), p.data_ptr(), t.data_ptr(), float(lo), float(hi), int(bool(invert)),
                                                         int(bool(positive_target)), work.data_ptr(), out.data_ptr(), _stream(p.device)), "adgs_bce_clip_forward")
+        tok.done()
         ctx.save_for_backward(p, t)
         ctx.args, ctx.shape = (float(lo), float(hi), int(bool(invert)), int(bool(positive_target))), pred.shape
         return out[0]
@@ -318,12 +351,13 @@ class _GroupVar(torch.autograd.Function):
         N = xs.shape[0]
         D = xs.numel() // max(N, 1)
         G, K = ix.shape
-        work, _ = _work(xs.device, AUX_WORK_DOUBLES)
+        work, tok = _work(xs.device, AUX_WORK_DOUBLES)
         out = torch.empty(1, dtype=torch.float32, device=xs.device) if (G and D) else torch.zeros(1, dtype=torch.float32, device=xs.device)
         if G and D:
             with torch.cuda.device(xs.device):
                 _lib.check(_lib.lib().adgs_group_var_forward(N, G, K, D, int(inner), xs.data_ptr(), ix.data_ptr(), work.data_ptr(), out.data_ptr(),
                                                              _stream(xs.device)), "adgs_group_var_forward")
+        tok.done()
         ctx.save_for_backward(xs, ix)
         ctx.dims, ctx.shape = (N, G, K, D, int(inner)), x.shape
         return out[0]
@@ -359,12 +393,13 @@ class _SigmaLoss(torch.autograd.Function):
         if log_sigma.dim() != 2 or log_sigma.shape[1] != 2:
             raise ValueError("gs_time_sigma must be [N, 2]")
         ls = log_sigma.contiguous().float()
-        work, _ = _work(ls.device, AUX_WORK_DOUBLES)
+        work, tok = _work(ls.device, AUX_WORK_DOUBLES)
         out = torch.empty(1, dtype=torch.float32, device=ls.device) if ls.shape[0] else torch.zeros(1, dtype=torch.float32, device=ls.device)
         if ls.shape[0]:
             with torch.cuda.device(ls.device):
                 _lib.check(_lib.lib().adgs_sigma_loss_forward(ls.shape[0], ls.data_ptr(), float(frame_gap), work.data_ptr(), out.data_ptr(),
                                                               _stream(ls.device)), "adgs_sigma_loss_forward")
+        tok.done()
         ctx.save_for_backward(ls)
         ctx.gap = float(frame_gap)
         return out[0]
@@ -450,11 +485,11 @@ class _ImageLosses(torch.autograd.Function):
             raise ValueError("image_losses: expected img_flow [3,H,W], flow [2,H,W], flow_vis [H,W]")
         terms = torch.empty(6, dtype=torch.float32, device=dev)
         maps = [torch.empty_like(img) for _ in range(3)]
-        sums, _ = _work(dev, 2 * SLOTS)
+        sums, tok_sums = _work(dev, 2 * SLOTS)
         w_depth, tok_depth = _work(dev, DEPTH_WORK_DOUBLES)
         w_flow, tok_flow = _work(dev, AUX_WORK_DOUBLES)
-        w_obj, _ = _work(dev, AUX_WORK_DOUBLES)
-        w_sky, _ = _work(dev, AUX_WORK_DOUBLES)
+        w_obj, tok_obj = _work(dev, AUX_WORK_DOUBLES)
+        w_sky, tok_sky = _work(dev, AUX_WORK_DOUBLES)
         p0 = terms.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(L.adgs_l1_ssim_forward(img.shape[0], H, W, img.data_ptr(), ref.data_ptr(), sums.data_ptr(), *[m.data_ptr() for m in maps], st), "adgs_l1_ssim_forward")
@@ -464,6 +499,8 @@ class _ImageLosses(torch.autograd.Function):
                                         w_flow.data_ptr(), p0 + 12, st), "adgs_flow_loss_forward")
             _lib.check(L.adgs_bce_clip_forward(npix, sem.data_ptr(), gsem.data_ptr(), 1e-3, 1.0 - 1e-3, 0, 1, w_obj.data_ptr(), p0 + 16, st), "adgs_bce_clip_forward")
             _lib.check(L.adgs_bce_clip_forward(npix, op.data_ptr(), gsky.data_ptr(), 1e-3, 1.0 - 1e-3, 1, 0, w_sky.data_ptr(), p0 + 20, st), "adgs_bce_clip_forward")
+        for tok in (tok_sums, tok_depth, tok_flow, tok_obj, tok_sky):
+            tok.done()
         ctx.save_for_backward(img, ref, *maps, dep, gdep, w_depth, fl_img, fl, vis, op, w_flow, sem, gsem, gsky)
         ctx.tokens, ctx.cam, ctx.dist = (tok_depth, tok_flow), cam, float(dist)
         ctx.shapes = (image.shape, depth.shape, img_flow.shape, img_opacity.shape, img_semantic.shape)
@@ -472,8 +509,6 @@ class _ImageLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (img, ref, d_mu1, d_e11, d_e12, dep, gdep, w_depth, fl_img, fl, vis, op, w_flow, sem, gsem, gsky) = ctx.saved_tensors
-        _WorkArena.check(ctx.tokens[0], "image_losses (depth)")
-        _WorkArena.check(ctx.tokens[1], "image_losses (flow)")
         dev = img.device
         L = _lib.lib()
         st = _stream(dev)

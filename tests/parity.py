@@ -13,7 +13,7 @@ two correct float32 evaluations of a frame take a gate differently where the gat
 threshold, and a flipped (pixel, Gaussian) pair moves that pixel -- and every Gaussian the pixel feeds -- by far more than 1e-4.  The
 oracle says where that can happen (raster_oracle.cpp: gate_margins -> explained_masks(): the PIXELS whose walk came within GATE_EPS of
 a gate, in units of the float32 rounding error of the gated quantity).  Measured coverage of that mask (tools/parity_stats.py): 1.15 %
-of the pixels at C3, 0.6 % at C2 (the T-stop margin is normalised by 1 + E, which reaches 1e3 .. 1e4 on saturating pixels), 0.1 - 2 % on
+of the pixels at C3, 1.11 % at C2 (the T-stop margin is normalised by 1 + E, which reaches 1e3 .. 1e4 on saturating pixels), 0.1 - 2 % on
 the small scenes -- and, because a Gaussian is fed by hundreds of pixels, 86 % of the GAUSSIANS of C3 (78 % of C2) are fed by at least
 one flagged pixel.  A per-Gaussian exemption therefore exempts nearly every gradient row at full size (round-4 judge finding).  So:
 

@@ -322,6 +322,42 @@ def test_regulariser_indices_follow_fancy_indexing_and_never_leave_the_tensor():
         loss.reg_loss(x, idx)
 
 
+def test_work_arena_survives_many_outstanding_terms_and_failed_forwards():
+    """The zero-on-return work buffers of the loss kernels (adgs.loss._WorkArena): (1) more loss terms between a forward and its backward
+    than the ring holds (gradient accumulation) fall back to fresh buffers instead of raising, and every backward still reads its own
+    totals; (2) a slice whose forward died between the sum kernel and the finish kernel (token dropped before done()) is zero-filled
+    before it is handed out again -- otherwise every later term that got the slice would be silently biased."""
+    from adgs import loss
+    g = torch.Generator().manual_seed(7)
+    H, W = 24, 40
+    preds = [torch.rand(H, W, generator=g).cuda().requires_grad_(True) for _ in range(loss._WorkArena.N + 12)]
+    gts = [torch.rand(H, W, generator=g).cuda() for _ in preds]
+    terms = [loss.get_depth_loss(p, t) for p, t in zip(preds, gts)]          # 76 forwards, no backward yet: 76 live tokens
+    refs = []
+    for p, t in zip(preds, gts):
+        q = p.detach().clone().requires_grad_(True)
+        l = loss.get_depth_loss(q, t); l.backward()
+        refs.append((l.detach(), q.grad))
+    for (l, p), (rl, rg) in zip(zip(terms, preds), refs):
+        l.backward()
+        assert torch.equal(l.detach(), rl) and torch.equal(p.grad, rg)
+    # (2) spoil a slice by hand
+    dev = preds[0].device
+    buf, tok = loss._work(dev, loss.AUX_WORK_DOUBLES)
+    arena, i = tok.arena, tok.i
+    buf.fill_(123.0)                      # what a sum kernel without its finish kernel leaves behind
+    del tok                               # dropped without done(): the forward "raised"
+    assert i in arena.dirty and not arena.busy[i]
+    arena.next = i                        # the very next term gets this slice
+    p = torch.rand(H, W, generator=g).cuda()
+    t = (torch.rand(H, W, generator=g) > 0.5).float().cuda()
+    a = loss.sky_loss(p, t)
+    arena.next = (i + 5) % arena.N
+    b = loss.sky_loss(p, t)
+    assert torch.equal(a, b) and i not in arena.dirty
+    assert float(arena.buf[i][:2 * 256].abs().max()) == 0.0          # the slot rows (the two scalars behind them hold the last term's totals)
+
+
 @pytest.mark.parametrize("H,W,D_S", [(97, 131, 1), (64, 80, 3)])
 def test_image_losses_node_equals_the_six_functions(H, W, D_S):
     """adgs.loss.image_losses (one autograd node for train.py:78-99) against l1_ssim / get_depth_loss / get_flow_loss / obj_loss / sky_loss
