@@ -36,7 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, densify_every=10)}
 
 
@@ -366,7 +366,7 @@ def library_stamp():
 
 def committed_pmc(stage, config, measured_case):
     """HBM traffic / VALU issue rate of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's build
-    (profiles/r04/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
+    (profiles/r05/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
     the case they were measured on (C3, flow+semantic, default pipeline); absent files leave `traffic` null; counters collected on
     another build of the library are flagged (`counters_stale`)."""
     if config != "C3" or not measured_case:
@@ -380,7 +380,7 @@ def committed_pmc(stage, config, measured_case):
         for k, v in tr.items():
             if kname and kname in k:
                 out["traffic"] = v["hbm_bytes_per_launch"]
-                out["traffic_source"] = ("profiles/r04/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
+                out["traffic_source"] = ("profiles/r05/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
                                          "FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, per launch)")
                 break
         pmf = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))
@@ -391,7 +391,7 @@ def committed_pmc(stage, config, measured_case):
             out["wave_state_shares"] = pm.get("wave_state_shares")
             out["waves_per_simd_mean"] = pm.get("waves_per_simd_mean")
             out["valu_note"] = ("the blend kernels are far from the HBM roof by construction (SURVEY.md 8(d)): wave64 VALU instructions per SIMD and cycle "
-                                "(rocprofv3 --pmc, profiles/r04/pmc_blend_kernels.json; normalisation: tools/pmc_blend.py) against the full-rate fp32 issue rate "
+                                "(rocprofv3 --pmc, profiles/r05/pmc_blend_kernels.json; normalisation: tools/pmc_blend.py) against the full-rate fp32 issue rate "
                                 "0.5 x the sustained shader clock over the nominal 2.4 GHz = %.3f -- a ceiling the kernels' instruction mixes cannot reach (half-rate "
                                 "compares / selects, quarter-rate exp / rcp: tools/isa_mix.py, tools/microbench/issue_hazards.hip); wave_state_shares: where the "
                                 "resident waves' cycles go (issuing / parked at s_waitcnt / ready but not issued)" % VALU_PEAK_PER_SIMD_CYCLE)
@@ -457,7 +457,7 @@ STAGE_KERNELS = {"preprocess_fwd": (("sh0_rows_kernel", "sh0_kernel", "preproces
 
 
 def committed_kernel_stats():
-    """Per-stage kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this round (profiles/r04/kernel_stats.csv):
+    """Per-stage kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this round (profiles/r05/kernel_stats.csv):
     total duration of the stage's kernels over the number of forwards / backwards in the profiled run (= the calls of the blend kernel of that
     direction).  Empty when the file is absent."""
     import csv

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the rasterizer fuzz families (tests/test_gpu_random_configs.py: strict gradient pass, no exemptions) over other seed ranges:
-#   gpurun --timeout 3000 -- 'bash tools/gpu/r05_fuzz_raster.sh <base> <n> [<base> <n> ...]'
+#   gpurun --timeout 3000 -- 'bash tools/gpu/fuzz_raster.sh <base> <n> [<base> <n> ...]'
 R=$GRAFT_REPO_ROOT; cd $R
 while [ $# -ge 2 ]; do
 b=$1; n=$2; shift 2; o=$R/gpurun_out/r05_fuzz_$b; mkdir -p $o

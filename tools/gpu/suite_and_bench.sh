@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU suite (no -x: every failure is listed) + the driver-settings bench line: gpurun --timeout 2400 -- "bash tools/gpu/r05_suite.sh <tag> [pytest args]" -> gpurun_out/<tag>/
+# GPU suite (no -x: every failure is listed) + the driver-settings bench line: gpurun --timeout 2400 -- "bash tools/gpu/suite_and_bench.sh <tag> [pytest args]" -> gpurun_out/<tag>/
 R=$GRAFT_REPO_ROOT; tag=${1:-r05}; shift; o=$R/gpurun_out/$tag; mkdir -p $o; cd $R
 timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider -rf "$@" > $o/gpu_tests.log 2>&1
 grep -E "^(FAILED|ERROR)|passed|failed" $o/gpu_tests.log | cut -c1-400 | tail -60
