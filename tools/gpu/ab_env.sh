@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds and split modes on one box: bash tools/gpu/r05_ab.sh <tag> ; 200-step C3 eager runs, interleaved twice
+# A/B of environment switches / library builds on one box: bash tools/gpu/ab_env.sh <tag> ; 200-step C3 eager runs, interleaved twice (edit the `run` lines)
 R=$GRAFT_REPO_ROOT; o=$R/gpurun_out/r05_ab_$1; mkdir -p $o; cd $R
 run() { # name, env...
   name=$1; shift
@@ -14,8 +14,7 @@ except Exception as e:
 PY
 }
 for rep in 1 2; do
-run base_split0_$rep ADGS_SPLIT_SH=0
-run row4_split0_$rep ADGS_SPLIT_SH=0 ADGS_LIB=$R/ad-gs_amd/lib/libadgs_hip_row4.so
-run split1_$rep ADGS_SPLIT_SH=1
-run split2_$rep ADGS_SPLIT_SH=2
+run base_$rep ADGS_X=0
+run cell10_$rep ADGS_CELL_TILES=10
+# run variant_$rep ADGS_LIB=$R/ad-gs_amd/lib/libadgs_hip_<tag>.so      # make -C ad-gs_amd/csrc variant TAG=<tag> DEFS=...
 done
