@@ -547,8 +547,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
 		(void)hipStreamIsCapturing(stream, &cap_status);
 		const bool capturing = cap_status == hipStreamCaptureStatusActive;
-		const int dbg_stop = env_int("ADGS_V2_STOP", 99);
-		const bool speculate = capturing || (env_int("ADGS_NO_SPECULATION", 0) == 0 && dbg_stop >= 99);
+		const bool speculate = capturing || env_int("ADGS_NO_SPECULATION", 0) == 0;
 		const size_t cap_cells = std::min<size_t>(std::max<size_t>(fc->hint_cells, (size_t)P + 4096), 0x7fffffffu);
 		const size_t cap_fine = std::max<size_t>(fc->hint_fine, (size_t)8 * P + 4096);
 		mb->cap_cells = cap_cells; mb->cap_fine = cap_fine;
@@ -656,10 +655,6 @@ static int raster_forward_impl(const ShSource* sh_src,
 		}
 		if (wait_mailbox(mb, seq, stream) != 0) return -1;
 		const size_t R_cells = mb->host->r_cells, R_fine = (size_t)mb->host->r_fine;
-		if (dbg_stop < 99) fprintf(stderr, "[adgs v2] P=%d cells=%zu R_cells=%zu R_fine=%zu buckets=%d chunks=%u overflow=%u\n", P, ncells, R_cells, R_fine,
-			(int)buckets, mb->host->n_groups, mb->host->oversize);
-#define ADGS_DBG_STOP(k) if (dbg_stop == (k)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[adgs v2] stop after stage %d: %s\n", (k), hipGetErrorString(e_)); return 0; }
-		ADGS_DBG_STOP(0)
 		if (mb->host->overflow) mb->repaired++;      // an eager frame that did not fit is enqueued again below, before this call returns
 		const bool chunk_table_full = buckets && mb->host->oversize;
 		if (!speculate || chunk_table_full || R_cells > cap_cells || R_fine > cap_fine) {
@@ -677,7 +672,6 @@ static int raster_forward_impl(const ShSource* sh_src,
 				if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
 			}
 			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
-			ADGS_DBG_STOP(3)
 			if (launch_blend() != 0) return -1;
 		}
 		{	// capacity hints for the next frame: 25% head-room over this frame, slow decay of older peaks

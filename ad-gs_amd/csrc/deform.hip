@@ -858,10 +858,8 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(DeformBwdArgs a, int nb
 	else deform_bwd_body<DP_XYZ | DP_ROT | DP_REST, false, 0>(a, b - nb_rot - nb_xyz, 0, a.p.Ns, s_rows, s_bg);
 }
 
-// the four-Gaussians-per-thread scene path needs every (non-NULL) scene pointer 16-byte aligned; ADGS_NO_SCENE4=1 switches it off
+// the four-Gaussians-per-thread scene path needs every (non-NULL) scene pointer 16-byte aligned
 static int scene4_ok(std::initializer_list<const void*> ptrs) {
-	static const bool off = getenv("ADGS_NO_SCENE4") != nullptr;
-	if (off) return 0;
 	for (const void* q : ptrs) if (reinterpret_cast<uintptr_t>(q) & 15) return 0;
 	return 1;
 }
@@ -982,8 +980,7 @@ constexpr size_t MAX_STAGING_LDS = 156 * 1024;
 // block size / LDS of the staged geometry kernels: the largest block whose rows fit 48 KiB; one-wave blocks may take up to
 // MAX_STAGING_LDS of the CU's 160 KiB (very long parameter rows: B-spline + polynomial + Fourier + quaternion parts together)
 static int pick_block(int row_floats, size_t* lds) {
-	static const int max_block = []() { const char* e = getenv("ADGS_DEFORM_BLOCK"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128) ? v : 256; }();      // measurement knob
-	for (int B = max_block; B >= 64; B >>= 1) {
+	for (int B = 256; B >= 64; B >>= 1) {
 		const size_t bytes = (size_t)B * row_floats * sizeof(float);
 		if (bytes <= 48 * 1024 || B == 64) { *lds = bytes; return B; }
 	}
@@ -1112,7 +1109,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 			size_t lds = 0;
 			// object xyz rows: direct 8-byte reads when the row length is even (rows are then 8-byte aligned), else staged through LDS
 			a.xyz_rows = p->No > 0 && np_x > 0 && np_x % 2 == 0 && p->xyz_deform_param && (reinterpret_cast<uintptr_t>(p->xyz_deform_param) & 7) == 0 &&
-				p->obj_xyz && getenv("ADGS_NO_XYZ_ROWS") == nullptr;
+				p->obj_xyz;
 			const int B = p->No > 0 ? pick_block(a.xyz_rows ? a.stride_r : std::max(a.stride_x, a.stride_r), &lds) : 256;
 			if (a.xyz_rows) lds = std::max(lds, (size_t)2 * np_x * sizeof(float));
 			if (lds > MAX_STAGING_LDS) { set_error("adgs_deform_forward: deformation rows too large for the LDS staging buffer"); return -1; }

@@ -140,8 +140,7 @@ int exclusive_scan_u32_sum(const uint32_t* in, uint32_t* out, size_t n, char* te
 	char* next_temp = temp + align_up(nb * sizeof(uint32_t), 256);
 	hipLaunchKernelGGL(scan_tile_kernel<0>, dim3((unsigned)nb), dim3(PB), 0, stream, in, (uint32_t*)nullptr, n, (const uint32_t*)nullptr, sums, aux_in, aux_total);
 	ADGS_HIP_CHECK(hipGetLastError());
-	static const bool three_launch = getenv("ADGS_SCAN3") != nullptr;
-	if (nb <= 4096 && !three_launch) {            // two launches: the blocks of the second pass add up the preceding block sums themselves
+	if (nb <= 4096) {            // two launches: the blocks of the second pass add up the preceding block sums themselves
 		hipLaunchKernelGGL(scan_tile_kernel<2>, dim3((unsigned)nb), dim3(PB), 0, stream, in, out, n, (const uint32_t*)sums, (uint32_t*)nullptr, no_aux, no_tot);
 		ADGS_HIP_CHECK(hipGetLastError());
 		return 0;

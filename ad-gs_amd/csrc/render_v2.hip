@@ -36,10 +36,7 @@ constexpr float PIXEL_DONE = 3.0e38f;      // row coordinate of a pixel that tak
 // pixels per lane: 4 (one wave = one 16x16 tile) or, for small images that would leave the chip idle, 2 (one wave = a 16x8
 // half tile: twice the waves, a shorter dependent chain per wave); PPL is a template parameter of both blend kernels
 constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu;
-#ifndef ADGS_SPLAT_ROW
-#define ADGS_SPLAT_ROW 5           // float4 quads between two gathered Splat rows in LDS (4: dense, the round-4 layout; A/B builds)
-#endif
-constexpr int SPLAT_ROW = ADGS_SPLAT_ROW;
+constexpr int SPLAT_ROW = 5;       // float4 quads between two gathered Splat rows in LDS (4 data quads + 1 pad quad: conflict-free row stores, render_fwd_v2_kernel)
 
 // The exponent is kept in log2 units (entry_geom scales the conic by log2 e once per entry): G = 2^pw is ONE v_exp_f32 per pixel
 // (~1 ulp), not v_mul + v_exp.  ADGS_PRECISE_EXP: libm's exp2f (parity experiments: the share of gate flips the fast exp owns).
@@ -48,25 +45,9 @@ constexpr int SPLAT_ROW = ADGS_SPLAT_ROW;
 #else
 #define ADGS_EXP2(x) exp2f(x)
 #endif
-#ifndef ADGS_LEAN
-#define ADGS_LEAN 1                // 0: every entry takes the general evaluation (A/B builds)
-#endif
-#ifndef ADGS_SETPRIO
-#define ADGS_SETPRIO 1             // 0: no s_setprio around the memory phases (A/B builds)
-#endif
 constexpr float LOG2E = 1.4426950408889634f;
-#ifndef ADGS_BWD_PF2
-#define ADGS_BWD_PF2 1             // 0: the backward gathers a chunk's Splat lines when it reaches the chunk (A/B builds)
-#endif
-#ifndef ADGS_FWD_DMA
-#define ADGS_FWD_DMA 1             // 0: the forward loads the key stream into registers at the moment it needs it (A/B builds)
-#endif
-#ifndef ADGS_FWD_SCAN_ROUNDS
-#define ADGS_FWD_SCAN_ROUNDS 2     // staged scan: rounds of 64 list entries per step (1 or 2)
-#endif
-#ifndef ADGS_FWD_KEY_RING
-#define ADGS_FWD_KEY_RING 1        // staged key-stream blocks per wave (2 KiB of LDS each): a block is requested KEY_RING blocks before it is scanned (2 / 3: measured slower, see below)
-#endif
+// (The A/B switches of rounds 3 - 5 -- ADGS_LEAN, ADGS_SETPRIO, ADGS_BWD_PF2, ADGS_FWD_DMA, ADGS_FWD_SCAN_ROUNDS, ADGS_FWD_KEY_RING, ADGS_FWD_WAVES /
+// ADGS_BWD_WAVES, ADGS_SPLAT_ROW -- are retired: every one was measured, the winner is the code below, the losers are in EXPERIMENTS.md.)
 
 // Can the Gaussian of Splat line (q0 = x y ca cb, cc, tau) reach alpha >= 1/255 on any pixel centre of the wave's tile (column tx, pixel rows
 // row0 .. row0 + rows - 1)?  Exact minimum of the quadratic form d^T Q d over the tile's pixel-centre rectangle (a lower bound of the
@@ -144,14 +125,8 @@ __device__ __forceinline__ uint64_t eval_entry_fwd(const EntryGeom& eg, const fl
 	return any_m;
 }
 
-#ifndef ADGS_FWD_WAVES
-#define ADGS_FWD_WAVES 1
-#endif
-#ifndef ADGS_BWD_WAVES
-#define ADGS_BWD_WAVES 1
-#endif
 template <int PPL>
-__global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(RenderV2FwdArgs a) {
+__global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	// Gathered Splat lines, one ROW per candidate.  Rows are SPLAT_ROW = 5 quads apart (80 bytes), not 4: lane l stores its line with four
 	// ds_write_b128 at l * 64 bytes otherwise, and the sixteen lanes of a pass land on four bank quads (round 4: SQ_LDS_BANK_CONFLICT = 23 % of
@@ -160,23 +135,18 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	__shared__ uint32_t s_pub[2 * WAVE];         // live ids waiting to leave as a full chunk
 	// key-stream scan: SCAN_ROUNDS x 64 list entries per step; ring: < 64 waiting + one step's survivors, power of two.  With the
 	// staged key stream (below) a step is half a staged block: 4096 + 512 + 1024 + 2048 bytes of LDS = 21 workgroups per CU.
-	constexpr int SCAN_ROUNDS = ADGS_FWD_DMA ? ADGS_FWD_SCAN_ROUNDS : 4, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
-	constexpr bool CAND_IN_PAD = CAND_RING == 4 * WAVE && SPLAT_ROW == 5;        // the ring lives in the rows' pad quads (else: behind the rows)
-	constexpr int SPLAT_BYTES = WAVE * SPLAT_ROW * (int)sizeof(float4);
-	__shared__ __attribute__((aligned(16))) unsigned char s_rows[SPLAT_BYTES + (CAND_IN_PAD ? 0 : CAND_RING * (int)sizeof(uint32_t))];
-	float4* const s_splat = reinterpret_cast<float4*>(s_rows);
-	uint32_t* const s_cand_own = reinterpret_cast<uint32_t*>(s_rows + SPLAT_BYTES);
-	auto cand = [&](uint32_t i) -> uint32_t& {
-		return CAND_IN_PAD ? reinterpret_cast<uint32_t*>(s_splat)[(i >> 2) * (4 * SPLAT_ROW) + 16 + (i & 3u)] : s_cand_own[i];
-	};
+	constexpr int SCAN_ROUNDS = 2, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
+	static_assert(CAND_RING == 4 * WAVE && SPLAT_ROW == 5, "the candidate ring lives in the pad quads of the 64 gathered rows");
+	__shared__ float4 s_splat[WAVE * SPLAT_ROW];
+	auto cand = [&](uint32_t i) -> uint32_t& { return reinterpret_cast<uint32_t*>(s_splat)[(i >> 2) * (4 * SPLAT_ROW) + 16 + (i & 3u)]; };
 	// The key stream of a cell is SEQUENTIAL and the tile's position in it is known long before the entries are needed: the next
 	// block of KEY_BLOCK (id, mask) entries is copied global -> LDS by the DMA path of the load unit (global_load_lds_dwordx4: no
 	// registers, two instructions per block) as soon as the previous block has been scanned, i.e. it flies under the filter round, the
 	// Splat gather and the whole blend loop of the batch.  Until round 3 the scan loaded 256 entries into registers when it needed
 	// them: ~10 exposed round trips per tile at several microseconds each under load (tools/blend_phase_timing.py) -- a third of a
 	// wave's life.  Bucket-binned frames only (cell_entries); the device-wide-sort fallback keeps the register path.
-	constexpr int KEY_BLOCK = 2 * SCAN_ROUNDS * WAVE, KEY_RING = ADGS_FWD_KEY_RING;      // a block = two scan steps; one DMA instruction copies 128 entries
-	__shared__ __attribute__((aligned(16))) uint2 s_keys[ADGS_FWD_DMA ? KEY_RING * KEY_BLOCK : 2];
+	constexpr int KEY_BLOCK = 2 * SCAN_ROUNDS * WAVE, KEY_RING = 1;      // a block = two scan steps; one DMA instruction copies 128 entries; ONE staged block per wave (2 / 3: slower, below)
+	__shared__ __attribute__((aligned(16))) uint2 s_keys[KEY_RING * KEY_BLOCK];
 	const int lane = threadIdx.x;
 	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
 	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
@@ -229,7 +199,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 	const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 	// stage-1 state: candidates whose rectangle holds this tile (ring buffer), the prefetched next batch of the key stream
 	uint32_t chead = 0, ccount = 0;
-	const bool staged = ADGS_FWD_DMA && a.cell_entries != nullptr;
+	const bool staged = a.cell_entries != nullptr;
 	// The staged blocks form a ring: block j of the cell's list (positions range.x + j KEY_BLOCK ...) lives in slot j % KEY_RING and is
 	// requested as soon as that slot is free, i.e. KEY_RING blocks before the scan reaches it.  With ONE slot (the default) a block is
 	// requested when the previous one is exhausted: the scan of a batch needs ~2.4 blocks and most of them are waited for at full latency
@@ -301,7 +271,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		if (all_done) break;
 		// The memory phases (refill, gather) are a few dozen instructions between long waits: raised priority lets the wave issue its loads
 		// at once when it returns from one; the blend loops of the other waves, which only need throughput, fill the rest.
-		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(2);
+		__builtin_amdgcn_s_setprio(2);
 		// ---- refill.  Stage 1 scans the cell's depth-sorted list: every entry carries which tile rows and columns of the cell the
 		// Gaussian's rectangle covers (cell_scatter / duplicate_cells), so the rectangle test costs 8 sequential bytes and two shifts per
 		// candidate -- at C3 a tile scans ~2400 candidates to find ~250.  Stage 2 gathers the 64-byte Splat line of up to 64 of them,
@@ -380,7 +350,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 			s_splat[lane * SPLAT_ROW + 2] = g2; s_splat[lane * SPLAT_ROW + 3] = g3;
 			s_splat[lane * SPLAT_ROW + 0] = g0; s_splat[lane * SPLAT_ROW + 1] = g1;
 			pass = tile_may_contribute(g0, g1.x, g3.z, tx, ty * ROWS, ROWS);      // g3.z: tau (Splat::aux)
-			my_lean = ADGS_LEAN && pass && g3.w != 0.f;
+			my_lean = pass && g3.w != 0.f;
 		}
 		landed = issued;          // the gather's lines (nc >= 1 lanes took part) are younger than every block requested so far: those have arrived
 		chead = (chead + nc) & (CAND_RING - 1); ccount -= nc;
@@ -402,7 +372,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_FWD_WAVES) render_fwd_v2_kernel(Ren
 		// over the tile rectangle, and pixels saturate), and positions (n_contrib) count live entries only.
 		uint64_t live = 0ull;
 		PT(t_b0); PT_ACC(2, t_g0, t_b0);
-		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
+		__builtin_amdgcn_s_setprio(0);
 		for (uint64_t todo = pm; todo != 0ull; todo &= todo - 1ull) {
 			const uint32_t j = (uint32_t)__builtin_ctzll(todo);
 			const float4 q0 = s_splat[j * SPLAT_ROW + 0];      // x y ca cb
@@ -569,7 +539,7 @@ __device__ __forceinline__ uint64_t eval_entry_bwd(const EntryGeom& eg, float py
 // FULL: colour, depth, opacity, flow and semantic gradients all present (the training configuration) --
 // the channel switches fold at compile time; otherwise they are wave-uniform run-time flags.
 template <int PPL, bool FULL>
-__global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(RenderV2BwdArgs a) {
+__global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) {
 	constexpr int ROWS = 4 * PPL;
 	const bool do_color = FULL || a.do_color, do_flow = FULL || a.do_flow, do_sem = FULL || a.do_sem, do_depth = FULL || a.do_depth, do_opacity = FULL || a.do_opacity;
 	// 4096 + 3584 bytes: 21 one-wave workgroups per CU (8768 bytes until round 3 capped the kernel at 18 = 4.5 waves per SIMD whatever
@@ -672,7 +642,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 	bool rows_ready = false;                      // nx0 .. nx3 hold the CURRENT chunk's lines (requested one chunk ago)
 	while (chunk != NO_CHUNK) {
 		PT(t_c0);
-		if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(2);      // a chunk boundary is a dozen instructions between two waits: do not starve behind the older waves' entry loops
+		__builtin_amdgcn_s_setprio(2);      // a chunk boundary is a dozen instructions between two waits: do not starve behind the older waves' entry loops
 		const uint32_t prev = (uint32_t)__builtin_amdgcn_readlane((int)link, 0);
 		const int n = __builtin_amdgcn_readlane((int)link, 1);
 #ifdef ADGS_PHASE_TIMING
@@ -682,7 +652,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 		base -= n;
 		const uint32_t cur_id = my_id;
 		float4 c0, c1, c2, c3;
-		if (ADGS_BWD_PF2 && rows_ready) { c0 = nx0; c1 = nx1; c2 = nx2; c3 = nx3; }
+		if (rows_ready) { c0 = nx0; c1 = nx1; c2 = nx2; c3 = nx3; }
 		else {
 			// the tile's first chunk: its lines now, the next chunk's ids at the same time
 			if (prev != NO_CHUNK) { const uint32_t* cn = a.pool + (size_t)prev * CHUNK_WORDS; nx_id = cn[lane]; nx_link = cn[CHUNK_PREV + (lane & 1)]; }
@@ -694,12 +664,12 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 			bool my_lean = false;
 			if (lane < n) {
 				s_splat[lane * BROW + 0] = c0; s_splat[lane * BROW + 1] = c1; s_splat[lane * BROW + 2] = c2; s_splat[lane * BROW + 3] = c3;
-				my_lean = ADGS_LEAN && c3.w != 0.f;
+				my_lean = c3.w != 0.f;
 			}
 			// the chunk behind this one: its lines fly while this chunk is replayed; the ids of the one behind that follow
 			uint32_t nn_id = 0, nn_link = 0;
 			if (prev != NO_CHUNK) {
-				if (ADGS_BWD_PF2) {
+				{
 					const uint32_t pprev = (uint32_t)__builtin_amdgcn_readlane((int)nx_link, 0);
 					request_rows(nx_id, __builtin_amdgcn_readlane((int)nx_link, 1), nx0, nx1, nx2, nx3);
 					if (pprev != NO_CHUNK) { const uint32_t* cp = a.pool + (size_t)pprev * CHUNK_WORDS; nn_id = cp[lane]; nn_link = cp[CHUNK_PREV + (lane & 1)]; }
@@ -707,13 +677,12 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 				}
 			}
 			my_id = nx_id; link = nx_link; nx_id = nn_id; nx_link = nn_link;
-			if (!ADGS_BWD_PF2) rows_ready = false;
 			// bit j: entry j takes the lean evaluation -- its Gaussian allows it and its position lies before every pixel's last contributor
 			// (contributor = base + j < min_contrib: the position test holds for all pixels)
 			const int n_before = min_contrib - base;
 			const uint64_t lean_m = __builtin_amdgcn_ballot_w64(my_lean) & (n_before >= WAVE ? ~0ull : n_before <= 0 ? 0ull : ((1ull << n_before) - 1ull));
 			__syncthreads();
-			if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
+			__builtin_amdgcn_s_setprio(0);
 			PT(t_g1); PT_ACC(1, t_c1, t_g1);
 			// entries at or behind every pixel's last contributor are not replayed: the loop starts below them
 			const int j_first = min(n - 1, max_contrib - base - 1);
@@ -769,7 +738,7 @@ __global__ void __launch_bounds__(WAVE, ADGS_BWD_WAVES) render_bwd_v2_kernel(Ren
 		}
 		chunk = prev;
 	}
-	if (ADGS_SETPRIO) __builtin_amdgcn_s_setprio(0);
+	__builtin_amdgcn_s_setprio(0);
 	{ PT(t_wave1); PT_ACC(4, t_wave0, t_wave1); PT_ADD(5, 1ull); PT_FLUSH(16, 9, lane); }
 	TL_STORE(lane, a.tl_start, a.tl_end, tile);
 	PROBE_FLUSH(8, lane);

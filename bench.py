@@ -403,7 +403,7 @@ def committed_pmc(stage, config, measured_case):
     return out
 
 
-def measure_traffic_in_run(stage, argv_config, timeout_s=170):
+def measure_traffic_in_run(stage, argv_config, timeout_s=75):
     """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child processes of this same script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md, HBM section; FETCH_SIZE counts
     128-byte requests at 64 bytes on gfx950: x 2; both in KiB), a handful of steps each, the program itself after `--`.  Returns

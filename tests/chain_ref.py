@@ -42,13 +42,14 @@ def deformed_xyz32(raw, t, oa):
     return np.asarray(xyz, np.float32)
 
 
-def run_chain(raw, oa, use_time_mask, t, t_flow, cam, H, W, degree, ups, semantic=None, precision="f32", env=None, inv_depth=True, strict=False):
+def run_chain(raw, oa, use_time_mask, t, t_flow, cam, H, W, degree, ups, semantic=None, precision="f32", env=None, inv_depth=True, strict=False, strict_mask=None):
     """raw: raw_numpy(model).  ups: dict of upstream image gradients (numpy): 'color' (or 'render' with env), 'depth', 'img_opacity',
     and with t_flow / semantic 'flow' / 'semantic' -- or a callable(images dict) -> such a dict (a loss evaluated on the chain's own images).
     env: None or dict(grid_map [C,Hm,Wm], focal, R [3,3]).
     Returns dict(images..., radii, act (activated f32 tensors), act_grads, raw_grads {name: float64 array}, env_grad, explained (the
     oracle's gate-flip masks, tests/parity.py)); with strict=True also raw_grads_strict / act_grads_strict / env_grad_strict: the same
-    backward with every upstream gradient zeroed at the gate-flip pixels (the strict gradient pass of tests/parity.py)."""
+    backward with every upstream gradient zeroed at the gate-flip pixels (the strict gradient pass of tests/parity.py); strict_mask: use
+    this [H, W] pixel mask instead of the run's own (the conditioning draws of a failed strict comparison: float64 run, perturbed run)."""
     from tests import parity
     npm = dict(raw)
     npm["order_args"], npm["use_time_mask"] = oa, use_time_mask
@@ -59,6 +60,7 @@ def run_chain(raw, oa, use_time_mask, t, t_flow, cam, H, W, degree, ups, semanti
                     cam["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, act["shs"], flow, semantic, degree, cam["campos"], False, inv_depth)
     z = lambda c: np.zeros((c, H, W), np.float32)
     out = dict(fwd)
+    strict = strict or strict_mask is not None
     out["explained"] = parity.explained_masks(o.gate_margins()) if strict else None
     bg = None
     O = np.asarray(fwd["img_opacity"], np.float64)
@@ -101,6 +103,6 @@ def run_chain(raw, oa, use_time_mask, t, t_flow, cam, H, W, degree, ups, semanti
     bw, raw_grads, env_grad = backward(ups, strict)
     out.update(act=act, flow_points=flow, act_grads=bw, raw_grads=raw_grads, env_grad=env_grad)
     if strict:
-        bw_s, raw_s, env_s = backward(parity.mask_upstream(ups, out["explained"]["pixel"]), False)
+        bw_s, raw_s, env_s = backward(parity.mask_upstream(ups, out["explained"]["pixel"] if strict_mask is None else strict_mask), False)
         out.update(act_grads_strict=bw_s, raw_grads_strict=raw_s, env_grad_strict=env_s)
     return out
