@@ -279,22 +279,61 @@ static MailboxRef* mailbox() {
 	}
 	return &m;
 }
+// Forward tile order from the camera's previous render (render_v2.hip: order_mode 2).  One hint buffer (a permutation of the wave tiles,
+// written by launch_tile_order right behind every blend forward) per camera, per (host thread, device).  A camera is recognised by the
+// device addresses of its view / projection matrices -- the reference's Camera keeps them on the GPU (scene/cameras.py:77-80), the wrapper of
+// gaussian_renderer.render() uploads them once per camera -- together with the image shape.  A wrong guess (recycled addresses, a camera
+// that moved) costs speed only: ANY permutation renders the same images.  The table is bounded (OLDEST entry recycled: no hipFree / hipMalloc
+// in steady state); under stream capture only existing entries are used (no allocation inside a capture) and those stay pinned for the
+// graph's lifetime.
+struct OrderHints {
+	struct Entry { const void* view; const void* proj; int W, H; size_t tiles; uint32_t* buf; bool valid; bool pinned; unsigned long long used; };
+	std::vector<Entry> entries;
+	unsigned long long clock = 0;
+	static constexpr size_t MAX_ENTRIES = 1024;
+	Entry* find(const void* view, const void* proj, int W, int H, size_t tiles) {
+		for (Entry& e : entries) if (e.view == view && e.proj == proj && e.W == W && e.H == H && e.tiles == tiles) { e.used = ++clock; return &e; }
+		return nullptr;
+	}
+	Entry* create(const void* view, const void* proj, int W, int H, size_t tiles) {
+		if (entries.size() >= MAX_ENTRIES) {      // recycle the least recently used entry that no graph holds
+			Entry* lru = nullptr;
+			for (Entry& e : entries) if (!e.pinned && (!lru || e.used < lru->used)) lru = &e;
+			if (!lru) return nullptr;
+			if (lru->tiles != tiles) { (void)hipFree(lru->buf); lru->buf = nullptr; if (hipMalloc((void**)&lru->buf, tiles * sizeof(uint32_t)) != hipSuccess) { lru->tiles = 0; lru->view = nullptr; return nullptr; } }
+			lru->view = view; lru->proj = proj; lru->W = W; lru->H = H; lru->tiles = tiles; lru->valid = false; lru->used = ++clock;
+			return lru;
+		}
+		Entry e{ view, proj, W, H, tiles, nullptr, false, false, ++clock };
+		if (hipMalloc((void**)&e.buf, tiles * sizeof(uint32_t)) != hipSuccess) return nullptr;
+		entries.push_back(e);
+		return &entries.back();
+	}
+};
+static OrderHints* order_hints() {
+	constexpr int MAX_DEV = 64;
+	static thread_local OrderHints hints[MAX_DEV];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+	return &hints[dev];
+}
 // What the forward decided from the environment (pipeline, cell size, pixels per lane), remembered per forward state so that the
 // backward of THAT forward carves the saved buffers the same way even if the environment changed in between.  The buffers are opaque
 // device memory, so the key is host-side: the (image, geometry) buffer addresses autograd hands back TOGETHER WITH the frame's shape
 // (W, H, P).  A state that reaches the backward under another address (cloned / offloaded saved tensors) or another shape is "not
 // found": the backward then carves by today's environment and zeroes the accumulator lines itself -- it never trusts a stale entry.
 // tile_order / sh_staging / timeline: the backward's own measurement knobs (ADGS_TILE_ORDER, ADGS_NO_SH_STAGING, ADGS_TIMELINE_BWD), read by the FORWARD
-struct FrameCfg { int v2; int cell_tiles; int ppl; int tile_order = 1; int sh_staging = 1; int timeline = 0; int backwards = 0; };      // backwards: how many backward passes have consumed this forward's accumulator lines
+struct FrameCfg { int v2; int cell_tiles; int ppl; int tile_order = 1; int sh_staging = 1; int timeline = 0; int order_ready = 0; int backwards = 0; };      // order_ready: the forward already built img.tile_order      // backwards: how many backward passes have consumed this forward's accumulator lines
 // FrameCfg <-> the configuration word in the image state's header (kernels.h: PreprocessArgs::cfg_word)
 static uint32_t frame_cfg_word(const FrameCfg& c) {
 	return 0xAD600000u | ((uint32_t)(c.v2 & 1) << 19) | ((uint32_t)(c.tile_order & 1) << 18) | ((uint32_t)(c.sh_staging & 1) << 17) | ((uint32_t)(c.timeline & 1) << 16) |
-	       ((uint32_t)(c.ppl & 0xff) << 8) | (uint32_t)(c.cell_tiles & 0xff);
+	       ((uint32_t)(c.order_ready & 1) << 15) |
+	       ((uint32_t)(c.ppl & 0x7f) << 8) | (uint32_t)(c.cell_tiles & 0xff);
 }
 static bool frame_cfg_from_word(uint32_t w, FrameCfg* c) {
 	if ((w & 0xFFF00000u) != 0xAD600000u) return false;
-	*c = FrameCfg{ (int)((w >> 19) & 1u), (int)(w & 0xffu), (int)((w >> 8) & 0xffu) };
-	c->tile_order = (int)((w >> 18) & 1u); c->sh_staging = (int)((w >> 17) & 1u); c->timeline = (int)((w >> 16) & 1u);
+	*c = FrameCfg{ (int)((w >> 19) & 1u), (int)(w & 0xffu), (int)((w >> 8) & 0x7fu) };
+	c->tile_order = (int)((w >> 18) & 1u); c->sh_staging = (int)((w >> 17) & 1u); c->timeline = (int)((w >> 16) & 1u); c->order_ready = (int)((w >> 15) & 1u);
 	return c->cell_tiles >= 1 && (c->ppl == 1 || c->ppl == 2 || c->ppl == 4);
 }
 struct FrameKey {
@@ -487,12 +526,31 @@ static int raster_forward_impl(const ShSource* sh_src,
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
 		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, count_cells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
-		uint32_t frame_word = 0;
+		uint32_t frame_word = 0; bool order_tiles = false;
 		{
 			FrameCfg fcfg{ 1, cell_tiles, ppl };
 			fcfg.tile_order = env_int("ADGS_TILE_ORDER", 1) != 0; fcfg.sh_staging = env_str("ADGS_NO_SH_STAGING") == nullptr; fcfg.timeline = env_int("ADGS_TIMELINE_BWD", 0) != 0;
+			// fewer tiles than wave slots: nothing to balance, neither in the backward nor in the forward
+			order_tiles = wtiles >= 2048 && fcfg.tile_order;
+			fcfg.order_ready = order_tiles ? 1 : 0;
 			remember_frame(FrameKey{ ich, gch, width, height, P }, fcfg);
 			frame_word = frame_cfg_word(fcfg);
+		}
+		// ADGS_FWD_ORDER: 2 (default) = this camera's previous render decides the forward's tile order (bottom-up without one), 1 = bottom-up, 0 = top-down
+		const int fwd_order_mode = env_int("ADGS_FWD_ORDER", 2);
+		OrderHints::Entry* hint = nullptr;
+		const uint32_t* hint_read = nullptr;
+		if (order_tiles && fwd_order_mode == 2) {
+			hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+			(void)hipStreamIsCapturing(stream, &cs0);
+			if (OrderHints* oh = order_hints()) {
+				hint = oh->find(viewmatrix, projmatrix, width, height, wtiles);
+				// a camera's first render has no hint (bottom-up).  Another camera's order is no substitute: measured with the bench's jittered
+				// cameras (0.04 rad of yaw: the image shifts by a few tiles) it is WORSE than bottom-up, 910 - 920 against 928 frames/s
+				if (!hint && cs0 != hipStreamCaptureStatusActive) hint = oh->create(viewmatrix, projmatrix, width, height, wtiles);
+				if (hint && cs0 == hipStreamCaptureStatusActive) hint->pinned = true;
+				if (hint && hint->valid) hint_read = hint->buf;
+			}
 		}
 
 		PreprocessArgs pa;
@@ -629,7 +687,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 			ra.pool = bin.pool; ra.pool_cursor = bin.pool_cursor; ra.tile_last_chunk = img.tile_last_chunk; ra.tile_consumed = img.tile_consumed; ra.tile_scanned = img.tile_scanned; ra.tile_batches = img.tile_batches;
 			ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 			ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
-			ra.order_mode = env_int("ADGS_FWD_ORDER", 1);
+			ra.order_mode = fwd_order_mode == 2 ? 1 : fwd_order_mode; ra.fwd_order = nullptr;
+			if (hint_read) { ra.order_mode = 2; ra.fwd_order = hint_read; }
 			ra.overflow_flag = overflow_flag;
 			{ StageTimer t(ST_RENDER_FWD, stream);
 			  if (launch_render_fwd_v2(ra, stream) != 0) return -1;
@@ -640,6 +699,12 @@ static int raster_forward_impl(const ShSource* sh_src,
 				sa.semantic = semantic; sa.D_S = D_S; sa.c0 = c0; sa.nch = std::min(4, D_S - c0); sa.out_semantic = img_semantic;
 				if (launch_render_sem_fwd_v2(sa, stream) != 0) return -1;
 			  } }
+			// the longest-first order of the tiles: for this frame's backward (it used to launch this itself) and, as a copy, for the next forward of this camera
+			if (order_tiles) {
+				StageTimer t(ST_RENDER_FWD, stream);
+				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream, hint ? hint->buf : nullptr) != 0) return -1;
+				if (hint) { hint->valid = true; hint_read = hint->buf; }      // (a second blend of this call -- the capacity re-run -- reads the order the first one left)
+			}
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
 		};
@@ -831,7 +896,8 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		{
 			StageTimer t(ST_RENDER_BWD, stream);
 			if (wtiles >= 2048 && cfg.tile_order) {      // fewer tiles than wave slots: nothing to balance
-				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream) != 0) return -1;
+				// the forward built the order behind its blend kernel (order_ready); a state from a library build that did not: here
+				if (!cfg.order_ready && launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream) != 0) return -1;
 				ra.tile_order = img.tile_order;
 			}
 			// geom.gacc lines of the visible Gaussians were zeroed by the forward preprocess: the FIRST backward over a forward

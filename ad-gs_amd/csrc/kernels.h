@@ -148,7 +148,8 @@ struct RenderV2FwdArgs {
 	uint32_t* pool; uint32_t* pool_cursor; uint32_t* tile_last_chunk; uint32_t* tile_consumed; uint32_t* tile_scanned; uint32_t* tile_batches;
 	float* final_T; uint32_t* n_contrib;
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
-	int order_mode;                         // 1: workgroups walk the tiles bottom-up (default), 0: top-down
+	int order_mode;                         // 1: workgroups walk the tiles bottom-up, 0: top-down, 2: in the order `fwd_order` gives
+	const uint32_t* fwd_order;              // order_mode 2: workgroup -> tile, the longest-first order of THIS CAMERA'S PREVIOUS render (api.hip: OrderHints)
 	const uint32_t* overflow_flag;          // device word: != 0 = the frame does not fit the capacity of this launch (blend nothing)
 };
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
@@ -181,7 +182,7 @@ struct RenderV2SemFwdArgs {
 };
 int launch_render_sem_fwd_v2(const RenderV2SemFwdArgs& a, hipStream_t stream);
 // order[i] = tile with the i-th largest number of consumed entries (bucketed): the backward starts the long tiles first
-int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream);
+int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy = nullptr);      // order_copy: the same permutation a second time (the camera's hint buffer)
 
 // flat coalesced d/dparam[m, d, k] = w_k * g[m * gstride + d] for the linear families (deform.hip)
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);

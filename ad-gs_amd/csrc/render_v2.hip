@@ -148,11 +148,15 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	constexpr int KEY_BLOCK = 2 * SCAN_ROUNDS * WAVE, KEY_RING = 1;      // a block = two scan steps; one DMA instruction copies 128 entries; ONE staged block per wave (2 / 3: slower, below)
 	__shared__ __attribute__((aligned(16))) uint2 s_keys[KEY_RING * KEY_BLOCK];
 	const int lane = threadIdx.x;
-	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order); the forward does
-	// not, and walks the image bottom-up by default: in driving scenes (the reference's KITTI / Waymo data, and the road-plane
-	// objects of the synthetic configs) the lower image rows carry the long lists, and tiles dispatched last run on a draining
-	// machine.  Measured at C3: 0.409 -> 0.400 ms; a strided permutation of the tiles: 0.412 ms.  ADGS_FWD_ORDER=0: top-down.
-	uint32_t tile = a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	// Dispatch order.  The backward knows every tile's length and starts the longest first (launch_tile_order).  The forward does not know
+	// its lengths -- but it knows the lengths of the LAST render of the same camera (api.hip: OrderHints; a training run returns to every
+	// camera once per epoch, the bench every 16 steps): order_mode 2 walks the tiles longest-first by that hint.  9600 one-wave workgroups
+	// over 5120 slots ran 1.9 rounds with 28 % of the kernel below half occupancy (profiles/r04/wave_timeline_c3.json: wave-time / slots =
+	// 165 us against 238 us): with the hint 0.231 -> 0.198 ms at C3 (round 5; round 2's forward, which had no such tail, gained nothing).
+	// Without a hint: bottom-up (order_mode 1) -- in driving scenes (the reference's KITTI / Waymo data, and the road-plane objects of
+	// the synthetic configs) the lower image rows carry the long lists: 0.409 -> 0.400 ms at the time; ADGS_FWD_ORDER=0: top-down.
+	// Any order gives the same images bit for bit: a tile's result does not depend on when it runs.
+	uint32_t tile = a.order_mode == 2 ? a.fwd_order[blockIdx.x] : (a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	if (*a.overflow_flag != 0u) {
 		// The frame does not fit the capacity this launch was enqueued against (api.hip: the totals are compared on the device): the
@@ -840,9 +844,10 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 // Longest-list-first order of the tiles for the backward (the forward recorded how many entries every tile consumed): one
 // workgroup, counting sort into 256 buckets of 8 entries.  9600 one-wave workgroups over 4096 wave slots are ~2.3 rounds;
 // without this the last round ends with whatever long tiles happen to sit at the end of the grid (backward 506 -> 466 us at C3).
-// (For the forward the counts are not known yet; ordering by the length of the tile's cell list was measured and does not help.)
+// Since round 5 the FORWARD launches it, right behind its blend kernel: the order serves this frame's backward (img.tile_order) and, as a copy in
+// the camera's hint buffer, the next forward of the same camera.  (Ordering the forward by the length of the tile's cell list was measured and does not help.)
 namespace {
-__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order) {
+__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy) {
 	// 1024 buckets of one entry: the LDS atomics of the histogram and of the scatter are what this kernel costs, and they
 	// serialise per address -- with coarse buckets most tiles of a frame fall into a handful of them
 	constexpr int NB = 1024, PER = 16;            // tiles per thread kept in registers: one round of loads (T <= 16384), else the generic loops
@@ -876,15 +881,18 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t*
 	__syncthreads();
 	if (fits) {
 #pragma unroll
-		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) order[atomicAdd(&start[b[k]], 1u)] = (uint32_t)(tid + k * 1024);
+		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) { const uint32_t at = atomicAdd(&start[b[k]], 1u); order[at] = (uint32_t)(tid + k * 1024); if (order_copy) order_copy[at] = (uint32_t)(tid + k * 1024); }
 	} else {
-		for (int t = tid; t < T; t += 1024) order[atomicAdd(&start[(uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1))], 1u)] = (uint32_t)t;
+		for (int t = tid; t < T; t += 1024) {
+			const uint32_t at = atomicAdd(&start[(uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1))], 1u);
+			order[at] = (uint32_t)t; if (order_copy) order_copy[at] = (uint32_t)t;
+		}
 	}
 }
 } // namespace
-int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream) {
+int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy) {
 	if (ntiles <= 0) return 0;
-	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_consumed, order);
+	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_consumed, order, order_copy);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

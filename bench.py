@@ -448,8 +448,8 @@ def measure_traffic_in_run(stage, argv_config, timeout_s=75):
 
 
 # stage of the bench line -> (kernels of the stage, "f" / "b": launched once per forward / per backward)
-STAGE_KERNELS = {"preprocess_fwd": (("sh0_rows_kernel", "sh0_kernel", "preprocess_fwd_kernel"), "f"), "render_fwd": (("render_fwd_v2_kernel",), "f"),
-                 "render_bwd": (("render_bwd_v2_kernel", "tile_order_kernel"), "b"),
+STAGE_KERNELS = {"preprocess_fwd": (("sh0_rows_kernel", "sh0_kernel", "preprocess_fwd_kernel"), "f"), "render_fwd": (("render_fwd_v2_kernel", "tile_order_kernel"), "f"),      # + the tile order for the backward and for this camera's next forward
+                 "render_bwd": (("render_bwd_v2_kernel",), "b"),
                  "preprocess_bwd": (("preprocess_bwd_kernel", "deform_lin_param_grad_kernel"), "b"),      # + the SH-deformation gradient rows of the raw-SH path (launched by the raster backward)
                  "deform_fwd": (("deform_fwd_kernel",), "f"), "deform_bwd": (("deform_bwd_kernel",), "b"),
                  "scan": (("cell_colscan_kernel", "cell_scan_kernel"), "f"), "duplicate_keys": (("cell_scatter_kernel",), "f"),
@@ -1068,6 +1068,9 @@ def main():
             "P": P, "cameras_per_step": cams_per_step,
             "camera_pool": ("%d cameras / time stamps per GPU, cycled one per step (train.py:55-61)" % pool_k) if not iteration_mode else "the iteration's cameras, every step",
             "settle_steps": settle_steps, "capacity_reruns": capacity_reruns, "library_sha256_16": library_stamp(),
+            "forward_tile_order": {"0": "top-down", "1": "bottom-up"}.get(os.environ.get("ADGS_FWD_ORDER", "2"),
+                                                                          "longest lists first by the previous render of the same camera (bottom-up for a camera's first render); "
+                                                                          "the pool's cameras return every %d steps with unchanged parameters, a training run returns once per epoch" % pool_k),
             "launch": ("HIP graph replay, one graph per camera (adgs.graph); every replay fitted its capacity: %s" % graph_ok) if use_graph else "eager",
             "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
             "step_ms_hip_events": dict(step_stats(step_ms), first=round(step_ms[0], 4))}

@@ -519,6 +519,47 @@ def test_backward_over_cloned_state_reads_the_forwards_configuration_from_the_st
         backward(r, r[5].clone(), r[6].clone(), junk)
 
 
+def test_forward_tile_order_hint_changes_nothing_but_the_schedule(monkeypatch):
+    """Round 5: the blend forward walks its tiles longest-first by the PREVIOUS render of the same camera (the library keeps one hint per
+    camera, recognised by the device addresses of its matrices; api.hip: OrderHints).  Any order must give the same frame bit for bit --
+    first render of a camera (bottom-up), second render (its own hint), a hint left by a different scene behind the same camera, and
+    ADGS_FWD_ORDER=1 / 0 -- and the backward (which gets its order from the forward now) the same gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = synthetic.make_scene(60000, 1024, 1024, 900.0, seed=81, n_objects=3, scale_mult=0.006)       # 4096 wave tiles: the ordered path
+    other = synthetic.make_scene(60000, 1024, 1024, 900.0, seed=82, n_objects=3, scale_mult=0.012)
+    g = synthetic.make_upstream_grads(sc, 81)
+    view, proj, campos, bg = dev(sc["viewmatrix"]), dev(sc["projmatrix"]), dev(sc["campos"]), dev(sc["bg"])       # ONE camera: the same matrices for every render below
+    settings = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], bg, 1.0, view, proj, 3, campos, False, True, False)
+    rast = GaussianRasterizer(settings)
+
+    def render(scene, with_grads=True):
+        L = {k: scene[k].cuda().clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        m2 = torch.zeros(scene["P"], 3, device="cuda", requires_grad=True)
+        out = rast(means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"], rotations=L["rotations"],
+                   flow_points=dev(scene["flow_points"]), semantic=dev(scene["semantic"]))
+        grads = None
+        if with_grads:
+            torch.autograd.backward([out[0], out[2], out[3], out[4], out[5]], [dev(g["color"]), dev(g["depth"]), dev(g["img_opacity"]), dev(g["flow"]), dev(g["semantic"])])
+            grads = {k: v.grad.clone() for k, v in L.items()}
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out], grads
+    first, g_first = render(sc)                       # no hint yet: bottom-up
+    assert _lib.frame_stats()["tiles"] >= 2048
+    second, g_second = render(sc)                     # the camera's own hint
+    render(other, with_grads=False)                   # another scene behind the same camera leaves ITS order as the hint ...
+    third, g_third = render(sc)                       # ... which is a poor guess and still only a schedule
+    runs = [(second, g_second), (third, g_third)]
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ADGS_FWD_ORDER", mode)
+        runs.append(render(sc))
+    monkeypatch.delenv("ADGS_FWD_ORDER")
+    for outs, grads in runs:
+        for a, b in zip(outs, first):
+            assert torch.equal(a, b)                  # images, radii: bit for bit
+        for k, v in g_first.items():                  # gradients: float atomics in another order
+            assert_close("grad_" + k, grads[k].cpu().numpy(), v.cpu().numpy(), tol=2e-5, max_frac=1e-4, rel_l2=2e-5)
+
+
 def test_repeated_backward_over_one_forward_state():
     """retain_graph: the per-Gaussian accumulator lines of a forward are consumed by its first backward and zeroed again (by the
     library, api.hip: note_backward) before every further one -- three backward passes over one forward give the same gradients
