@@ -300,12 +300,12 @@ struct OrderHints {
 			Entry* lru = nullptr;
 			for (Entry& e : entries) if (!e.pinned && (!lru || e.used < lru->used)) lru = &e;
 			if (!lru) return nullptr;
-			if (lru->tiles != tiles) { (void)hipFree(lru->buf); lru->buf = nullptr; if (hipMalloc((void**)&lru->buf, tiles * sizeof(uint32_t)) != hipSuccess) { lru->tiles = 0; lru->view = nullptr; return nullptr; } }
+			if (lru->tiles != tiles) { (void)hipFree(lru->buf); lru->buf = nullptr; if (hipMalloc((void**)&lru->buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) { lru->tiles = 0; lru->view = nullptr; return nullptr; } }
 			lru->view = view; lru->proj = proj; lru->W = W; lru->H = H; lru->tiles = tiles; lru->valid = false; lru->used = ++clock;
 			return lru;
 		}
 		Entry e{ view, proj, W, H, tiles, nullptr, false, false, ++clock };
-		if (hipMalloc((void**)&e.buf, tiles * sizeof(uint32_t)) != hipSuccess) return nullptr;
+		if (hipMalloc((void**)&e.buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) return nullptr;      // the permutation + the 16 floats of the view matrix it was made under
 		entries.push_back(e);
 		return &entries.back();
 	}
@@ -688,7 +688,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 			ra.final_T = img_opacity; ra.n_contrib = img.n_contrib;
 			ra.out_color = out_color; ra.out_depth = out_depth; ra.out_flow = img_flow; ra.out_semantic = img_semantic;
 			ra.order_mode = fwd_order_mode == 2 ? 1 : fwd_order_mode; ra.fwd_order = nullptr;
-			if (hint_read) { ra.order_mode = 2; ra.fwd_order = hint_read; }
+			ra.fwd_view = viewmatrix; ra.fwd_sig = nullptr;
+			if (hint_read) { ra.order_mode = 2; ra.fwd_order = hint_read; ra.fwd_sig = reinterpret_cast<const float*>(hint_read + wtiles); }
 			ra.overflow_flag = overflow_flag;
 			{ StageTimer t(ST_RENDER_FWD, stream);
 			  if (launch_render_fwd_v2(ra, stream) != 0) return -1;
@@ -702,7 +703,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 			// the longest-first order of the tiles: for this frame's backward (it used to launch this itself) and, as a copy, for the next forward of this camera
 			if (order_tiles) {
 				StageTimer t(ST_RENDER_FWD, stream);
-				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream, hint ? hint->buf : nullptr) != 0) return -1;
+				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream, hint ? hint->buf : nullptr, viewmatrix) != 0) return -1;
 				if (hint) { hint->valid = true; hint_read = hint->buf; }      // (a second blend of this call -- the capacity re-run -- reads the order the first one left)
 			}
 			ADGS_LAUNCH_CHECK(debug, stream);

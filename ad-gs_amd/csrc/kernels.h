@@ -150,6 +150,7 @@ struct RenderV2FwdArgs {
 	float* out_color; float* out_depth; float* out_flow; float* out_semantic;
 	int order_mode;                         // 1: workgroups walk the tiles bottom-up, 0: top-down, 2: in the order `fwd_order` gives
 	const uint32_t* fwd_order;              // order_mode 2: workgroup -> tile, the longest-first order of THIS CAMERA'S PREVIOUS render (api.hip: OrderHints)
+	const float* fwd_view; const float* fwd_sig;      // this frame's view matrix / the one the hint was made under (16 floats each): a hint of another pose is ignored
 	const uint32_t* overflow_flag;          // device word: != 0 = the frame does not fit the capacity of this launch (blend nothing)
 };
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
@@ -182,7 +183,8 @@ struct RenderV2SemFwdArgs {
 };
 int launch_render_sem_fwd_v2(const RenderV2SemFwdArgs& a, hipStream_t stream);
 // order[i] = tile with the i-th largest number of consumed entries (bucketed): the backward starts the long tiles first
-int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy = nullptr);      // order_copy: the same permutation a second time (the camera's hint buffer)
+// order_copy: the same permutation a second time (the camera's hint buffer), followed by the 16 floats of `view` (the pose the hint belongs to)
+int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy = nullptr, const float* view = nullptr);
 
 // flat coalesced d/dparam[m, d, k] = w_k * g[m * gstride + d] for the linear families (deform.hip)
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);

@@ -156,7 +156,14 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	// Without a hint: bottom-up (order_mode 1) -- in driving scenes (the reference's KITTI / Waymo data, and the road-plane objects of
 	// the synthetic configs) the lower image rows carry the long lists: 0.409 -> 0.400 ms at the time; ADGS_FWD_ORDER=0: top-down.
 	// Any order gives the same images bit for bit: a tile's result does not depend on when it runs.
-	uint32_t tile = a.order_mode == 2 ? a.fwd_order[blockIdx.x] : (a.order_mode == 1 ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+	// A camera is recognised by the addresses of its matrices (api.hip); the hint carries the view matrix it was made under, and a hint of
+	// ANOTHER pose (recycled addresses, a camera that moved) is ignored here -- measured: a neighbouring camera's order is worse than bottom-up.
+	bool use_hint = a.order_mode == 2;
+	if (use_hint) {
+#pragma unroll
+		for (int i = 0; i < 16; i++) use_hint = use_hint && (a.fwd_view[i] == a.fwd_sig[i]);      // 32 cached scalar loads
+	}
+	uint32_t tile = use_hint ? a.fwd_order[blockIdx.x] : (a.order_mode != 0 ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
 	const uint32_t tx = tile % a.gx, ty = tile / a.gx;
 	if (*a.overflow_flag != 0u) {
 		// The frame does not fit the capacity this launch was enqueued against (api.hip: the totals are compared on the device): the
@@ -847,7 +854,8 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 // Since round 5 the FORWARD launches it, right behind its blend kernel: the order serves this frame's backward (img.tile_order) and, as a copy in
 // the camera's hint buffer, the next forward of the same camera.  (Ordering the forward by the length of the tile's cell list was measured and does not help.)
 namespace {
-__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy) {
+__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy,
+	const float* __restrict__ view) {
 	// 1024 buckets of one entry: the LDS atomics of the histogram and of the scatter are what this kernel costs, and they
 	// serialise per address -- with coarse buckets most tiles of a frame fall into a handful of them
 	constexpr int NB = 1024, PER = 16;            // tiles per thread kept in registers: one round of loads (T <= 16384), else the generic loops
@@ -855,6 +863,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t*
 	__shared__ uint32_t start[NB];
 	const int tid = threadIdx.x;
 	hist[tid] = 0;
+	if (order_copy && view && tid < 16) reinterpret_cast<float*>(order_copy + T)[tid] = view[tid];      // the pose this hint belongs to
 	__syncthreads();
 	uint32_t b[PER];
 	const bool fits = T <= 1024 * PER;
@@ -890,9 +899,9 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t*
 	}
 }
 } // namespace
-int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy) {
+int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy, const float* view) {
 	if (ntiles <= 0) return 0;
-	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_consumed, order, order_copy);
+	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_consumed, order, order_copy, view);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -14,7 +14,8 @@ except Exception as e:
 PY
 }
 for rep in 1 2; do
-run own_hint_$rep ADGS_X=0
-run other_cam_hint_$rep ADGS_FWD_ORDER_STANDIN=2
+run hint_$rep ADGS_X=0
 run bottomup_$rep ADGS_FWD_ORDER=1
 done
+STEPS=20 WARM=5
+for rep in 1 2 3; do run driver_$rep ADGS_X=0; done
