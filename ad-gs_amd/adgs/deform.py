@@ -328,7 +328,8 @@ def get_deformed_pkg(model, t, want=("xyz", "rotation", "shs", "opacity", "scale
         out["shs"] = RawSH(model._scene_shs_dc, model._obj_shs_dc, model._scene_shs_rest, model._obj_shs_rest, sp, model.shs_deform_param_obj,
                            make_func_eval(float(t), model.order_args["shs"], sp.shape[-1]),
                            *((model._scene_xyz, model._scene_scaling, model._scene_rotation, model._scene_opacity, getattr(model, "grad_arena", None))
-                             if geo else ()))
+                             if geo else ()),
+                           adam=getattr(getattr(model, "optimizer", None), "backward_epilogue", None))
         return out
     tensors = [getattr(model, _MODEL_ATTRS[n], None) for n in _PTRS]
     meta = (float(t), dict(model.order_args), bool(getattr(model, "use_time_mask", False)), tuple(want),

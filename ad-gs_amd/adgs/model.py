@@ -132,9 +132,11 @@ class SyntheticGaussianModel:
     percent_dense, scene_extent, object_extent = 0.01, 1.0, 1.0
     use_near_idx, near_num, obj_near_idx, optimizer = False, 0, None, None
 
-    def training_setup(self, lrs=None, percent_dense=0.01, scene_extent=None, object_extent=None, near_num=0):
+    def training_setup(self, lrs=None, percent_dense=0.01, scene_extent=None, object_extent=None, near_num=0, adam_in_backward=False):
         """The optimizer of GaussianModel.training_setup (:338-372): one group per raw tensor, the reference's group names,
-        Adam(lr=0, eps=1e-15) -- here the fused HIP Adam.  `lrs`: {group name: lr} (default 1e-3 each)."""
+        Adam(lr=0, eps=1e-15) -- here the fused HIP Adam.  `lrs`: {group name: lr} (default 1e-3 each).
+        adam_in_backward: FusedAdam(in_backward=True) -- optimizer.arm_backward() then lets the rasterizer's backward apply the step
+        of the SH rest / SH deformation tensors itself (adgs.optim.BackwardEpilogue)."""
         from .optim import FusedAdam
         lrs = lrs or {}
         self.percent_dense = percent_dense
@@ -156,7 +158,7 @@ class SyntheticGaussianModel:
                 t = torch.nn.Parameter(t.detach().requires_grad_(True))
                 setattr(self, attr, t)
             groups.append({"params": [t], "lr": float(lrs.get(name, 1e-3)), "name": name})
-        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15, in_backward=bool(adam_in_backward))
         self.near_num, self.use_near_idx = near_num, near_num > 0
         self.set_obj_near_idx()
         return self.optimizer

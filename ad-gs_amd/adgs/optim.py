@@ -25,6 +25,17 @@ class AdamGroup(ctypes.Structure):
                 ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class AdamSlot(ctypes.Structure):
+    """adgs_adam_slot (include/adgs_optim.h)."""
+    _fields_ = [("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("lr", ctypes.c_float), ("step", ctypes.c_int32)]
+
+
+class ShAdam(ctypes.Structure):
+    """adgs_sh_adam (include/adgs_optim.h)."""
+    _fields_ = [(n, AdamSlot) for n in ("scene_rest", "obj_rest", "scene_deform", "obj_deform")] + \
+               [("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
 ADAM_TILE = 256            # ADGS_ADAM_TILE
 TILES_MARKED, ZERO_GRAD = 1, 2          # adgs_adam_group.flags
 
@@ -67,8 +78,82 @@ class MarkedGradient:
         self._live = None
 
 
+class BackwardClaim:
+    """What one rasterizer backward was granted by BackwardEpilogue.claim: the adgs_sh_adam block, which tensors it covers (`fused`:
+    name -> True) and the tensors that must stay alive until the kernels have been enqueued."""
+
+    def __init__(self, struct, fused, keep):
+        self.struct, self.fused, self.keep = struct, fused, keep
+
+
+class BackwardEpilogue:
+    """The optimizer's side of the in-backward Adam step (FusedAdam(in_backward=True); include/adgs_optim.h: adgs_sh_adam).
+
+    The reference's iteration is one backward followed by optimizer.step() (train.py:116, 163-167).  The kernels that produce the
+    gradients of the SH `rest` tensors and of the SH deformation rows hold every element of them exactly once, and nothing else in
+    AD-GS's loss reaches those tensors (the regularisers of train.py:101-110 act on xyz_deform_param and gs_time_sigma): armed for
+    ONE backward (FusedAdam.arm_backward()), that backward applies the step to them where the gradient is produced -- 24 instead
+    of 4 + 28 bytes per parameter -- and leaves their .grad None, so the step() that follows skips them exactly as torch.optim.Adam
+    skips a parameter without a gradient.  Their `step` counters are advanced at the claim.
+
+    Not for iterations that accumulate several backwards into one step (bench.py --config C4 / C5, data-parallel training): a second
+    claim before step() raises, and so does a step() that finds a gradient on a tensor this backward has already stepped."""
+
+    NAMES = ("scene_rest", "obj_rest", "scene_deform", "obj_deform")
+
+    def __init__(self, opt):
+        self.opt, self.armed, self.claimed = opt, False, []
+
+    def claim(self, tensors, needs, factored=False):
+        """Called by the rasterizer's backward.  tensors / needs: name -> tensor / needs_input_grad for NAMES.  Returns a BackwardClaim or
+        None (not armed)."""
+        if not self.armed:
+            return None
+        if factored:
+            raise RuntimeError("FusedAdam.arm_backward(): the factored SH-gradient exchange (data-parallel training) sums the gradients of "
+                               "several cameras before the step; the in-backward step is for the single-camera iteration")
+        if self.claimed:
+            raise RuntimeError("FusedAdam.arm_backward(): a second rasterizer backward before step() -- the in-backward Adam step is for "
+                               "iterations of ONE backward (train.py:116, 163-167)")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedAdam.arm_backward(): the in-backward Adam step cannot be captured into a graph")
+        self.armed = False
+        opt = self.opt
+        where = {id(p): g for g in opt.param_groups for p in g["params"]}
+        st_block, fused, keep, betas_eps = ShAdam(), {}, [], None
+        pairs = (("scene_rest", "obj_rest"), ("scene_deform", "obj_deform"))
+        for pair in pairs:
+            # the two halves of a pair take the step together or not at all (adgs_raster_backward_rawsh)
+            cand = [(n, tensors.get(n)) for n in pair]
+            cand = [(n, t) for n, t in cand if t is not None and t.numel() != 0]
+            ok = bool(cand) and all(needs.get(n) and id(t) in where and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.grad is None
+                                    for n, t in cand)
+            if ok:
+                keys = {(tuple(where[id(t)]["betas"]), float(where[id(t)]["eps"])) for _, t in cand}
+                ok = len(keys) == 1 and (betas_eps is None or keys == {betas_eps})
+                if ok:
+                    betas_eps = next(iter(keys))
+            if not ok:
+                continue
+            for n, t in cand:
+                group = where[id(t)]
+                st = opt._init_state(t)
+                st["step"] += 1
+                if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+                setattr(st_block, n, AdamSlot(t.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(group["lr"]), int(st["step"])))
+                fused[n] = True
+                keep += [t, st["exp_avg"], st["exp_avg_sq"]]
+                self.claimed.append(t)
+        if not fused:
+            return None
+        (b1, b2), eps = betas_eps
+        st_block.beta1, st_block.beta2, st_block.eps = float(b1), float(b2), float(eps)
+        return BackwardClaim(st_block, fused, keep)
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, skip_dormant_tiles=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, skip_dormant_tiles=False, in_backward=False):
         """skip_dormant_tiles: keep, per parameter, one byte per 256 elements saying whether that tile has ever seen a non-zero
         gradient; a tile that has not is left untouched by the step -- which is exactly what Adam does to it (zero moments, zero
         update) at 4 instead of 28 bytes of traffic per element.  For parameters most of which never receive a gradient (the
@@ -82,6 +167,19 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tile_maps = {}        # id(param) -> (byte map, exp_avg address, exp_avg_sq address, numel)
         self._marked = {}           # id(param) -> MarkedGradient
+        # in_backward=True: the rasterizer's backward may apply the step to the tensors only it produces gradients for (BackwardEpilogue);
+        # opt-in per backward with arm_backward()
+        self.backward_epilogue = BackwardEpilogue(self) if in_backward else None
+
+    def arm_backward(self):
+        """The NEXT rasterizer backward over this optimizer's SH tensors applies their Adam step itself (BackwardEpilogue); call it in an
+        iteration whose step() follows its one backward unconditionally -- not before a densification, after which the reference's
+        step finds no gradients and changes nothing (train.py:152-167)."""
+        if self.backward_epilogue is None:
+            raise RuntimeError("arm_backward() needs FusedAdam(in_backward=True)")
+        if self.backward_epilogue.claimed:
+            raise RuntimeError("arm_backward(): the previous armed backward has not been followed by step()")
+        self.backward_epilogue.armed = True
 
     def _init_state(self, p):
         st = self.state[p]
@@ -121,6 +219,13 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.backward_epilogue is not None:
+            epi = self.backward_epilogue
+            for p in epi.claimed:
+                if p.grad is not None:
+                    raise RuntimeError("FusedAdam.step(): a tensor whose Adam step was applied inside the rasterizer's backward has received a "
+                                       "gradient from elsewhere; stepping it again would apply this iteration twice")
+            epi.claimed, epi.armed = [], False
         batches = {}       # (device, betas, eps) -> list of AdamGroup
         keep = []
         recycle = []       # (MarkedGradient, its gradient buffer): zero again after this step

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "../../include/adgs_rasterizer.h"
+#include "../../include/adgs_optim.h"
 
 #include <atomic>
 #include <chrono>
@@ -935,7 +936,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		pa.dL_dmean2D = nullptr; pa.dL_dconic = nullptr; pa.dL_dcolor = nullptr; pa.dL_ddepth = nullptr;
 		pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
 		pa.gacc = geom.gacc; pa.splats = geom.splats; pa.W = width; pa.H = height;
-		memset(&pa.sh_src, 0, sizeof(pa.sh_src)); memset(&pa.sh_dst, 0, sizeof(pa.sh_dst));
+		memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh_dst = ShGradDst{};
 		if (sh_src) { pa.sh_src = *sh_src; if (sh_dst) pa.sh_dst = *sh_dst; }
 		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
 		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
@@ -980,7 +981,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	pa.dL_dmean2D = dL_dmean2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolor; pa.dL_ddepth = dL_ddepth;
 	pa.dL_dmean3D = dL_dmean3D; pa.dL_dcov3D = dL_dcov3D; pa.dL_dsh = dL_dsh; pa.dL_dscale = dL_dscale; pa.dL_drot = dL_drot;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
-	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); memset(&pa.sh_dst, 0, sizeof(pa.sh_dst));
+	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh_dst = ShGradDst{};
 	pa.gacc = nullptr; pa.splats = nullptr; pa.W = width; pa.H = height; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
 	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;
 	pa.sh_staging = cfg.sh_staging;
@@ -1084,6 +1085,36 @@ extern "C" int adgs_raster_backward_rawsh(
 	if (src.scene_xyz && !(dst.scene_xyz && dst.scene_scaling && dst.scene_rotation && dst.scene_opacity)) {
 		set_error("adgs_raster_backward_rawsh: the source carries raw scene geometry, its four gradient destinations are required"); return -1;
 	}
+	if (dL_dsh->adam && P > 0) {
+		// the Adam step in place of the gradient stores (include/adgs_optim.h: adgs_sh_adam)
+		const adgs_sh_adam& ad = *dL_dsh->adam;
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		(void)hipStreamIsCapturing((hipStream_t)stream, &cs);
+		if (cs != hipStreamCaptureStatusNone) { set_error("adgs_raster_backward_rawsh: the in-backward Adam step cannot be captured into a graph (its bias corrections are launch arguments)"); return -1; }
+		if (!(ad.beta1 >= 0.f && ad.beta1 < 1.f && ad.beta2 >= 0.f && ad.beta2 < 1.f && ad.eps >= 0.f)) { set_error("adgs_raster_backward_rawsh: invalid Adam hyper-parameter"); return -1; }
+		dst.adam.beta1 = ad.beta1; dst.adam.beta2 = ad.beta2; dst.adam.eps = ad.eps;
+		const int No = P - src.Ns;
+		struct { const adgs_adam_slot* in; AdamSlot* out; const float* source; float* grad_dst; int rows; const char* name; } slots[4] = {
+			{ &ad.scene_rest, &dst.adam.scene_rest, src.scene_rest, dst.scene_rest, src.Ns, "scene_rest" },
+			{ &ad.obj_rest, &dst.adam.obj_rest, src.obj_rest, dst.obj_rest, No, "obj_rest" },
+			{ &ad.scene_deform, &dst.adam.scene_sp, src.scene_sp, dst.scene_sp, src.Ns, "scene_deform" },
+			{ &ad.obj_deform, &dst.adam.obj_sp, src.obj_sp, dst.obj_sp, No, "obj_deform" } };
+		for (auto& sl : slots) {
+			if (!sl.in->param || sl.rows <= 0) continue;
+			if (sl.in->param != sl.source) { set_error(std::string("adgs_raster_backward_rawsh: Adam slot ") + sl.name + " does not point at the tensor the frame reads"); return -1; }
+			if (sl.grad_dst) { set_error(std::string("adgs_raster_backward_rawsh: ") + sl.name + " has a gradient destination AND an Adam slot"); return -1; }
+			if (!sl.in->exp_avg || !sl.in->exp_avg_sq || sl.in->step < 1) { set_error(std::string("adgs_raster_backward_rawsh: Adam slot ") + sl.name + ": NULL moments or step < 1"); return -1; }
+			sl.out->p = sl.in->param; sl.out->m = sl.in->exp_avg; sl.out->v = sl.in->exp_avg_sq;
+			adam_bias_terms(sl.in->lr, sl.in->step, ad.beta1, ad.beta2, &sl.out->step_size, &sl.out->inv_bc2_sqrt);
+		}
+		// one side of a tensor pair fused and the other stored would leave the caller with half a gradient
+		if ((dst.adam.scene_rest.p && dst.obj_rest) || (dst.adam.obj_rest.p && dst.scene_rest) || (dst.adam.scene_sp.p && dst.obj_sp) || (dst.adam.obj_sp.p && dst.scene_sp)) {
+			set_error("adgs_raster_backward_rawsh: the scene and object halves of a tensor pair take the Adam step together or not at all"); return -1;
+		}
+		if ((dst.adam.scene_sp.p && !dst.scene_dc) || (dst.adam.obj_sp.p && !dst.obj_dc)) {
+			set_error("adgs_raster_backward_rawsh: the Adam step of the SH deformation rows needs the dc gradient destinations (their rows are multiples of it)"); return -1;
+		}
+	}
 	return raster_backward_impl(&src, &dst, P, D, M, R, D_S, background, width, height, means3D, nullptr, nullptr, flow_points, semantic,
 		scales, scale_modifier, rotations, nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
 		img_buffer, dL_dpix, dL_dpix_depth, dL_dpix_flow, dL_dpix_semantic, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
@@ -1179,7 +1210,7 @@ extern "C" long long adgs_test_v2_scanned_candidates(const char* img_buffer, int
 	return sum_tile_words(v.img.tile_scanned, v.wtiles, (hipStream_t)stream_);
 }
 // sizeof of the structs that cross the ABI by pointer: lets a binding check its mirror (which: 0 adgs_sh_source, 1 adgs_sh_grads,
-// 2 adgs_frame_stats, 3 adgs_frame_status, 4 adgs_func_eval, 5 adgs_adam_group)
+// 2 adgs_frame_stats, 3 adgs_frame_status, 4 adgs_func_eval, 5 adgs_adam_group, 6 adgs_sh_adam)
 extern "C" unsigned long long adgs_test_env_reads(void) { return g_env_reads.load(); }
 extern "C" size_t adgs_test_abi_sizeof(int which) {
 	switch (which) {
@@ -1189,6 +1220,7 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 	case 3: return sizeof(adgs_frame_status);
 	case 4: return sizeof(adgs_func_eval);
 	case 5: return sizeof(adgs_adam_group);
+	case 6: return sizeof(adgs_sh_adam);
 	default: return 0;
 	}
 }

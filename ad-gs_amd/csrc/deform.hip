@@ -520,10 +520,15 @@ struct ParamGradArgs {
 	adgs_func_eval f;
 	// optional second segment in the same launch (blocks >= nb0): the object side after the scene side
 	int nb0, n0_b, count_b; const float* g_b; float* out_b;
+	// ADAM instantiation: a segment whose slot is on (p != nullptr) applies the step to its parameter rows -- which have the layout
+	// of `out` -- instead of storing the gradient (include/adgs_optim.h: adgs_sh_adam)
+	AdamSlot adam = { nullptr, nullptr, nullptr, 0.f, 0.f }, adam_b = { nullptr, nullptr, nullptr, 0.f, 0.f };
+	float beta1 = 0.f, beta2 = 0.f, eps = 0.f;
 };
 constexpr int PG_ITEMS = 8;                          // outputs per thread: two 16-byte stores, 256 float4 apart
 // Every store instruction of a wave covers 1 KiB of consecutive bytes (lane i writes float4 number base + i; the thread's second
 // float4 lies one block width further): 16 full 64-byte lines per instruction instead of 64 half-covered 32-byte pieces.
+template <bool ADAM>
 __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArgs a) {
 	extern __shared__ float s_w[];
 	const int np = a.f.n_params;
@@ -548,6 +553,20 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 		m0[half] = row / a.D; d0[half] = (int)(row - m0[half] * a.D);
 		gv0[half] = seg_g[(seg_n0 + m0[half]) * (size_t)a.gstride + d0[half]];
 	}
+	// ADAM: the parameter and its moments, requested in the same round trip (clamped quad index: unconditional loads)
+	float* const ad_p = ADAM ? (second ? a.adam_b.p : a.adam.p) : nullptr;
+	float* const ad_m = ADAM ? (second ? a.adam_b.m : a.adam.m) : nullptr;
+	float* const ad_v = ADAM ? (second ? a.adam_b.v : a.adam.v) : nullptr;
+	const float ad_step = ADAM ? (second ? a.adam_b.step_size : a.adam.step_size) : 0.f, ad_ibc2 = ADAM ? (second ? a.adam_b.inv_bc2_sqrt : a.adam.inv_bc2_sqrt) : 0.f;
+	float4 p4[HALVES], m4[HALVES], v4[HALVES];
+	if (ADAM && ad_p) {
+		const size_t last4 = tot >= 4 ? (tot - 4) & ~(size_t)3 : 0;
+#pragma unroll
+		for (int half = 0; half < HALVES; half++) {
+			const size_t e = tot >= 4 ? min(e0[half], last4) : 0;
+			if (tot >= 4) { p4[half] = *reinterpret_cast<const float4*>(ad_p + e); m4[half] = *reinterpret_cast<const float4*>(ad_m + e); v4[half] = *reinterpret_cast<const float4*>(ad_v + e); }
+		}
+	}
 	for (int k = threadIdx.x; k < np; k += blockDim.x) s_w[k] = 0.f;
 	__syncthreads();
 	const int total = a.f.n_terms[0] + a.f.n_terms[1] + a.f.n_terms[2];
@@ -561,12 +580,24 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 		float v[4];
 #pragma unroll
 		for (int it = 0; it < 4; it++) {
-			v[it] = s_w[k] * gv;
+			v[it] = __fmul_rn(s_w[k], gv);       // rounded as the stored gradient is: the ADAM instantiation must not contract it into the update
 			if (++k == np) {
 				k = 0;
 				if (++d == a.D) { d = 0; m++; }
 				if (e0[half] + it + 1 < tot) gv = seg_g[(seg_n0 + m) * (size_t)a.gstride + d];
 			}
+		}
+		if (ADAM && ad_p) {
+			if (e0[half] + 4 <= tot) {
+				adam_update4(p4[half], m4[half], v4[half], make_float4(v[0], v[1], v[2], v[3]), a.beta1, a.beta2, a.eps, ad_step, ad_ibc2);
+				*reinterpret_cast<float4*>(ad_p + e0[half]) = p4[half]; *reinterpret_cast<float4*>(ad_m + e0[half]) = m4[half]; *reinterpret_cast<float4*>(ad_v + e0[half]) = v4[half];
+			} else for (int it = 0; it < 4 && e0[half] + it < tot; it++) {
+				const size_t e = e0[half] + it;
+				float pp = ad_p[e], mm = ad_m[e], vv = ad_v[e];
+				adam_update(pp, mm, vv, v[it], a.beta1, a.beta2, a.eps, ad_step, ad_ibc2);
+				ad_p[e] = pp; ad_m[e] = mm; ad_v[e] = vv;
+			}
+			continue;
 		}
 		if (e0[half] + 4 <= tot) *reinterpret_cast<float4*>(seg_out + e0[half]) = make_float4(v[0], v[1], v[2], v[3]);
 		else for (int it = 0; it < 4 && e0[half] + it < tot; it++) seg_out[e0[half] + it] = v[it];
@@ -1018,33 +1049,34 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);
 // two segments (scene side, object side) in ONE launch: a kernel boundary costs ~5 us, as much as a quarter of one side's work
 int launch_lin_param_grad2(int count_a, const float* g_a, float* out_a, int count_b, const float* g_b, float* out_b, int D, int gstride,
-	const adgs_func_eval& f, hipStream_t stream) {
+	const adgs_func_eval& f, hipStream_t stream, const AdamSlot* adam_a, const AdamSlot* adam_b, float beta1, float beta2, float eps) {
 	if (f.n_params <= 0) return 0;
-	if (!(out_a && count_a > 0) || !(out_b && count_b > 0)) {          // at most one side: the plain launcher
-		if (out_a && count_a > 0) return launch_lin_param_grad(count_a, D, g_a, gstride, out_a, f, stream);
-		if (out_b && count_b > 0) return launch_lin_param_grad(count_b, D, g_b, gstride, out_b, f, stream);
-		return 0;
-	}
-	if (!g_a || !g_b) { set_error("launch_lin_param_grad2: NULL gradient buffer"); return -1; }
+	const AdamSlot off = { nullptr, nullptr, nullptr, 0.f, 0.f };
+	const AdamSlot sa = adam_a ? *adam_a : off, sb = adam_b ? *adam_b : off;
+	const bool on_a = (out_a || sa.p) && count_a > 0, on_b = (out_b || sb.p) && count_b > 0;
+	if (!on_a && !on_b) return 0;
+	if ((on_a && !g_a) || (on_b && !g_b)) { set_error("launch_lin_param_grad2: NULL gradient buffer"); return -1; }
+	if ((on_a && out_a && sa.p) || (on_b && out_b && sb.p)) { set_error("launch_lin_param_grad2: a side takes the gradient store OR the Adam step"); return -1; }
 	ParamGradArgs pg;
-	pg.n0 = 0; pg.count = count_a; pg.D = D; pg.gstride = gstride; pg.g = g_a; pg.out = out_a; pg.f = f;
+	pg.D = D; pg.gstride = gstride; pg.f = f; pg.beta1 = beta1; pg.beta2 = beta2; pg.eps = eps;
 	const size_t per_block = (size_t)256 * PG_ITEMS;
-	const size_t nb_a = ((size_t)count_a * D * f.n_params + per_block - 1) / per_block, nb_b = ((size_t)count_b * D * f.n_params + per_block - 1) / per_block;
-	pg.nb0 = (int)nb_a; pg.n0_b = 0; pg.count_b = count_b; pg.g_b = g_b; pg.out_b = out_b;
-	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)(nb_a + nb_b)), dim3(256), f.n_params * sizeof(float), stream, pg);
+	const size_t nb_a = on_a ? ((size_t)count_a * D * f.n_params + per_block - 1) / per_block : 0, nb_b = on_b ? ((size_t)count_b * D * f.n_params + per_block - 1) / per_block : 0;
+	if (on_a) {
+		pg.n0 = 0; pg.count = count_a; pg.g = g_a; pg.out = out_a; pg.adam = sa;
+		pg.nb0 = on_b ? (int)nb_a : 0; pg.n0_b = 0; pg.count_b = on_b ? count_b : 0; pg.g_b = on_b ? g_b : nullptr; pg.out_b = on_b ? out_b : nullptr; pg.adam_b = on_b ? sb : off;
+	} else {
+		pg.n0 = 0; pg.count = count_b; pg.g = g_b; pg.out = out_b; pg.adam = sb;
+		pg.nb0 = 0; pg.n0_b = 0; pg.count_b = 0; pg.g_b = nullptr; pg.out_b = nullptr; pg.adam_b = off;
+	}
+	if (sa.p || sb.p) hipLaunchKernelGGL(deform_lin_param_grad_kernel<true>, dim3((unsigned)(nb_a + nb_b)), dim3(256), f.n_params * sizeof(float), stream, pg);
+	else hipLaunchKernelGGL(deform_lin_param_grad_kernel<false>, dim3((unsigned)(nb_a + nb_b)), dim3(256), f.n_params * sizeof(float), stream, pg);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream) {
 	if (count <= 0 || f.n_params <= 0) return 0;
 	if (!g || !out) { set_error("launch_lin_param_grad: NULL gradient buffer"); return -1; }
-	ParamGradArgs pg;
-	pg.n0 = 0; pg.count = count; pg.D = D; pg.gstride = gstride; pg.g = g; pg.out = out; pg.f = f;
-	pg.nb0 = 0; pg.n0_b = 0; pg.count_b = 0; pg.g_b = nullptr; pg.out_b = nullptr;
-	const size_t tot = (size_t)count * D * f.n_params;
-	hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((tot + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), f.n_params * sizeof(float), stream, pg);
-	ADGS_HIP_CHECK(hipGetLastError());
-	return 0;
+	return launch_lin_param_grad2(count, g, out, 0, nullptr, nullptr, D, gstride, f, stream, nullptr, nullptr, 0.f, 0.f, 0.f);
 }
 } // namespace adgs
 
@@ -1213,7 +1245,7 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 			pg.n0 = part == 0 ? 0 : p->Ns; pg.count = count; pg.D = 3; pg.gstride = M * 3; pg.g = dL_dshs; pg.out = out; pg.f = fs;
 			pg.nb0 = 0; pg.n0_b = 0; pg.count_b = 0; pg.g_b = nullptr; pg.out_b = nullptr;
 			const size_t t2 = (size_t)count * 3 * fs.n_params;
-			hipLaunchKernelGGL(deform_lin_param_grad_kernel, dim3((unsigned)((t2 + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), fs.n_params * sizeof(float), stream, pg);
+			hipLaunchKernelGGL(deform_lin_param_grad_kernel<false>, dim3((unsigned)((t2 + 256 * PG_ITEMS - 1) / (256 * PG_ITEMS))), dim3(256), fs.n_params * sizeof(float), stream, pg);
 			ADGS_HIP_CHECK(hipGetLastError());
 		}
 	}

@@ -1,6 +1,7 @@
 // Device helpers shared by the deformation kernels and the raw-SH path of the preprocess kernels.
 #pragma once
 #include "common.h"
+#include "adam_update.h"
 #include "../../include/adgs_deform.h"
 
 namespace adgs {
@@ -139,6 +140,9 @@ struct ShGradDst {
 	float *rgb_factor;   // [P,3] clamp-masked colour gradient: the per-camera factor every SH gradient row is a multiple of
 	float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;   // raw scene geometry gradients ([Ns,3] [Ns,3] [Ns,4] [Ns,1])
 	float *bg_image;          // [3,H,W] gradient of the per-pixel background (every pixel written) or nullptr
+	// slots with p != nullptr: the Adam step in place of that tensor's gradient store (include/adgs_optim.h: adgs_sh_adam)
+	AdamEpilogue adam = { { nullptr, nullptr, nullptr, 0.f, 0.f }, { nullptr, nullptr, nullptr, 0.f, 0.f }, { nullptr, nullptr, nullptr, 0.f, 0.f },
+	                      { nullptr, nullptr, nullptr, 0.f, 0.f }, 0.f, 0.f, 0.f };
 };
 
 } // namespace adgs

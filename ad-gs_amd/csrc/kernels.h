@@ -188,8 +188,12 @@ int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order
 
 // flat coalesced d/dparam[m, d, k] = w_k * g[m * gstride + d] for the linear families (deform.hip)
 int launch_lin_param_grad(int count, int D, const float* g, int gstride, float* out, const adgs_func_eval& f, hipStream_t stream);
+// adam_a / adam_b (p != nullptr): the Adam step on that side's parameter rows in place of the store to out_a / out_b
 int launch_lin_param_grad2(int count_a, const float* g_a, float* out_a, int count_b, const float* g_b, float* out_b, int D, int gstride,
-	const adgs_func_eval& f, hipStream_t stream);
+	const adgs_func_eval& f, hipStream_t stream, const AdamSlot* adam_a = nullptr, const AdamSlot* adam_b = nullptr, float beta1 = 0.f, float beta2 = 0.f,
+	float eps = 0.f);
+// lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t), formed in double and rounded once (optim.hip)
+void adam_bias_terms(float lr, int step, float beta1, float beta2, float* step_size, float* inv_bc2_sqrt);
 // sh0[N,3] = dc + f_shs(t); optionally zeroes n_zero 32-bit words for the next kernel's counters
 int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words = nullptr, int n_zero = 0, int ostride = 3);      // ostride: floats per Gaussian in `out`
 inline bool has_lin_host(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0 && f.n_params > 0; }

@@ -3,6 +3,8 @@
 // the HBM-streaming floor of the update.  Reference: torch.optim.Adam as configured at
 // scene/gaussian_model.py:370 (eps = 1e-15, no weight decay), stepped at train.py:163-167.
 #include "common.h"
+#include "adam_update.h"
+#include "kernels.h"
 #include "../../include/adgs_optim.h"
 #include <cmath>
 
@@ -24,13 +26,6 @@ struct AdamTable {
 	float beta1, beta2, eps;
 	int zero_grad;
 };
-
-__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float beta1, float beta2, float eps, float step_size, float inv_bc2_sqrt) {
-	m = m + (1.f - beta1) * (g - m);                     // exp_avg.lerp_(grad, 1 - beta1)
-	v = beta2 * v + (1.f - beta2) * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-	const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-	p = p - step_size * (m / denom);
-}
 
 __global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
 	// which group does this block belong to (block-uniform binary search over <= 32 entries)
@@ -100,6 +95,13 @@ __global__ void __launch_bounds__(256) densification_stats_kernel(int N, const i
 }
 
 } // namespace
+
+// the host forms the bias corrections in double like torch does (python floats), then rounds once
+void adam_bias_terms(float lr, int step, float beta1, float beta2, float* step_size, float* inv_bc2_sqrt) {
+	const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+	*step_size = (float)((double)lr / bc1);
+	*inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+}
 } // namespace adgs
 
 using namespace adgs;
@@ -125,10 +127,7 @@ extern "C" int adgs_adam_step(const adgs_adam_group* groups, int n_groups, float
 		if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || g.step < 1) { set_error("adgs_adam_step: NULL pointer or step < 1 in a group"); return -1; }
 		t.g[t.n] = g;
 		t.first_block[t.n] = (uint32_t)blocks;
-		// the host forms the bias corrections in double like torch does (python floats), then rounds once
-		const double bc1 = 1.0 - std::pow((double)beta1, (double)g.step), bc2 = 1.0 - std::pow((double)beta2, (double)g.step);
-		t.step_size[t.n] = (float)((double)g.lr / bc1);
-		t.inv_bc2_sqrt[t.n] = (float)(1.0 / std::sqrt(bc2));
+		adam_bias_terms(g.lr, g.step, beta1, beta2, &t.step_size[t.n], &t.inv_bc2_sqrt[t.n]);
 		blocks += (uint64_t)((g.numel + ATILE - 1) / ATILE);
 		t.n++;
 	}

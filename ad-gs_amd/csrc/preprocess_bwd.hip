@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	const int nvalid = min(BW_THREADS, a.P - base);
 	// prefetched inputs: the staged v2 path that recomputes cov3D from scales / rotations (what the raw-SH frames run)
 	const bool pf = STAGED && a.gacc != nullptr && a.cov3D == nullptr && a.scales != nullptr && a.rotations != nullptr;      // kernel-uniform
+	// the Adam step in place of the store of the `rest` gradient rows (adgs_sh_adam): the rows are assembled in LDS either way
+	const bool adam_rest = STAGED && raw && (a.sh_dst.adam.scene_rest.p != nullptr || a.sh_dst.adam.obj_rest.p != nullptr);      // kernel-uniform
 	PreBIn in;
 	if (STAGED) {
 		if (raw) {
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 				float* gre = (is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest);
 				if (gdc) { gdc[3 * m] = 0.f; gdc[3 * m + 1] = 0.f; gdc[3 * m + 2] = 0.f; }
 				if (a.sh_dst.rgb_factor) { float* rf = a.sh_dst.rgb_factor + 3 * (size_t)idx; rf[0] = 0.f; rf[1] = 0.f; rf[2] = 0.f; }
-				if (STAGED) { if (gre) for (int i = 0; i < SH_ROW_REST; i++) s_sh[tid * SH_ROW_REST + i] = 0.f; }
+				if (STAGED) { if (gre || adam_rest) for (int i = 0; i < SH_ROW_REST; i++) s_sh[tid * SH_ROW_REST + i] = 0.f; }
 				else if (gre) for (int i = 0; i < (a.M - 1) * 3; i++) gre[m * (size_t)(a.M - 1) * 3 + i] = 0.f;
 			} else if (a.shs) {
 				if (STAGED) { for (int i = 0; i < SH_ROW_FULL; i++) s_sh[tid * SH_ROW_FULL_LDS + i] = 0.f; }
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			float* gdc = is_obj ? a.sh_dst.obj_dc : a.sh_dst.scene_dc;
 			float* gre = is_obj ? a.sh_dst.obj_rest : a.sh_dst.scene_rest;
 			dsh0 = gdc ? gdc + 3 * m : nullptr;
-			want_rows = gre != nullptr;
+			want_rows = gre != nullptr || adam_rest;
 			if (STAGED) { dsh = s_sh + tid * SH_ROW_REST - 3; sh = dsh; }
 			else {
 				sh = (is_obj ? a.sh_src.obj_rest : a.sh_src.scene_rest) + m * (size_t)(a.M - 1) * 3 - 3;
@@ -424,7 +426,11 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	if (STAGED) {
 		// the LDS rows now hold the SH gradients: stream them out fully coalesced
 		__syncthreads();
-		if (raw) {
+		if (raw && adam_rest) {
+			// a Gaussian outside the frustum has a zero gradient row, not no row: Adam moves it by its moments (torch.optim.Adam is dense)
+			adam_rows<4>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_dst.adam.scene_rest, a.sh_dst.adam.obj_rest, a.sh_dst.adam.beta1, a.sh_dst.adam.beta2, a.sh_dst.adam.eps,
+				tid, BW_THREADS);
+		} else if (raw) {
 			stage_rows<false>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_dst.scene_rest, a.sh_dst.obj_rest, tid, BW_THREADS);
 		} else {
 			float4* dst = reinterpret_cast<float4*>(a.dL_dsh + (size_t)base * SH_ROW_FULL);
@@ -445,6 +451,13 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
 	// the staged kernel needs 16 SH coefficients and, in the v2 (gacc) path, writes every row
 	const bool staged = a.M == 16 && (raw || a.shs) && a.gacc != nullptr && a.sh_staging != 0;
 	const unsigned grid = (unsigned)((a.P + BW_THREADS - 1) / BW_THREADS);
+	const bool adam_rest = a.sh_dst.adam.scene_rest.p || a.sh_dst.adam.obj_rest.p, adam_sp = a.sh_dst.adam.scene_sp.p || a.sh_dst.adam.obj_sp.p;
+	if ((adam_rest || adam_sp) && !raw) { set_error("preprocess backward: the in-backward Adam step needs the raw-SH path"); return -1; }
+	if (adam_rest && !staged) {
+		set_error("preprocess backward: the in-backward Adam step of the SH `rest` tensors needs 16 SH coefficients and the LDS row staging "
+		          "(the frame's forward ran with ADGS_NO_SH_STAGING, or M != 16)");
+		return -1;
+	}
 	if (staged) {
 		const size_t lds = (size_t)BW_THREADS * (raw ? SH_ROW_REST : SH_ROW_FULL_LDS) * sizeof(float);
 		hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(grid), dim3(BW_THREADS), lds, stream, a);
@@ -455,7 +468,8 @@ int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
 	// raw-SH path: d/d(shs_deform_param[m, c, k]) = w_k * dL/d(dc[m, c]) as flat coalesced passes
 	if (raw && has_lin_host(a.sh_src.f)) {
 		const int No = a.P - a.sh_src.Ns;
-		if (launch_lin_param_grad2(a.sh_src.Ns, a.sh_dst.scene_dc, a.sh_dst.scene_sp, No, a.sh_dst.obj_dc, a.sh_dst.obj_sp, 3, 3, a.sh_src.f, stream) != 0) return -1;
+		if (launch_lin_param_grad2(a.sh_src.Ns, a.sh_dst.scene_dc, a.sh_dst.scene_sp, No, a.sh_dst.obj_dc, a.sh_dst.obj_sp, 3, 3, a.sh_src.f, stream,
+		                           &a.sh_dst.adam.scene_sp, &a.sh_dst.adam.obj_sp, a.sh_dst.adam.beta1, a.sh_dst.adam.beta2, a.sh_dst.adam.eps) != 0) return -1;
 	}
 	return 0;
 }

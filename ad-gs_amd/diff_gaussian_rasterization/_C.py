@@ -195,7 +195,7 @@ class ShSource(ctypes.Structure):
 class ShGrads(ctypes.Structure):
     """adgs_sh_grads (include/adgs_rasterizer.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor",
-                                               "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity", "bg_image")]
+                                               "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity", "bg_image", "adam")]
 
 
 def _sh_source(raw, dev):
@@ -277,9 +277,11 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
 def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_semantic, semantic, flow_points, sh_raw,
                                        sh_needs_grad, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, img_opacity, grad_img_opacity,
-                                       inv_depth, debug, want_rgb_factor=False, geo_grad_alloc=None):
+                                       inv_depth, debug, want_rgb_factor=False, geo_grad_alloc=None, adam=None):
     """With want_rgb_factor the result carries one more entry: the [P,3] clamp-masked colour gradient every SH gradient row is a
-    multiple of (include/adgs_exchange.h); combined with sh_needs_grad all False the SH rows are not materialised at all."""
+    multiple of (include/adgs_exchange.h); combined with sh_needs_grad all False the SH rows are not materialised at all.
+    adam: an adgs.optim.BackwardClaim (FusedAdam(in_backward=True)) -- the tensors it names take the Adam step inside the backward
+    kernels and get no gradient tensor (include/adgs_optim.h: adgs_sh_adam)."""
     lib = _lib.lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -295,8 +297,14 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     dL_dcolors = dL_ddepths = dL_dconic = dL_dcov3D = None
     dL_dflow_points = e(P, FLOW_CHANNELS) if has_flow else torch.zeros((P, FLOW_CHANNELS), dtype=torch.float32, device=dev)
     dL_dsemantic = e(P, D_S) if has_sem else torch.zeros((P, D_S), dtype=torch.float32, device=dev)
+    sh_needs_grad = list(sh_needs_grad)
+    fused = adam.fused if (adam is not None and P != 0) else {}
+    for i, name in enumerate(("scene_rest", "obj_rest", "scene_deform", "obj_deform")):
+        if fused.get(name):
+            sh_needs_grad[2 + i] = False                           # updated in place of being stored
     need = list(sh_needs_grad)
-    need[0], need[1] = need[0] or need[4], need[1] or need[5]      # the deform-param gradients are derived from the dc gradients
+    # the deform-param gradients (stored or applied) are derived from the dc gradients
+    need[0], need[1] = need[0] or need[4] or bool(fused.get("scene_deform")), need[1] or need[5] or bool(fused.get("obj_deform"))
     sh_grads = [torch.empty_like(t) if (nd and t is not None and t.numel() != 0) else None for t, nd in zip(sh_raw[:6], need)]
     if torch.is_tensor(want_rgb_factor):           # the caller's own [P,3] destination (adgs.dp.FactoredSHExchange's send buffer)
         rgb_factor = want_rgb_factor
@@ -314,6 +322,8 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
         for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
             setattr(gs, name, _ptr(t))
         gs.rgb_factor = _ptr(rgb_factor)
+        if fused:
+            gs.adam = ctypes.addressof(adam.struct)
         bg_image = sh_raw[8] if len(sh_raw) > 8 else None
         if bg_image is not None:
             bg_grad = torch.empty_like(bg_image, memory_format=torch.contiguous_format)

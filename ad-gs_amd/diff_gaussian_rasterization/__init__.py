@@ -109,6 +109,8 @@ class RawSH(NamedTuple):
     scene_rotation: object = None
     scene_opacity: object = None
     grad_arena: object = None  # adgs.dp.GradArena: where the raw scene geometry gradients are written (one flat all-reduce buffer)
+    adam: object = None        # adgs.optim.BackwardEpilogue (FusedAdam(in_backward=True)): when armed, the backward applies the Adam step to the
+    #                            rest / deformation tensors in place of storing their gradients (their .grad stays None)
 
 
 class _RasterizeGaussiansRawSH(torch.autograd.Function):
@@ -121,7 +123,7 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, scales, rotations, flow_points, semantic, scene_dc, obj_dc, scene_rest, obj_rest,
                 scene_deform, obj_deform, func_eval, raster_settings, factor_sink=None, scene_xyz=None, scene_scaling=None, scene_rotation=None,
-                scene_opacity=None, grad_arena=None, bg_image=None):
+                scene_opacity=None, grad_arena=None, bg_image=None, adam=None):
         s = raster_settings
         geo = (scene_xyz, scene_scaling, scene_rotation, scene_opacity) if scene_xyz is not None else None
         raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval, geo, bg_image)
@@ -129,7 +131,7 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
             s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
             s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
         ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink = s, num_rendered, func_eval, factor_sink
-        ctx.has_geo, ctx.grad_arena, ctx.has_bg = geo is not None, grad_arena, bg_image is not None
+        ctx.has_geo, ctx.grad_arena, ctx.has_bg, ctx.adam = geo is not None, grad_arena, bg_image is not None, adam
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
                               scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, *(geo or ()), *((bg_image,) if bg_image is not None else ()))
@@ -149,17 +151,20 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         factored = ctx.factor_sink is not None
         need = (False,) * 6 if factored else ctx.needs_input_grad[7:13]
         arena = ctx.grad_arena
+        # FusedAdam(in_backward=True), armed for this backward: the step is applied where the gradient rows are produced
+        claim = ctx.adam.claim(dict(scene_rest=scene_rest, obj_rest=obj_rest, scene_deform=scene_deform, obj_deform=obj_deform),
+                               dict(zip(("scene_rest", "obj_rest", "scene_deform", "obj_deform"), need[2:6])), factored) if ctx.adam is not None else None
         res = _C.rasterize_gaussians_backward_rawsh(
             s.bg, means3D, radii, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
             grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, need, s.sh_degree, s.campos,
             geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
             want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False,
-            geo_grad_alloc=(arena.take if arena is not None else None))
+            geo_grad_alloc=(arena.take if arena is not None else None), adam=claim)
         (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem, g_factor, g_geo, g_bg) = res
         if factored:
             ctx.factor_sink.append(g_factor)
         g_geo = tuple(g_geo) if g_geo is not None else (None,) * 4
-        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None) + g_geo + (None, g_bg)
+        return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None) + g_geo + (None, g_bg, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
@@ -190,7 +195,7 @@ class GaussianRasterizer(nn.Module):
                                               sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings, factor_sink,
                                               getattr(sh_raw, "scene_xyz", None), getattr(sh_raw, "scene_scaling", None),
                                               getattr(sh_raw, "scene_rotation", None), getattr(sh_raw, "scene_opacity", None),
-                                              getattr(sh_raw, "grad_arena", None), bg_image)
+                                              getattr(sh_raw, "grad_arena", None), bg_image, getattr(sh_raw, "adam", None))
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, flow_points=None, semantic=None):

@@ -8,7 +8,11 @@
        `near_idx_reset_interval` iterations set_obj_near_idx, every `opacity_reset_interval` iterations reset_opacity (train.py:146-158)
        -> both Adam steps (train.py:163-167).
 
-    python examples/train_iteration.py [--config C3] [--iters 60] [--env-res 8192] [--cameras 16] [--json]
+    python examples/train_iteration.py [--config C3] [--iters 60] [--env-res 8192] [--cameras 16] [--no-adam-in-backward] [--json]
+
+The Adam step of the SH `rest` and SH deformation tensors (81 of a scene Gaussian's 95 parameters) is applied inside the rasterizer's
+backward (FusedAdam(in_backward=True) + arm_backward(): bit-identical to the separate step, tests/test_gpu_optim.py) in the
+iterations whose step follows their backward unconditionally; --no-adam-in-backward steps everything from materialised gradients.
 
 Synthetic scene, cameras and targets; the lambdas and intervals are the reference's defaults
 (arguments/__init__.py:104-133).  The reference reads `loss.item()` every iteration (train.py:132: a host synchronisation per
@@ -36,7 +40,7 @@ FUSED_IMAGE_LOSSES = os.environ.get("ADGS_FUSED_IMAGE_LOSSES", "1") != "0"
 STAGES = ("regularisers", "render", "losses", "backward", "densify_stats", "near_idx_or_densify", "adam_gaussians", "adam_env_map")
 
 
-def build(config, env_res, device, n_cameras=16):
+def build(config, env_res, device, n_cameras=16, adam_in_backward=True):
     import torch
     from adgs import synthetic, env
     from adgs.model import SyntheticGaussianModel
@@ -50,7 +54,7 @@ def build(config, env_res, device, n_cameras=16):
     model.frame_gap = 0.02          # scene/gaussian_model.py:266 (1 / number of frames)
     lrs = {"scene_xyz": 1.6e-4, "obj_xyz": 1.6e-4, "scene_shs_dc": 2.5e-3, "obj_shs_dc": 2.5e-3, "scene_shs_rest": 1.25e-4, "obj_shs_rest": 1.25e-4,
            "scene_opacity": 0.05, "obj_opacity": 0.05, "scene_scaling": 5e-3, "obj_scaling": 5e-3, "scene_rotation": 1e-3, "obj_rotation": 1e-3}
-    model.training_setup(lrs=lrs, scene_extent=20.0, object_extent=4.0, near_num=OPT.near_num)
+    model.training_setup(lrs=lrs, scene_extent=20.0, object_extent=4.0, near_num=OPT.near_num, adam_in_backward=adam_in_backward)
     # sparse_grad: the map's backward marks the tiles it writes and reuses the gradient buffer the optimizer zeroes (adgs/env.py) --
     # no 0.8 GB fill and no 0.8 GB scan of the dense gradient per iteration; the update itself is unchanged
     env_map = env.EnvironmentMap(env_res, 3, device=device, sparse_grad=True)
@@ -163,6 +167,10 @@ def iteration(it, model, cams, env_map, clock, state):
                                  (opt.lambda_flow, flow_loss), (opt.lambda_sky, sky_loss), (opt.lambda_obj, obj_loss), (opt.lambda_sigma, sigma_loss),
                                  (opt.lambda_reg, reg_loss), (opt.lambda_sigma_reg, reg_sigma_loss)])
     clock.mark("losses")
+    if getattr(model.optimizer, "backward_epilogue", None) is not None and (it + 1) % opt.densification_interval != 0:
+        # the step of this iteration follows its one backward whatever happens in between (a densification replaces the parameter
+        # tensors: the reference's step then finds no gradients and changes nothing, so those iterations stay on the ordinary path)
+        model.optimizer.arm_backward()
     total.backward()                                                         # :116
     clock.mark("backward")
     with torch.no_grad():
@@ -189,10 +197,10 @@ def iteration(it, model, cams, env_map, clock, state):
     return total.detach()
 
 
-def run(config="C3", iters=60, env_res=8192, cameras=16, warm=12, device=None, stages=True):
+def run(config="C3", iters=60, env_res=8192, cameras=16, warm=12, device=None, stages=True, adam_in_backward=True):
     import torch
     device = device or torch.device("cuda", 0)
-    cfg, model, cams, env_map = build(config, env_res, device, cameras)
+    cfg, model, cams, env_map = build(config, env_res, device, cameras, adam_in_backward)
     state = {}
     off = StageClock(False)
     for i in range(warm):
@@ -218,7 +226,7 @@ def run(config="C3", iters=60, env_res=8192, cameras=16, warm=12, device=None, s
     return {"workload": "%s training iteration: render (deformation, flow, semantic, %d^2 environment map) + L1/SSIM + depth + flow + 2 BCE + 3 regularisers "
                         "+ backward + densification statistics + fused Adam (Gaussians, environment map); set_obj_near_idx every %d and "
                         "densify_and_prune every %d iterations; %d cameras" % (config, env_res, OPT.near_idx_reset_interval, OPT.densification_interval, len(cams)),
-            "iterations": iters, "ms_per_iteration": round(dt * 1e3, 4), "iterations_per_s": round(1.0 / dt, 2),
+            "iterations": iters, "adam_in_backward": bool(adam_in_backward), "ms_per_iteration": round(dt * 1e3, 4), "iterations_per_s": round(1.0 / dt, 2),
             "stage_ms": clock.summary(), "host_stage_ms": clock.host_summary(), "densify_calls": state.get("densified", 0), "points_end": int(model.get_pts_num),
             "loss_first_last": [round(float(first), 6), round(float(last), 6)],
             "note": "stage_ms: HIP events on the launch stream, mean per iteration (near_idx_or_densify is amortised over the iterations)"}
@@ -230,12 +238,13 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--env-res", type=int, default=8192)
     ap.add_argument("--cameras", type=int, default=16)
+    ap.add_argument("--no-adam-in-backward", action="store_true")
     ap.add_argument("--json", action="store_true")
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X: there is no CPU fallback")
-    res = run(args.config, args.iters, args.env_res, args.cameras)
+    res = run(args.config, args.iters, args.env_res, args.cameras, adam_in_backward=not args.no_adam_in_backward)
     if args.json:
         print(json.dumps(res))
     else:

@@ -53,6 +53,26 @@ typedef struct adgs_adam_group {
  * code with adgs_last_error() set. */
 int adgs_adam_step(const adgs_adam_group* groups, int n_groups, float beta1, float beta2, float eps, int zero_grad, void* stream);
 
+/* The same step applied INSIDE the rasterizer's backward (adgs_sh_grads.adam, adgs_rasterizer.h), for the single-camera iteration
+ * of train.py:47-167 (one backward, then optimizer.step() -- :163-167).  The kernels that produce the gradient of a raw SH tensor
+ * hold each element of it in a register or in LDS exactly once: they read (p, m, v), apply the update above and write (p, m, v)
+ * back instead of storing the gradient -- 24 instead of 4 + 28 bytes per parameter, no gradient buffer.  Per slot the arithmetic
+ * is the arithmetic of adgs_adam_step on the gradient that would have been stored (bit for bit: tests/test_gpu_optim.py).
+ * A slot with param == NULL is off (that tensor's gradient is written as usual). */
+typedef struct adgs_adam_slot {
+	float* param;           /* must be the tensor the frame reads (the same pointer as in adgs_sh_source) */
+	float* exp_avg;
+	float* exp_avg_sq;
+	float lr;
+	int32_t step;           /* t of this parameter after the increment (>= 1) */
+} adgs_adam_slot;
+typedef struct adgs_sh_adam {
+	adgs_adam_slot scene_rest, obj_rest;       /* updated by the preprocess backward (needs M == 16 and its LDS row staging) */
+	adgs_adam_slot scene_deform, obj_deform;   /* updated by the pass that expands dL/d(dc) into the deformation rows */
+	float beta1, beta2, eps;
+	int32_t reserved;
+} adgs_sh_adam;
+
 /* Per-iteration densification statistics (train.py:148-150):
  *   gaussians.max_radii2D[vis] = max(gaussians.max_radii2D[vis], radii[vis])
  *   GaussianModel.add_densification_stats (scene/gaussian_model.py:863-867):

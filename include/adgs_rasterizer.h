@@ -145,6 +145,7 @@ typedef struct adgs_sh_source {
 	 * background in its `bg . dL/dC` term and writes dL/dbg_image = T_final * dL/dC (adgs_sh_grads.bg_image). */
 	const float *bg_image;
 } adgs_sh_source;
+struct adgs_sh_adam;      /* adgs_optim.h */
 typedef struct adgs_sh_grads {
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_deform, *obj_deform;   /* NULL = not wanted */
 	float *rgb_factor;   /* [P,3] or NULL: the clamp-masked colour gradient dL/dRGB * (1 - clamped) (backward.cu:20-139), 0 for
@@ -153,6 +154,11 @@ typedef struct adgs_sh_grads {
 	float *scene_xyz, *scene_scaling, *scene_rotation, *scene_opacity;   /* raw scene geometry gradients (required when the
 	                        source carries raw scene geometry): every row written */
 	float *bg_image;     /* [3,H,W] gradient of the per-pixel background or NULL (not wanted) */
+	/* NULL, or the Adam step to apply in place of storing gradients (adgs_optim.h: adgs_sh_adam).  For every slot that is on, the
+	 * gradient destination of the same name above must be NULL (the gradient is never materialised); the deformation slots need the
+	 * dc destinations (their rows are multiples of dL/d(dc)).  Refused while the stream is being captured into a graph (the bias
+	 * corrections of step t are launch arguments). */
+	const struct adgs_sh_adam* adam;
 } adgs_sh_grads;
 
 int adgs_raster_forward_rawsh(

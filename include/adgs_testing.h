@@ -31,7 +31,7 @@ long long adgs_test_v2_blend_batches(const char* img_buffer, int width, int heig
 long long adgs_test_v2_cell_ranges(const char* img_buffer, int width, int height, uint32_t* out_ranges, long long capacity, void* stream);
 
 /* sizeof of the structs that cross the ABI by pointer (0 adgs_sh_source, 1 adgs_sh_grads, 2 adgs_frame_stats, 3 adgs_frame_status,
- * 4 adgs_func_eval): a binding checks its mirror against it. */
+ * 4 adgs_func_eval, 5 adgs_adam_group, 6 adgs_sh_adam): a binding checks its mirror against it. */
 size_t adgs_test_abi_sizeof(int which);
 
 /* How many times the rasterizer has read an ADGS_* environment switch so far (process-wide).  The backward of a frame must not read any:

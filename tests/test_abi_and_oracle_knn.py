@@ -84,9 +84,9 @@ def test_ctypes_mirrors_have_the_size_of_the_c_structs():
     (adgs_sh_grads grew to 12 members while one mirror kept 7)."""
     import ctypes
     from adgs import _lib, deform
-    from adgs.optim import AdamGroup
+    from adgs.optim import AdamGroup, ShAdam
     from diff_gaussian_rasterization._C import ShSource, ShGrads
     lib = _lib.lib()
-    mirrors = {0: ShSource, 1: ShGrads, 2: _lib.FrameStats, 3: _lib.FrameStatus, 4: deform.FuncEval, 5: AdamGroup}
+    mirrors = {0: ShSource, 1: ShGrads, 2: _lib.FrameStats, 3: _lib.FrameStatus, 4: deform.FuncEval, 5: AdamGroup, 6: ShAdam}
     for which, cls in mirrors.items():
         assert ctypes.sizeof(cls) == lib.adgs_test_abi_sizeof(which), (which, cls.__name__)

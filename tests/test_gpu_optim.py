@@ -227,3 +227,110 @@ def test_dormant_tiles_are_skipped_exactly():
     oa.step(); ob.step()
     assert torch.equal(a, b) and not torch.equal(a[:ADAM_TILE], p0[:ADAM_TILE])
     assert all(oa._tile_maps[id(a)][0].cpu().tolist())
+
+
+# ---------------------------------------------------------------- the Adam step inside the rasterizer's backward (adgs_sh_adam)
+def _render_model(P, n_objects, seed, dev, in_backward, W=176, H=112):
+    from adgs import synthetic
+    from adgs.model import SyntheticGaussianModel
+    import bench
+    sc = synthetic.to_z_up_world(synthetic.make_scene(P, W, H, 140.0, sh_degree=3, seed=seed, n_objects=n_objects))
+    model = SyntheticGaussianModel.from_scene(sc, device=dev, seed=seed)
+    model.raw_sh = model.raw_scene = True
+    lrs = {"scene_shs_rest": 1.25e-4, "obj_shs_rest": 2.5e-4, "deform_shs_scene": 1e-3, "deform_shs_obj": 2e-3, "scene_shs_dc": 2.5e-3, "obj_shs_dc": 2.5e-3}
+    model.training_setup(lrs=lrs, scene_extent=20.0, object_extent=4.0, near_num=0, adam_in_backward=in_backward)
+    cams = []
+    for cam, t in bench.camera_pool(dict(P=P, W=W, H=H, focal=140.0, sh_degree=3, n_objects=n_objects, seed=seed), 3):
+        c = synthetic.camera_object(synthetic.camera_to_z_up(cam), time=t)
+        for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(c, name, getattr(c, name).to(dev))
+        cams.append(c)
+    return model, cams
+
+
+def _one_iteration(model, cam, weights, arm):
+    import types
+    from gaussian_renderer import render
+    pkg = render(cam, model, None, types.SimpleNamespace(inv_depth=True, debug=False), render_objmask=True)
+    loss = (pkg["render"] * weights[0]).sum() + (pkg["depth"] * weights[1]).sum() + (pkg["img_opacity"] * weights[2]).sum()
+    if arm:
+        model.optimizer.arm_backward()
+    loss.backward()
+    fused = {g["name"]: g["params"][0].grad is None for g in model.optimizer.param_groups}
+    model.optimizer.step(zero_grad=True)
+    return fused
+
+
+@pytest.mark.parametrize("P,n_objects,seed,W,H", [(5000, 2, 3, 32, 4), (4099, 3, 4, 32, 4), (700, 1, 5, 32, 4)])
+def test_adam_in_the_backward_is_the_two_kernel_step_bit_for_bit(P, n_objects, seed, W, H):
+    """FusedAdam(in_backward=True) + arm_backward(): the rasterizer's backward applies the step of the SH rest tensors (preprocess
+    backward, from its LDS gradient rows) and of the SH deformation rows (the pass that expands dL/d(dc)) itself.  Against the same
+    model stepped by adgs_adam_step from materialised gradients: parameters, both moments and the step counters of EVERY group
+    bit-identical after every iteration -- armed and unarmed iterations mixed, three cameras, scene / object boundaries that are and
+    are not multiples of the block size and of the 16-byte quads (the straddling block goes element by element), Gaussians outside
+    the frustum (zero gradient rows: Adam still moves them by their moments).
+
+    Two runs of the blend backward agree bit for bit only where no Gaussian sums more than two tiles (its per-(tile, Gaussian)
+    float atomics commute, they do not associate): the 32 x 4 frames have two tiles.  Full-size frames on both paths against the CPU
+    trajectory: tests/test_gpu_trajectory.py."""
+    dev = torch.device("cuda", 0)
+    exact, same = True, torch.equal
+    a, cams = _render_model(P, n_objects, seed, dev, True, W, H)
+    b, _ = _render_model(P, n_objects, seed, dev, False, W, H)
+    g = torch.Generator().manual_seed(seed)
+    H, W = int(cams[0].image_height), int(cams[0].image_width)
+    names = ("scene_shs_rest", "obj_shs_rest", "deform_shs_scene", "deform_shs_obj")
+    for it in range(7):
+        cam = cams[it % len(cams)]
+        weights = [torch.randn(3, H, W, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev) * 0.1, torch.randn(H, W, generator=g).to(dev) * 0.1]
+        arm = it not in (2, 5)                       # unarmed iterations go through the gradient tensors on both models
+        if it == 4:                                  # schedulers write group['lr'] between iterations
+            for m in (a, b):
+                for grp in m.optimizer.param_groups:
+                    grp["lr"] *= 0.7
+        fa = _one_iteration(a, cam, weights, arm)
+        fb = _one_iteration(b, cam, weights, False)
+        for n in names:
+            assert fa[n] == arm and not fb[n], (it, n, fa, fb)      # the fused tensors never had a gradient tensor
+        assert all(fa[k] == fb[k] for k in fa if k not in names), (fa, fb)
+        torch.cuda.synchronize()
+        for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+            pa, pb = ga["params"][0], gb["params"][0]
+            if pa.numel() == 0 or (pa.grad is None and pa not in a.optimizer.state):
+                continue
+            assert same(pa.detach(), pb.detach()), (it, ga["name"], float((pa.detach() - pb.detach()).abs().max()))
+            sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+            assert int(sa["step"]) == int(sb["step"]) == it + 1, (it, ga["name"])
+            assert same(sa["exp_avg"], sb["exp_avg"]) and same(sa["exp_avg_sq"], sb["exp_avg_sq"]), (it, ga["name"])
+    if exact:
+        seen = a.optimizer.state[a._scene_shs_rest]["exp_avg_sq"].flatten(1).amax(1)
+        assert bool((seen > 0).any()) and bool((seen == 0).any()), "the frames should leave Gaussians inside and outside the frustum"
+
+
+def test_adam_in_the_backward_refuses_what_it_cannot_do_exactly():
+    from adgs.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    m, cams = _render_model(900, 1, 8, dev, True)
+    H, W = int(cams[0].image_height), int(cams[0].image_width)
+    w = [torch.ones(3, H, W, device=dev), torch.zeros(H, W, device=dev), torch.zeros(H, W, device=dev)]
+    # a second armed backward before step()
+    import types
+    from gaussian_renderer import render
+    pipe = types.SimpleNamespace(inv_depth=True, debug=False)
+    m.optimizer.arm_backward()
+    render(cams[0], m, None, pipe)["render"].sum().backward()
+    with pytest.raises(RuntimeError, match="has not been followed by step"):
+        m.optimizer.arm_backward()
+    # a gradient from elsewhere on a tensor the backward has already stepped
+    m._scene_shs_rest.grad = torch.zeros_like(m._scene_shs_rest)
+    with pytest.raises(RuntimeError, match="received a gradient from elsewhere"):
+        m.optimizer.step(zero_grad=True)
+    m._scene_shs_rest.grad = None
+    m.optimizer.step(zero_grad=True)
+    # an optimizer built without in_backward
+    plain = FusedAdam([{"params": [torch.zeros(4, device=dev, requires_grad=True)], "lr": 1e-3}], lr=0.0)
+    with pytest.raises(RuntimeError, match="in_backward=True"):
+        plain.arm_backward()
+    # unarmed: nothing changes about the ordinary path
+    fused = _one_iteration(m, cams[1], w, False)
+    assert not any(fused.values())

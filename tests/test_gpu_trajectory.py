@@ -110,15 +110,29 @@ def _rel_l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-300))
 
 
-def test_thirty_iterations_follow_the_cpu_reference_trajectory():
+_REFERENCE = {}
+
+
+def _reference():
+    """The CPU trajectory, computed once for both parametrisations."""
+    if not _REFERENCE:
+        cfg, sc, model_cpu, cams = tj.build_case()
+        env_grid = ((torch.rand((1, 3, ENV_RES, ENV_RES), generator=torch.Generator().manual_seed(5)) * 2.0 - 1.0) * 0.5).numpy()
+        _REFERENCE["case"] = (cfg, sc, model_cpu, cams, env_grid)
+        _REFERENCE["run"] = reference_run(model_cpu, cams, env_grid)
+    return _REFERENCE["case"], _REFERENCE["run"]
+
+
+@pytest.mark.parametrize("adam_in_backward", [False, True])
+def test_thirty_iterations_follow_the_cpu_reference_trajectory(adam_in_backward):
+    """adam_in_backward: the example's default -- the Adam step of the SH rest / SH deformation tensors applied inside the rasterizer's
+    backward in the iterations without a densification (FusedAdam(in_backward=True)); False: every step from materialised gradients."""
     spec = importlib.util.spec_from_file_location("train_iteration", os.path.join(ROOT, "examples", "train_iteration.py"))
     ti = importlib.util.module_from_spec(spec); spec.loader.exec_module(ti)
     from adgs import env, synthetic
     from adgs.model import SyntheticGaussianModel
     dev = torch.device("cuda", 0)
-    cfg, sc, model_cpu, cams = tj.build_case()
-    env_grid = ((torch.rand((1, 3, ENV_RES, ENV_RES), generator=torch.Generator().manual_seed(5)) * 2.0 - 1.0) * 0.5).numpy()
-    ref, rec, draws, plan = reference_run(model_cpu, cams, env_grid)
+    (cfg, sc, model_cpu, cams, env_grid), (ref, rec, draws, plan) = _reference()
     assert len(plan) == 2 and all(sum(p["counts"][s][0] + p["counts"][s][1] for s in ("scene", "obj")) > 20 for p in plan.values()), plan
 
     # ---- the HIP side: the example's own build, from the same scene
@@ -147,7 +161,8 @@ def test_thirty_iterations_follow_the_cpu_reference_trajectory():
     totals, report = [], []
     try:
         with scripted_draws(draws) as pos:
-            model.training_setup(lrs=tj.LRS, percent_dense=0.01, scene_extent=SCENE_EXTENT, object_extent=OBJECT_EXTENT, near_num=NEAR_NUM)
+            model.training_setup(lrs=tj.LRS, percent_dense=0.01, scene_extent=SCENE_EXTENT, object_extent=OBJECT_EXTENT, near_num=NEAR_NUM,
+                                 adam_in_backward=adam_in_backward)
             state, clock = {}, ti.StageClock(False)
             for it in range(ITERS):
                 n = it + 1
