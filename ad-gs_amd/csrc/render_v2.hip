@@ -477,28 +477,12 @@ __device__ __forceinline__ float wave_sum14_lds(float* s_red, const RedAddr& ra,
 	w[0 * RED_STRIDE] = x0; w[1 * RED_STRIDE] = x1; w[2 * RED_STRIDE] = x2; w[3 * RED_STRIDE] = x3; w[4 * RED_STRIDE] = x4;
 	w[5 * RED_STRIDE] = x5; w[6 * RED_STRIDE] = x6; w[7 * RED_STRIDE] = x7; w[8 * RED_STRIDE] = x8; w[9 * RED_STRIDE] = x9;
 	w[10 * RED_STRIDE] = x10; w[11 * RED_STRIDE] = x11; w[12 * RED_STRIDE] = x12; w[13 * RED_STRIDE] = x13;
-#ifdef ADGS_BWD_PIPELINED_REDUCTION
-	return 0.f;          // the read-back happens one entry later (red_issue / red_finish)
-#else
 	const float4 a = *ra.r[0], b = *ra.r[1], c = *ra.r[2], d = *ra.r[3];
 	float v = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
 	v += ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
 	int x = __float_as_int(v);
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = __float_as_int(v);      // quad_perm [1,0,3,2]
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));                               // quad_perm [2,3,0,1]
-	return v;
-#endif
-}
-// the same reduction in two halves (experiment): the four 16-byte reads of an entry's sums are ISSUED at the top of the
-// next entry's evaluation and consumed behind it -- the LDS round trip runs under ~70 vector instructions instead of in front of them
-struct RedQuads { float4 a, b, c, d; };
-__device__ __forceinline__ void red_issue(const RedAddr& ra, RedQuads& q) { q.a = *ra.r[0]; q.b = *ra.r[1]; q.c = *ra.r[2]; q.d = *ra.r[3]; }
-__device__ __forceinline__ float red_finish(const RedQuads& q) {
-	float v = ((q.a.x + q.a.y) + (q.a.z + q.a.w)) + ((q.b.x + q.b.y) + (q.b.z + q.b.w));
-	v += ((q.c.x + q.c.y) + (q.c.z + q.c.w)) + ((q.d.x + q.d.y) + (q.d.z + q.d.w));
-	int x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = __float_as_int(v);
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));
 	return v;
 }
 
@@ -667,15 +651,6 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 		my_id = c[lane]; link = c[CHUNK_PREV + (lane & 1)];
 	}
 	bool rows_ready = false;                      // nx0 .. nx3 hold the CURRENT chunk's lines (requested one chunk ago)
-#ifdef ADGS_BWD_PIPELINED_REDUCTION
-	bool red_pending = false; uint32_t red_gid = 0;      // wave-uniform: the sums of entry red_gid sit in s_red
-	auto red_flush = [&](const RedQuads& rq) {
-		const float out = red_finish(rq);
-		if (!FULL && a.sem_dst) {
-			if (writer && (slot < 6 || slot == GACC_USED - 1)) atomicAdd(slot == GACC_USED - 1 ? a.sem_dst + (size_t)red_gid * a.sem_stride : a.gacc + (size_t)red_gid * GACC_STRIDE + slot, out);
-		} else if (writer) atomicAdd(a.gacc + (size_t)red_gid * GACC_STRIDE + slot, out);
-	};
-#endif
 	while (chunk != NO_CHUNK) {
 		PT(t_c0);
 		__builtin_amdgcn_s_setprio(2);      // a chunk boundary is a dozen instructions between two waits: do not starve behind the older waves' entry loops
@@ -725,11 +700,6 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 			for (int j = j_first; j >= 0; j--) {
 				const int contributor = base + j;
 				PT_ADD(7, 1ull);
-#ifdef ADGS_BWD_PIPELINED_REDUCTION
-				RedQuads rq;
-				const bool red_now = red_pending;
-				if (red_now) red_issue(red, rq);
-#endif
 				const float4 q0 = s_splat[j * BROW + 0], q1 = s_splat[j * BROW + 1];
 				const float dx = q0.x - pxf;
 				const EntryGeom eg = entry_geom(q0, q1, dx);
@@ -739,9 +709,6 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 				float alpha[PPL], G[PPL], dy[PPL]; uint64_t actm[PPL];      // lane masks on the scalar unit, as in the forward
 				const uint64_t any_m = ((lean_m >> j) & 1ull) ? eval_entry_bwd<true, PPL>(eg, pyf0, contributor, last_contributor, alpha, G, dy, actm)
 				                            : eval_entry_bwd<false, PPL>(eg, pyf0, contributor, last_contributor, alpha, G, dy, actm);
-#ifdef ADGS_BWD_PIPELINED_REDUCTION
-				if (red_now) { red_flush(rq); red_pending = false; }
-#endif
 				if (any_m == 0ull) continue;
 				const float4 q2 = s_splat[j * BROW + 2];
 				const float4 q3 = s_splat[j * BROW + 3];
@@ -773,11 +740,6 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 				// instruction on one 64-byte line.  Absent channels stay exactly 0.
 				PT(t_r0);
 				const float out = wave_sum14_lds(s_red, red, lane, v.op, v.mx, v.my, v.ca, v.cb, v.cc, v.c0, v.c1, v.c2, v.d, v.f0, v.f1, v.f2, v.s);
-#ifdef ADGS_BWD_PIPELINED_REDUCTION
-				red_pending = true; red_gid = gid; (void)out;
-				PT(t_r1); PT_ACC(3, t_r0, t_r1);
-				continue;
-#endif
 				if (!FULL && a.sem_dst) {
 					if (writer && (slot < 6 || slot == GACC_USED - 1)) atomicAdd(slot == GACC_USED - 1 ? a.sem_dst + (size_t)gid * a.sem_stride : a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
 				} else if (writer) atomicAdd(a.gacc + (size_t)gid * GACC_STRIDE + slot, out);
@@ -787,9 +749,6 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 		}
 		chunk = prev;
 	}
-#ifdef ADGS_BWD_PIPELINED_REDUCTION
-	if (red_pending) { RedQuads rq; red_issue(red, rq); red_flush(rq); }
-#endif
 	__builtin_amdgcn_s_setprio(0);
 	{ PT(t_wave1); PT_ACC(4, t_wave0, t_wave1); PT_ADD(5, 1ull); PT_FLUSH(16, 9, lane); }
 	TL_STORE(lane, a.tl_start, a.tl_end, tile);
