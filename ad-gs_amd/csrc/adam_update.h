@@ -3,6 +3,7 @@
 // parameter takes the same bits whichever kernel updates it.
 #pragma once
 #include "common.h"
+#include "stream_access.h"
 
 namespace adgs {
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ void adam_rows(const float* __restrict__ s, int strid
 				for (int u = 0; u < U4; u++) {
 					so[u] = g * stride + c; cc[u] = c;
 					const int qq = min(q + u * nthreads, total4 - 1);         // unconditional loads at a clamped index (stage_rows)
-					p4[u] = reinterpret_cast<const float4*>(P)[qq]; m4[u] = reinterpret_cast<const float4*>(M)[qq]; v4[u] = reinterpret_cast<const float4*>(V)[qq];
+					p4[u] = ld_stream4(reinterpret_cast<const float4*>(P) + qq); m4[u] = ld_stream4(reinterpret_cast<const float4*>(M) + qq); v4[u] = ld_stream4(reinterpret_cast<const float4*>(V) + qq);
 					c += dr; g += dq;
 					if (c >= L) { c -= L; g++; }
 				}
@@ -61,7 +62,7 @@ __device__ __forceinline__ void adam_rows(const float* __restrict__ s, int strid
 					if (q + u * nthreads >= total4) continue;
 					const int o0 = so[u], o1 = so[u] + 1 + (cc[u] + 1 >= L ? pad : 0), o2 = so[u] + 2 + (cc[u] + 2 >= L ? pad : 0), o3 = so[u] + 3 + (cc[u] + 3 >= L ? pad : 0);
 					adam_update4(p4[u], m4[u], v4[u], make_float4(s[o0], s[o1], s[o2], s[o3]), beta1, beta2, eps, step_size, ibc2);
-					reinterpret_cast<float4*>(P)[q + u * nthreads] = p4[u]; reinterpret_cast<float4*>(M)[q + u * nthreads] = m4[u]; reinterpret_cast<float4*>(V)[q + u * nthreads] = v4[u];
+					st_stream4(reinterpret_cast<float4*>(P) + (q + u * nthreads), p4[u]); st_stream4(reinterpret_cast<float4*>(M) + (q + u * nthreads), m4[u]); st_stream4(reinterpret_cast<float4*>(V) + (q + u * nthreads), v4[u]);
 				}
 			}
 			e_begin = total4 << 2;

@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 #pragma unroll
 		for (int half = 0; half < HALVES; half++) {
 			const size_t e = tot >= 4 ? min(e0[half], last4) : 0;
-			if (tot >= 4) { p4[half] = *reinterpret_cast<const float4*>(ad_p + e); m4[half] = *reinterpret_cast<const float4*>(ad_m + e); v4[half] = *reinterpret_cast<const float4*>(ad_v + e); }
+			if (tot >= 4) { p4[half] = ld_stream4(reinterpret_cast<const float4*>(ad_p + e)); m4[half] = ld_stream4(reinterpret_cast<const float4*>(ad_m + e)); v4[half] = ld_stream4(reinterpret_cast<const float4*>(ad_v + e)); }
 		}
 	}
 	for (int k = threadIdx.x; k < np; k += blockDim.x) s_w[k] = 0.f;
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 		if (ADAM && ad_p) {
 			if (e0[half] + 4 <= tot) {
 				adam_update4(p4[half], m4[half], v4[half], make_float4(v[0], v[1], v[2], v[3]), a.beta1, a.beta2, a.eps, ad_step, ad_ibc2);
-				*reinterpret_cast<float4*>(ad_p + e0[half]) = p4[half]; *reinterpret_cast<float4*>(ad_m + e0[half]) = m4[half]; *reinterpret_cast<float4*>(ad_v + e0[half]) = v4[half];
+				st_stream4(reinterpret_cast<float4*>(ad_p + e0[half]), p4[half]); st_stream4(reinterpret_cast<float4*>(ad_m + e0[half]), m4[half]); st_stream4(reinterpret_cast<float4*>(ad_v + e0[half]), v4[half]);
 			} else for (int it = 0; it < 4 && e0[half] + it < tot; it++) {
 				const size_t e = e0[half] + it;
 				float pp = ad_p[e], mm = ad_m[e], vv = ad_v[e];
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) deform_lin_param_grad_kernel(ParamGradArg
 			}
 			continue;
 		}
-		if (e0[half] + 4 <= tot) *reinterpret_cast<float4*>(seg_out + e0[half]) = make_float4(v[0], v[1], v[2], v[3]);
+		if (e0[half] + 4 <= tot) st_stream4(reinterpret_cast<float4*>(seg_out + e0[half]), make_float4(v[0], v[1], v[2], v[3]));
 		else for (int it = 0; it < 4 && e0[half] + it < tot; it++) seg_out[e0[half] + it] = v[it];
 	}
 }
@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 		const float4* src = reinterpret_cast<const float4*>(sp + r0 * (NV4 * 4));
 		const int words = rows * NV4;
 #pragma unroll
-		for (int k = 0; k < NV4; k++) { const int wd = k * 256 + threadIdx.x; q[k] = src[min(wd, words - 1)]; }
+		for (int k = 0; k < NV4; k++) { const int wd = k * 256 + threadIdx.x; q[k] = ld_stream4(src + min(wd, words - 1)); }
 		dc = (ob ? s.obj_dc : s.scene_dc)[r0 + min((int)threadIdx.x, rows - 1)];
 	}
 	for (int k = threadIdx.x; k < NV4 * 4; k += 256) s_w[k] = 0.f;

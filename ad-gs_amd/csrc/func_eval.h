@@ -1,6 +1,7 @@
 // Device helpers shared by the deformation kernels and the raw-SH path of the preprocess kernels.
 #pragma once
 #include "common.h"
+#include "stream_access.h"
 #include "adam_update.h"
 #include "../../include/adgs_deform.h"
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 					so[u] = g * stride + c; cc[u] = c;
 					// UNCONDITIONAL load at a clamped index: a load under `in[u] ? ... : ...` sits in its own exec-masked block, whose end
 					// waits for it (s_waitcnt vmcnt(0)) -- the U4 round trips of a batch then run one after the other
-					if (TO_LDS) v[u] = reinterpret_cast<const float4*>(slab)[min(q + u * nthreads, total4 - 1)];
+					if (TO_LDS) v[u] = ld_stream4(reinterpret_cast<const float4*>(slab) + min(q + u * nthreads, total4 - 1));
 					c += dr; g += dq;
 					if (c >= L) { c -= L; g++; }
 				}
@@ -82,7 +83,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 					const int pad = stride - L;
 					const int o0 = so[u], o1 = so[u] + 1 + (cc[u] + 1 >= L ? pad : 0), o2 = so[u] + 2 + (cc[u] + 2 >= L ? pad : 0), o3 = so[u] + 3 + (cc[u] + 3 >= L ? pad : 0);
 					if (TO_LDS) { s[o0] = v[u].x; s[o1] = v[u].y; s[o2] = v[u].z; s[o3] = v[u].w; }
-					else reinterpret_cast<float4*>(const_cast<float*>(slab))[q + u * nthreads] = make_float4(s[o0], s[o1], s[o2], s[o3]);
+					else st_stream4(reinterpret_cast<float4*>(const_cast<float*>(slab)) + (q + u * nthreads), make_float4(s[o0], s[o1], s[o2], s[o3]));
 				}
 			}
 			e_begin = total4 << 2;            // at most three tail elements go through the generic loop
@@ -110,14 +111,14 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, int stride, in
 			const bool scene_rows = scene && gi0 < Ns, obj_rows = obj && gi0 + count > Ns;
 			PtrT dummy = scene_rows ? scene + (size_t)gi0 * L : (obj_rows ? obj + (size_t)(max(gi0, Ns) - Ns) * L : (scene ? scene : obj));
 #pragma unroll
-			for (int u = 0; u < U; u++) v[u] = *(p[u] ? p[u] : dummy);
+			for (int u = 0; u < U; u++) v[u] = ld_stream(p[u] ? p[u] : dummy);
 #pragma unroll
 			for (int u = 0; u < U; u++) if (p[u]) s[so[u]] = v[u];
 		} else {
 #pragma unroll
 			for (int u = 0; u < U; u++) v[u] = p[u] ? s[so[u]] : 0.f;
 #pragma unroll
-			for (int u = 0; u < U; u++) if (p[u]) *const_cast<float*>(p[u]) = v[u];
+			for (int u = 0; u < U; u++) if (p[u]) st_stream(const_cast<float*>(p[u]), v[u]);
 		}
 	}
 }

@@ -61,15 +61,15 @@ __global__ void __launch_bounds__(AB) adam_kernel(AdamTable t) {
 		}
 		if (i >= G.numel) continue;
 		if (vec && i + AV <= G.numel) {
-			float4 p = *reinterpret_cast<float4*>(G.param + i), g = *reinterpret_cast<const float4*>(G.grad + i);
-			float4 m = *reinterpret_cast<float4*>(G.exp_avg + i), v = *reinterpret_cast<float4*>(G.exp_avg_sq + i);
+			float4 p = ld_stream4(reinterpret_cast<const float4*>(G.param + i)), g = ld_stream4(reinterpret_cast<const float4*>(G.grad + i));
+			float4 m = ld_stream4(reinterpret_cast<const float4*>(G.exp_avg + i)), v = ld_stream4(reinterpret_cast<const float4*>(G.exp_avg_sq + i));
 			adam_update(p.x, m.x, v.x, g.x, t.beta1, t.beta2, t.eps, step_size, ibc2);
 			adam_update(p.y, m.y, v.y, g.y, t.beta1, t.beta2, t.eps, step_size, ibc2);
 			adam_update(p.z, m.z, v.z, g.z, t.beta1, t.beta2, t.eps, step_size, ibc2);
 			adam_update(p.w, m.w, v.w, g.w, t.beta1, t.beta2, t.eps, step_size, ibc2);
-			*reinterpret_cast<float4*>(G.param + i) = p;
-			*reinterpret_cast<float4*>(G.exp_avg + i) = m;
-			*reinterpret_cast<float4*>(G.exp_avg_sq + i) = v;
+			st_stream4(reinterpret_cast<float4*>(G.param + i), p);
+			st_stream4(reinterpret_cast<float4*>(G.exp_avg + i), m);
+			st_stream4(reinterpret_cast<float4*>(G.exp_avg_sq + i), v);
 			if (zero_grad) *reinterpret_cast<float4*>(G.grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 		} else {
 			for (int k = 0; k < AV && i + k < G.numel; k++) {

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 			const int total4 = nvalid * NQ4;
 			float4 v[NQ4];
 #pragma unroll
-			for (int u = 0; u < NQ4; u++) v[u] = src[min(tid + u * 256, total4 - 1)];
+			for (int u = 0; u < NQ4; u++) v[u] = ld_stream4(src + min(tid + u * 256, total4 - 1));
 			in = load_pre_in(a, idx);
 #pragma unroll
 			for (int u = 0; u < NQ4; u++) {

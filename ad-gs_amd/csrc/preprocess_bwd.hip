@@ -65,9 +65,9 @@ __device__ __forceinline__ PreBIn load_preb_in(const PreprocessBwdArgs& a, const
 	in.q[0] = r.x; in.q[1] = r.y; in.q[2] = r.z; in.q[3] = r.w;
 	in.op = rs ? a.sh_src.scene_opacity[i] : 0.f;
 	const float4* ga = reinterpret_cast<const float4*>(a.gacc + i * GACC_STRIDE);
-	in.u0 = ga[0]; in.u1 = ga[1]; in.u2 = ga[2]; in.u3 = ga[3];
+	in.u0 = ld_stream4(ga); in.u1 = ld_stream4(ga + 1); in.u2 = ld_stream4(ga + 2); in.u3 = ld_stream4(ga + 3);
 	const float4* sp = reinterpret_cast<const float4*>(a.splats + i);
-	in.s0 = sp[0]; in.s1 = sp[1];
+	in.s0 = ld_stream4(sp); in.s1 = ld_stream4(sp + 1);
 	in.clamped = a.clamped[i];
 	return in;
 }
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			const int total4 = nvalid * NQ4;
 			float4 v[NQ4];
 #pragma unroll
-			for (int u = 0; u < NQ4; u++) v[u] = src[min(tid + u * BW_THREADS, total4 - 1)];
+			for (int u = 0; u < NQ4; u++) v[u] = ld_stream4(src + min(tid + u * BW_THREADS, total4 - 1));
 			if (pf) in = load_preb_in(a, idx);
 #pragma unroll
 			for (int u = 0; u < NQ4; u++) {
@@ -179,10 +179,10 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		g2y = -op * (qc * u0.z + qb * u0.y) * (float)(0.5 * a.H);
 		dcon_x = -0.5f * op * u0.w; dcon_y = -0.5f * op * u1.x; dcon_z = -0.5f * op * u1.y;
 		gcol[0] = u1.z; gcol[1] = u1.w; gcol[2] = u2.x; gd = u2.y;
-		a.out_mean2D[3 * (size_t)idx] = g2x; a.out_mean2D[3 * (size_t)idx + 1] = g2y; a.out_mean2D[3 * (size_t)idx + 2] = 0.f;
+		st_stream(a.out_mean2D + 3 * (size_t)idx, g2x); st_stream(a.out_mean2D + 3 * (size_t)idx + 1, g2y); st_stream(a.out_mean2D + 3 * (size_t)idx + 2, 0.f);
 		if (a.out_conic) *reinterpret_cast<float4*>(a.out_conic + 4 * (size_t)idx) = make_float4(dcon_x, dcon_y, 0.f, dcon_z);
-		if (rs) a.sh_dst.scene_opacity[idx] = u0.x * act.op * (1.f - act.op);      // d sigmoid
-		else a.out_opacity[idx] = u0.x;
+		if (rs) st_stream(a.sh_dst.scene_opacity + idx, u0.x * act.op * (1.f - act.op));      // d sigmoid
+		else st_stream(a.out_opacity + idx, u0.x);
 		if (a.out_color) { a.out_color[3 * (size_t)idx] = gcol[0]; a.out_color[3 * (size_t)idx + 1] = gcol[1]; a.out_color[3 * (size_t)idx + 2] = gcol[2]; }
 		if (a.out_depth) a.out_depth[idx] = gd;
 		if (a.out_flow && rs) { gflow[0] = u2.z; gflow[1] = u2.w; gflow[2] = u3.x; }
@@ -376,8 +376,8 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
 		gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
 	}
-	if (rs) { float* gx = a.sh_dst.scene_xyz + 3 * (size_t)idx; gx[0] = gmx + gflow[0]; gx[1] = gmy + gflow[1]; gx[2] = gmz + gflow[2]; }
-	else { a.dL_dmean3D[3 * (size_t)idx] = gmx; a.dL_dmean3D[3 * (size_t)idx + 1] = gmy; a.dL_dmean3D[3 * (size_t)idx + 2] = gmz; }
+	if (rs) { float* gx = a.sh_dst.scene_xyz + 3 * (size_t)idx; st_stream(gx, gmx + gflow[0]); st_stream(gx + 1, gmy + gflow[1]); st_stream(gx + 2, gmz + gflow[2]); }
+	else { st_stream(a.dL_dmean3D + 3 * (size_t)idx, gmx); st_stream(a.dL_dmean3D + 3 * (size_t)idx + 1, gmy); st_stream(a.dL_dmean3D + 3 * (size_t)idx + 2, gmz); }
 
 	// ---------------- cov3D -> scale / rotation (backward.cu:278-341)
 	if (a.scales) {
@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		const float ds0 = Rt.v[0][0] * dMt.v[0][0] + Rt.v[0][1] * dMt.v[0][1] + Rt.v[0][2] * dMt.v[0][2];
 		const float ds1 = Rt.v[1][0] * dMt.v[1][0] + Rt.v[1][1] * dMt.v[1][1] + Rt.v[1][2] * dMt.v[1][2];
 		const float ds2 = Rt.v[2][0] * dMt.v[2][0] + Rt.v[2][1] * dMt.v[2][1] + Rt.v[2][2] * dMt.v[2][2];
-		if (rs) { float* gs = a.sh_dst.scene_scaling + 3 * (size_t)idx; gs[0] = ds0 * sc0; gs[1] = ds1 * sc1; gs[2] = ds2 * sc2; }      // d exp
-		else { a.dL_dscale[3 * (size_t)idx + 0] = ds0; a.dL_dscale[3 * (size_t)idx + 1] = ds1; a.dL_dscale[3 * (size_t)idx + 2] = ds2; }
+		if (rs) { float* gs = a.sh_dst.scene_scaling + 3 * (size_t)idx; st_stream(gs, ds0 * sc0); st_stream(gs + 1, ds1 * sc1); st_stream(gs + 2, ds2 * sc2); }      // d exp
+		else { st_stream(a.dL_dscale + 3 * (size_t)idx + 0, ds0); st_stream(a.dL_dscale + 3 * (size_t)idx + 1, ds1); st_stream(a.dL_dscale + 3 * (size_t)idx + 2, ds2); }
 #pragma unroll
 		for (int k = 0; k < 3; k++) { dMt.v[0][k] *= s0; dMt.v[1][k] *= s1; dMt.v[2][k] *= s2; }
 #define MT(i, j) dMt.v[i][j]
@@ -418,9 +418,9 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 #undef MT
 		if (rs) {      // the Python-side F.normalize of the reference (scene/gaussian_model.py:44): (g - q (q . g)) / |raw|
 			const float qg = r * dq.x + x * dq.y + y * dq.z + z * dq.w;
-			*reinterpret_cast<float4*>(a.sh_dst.scene_rotation + 4 * (size_t)idx) =
-				make_float4((dq.x - r * qg) * act.inv_norm, (dq.y - x * qg) * act.inv_norm, (dq.z - y * qg) * act.inv_norm, (dq.w - z * qg) * act.inv_norm);
-		} else *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;     // no normalisation Jacobian (backward.cu:340)
+			st_stream4(reinterpret_cast<float4*>(a.sh_dst.scene_rotation + 4 * (size_t)idx),
+				make_float4((dq.x - r * qg) * act.inv_norm, (dq.y - x * qg) * act.inv_norm, (dq.z - y * qg) * act.inv_norm, (dq.w - z * qg) * act.inv_norm));
+		} else st_stream4(reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx), dq);     // no normalisation Jacobian (backward.cu:340)
 	}
 	}   // if (vis)
 	if (STAGED) {
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 			for (int q = tid; q < nvalid * (SH_ROW_FULL / 4); q += BW_THREADS) {
 				const int g = q / (SH_ROW_FULL / 4), c = (q - g * (SH_ROW_FULL / 4)) * 4;
 				const float* s = s_sh + g * SH_ROW_FULL_LDS + c;
-				dst[q] = make_float4(s[0], s[1], s[2], s[3]);
+				st_stream4(dst + q, make_float4(s[0], s[1], s[2], s[3]));
 			}
 		}
 	}

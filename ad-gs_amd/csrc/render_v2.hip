@@ -441,13 +441,13 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 				// background of gaussian_renderer/__init__.py:93-94 (render = foreground + (1 - O) * background, T = 1 - O)
 				const float b0 = a.bg[0] + (a.bg_image ? a.bg_image[0 * HW + pix_id] : 0.f), b1 = a.bg[1] + (a.bg_image ? a.bg_image[1 * HW + pix_id] : 0.f),
 					b2 = a.bg[2] + (a.bg_image ? a.bg_image[2 * HW + pix_id] : 0.f);
-				a.out_color[0 * HW + pix_id] = C0[k] + T[k] * b0;
-				a.out_color[1 * HW + pix_id] = C1[k] + T[k] * b1;
-				a.out_color[2 * HW + pix_id] = C2[k] + T[k] * b2;
+				st_stream(a.out_color + 0 * HW + pix_id, C0[k] + T[k] * b0);
+				st_stream(a.out_color + 1 * HW + pix_id, C1[k] + T[k] * b1);
+				st_stream(a.out_color + 2 * HW + pix_id, C2[k] + T[k] * b2);
 			}
-			if (a.has_flow) { a.out_flow[0 * HW + pix_id] = F0[k]; a.out_flow[1 * HW + pix_id] = F1[k]; a.out_flow[2 * HW + pix_id] = F2[k]; }
-			if (a.has_sem) a.out_semantic[pix_id] = S0[k];
-			a.out_depth[pix_id] = Dp[k];
+			if (a.has_flow) { st_stream(a.out_flow + 0 * HW + pix_id, F0[k]); st_stream(a.out_flow + 1 * HW + pix_id, F1[k]); st_stream(a.out_flow + 2 * HW + pix_id, F2[k]); }
+			if (a.has_sem) st_stream(a.out_semantic + pix_id, S0[k]);
+			st_stream(a.out_depth + pix_id, Dp[k]);
 		}
 	}
 }
@@ -591,11 +591,11 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 		Bsum[k] = 0.f;
 		gC0[k] = gC1[k] = gC2[k] = gF0[k] = gF1[k] = gF2[k] = gD[k] = gS[k] = 0.f;
 		if (inside[k]) {
-			if (do_color) { gC0[k] = a.dL_dpix[0 * HW + pix_id]; gC1[k] = a.dL_dpix[1 * HW + pix_id]; gC2[k] = a.dL_dpix[2 * HW + pix_id]; }
-			if (do_flow) { gF0[k] = a.dL_dpix_flow[0 * HW + pix_id]; gF1[k] = a.dL_dpix_flow[1 * HW + pix_id]; gF2[k] = a.dL_dpix_flow[2 * HW + pix_id]; }
-			if (do_sem) gS[k] = a.dL_dpix_sem[pix_id];
-			if (do_depth) gD[k] = a.dL_dpix_depth[pix_id];
-			if (do_opacity && a.dL_dpix_opacity) gO = a.dL_dpix_opacity[pix_id];
+			if (do_color) { gC0[k] = ld_stream(a.dL_dpix + 0 * HW + pix_id); gC1[k] = ld_stream(a.dL_dpix + 1 * HW + pix_id); gC2[k] = ld_stream(a.dL_dpix + 2 * HW + pix_id); }
+			if (do_flow) { gF0[k] = ld_stream(a.dL_dpix_flow + 0 * HW + pix_id); gF1[k] = ld_stream(a.dL_dpix_flow + 1 * HW + pix_id); gF2[k] = ld_stream(a.dL_dpix_flow + 2 * HW + pix_id); }
+			if (do_sem) gS[k] = ld_stream(a.dL_dpix_sem + pix_id);
+			if (do_depth) gD[k] = ld_stream(a.dL_dpix_depth + pix_id);
+			if (do_opacity && a.dL_dpix_opacity) gO = ld_stream(a.dL_dpix_opacity + pix_id);
 		}
 		float b = 0.f;
 		b += a.bg[0] * gC0[k]; b += a.bg[1] * gC1[k]; b += a.bg[2] * gC2[k];
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(WAVE) render_bwd_v2_kernel(RenderV2BwdArgs a) 
 			// "opacity-T quirk") -- unlike the constant background above, which the rasterizer differentiates itself.
 			gO -= a.bg_image[0 * HW + pix_id] * gC0[k] + a.bg_image[1 * HW + pix_id] * gC1[k] + a.bg_image[2 * HW + pix_id] * gC2[k];
 			if (a.dL_dbg_image) {      // d render / d background = T_final
-				a.dL_dbg_image[0 * HW + pix_id] = T_final * gC0[k]; a.dL_dbg_image[1 * HW + pix_id] = T_final * gC1[k]; a.dL_dbg_image[2 * HW + pix_id] = T_final * gC2[k];
+				st_stream(a.dL_dbg_image + 0 * HW + pix_id, T_final * gC0[k]); st_stream(a.dL_dbg_image + 1 * HW + pix_id, T_final * gC1[k]); st_stream(a.dL_dbg_image + 2 * HW + pix_id, T_final * gC2[k]);
 			}
 		}
 		tfo[k] = gO * T_final; tfb[k] = T_final * b;
