@@ -1251,8 +1251,7 @@ def main():
                     ti = importlib.util.module_from_spec(spec); spec.loader.exec_module(ti)
                     result["train_iteration"] = ti.run("C3", iters=int(os.environ.get("ADGS_BENCH_TRAIN_ITERS", "210")), cameras=K, device=device)
                     # the same iteration with every Adam step taken from materialised gradients (FusedAdam without in_backward)
-                    sep = ti.run("C3", iters=max(40, int(os.environ.get("ADGS_BENCH_TRAIN_ITERS", "210")) // 2), cameras=K, device=device, stages=False,
-                                 adam_in_backward=False)
+                    sep = ti.run("C3", iters=int(os.environ.get("ADGS_BENCH_TRAIN_ITERS", "210")), cameras=K, device=device, stages=False, adam_in_backward=False)
                     result["train_iteration"]["ms_per_iteration_separate_adam"] = sep["ms_per_iteration"]
                 except Exception as exc:
                     result["train_iteration"] = "failed: %r" % (exc,)
