@@ -98,6 +98,7 @@ struct BinState {
 struct GeomStateV2 {
 	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; uint4* dupinfo;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
+	float* ddir;      // [9][P]: d colour / d view direction of the raw-SH path (PreprocessArgs.ddir)
 	// bucket binning (binning.hip): ONE block of counters the host zeroes with a single memset -- pair counts / cursors per cell,
 	// the fine-tile total slots, the device-side (pairs, chunks, overflow) words -- then the cell starts and the chunk table
 	uint32_t* counters; uint32_t* cell_start; uint4* chunks; uint32_t* counts;      // counts[ceil(P / 256)][ncells]: pairs per (preprocess workgroup, cell)
@@ -120,6 +121,7 @@ struct GeomStateV2 {
 		g.sh0 = c.take<float>(P * 3);
 		g.fine_total = c.take<unsigned long long>(SCAN_AUX_SLOTS);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
+		g.ddir = c.take<float>(P * 9);
 		g.counts = c.take<uint32_t>(((P + 255) / 256) * std::min<size_t>(ncells, (size_t)MAX_CELLS + 1));      // last: the backward carves without it
 		if (bytes) *bytes = c.size();
 		return g;
@@ -570,6 +572,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
 		pa.bucket_count = nullptr;
 		pa.cfg_word = img.header; pa.cfg_value = frame_word;
+		pa.ddir = (sh_src && M == 16) ? geom.ddir : nullptr;      // raw-SH path: the backward will not read the `rest` rows a second time
 		// bucket binning accumulates the fine-tile total and a few device words: zeroed by the sh0 kernel on the raw-SH path (one
 		// launch less), by a memset otherwise
 		uint32_t* zero_words = nullptr; const int n_zero = 2 * SCAN_AUX_SLOTS + 8;
@@ -788,7 +791,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.v2 = 0; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
 	pa.bucket_count = nullptr;
-	pa.cfg_word = img.header; pa.cfg_value = frame_word;
+	pa.cfg_word = img.header; pa.cfg_value = frame_word; pa.ddir = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
@@ -941,6 +944,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
 		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
 		pa.sh_staging = cfg.sh_staging;
+		pa.ddir = (sh_src && M == 16) ? geom.ddir : nullptr;
 		{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		return 0;
@@ -984,7 +988,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh_dst = ShGradDst{};
 	pa.gacc = nullptr; pa.splats = nullptr; pa.W = width; pa.H = height; pa.out_mean2D = nullptr; pa.out_conic = nullptr; pa.out_opacity = nullptr; pa.out_color = nullptr; pa.out_depth = nullptr;
 	pa.out_flow = nullptr; pa.out_sem = nullptr; pa.D_S = D_S;
-	pa.sh_staging = cfg.sh_staging;
+	pa.sh_staging = cfg.sh_staging; pa.ddir = nullptr;
 	{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 	ADGS_LAUNCH_CHECK(debug, stream);
 	return 0;

@@ -32,6 +32,9 @@ struct PreprocessArgs {
 	// the frame's configuration word, written into the header of the image state (api.hip: frame_cfg_word): a backward that cannot find
 	// its forward in the host-side frame table (cloned / offloaded state buffers) reads it back instead of consulting the environment
 	uint32_t* cfg_word; uint32_t cfg_value;
+	// raw-SH path, 16 coefficients: d(colour channel c)/d(view direction) of every visible Gaussian, [9][P] (dx / dy / dz of channels 0..2 in
+	// planes 0..8) -- 36 bytes that spare the preprocess BACKWARD its second pass over the 180-byte `rest` rows (nullptr: not wanted)
+	float* ddir;
 };
 
 int launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t stream);
@@ -87,6 +90,7 @@ struct PreprocessBwdArgs {
 	float* out_mean2D; float* out_conic; float* out_opacity; float* out_color; float* out_depth; float* out_flow; float* out_sem;
 	int D_S;
 	int sh_staging;                  // 0: ADGS_NO_SH_STAGING was set when the FORWARD of this frame ran (api.hip: FrameCfg)
+	const float* ddir;               // [9][P] written by this frame's preprocess forward (PreprocessArgs.ddir) or nullptr: read the `rest` rows again
 };
 int launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
 

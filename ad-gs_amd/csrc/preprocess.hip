@@ -86,6 +86,29 @@ __device__ __forceinline__ float sh_channel(int deg, float sh0c, const float* sh
 	return result + 0.5f;
 }
 
+// d(colour channel c) / d(unit view direction), the expressions of backward.cu:44-112 (what the preprocess backward evaluated from a second
+// read of the SH row until round 5); degree 3
+__device__ __forceinline__ void sh_channel_ddir(const float* sh, int c, float x, float y, float z, float& ddx, float& ddy, float& ddz) {
+	const float C1 = 0.4886025119029199f;
+	const float C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
+	const float C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+		-0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+	const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+	float dx3 = -C1 * sh[3 * 3 + c], dy3 = -C1 * sh[1 * 3 + c], dz3 = C1 * sh[2 * 3 + c];
+	dx3 += C2[0] * y * sh[4 * 3 + c] + C2[2] * 2.f * -x * sh[6 * 3 + c] + C2[3] * z * sh[7 * 3 + c] + C2[4] * 2.f * x * sh[8 * 3 + c];
+	dy3 += C2[0] * x * sh[4 * 3 + c] + C2[1] * z * sh[5 * 3 + c] + C2[2] * 2.f * -y * sh[6 * 3 + c] + C2[4] * 2.f * -y * sh[8 * 3 + c];
+	dz3 += C2[1] * y * sh[5 * 3 + c] + C2[2] * 2.f * 2.f * z * sh[6 * 3 + c] + C2[3] * x * sh[7 * 3 + c];
+	dx3 += (C3[0] * sh[9 * 3 + c] * 3.f * 2.f * xy + C3[1] * sh[10 * 3 + c] * yz + C3[2] * sh[11 * 3 + c] * -2.f * xy +
+		C3[3] * sh[12 * 3 + c] * -3.f * 2.f * xz + C3[4] * sh[13 * 3 + c] * (-3.f * xx + 4.f * zz - yy) +
+		C3[5] * sh[14 * 3 + c] * 2.f * xz + C3[6] * sh[15 * 3 + c] * 3.f * (xx - yy));
+	dy3 += (C3[0] * sh[9 * 3 + c] * 3.f * (xx - yy) + C3[1] * sh[10 * 3 + c] * xz + C3[2] * sh[11 * 3 + c] * (-3.f * yy + 4.f * zz - xx) +
+		C3[3] * sh[12 * 3 + c] * -3.f * 2.f * yz + C3[4] * sh[13 * 3 + c] * -2.f * xy + C3[5] * sh[14 * 3 + c] * -2.f * yz +
+		C3[6] * sh[15 * 3 + c] * -3.f * 2.f * xy);
+	dz3 += (C3[1] * sh[10 * 3 + c] * xy + C3[2] * sh[11 * 3 + c] * 4.f * 2.f * yz + C3[3] * sh[12 * 3 + c] * 3.f * (2.f * zz - xx - yy) +
+		C3[4] * sh[13 * 3 + c] * 4.f * 2.f * xz + C3[5] * sh[14 * 3 + c] * (xx - yy));
+	ddx = dx3; ddy = dy3; ddz = dz3;
+}
+
 // STAGED (M == 16, SH input): the block's SH rows are loaded fully coalesced into LDS (odd row
 // stride: conflict-free per-thread reads) instead of 64 scattered 192-byte rows per wave access.
 constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
@@ -294,6 +317,15 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 			rgb[c] = fmaxf(v, 0.0f);
 		}
 		s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2];
+		if (a.ddir && a.D == 3) {
+			// nine floats per visible Gaussian in place of the backward's second read of its 45-float row (planes: consecutive lanes, consecutive words)
+#pragma unroll
+			for (int c = 0; c < 3; c++) {
+				float ddx, ddy, ddz;
+				sh_channel_ddir(sh, c, dx, dy, dz, ddx, ddy, ddz);
+				st_stream(a.ddir + (size_t)(3 * c + 0) * a.P + idx, ddx); st_stream(a.ddir + (size_t)(3 * c + 1) * a.P + idx, ddy); st_stream(a.ddir + (size_t)(3 * c + 2) * a.P + idx, ddz);
+			}
+		}
 	} else {
 		s.r = 0.f; s.g = 0.f; s.b = 0.f;
 	}

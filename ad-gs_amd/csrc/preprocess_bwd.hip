@@ -50,7 +50,7 @@ constexpr int SH_ROW_FULL = 48, SH_ROW_FULL_LDS = 49, SH_ROW_REST = 45;
 // Per-Gaussian inputs of the staged v2 kernel, requested with the SH rows (preprocess.hip: PreIn -- the same reasoning: radii -> (visible?)
 // -> position / scale / rotation / opacity / accumulator line / Splat line -> clamp bits are dependent round trips behind the staging
 // barrier otherwise).  Loaded unconditionally at a clamped index; the staged v2 paths that recompute cov3D (gacc != nullptr, no cov3D) use them.
-struct PreBIn { alignas(16) float q[4]; float4 u0, u1, u2, u3, s0, s1; float p[3], s[3], op; int radius; uint8_t clamped; };
+struct PreBIn { alignas(16) float q[4]; float4 u0, u1, u2, u3, s0, s1; float p[3], s[3], op; int radius; uint8_t clamped; float dd[9]; };
 __device__ __forceinline__ PreBIn load_preb_in(const PreprocessBwdArgs& a, const int idx) {
 	PreBIn in;
 	const size_t i = (size_t)min(idx, a.P - 1);
@@ -69,6 +69,10 @@ __device__ __forceinline__ PreBIn load_preb_in(const PreprocessBwdArgs& a, const
 	const float4* sp = reinterpret_cast<const float4*>(a.splats + i);
 	in.s0 = ld_stream4(sp); in.s1 = ld_stream4(sp + 1);
 	in.clamped = a.clamped[i];
+	if (a.ddir) {
+#pragma unroll
+		for (int k = 0; k < 9; k++) in.dd[k] = ld_stream(a.ddir + (size_t)k * a.P + i);      // (garbage for a culled Gaussian: never used)
+	}
 	return in;
 }
 
@@ -85,8 +89,12 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 	// the Adam step in place of the store of the `rest` gradient rows (adgs_sh_adam): the rows are assembled in LDS either way
 	const bool adam_rest = STAGED && raw && (a.sh_dst.adam.scene_rest.p != nullptr || a.sh_dst.adam.obj_rest.p != nullptr);      // kernel-uniform
 	PreBIn in;
+	// the forward left d colour / d direction behind (PreprocessArgs.ddir): no second pass over the `rest` rows -- the LDS rows only carry the gradients out
+	const bool have_ddir = STAGED && raw && pf && a.ddir != nullptr && a.D == 3;      // kernel-uniform
 	if (STAGED) {
-		if (raw) {
+		if (raw && have_ddir) {
+			in = load_preb_in(a, idx);
+		} else if (raw) {
 			stage_rows<true, ADGS_PREB_STAGE_U4>(s_sh, SH_ROW_REST, SH_ROW_REST, base, nvalid, a.sh_src.Ns, a.sh_src.scene_rest, a.sh_src.obj_rest, tid, BW_THREADS,
 				[&]() { if (pf) in = load_preb_in(a, idx); });
 		} else {
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 				}
 			}
 		}
-		__syncthreads();
+		if (!have_ddir) __syncthreads();      // (with ddir nothing was staged: every thread only ever touches its own LDS row until the closing barrier)
 	}
 	const bool valid = idx < a.P;
 	const bool vis = valid && ((pf ? in.radius : a.radii[idx]) > 0);
@@ -329,7 +337,10 @@ __global__ void __launch_bounds__(BW_THREADS) preprocess_bwd_kernel(PreprocessBw
 		const int deg = a.D;
 		// ---- pass A: everything that READS the coefficients (d colour / d direction)
 		float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, yz = 0.f, xz = 0.f;
-		if (deg > 0) {
+		if (have_ddir) {
+#pragma unroll
+			for (int c = 0; c < 3; c++) { dx3[c] = in.dd[3 * c]; dy3[c] = in.dd[3 * c + 1]; dz3[c] = in.dd[3 * c + 2]; }
+		} else if (deg > 0) {
 #pragma unroll
 			for (int c = 0; c < 3; c++) { dx3[c] = -C1 * sh[3 * 3 + c]; dy3[c] = -C1 * sh[1 * 3 + c]; dz3[c] = C1 * sh[2 * 3 + c]; }
 			if (deg > 1) {
