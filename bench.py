@@ -67,21 +67,23 @@ def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
     }
 
 
-def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None, bucket=False):
+def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None, bucket=False, ddir=True):
     """Algorithmic bytes per launch of the default (v2, coarse-binned) pipeline -- DESIGN.md section 5.
     Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries blended, E_pub = entries the backward replays.
     bucket: bucket binning (binning.hip) -- "scan" = the one-workgroup bucket scan (16384 counters in, starts + groups out),
     "duplicate_keys" = the scatter (16 B per Gaussian in, 12 B per pair out), "radix_sort" = the in-CU group sort (12 B per pair
-    in, 8 B out: the radix passes never leave the CU), no range pass."""
+    in, 8 B out: the radix passes never leave the CU), no range pass.
+    ddir: the preprocess forward stores d colour / d view direction (36 B per visible Gaussian) and the backward reads those instead of
+    the SH row a second time (raw-SH path, 16 coefficients: round 5)."""
     out = X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4)
     binning = ({"scan": 16384 * 4 * 3, "duplicate_keys": P * 16 + Rc * 12, "radix_sort": Rc * 20, "tile_ranges": 0} if bucket else
                {"scan": P * 12, "duplicate_keys": V * (8 + 4) + Rc * 12, "radix_sort": passes * Rc * 24 + Rc * 8, "tile_ranges": Rc * 8})
     return {
-        "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 24 + 1 + 64),      # Splat line, binning words, clamp byte, zeroed accumulator line (no filter record since round 4)
+        "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 24 + 1 + 64) + (V * 36 if ddir else 0),      # Splat line, binning words, clamp byte, zeroed accumulator line (no filter record since round 4)
         **binning,
         "render_fwd": E * (4 + 64 + 4) + out,
         "render_bwd": (E if E_pub is None else E_pub) * (4 + 64 + 56) + X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4 + 4),
-        "preprocess_bwd": P * (12 + 12 + 16 + 4 + 12 * M) + V * (64 + 32 + 24 + 1) + V * 64 + P * (12 + 12 * M + 12 + 16 + 12 + 16 + 4 + 12 + 4 + 24),
+        "preprocess_bwd": P * (12 + 12 + 16 + 4) + (V * 36 if ddir else P * 12 * M) + V * (64 + 32 + 24 + 1) + V * 64 + P * (12 + 12 * M + 12 + 16 + 12 + 16 + 4 + 12 + 4 + 24),
     }
 
 
