@@ -1136,10 +1136,10 @@ def main():
                         E, R_ref, E_pub, scanned = 0, 0, 0, 0
                 if pool_fig:
                     ab = alg_bytes_v2(Pn, pool_fig["P_visible"], pool_fig["cell_pairs_sorted"], pool_fig["blended_entries"], X, T, M, F, D_S, stats["sort_passes"],
-                                      pool_fig["published_entries"], bucket=bool(stats.get("bucket_binning")))
+                                      pool_fig["published_entries"], bucket=bool(stats.get("bucket_binning")), ddir=os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0")
                     config["camera_pool_work"] = pool_fig
                 else:
-                    ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub, bucket=bool(stats.get("bucket_binning")))
+                    ab = alg_bytes_v2(Pn, V, Rc, E, X, T, M, F, D_S, stats["sort_passes"], E_pub, bucket=bool(stats.get("bucket_binning")), ddir=os.environ.get("ADGS_BENCH_RAW_SH", "1") != "0")
                 config.update({"pipeline": "v2 (coarse cells, %s, lazy per-tile filtering)" % ("bucket binning: per-cell depth buckets sorted inside one CU each"
                                                                                                 if stats.get("bucket_binning") else "device-wide radix sort of (cell | depth) keys"), "P_visible": V, "tiles": T, "reference_pairs_R": R_ref,
                                "R_over_P": round(R_ref / max(Pn, 1), 2), "cell_pairs_sorted": Rc, "fine_pairs_bound": stats["fine_pairs"], "blended_entries": E,
