@@ -12,7 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_raster import GRAD_PAIRS, assert_close, compare_strict_grads, conditioning_draws, run_hip, run_oracle  # noqa: E402
-from tests.parity import assert_masked_coverage  # noqa: E402
+from tests.parity import TOL, assert_masked_coverage  # noqa: E402
 
 
 def _both_pipelines(sc, g, opts, env, mask):
@@ -84,7 +84,8 @@ def test_v2_matches_classic_and_oracle_on_random_configs(seed):
     for k, gv in v2["grads"].items():                                       # sanity: the unmasked backward, flips included
         if gv is None:
             continue
-        assert_close("grad " + k + " v2~classic", gv.cpu().numpy(), cl["grads"][k].cpu().numpy(), explained=ex["gauss"])
+        # two float32 pipelines that each meet TOL against the oracle (above) may sit 2 TOL apart (seed 52049: one opacity gradient at 1.5 TOL)
+        assert_close("grad " + k + " v2~classic", gv.cpu().numpy(), cl["grads"][k].cpu().numpy(), tol=2 * TOL, rel_l2=2e-4, explained=ex["gauss"])
 
 
 def _large_case(seed):
@@ -120,7 +121,7 @@ def test_v2_matches_classic_and_oracle_on_large_random_configs(seed):
         if gv is None:
             continue
         a = gv.cpu().numpy()
-        assert_close("grad " + k + " v2~classic", a, cl["grads"][k].cpu().numpy(), explained=ex["gauss"])
+        assert_close("grad " + k + " v2~classic", a, cl["grads"][k].cpu().numpy(), tol=2 * TOL, rel_l2=2e-4, explained=ex["gauss"])      # see the small configurations
         if k in names:
             assert_close("grad " + k + " v2~oracle", a, np.asarray(ref["grads"][names[k]]).reshape(a.shape), explained=ex["gauss"])
 
