@@ -118,7 +118,8 @@ class FrameStatus(ctypes.Structure):
     """adgs_frame_status (include/adgs_rasterizer.h)."""
     _fields_ = [("pairs", ctypes.c_int64), ("fine_pairs", ctypes.c_int64), ("capacity_pairs", ctypes.c_int64),
                 ("capacity_fine_pairs", ctypes.c_int64), ("overflow_count", ctypes.c_int64), ("eager_reruns", ctypes.c_int64),
-                ("overflow", ctypes.c_int32), ("reserved", ctypes.c_int32), ("unrepaired_overflow_count", ctypes.c_int64)]
+                ("overflow", ctypes.c_int32), ("order_hint", ctypes.c_int32), ("unrepaired_overflow_count", ctypes.c_int64),
+                ("order_hint_lookups", ctypes.c_int64), ("order_hint_hits", ctypes.c_int64)]
 
 
 def lib():

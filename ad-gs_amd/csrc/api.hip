@@ -29,6 +29,14 @@ struct FrameContext {
 	size_t hint_cells, hint_fine;          // speculative binning capacities (v2 forward): previous frames' counts + 25 %
 	unsigned hint_max_cell_chunks;         // chunks of the fullest cell of the last bucket-binned frame
 	long long reruns;                      // forwards whose capacity was too small (binning + blend enqueued twice)
+	int last_order_hint;                   // the last forward was handed a tile order an earlier forward of the same camera and stream left (OrderHints)
+	// Depth-slab bounds of the bucket binning (binning.hip): [MAX_CELLS][SLAB_ROW] device words, the 32-quantiles of every cell's depth keys
+	// as the most recent bucket-binned frame of this thread left them.  Every frame takes its own snapshot in its first kernel and bins
+	// by that; the sort kernels of the frame rewrite the table for the next one.  ANY contents are valid bounds (a torn snapshot beside
+	// another stream's writes, another camera's or another image shape's quantiles: the slab function stays monotone in the depth) --
+	// they only decide how evenly a cell's entries spread over its slabs.
+	uint32_t* slab_bounds;
+	hipStream_t service;                   // private non-blocking stream: one-off initialisations that must not become part of a capture
 };
 static FrameContext* frame_context() {
 	constexpr int MAX_DEV = 64;
@@ -99,18 +107,20 @@ struct GeomStateV2 {
 	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; uint4* dupinfo;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
 	float* ddir;      // [9][P]: d colour / d view direction of the raw-SH path (PreprocessArgs.ddir)
-	// bucket binning (binning.hip): ONE block of counters the host zeroes with a single memset -- pair counts / cursors per cell,
-	// the fine-tile total slots, the device-side (pairs, chunks, overflow) words -- then the cell starts and the chunk table
-	uint32_t* counters; uint32_t* cell_start; uint4* chunks; uint32_t* counts;      // counts[ceil(P / 256)][ncells]: pairs per (preprocess workgroup, cell)
-	static constexpr size_t COUNTER_WORDS = MAX_CELLS + 2 * SCAN_AUX_SLOTS + 8;
-	uint32_t* cell_count() const { return counters; }
-	unsigned long long* bucket_fine_total() const { return reinterpret_cast<unsigned long long*>(counters + MAX_CELLS); }
-	uint32_t* d_counts() const { return counters + MAX_CELLS + 2 * SCAN_AUX_SLOTS; }
+	// bucket binning (binning.hip): ONE block of counters the frame's prologue zeroes -- the fine-tile total slots, the device-side
+	// (pairs, chunks, overflow) words, the pair counts per (cell, depth slab) column -- then the column cursors, the chunk table and the
+	// frame's snapshot of the slab bounds
+	uint32_t* counters; uint32_t* col_cursor; BinChunk* chunks; uint32_t* chunk_flags; uint32_t* bounds;      // bounds[ncells][SLAB_ROW]
+	static constexpr size_t COUNTER_HEAD = 256, COUNTER_WORDS = COUNTER_HEAD + (size_t)BIN_COPIES * MAX_COLS;      // (the head: 2 * SCAN_AUX_SLOTS + 8 words used; 256 keep the copies 16-byte aligned)
+	unsigned long long* bucket_fine_total() const { return reinterpret_cast<unsigned long long*>(counters); }
+	uint32_t* d_counts() const { return counters + 2 * SCAN_AUX_SLOTS; }
+	uint32_t* col_count() const { return counters + COUNTER_HEAD; }
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes, size_t ncells = 0) {
 		Carver c(chunk); GeomStateV2 g;
 		g.counters = c.take<uint32_t>(COUNTER_WORDS);
-		g.cell_start = c.take<uint32_t>(MAX_CELLS + 1);
-		g.chunks = c.take<uint4>(MAX_CHUNKS);
+		g.col_cursor = c.take<uint32_t>((size_t)BIN_COPIES * MAX_COLS);
+		g.chunks = c.take<BinChunk>(MAX_CHUNKS);
+		g.chunk_flags = c.take<uint32_t>(MAX_CHUNKS);
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
 		g.dupinfo = c.take<uint4>(P);
@@ -122,7 +132,7 @@ struct GeomStateV2 {
 		g.fine_total = c.take<unsigned long long>(SCAN_AUX_SLOTS);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
 		g.ddir = c.take<float>(P * 9);
-		g.counts = c.take<uint32_t>(((P + 255) / 256) * std::min<size_t>(ncells, (size_t)MAX_CELLS + 1));      // last: the backward carves without it
+		g.bounds = c.take<uint32_t>(std::min<size_t>(ncells, (size_t)MAX_CELLS) * SLAB_ROW);      // last: the backward carves without it
 		if (bytes) *bytes = c.size();
 		return g;
 	}
@@ -150,8 +160,8 @@ struct BinStateV2 {
 	uint4* rec_unsorted; uint2* key_stage; uint32_t* mask_stage; uint2* entries;
 	// every tile's own block + blocks drawn from the cursor, each of which may end partly used
 	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + (2 * (size_t)POOL_BLOCK + 1) * ntiles + 1; }
-	// chunks of a frame: every cell has full chunks + one partial
-	static size_t max_chunks(size_t R_cells, size_t ncells) { return std::min<size_t>((size_t)MAX_CHUNKS, ncells + R_cells / GS_NMAX + 1); }
+	// chunks of a frame: every column has full chunks + one partial
+	static size_t max_chunks(size_t R_cells, size_t ncols) { return std::min<size_t>((size_t)MAX_CHUNKS, ncols + R_cells / GS_NMAX + 1); }
 	static BinStateV2 carve_buckets(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
 		Carver c(chunk); BinStateV2 b;
 		b.pool_cursor = c.take<uint32_t>(64);
@@ -283,34 +293,55 @@ static MailboxRef* mailbox() {
 	return &m;
 }
 // Forward tile order from the camera's previous render (render_v2.hip: order_mode 2).  One hint buffer (a permutation of the wave tiles,
-// written by launch_tile_order right behind every blend forward) per camera, per (host thread, device).  A camera is recognised by the
-// device addresses of its view / projection matrices -- the reference's Camera keeps them on the GPU (scene/cameras.py:77-80), the wrapper of
-// gaussian_renderer.render() uploads them once per camera -- together with the image shape.  A wrong guess (recycled addresses, a camera
-// that moved) costs speed only: ANY permutation renders the same images.  The table is bounded (OLDEST entry recycled: no hipFree / hipMalloc
-// in steady state); under stream capture only existing entries are used (no allocation inside a capture) and those stay pinned for the
-// graph's lifetime.
+// written by launch_tile_order right behind every blend forward) per (camera, STREAM), per (host thread, device).  A camera is recognised by
+// the device addresses of its view / projection matrices -- the reference's Camera keeps them on the GPU (scene/cameras.py:77-80);
+// gaussian_renderer.render() keeps one contiguous copy per camera object -- together with the image shape.  A wrong guess (recycled
+// addresses, a camera that moved) costs speed only: the kernel compares the pose the hint was made under with the frame's and ignores a
+// stale one, and ANY permutation renders the same images.
+// A hint is only ever read and rewritten by launches on the stream that produced it (round-5 advisor finding: a second forward of the same
+// camera on another stream -- an evaluation stream, a graph replay beside eager frames -- could read the buffer while tile_order of the
+// other stream rewrote it: the pose signature matches, the order is a mix of two permutations, tiles are rendered twice or never).  Work
+// of one stream is ordered, so reader and writer of an entry can never overlap; another stream gets an entry of its own.  Entries created
+// under stream capture belong to the graph being captured (`captured`): eager frames never touch them, whatever stream the graph is
+// replayed on, and they stay allocated for the graph's lifetime.  (Two graphs of the SAME camera captured on the same stream share an
+// entry: replaying them concurrently on different streams is the caller's race, like replaying one graph twice at once.)
+// The table is bounded (OLDEST entry recycled: no hipFree / hipMalloc in steady state); under capture only existing entries are used.
 struct OrderHints {
-	struct Entry { const void* view; const void* proj; int W, H; size_t tiles; uint32_t* buf; bool valid; bool pinned; unsigned long long used; };
+	struct Entry { const void* view; const void* proj; int W, H; size_t tiles; hipStream_t stream; bool captured; uint32_t* buf; unsigned long long used; bool written; };      // written: a tile_order launch has been enqueued into buf
 	std::vector<Entry> entries;
-	unsigned long long clock = 0;
+	unsigned long long clock = 0, lookups = 0, hits = 0;      // hits: forwards that found an entry (adgs_frame_status.order_hint: the last forward did)
+	hipStream_t service = nullptr;                            // a private non-blocking stream: buffer initialisation that is never part of a capture
 	static constexpr size_t MAX_ENTRIES = 1024;
-	Entry* find(const void* view, const void* proj, int W, int H, size_t tiles) {
-		for (Entry& e : entries) if (e.view == view && e.proj == proj && e.W == W && e.H == H && e.tiles == tiles) { e.used = ++clock; return &e; }
+	Entry* find(const void* view, const void* proj, int W, int H, size_t tiles, hipStream_t stream, bool captured) {
+		for (Entry& e : entries)
+			if (e.view == view && e.proj == proj && e.W == W && e.H == H && e.tiles == tiles && e.captured == captured && (captured || e.stream == stream)) { e.used = ++clock; return &e; }
 		return nullptr;
 	}
-	Entry* create(const void* view, const void* proj, int W, int H, size_t tiles) {
+	// A fresh buffer carries an all-zero pose signature (no view matrix is all zero: the kernel ignores the hint until tile_order has written
+	// one).  Zeroed on the service stream and waited for, so that it is neither captured nor ordered against the caller's stream by luck.
+	bool reset_signature(uint32_t* buf, size_t tiles) {
+		if (!service && hipStreamCreateWithFlags(&service, hipStreamNonBlocking) != hipSuccess) { service = nullptr; return false; }
+		return hipMemsetAsync(buf + tiles, 0, 16 * sizeof(uint32_t), service) == hipSuccess && hipStreamSynchronize(service) == hipSuccess;
+	}
+	// capturing: the caller's stream is being captured into a graph (no synchronisation of it, no recycling of a live entry)
+	Entry* create(const void* view, const void* proj, int W, int H, size_t tiles, hipStream_t stream, bool captured) {
+		Entry* e = nullptr;
 		if (entries.size() >= MAX_ENTRIES) {      // recycle the least recently used entry that no graph holds
-			Entry* lru = nullptr;
-			for (Entry& e : entries) if (!e.pinned && (!lru || e.used < lru->used)) lru = &e;
-			if (!lru) return nullptr;
-			if (lru->tiles != tiles) { (void)hipFree(lru->buf); lru->buf = nullptr; if (hipMalloc((void**)&lru->buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) { lru->tiles = 0; lru->view = nullptr; return nullptr; } }
-			lru->view = view; lru->proj = proj; lru->W = W; lru->H = H; lru->tiles = tiles; lru->valid = false; lru->used = ++clock;
-			return lru;
+			if (captured) return nullptr;
+			for (Entry& c : entries) if (!c.captured && (!e || c.used < e->used)) e = &c;
+			if (!e) return nullptr;
+			// the old owner's stream may still have launches in flight that read or write the buffer: drain it before the buffer changes hands
+			(void)hipStreamSynchronize(e->stream);
+			if (e->tiles != tiles) { (void)hipFree(e->buf); e->buf = nullptr; e->tiles = 0; e->view = nullptr; if (hipMalloc((void**)&e->buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) { e->buf = nullptr; return nullptr; } }
+		} else {
+			Entry fresh{ nullptr, nullptr, 0, 0, 0, nullptr, false, nullptr, 0, false };
+			if (hipMalloc((void**)&fresh.buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) return nullptr;      // the permutation + the 16 floats of the view matrix it was made under
+			entries.push_back(fresh);
+			e = &entries.back();
 		}
-		Entry e{ view, proj, W, H, tiles, nullptr, false, false, ++clock };
-		if (hipMalloc((void**)&e.buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) return nullptr;      // the permutation + the 16 floats of the view matrix it was made under
-		entries.push_back(e);
-		return &entries.back();
+		e->view = view; e->proj = proj; e->W = W; e->H = H; e->tiles = tiles; e->stream = stream; e->captured = captured; e->used = ++clock; e->written = false;
+		if (!reset_signature(e->buf, tiles)) { e->view = nullptr; e->tiles = 0; (void)hipFree(e->buf); e->buf = nullptr; return nullptr; }      // (an unusable slot: find() never matches tiles == 0 / buf == nullptr is never handed out)
+		return e;
 	}
 };
 static OrderHints* order_hints() {
@@ -421,6 +452,8 @@ extern "C" int adgs_get_frame_status(adgs_frame_status* out) {
 	out->capacity_fine_pairs = mb->host->cap_fine == ~0ull ? (int64_t)mb->host->r_fine : (int64_t)mb->host->cap_fine;
 	out->overflow = (int32_t)mb->host->overflow; out->overflow_count = (int64_t)mb->host->overflow_count;
 	out->eager_reruns = (int64_t)frame_context()->reruns;
+	out->order_hint = frame_context()->last_order_hint;
+	if (OrderHints* oh = order_hints()) { out->order_hint_lookups = (int64_t)oh->lookups; out->order_hint_hits = (int64_t)oh->hits; }
 	out->unrepaired_overflow_count = (int64_t)mb->host->overflow_count - (int64_t)mb->repaired;
 	return 0;
 }
@@ -501,24 +534,34 @@ static int raster_forward_impl(const ShSource* sh_src,
 		int cell_tiles = v2_cell_tiles(gx, gy, false);
 		int cgx = (gx + cell_tiles - 1) / cell_tiles, cgy = (gy + cell_tiles - 1) / cell_tiles;
 		size_t ncells = (size_t)cgx * cgy;
-		// Binning: bucket binning (binning.hip: per-cell lists sorted inside the CUs) unless the cell grid has more than MAX_CELLS cells,
-		// the previous frames averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of 8192 pairs per cell, or ADGS_BINNING=sort asks
-		// for the device-wide radix sort of (cell | depth) keys.  (A cell of k chunks pays k - 1 rank searches per entry in the merge,
-		// each against a whole staged chunk; measured crossover against the device-wide sort at about 4 chunks per cell -- C5's 3 M
-		// Gaussians, 9 chunks per cell, take the sort.  A merge over sampled WINDOWS of the other chunks -- linear in k -- was built
-		// and measured in round 3: bit-identical, but slower at both sizes; EXPERIMENTS.md.)
+		// Binning: bucket binning (binning.hip: per-cell lists built as independently sorted depth slabs, inside the CUs) unless the cell grid
+		// has more than MAX_CELLS cells, ADGS_BINNING=sort asks for the device-wide radix sort of (cell | depth) keys, the previous frames
+		// averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of GS_NMAX pairs per COLUMN at the largest slab count (tens of millions of
+		// pairs), or ONE column of the last bucket-binned frame held more than ADGS_BUCKET_MAX_CELL_CHUNKS (16) chunks (a column of k chunks
+		// pays k - 1 rank searches per entry in the merge).  Slabs per cell: the power of two that brings the previous frames' pairs per
+		// column to GS_NMAX / 2 or below (C3: 8 slabs of ~2.7 k, C5: 32 of ~2.1 k), so that a column stays one chunk when a camera's depths
+		// fit the bounds only roughly; ADGS_SLABS_LG overrides.  Until round 5 whole cells were sorted and merged, and C5 (9 chunks per
+		// cell) took the device-wide sort: EXPERIMENTS.md.
 		const char* binning_env = env_str("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
+		const size_t max_cols = std::min<size_t>(ncells << MAX_SLAB_LG, (size_t)MAX_COLS);
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
-			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * ncells &&
-			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));      // ... or ONE cell held more than 16 chunks
+			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * max_cols &&
+			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));
+		int slab_lg = 0;
+		if (buckets) {
+			const size_t per_cell = fc->hint_cells / std::max<size_t>(ncells, 1);
+			while (slab_lg < MAX_SLAB_LG && (per_cell >> slab_lg) > (size_t)GS_NMAX / 2 && (ncells << (slab_lg + 1)) <= (size_t)MAX_COLS) slab_lg++;
+			const int lg_env = env_int("ADGS_SLABS_LG", -1);
+			if (lg_env >= 0) { slab_lg = std::min(lg_env, MAX_SLAB_LG); while (slab_lg > 0 && (ncells << slab_lg) > (size_t)MAX_COLS) slab_lg--; }
+		}
 		if (!buckets && !v2_keys_fit(gx, gy, cell_tiles)) {
 			cell_tiles = v2_cell_tiles(gx, gy, true);
 			cgx = (gx + cell_tiles - 1) / cell_tiles; cgy = (gy + cell_tiles - 1) / cell_tiles; ncells = (size_t)cgx * cgy;
 		}
 		const bool sort_fallback_fits = v2_keys_fit(gx, gy, cell_tiles);      // may this frame still fall back to the sort (chunk table full)?
 		size_t gb = 0, ib = 0;
-		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] exists for bucket binning only
+		const size_t count_cells = buckets ? ncells : 0;      // the snapshot of the slab bounds [ncells][SLAB_ROW] exists for bucket binning only
 		GeomStateV2::carve(nullptr, P, &gb, count_cells);
 		char* gch = geometryBuffer(geometryUser, gb);
 		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
@@ -547,12 +590,21 @@ static int raster_forward_impl(const ShSource* sh_src,
 			hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
 			(void)hipStreamIsCapturing(stream, &cs0);
 			if (OrderHints* oh = order_hints()) {
-				hint = oh->find(viewmatrix, projmatrix, width, height, wtiles);
+				const bool cap0 = cs0 == hipStreamCaptureStatusActive;
+				hint = oh->find(viewmatrix, projmatrix, width, height, wtiles, stream, cap0);
 				// a camera's first render has no hint (bottom-up).  Another camera's order is no substitute: measured with the bench's jittered
-				// cameras (0.04 rad of yaw: the image shifts by a few tiles) it is WORSE than bottom-up, 910 - 920 against 928 frames/s
-				if (!hint && cs0 != hipStreamCaptureStatusActive) hint = oh->create(viewmatrix, projmatrix, width, height, wtiles);
-				if (hint && cs0 == hipStreamCaptureStatusActive) hint->pinned = true;
-				if (hint && hint->valid) hint_read = hint->buf;
+				// cameras (0.04 rad of yaw: the image shifts by a few tiles) it is WORSE than bottom-up, 910 - 920 against 928 frames/s.
+				if (!hint) {
+					// an entry is allocated outside the capture's rules: hipMalloc and the service stream's memset + wait are "potentially
+					// unsafe" calls that a global-mode capture (torch.cuda.graph's default) forbids unless this thread switches to relaxed mode
+					hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+					if (cap0) (void)hipThreadExchangeStreamCaptureMode(&mode);
+					hint = oh->create(viewmatrix, projmatrix, width, height, wtiles, stream, cap0);
+					if (cap0) (void)hipThreadExchangeStreamCaptureMode(&mode);
+					(void)hipGetLastError();      // a failed allocation costs the hint, not the frame
+				}
+				oh->lookups++;
+				if (hint && hint->buf) { hint_read = hint->buf; if (hint->written) oh->hits++; fc->last_order_hint = hint->written ? 1 : 0; } else { hint = nullptr; fc->last_order_hint = 0; }
 			}
 		}
 
@@ -570,18 +622,33 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.v2 = 1; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
-		pa.bucket_count = nullptr;
+		pa.bucket = 0;
 		pa.cfg_word = img.header; pa.cfg_value = frame_word;
 		pa.ddir = (sh_src && M == 16) ? geom.ddir : nullptr;      // raw-SH path: the backward will not read the `rest` rows a second time
-		// bucket binning accumulates the fine-tile total and a few device words: zeroed by the sh0 kernel on the raw-SH path (one
-		// launch less), by a memset otherwise
-		uint32_t* zero_words = nullptr; const int n_zero = 2 * SCAN_AUX_SLOTS + 8;
+		// bucket binning accumulates the fine-tile total, a few device words and the pair counts per column, and bins by a snapshot of the
+		// thread's slab bounds: zeroed / copied by the sh0 kernel on the raw-SH path (no launch of its own), by bin_prepare otherwise
+		FramePrologue pro{ nullptr, 0, nullptr, nullptr, 0 };
 		if (buckets) {
-			zero_words = reinterpret_cast<uint32_t*>(geom.bucket_fine_total());
-			if (!sh_src) ADGS_HIP_CHECK(hipMemsetAsync(zero_words, 0, n_zero * sizeof(uint32_t), stream));
-			pa.bucket_count = geom.counts; pa.fine_total = geom.bucket_fine_total();
+			if (!fc->slab_bounds) {
+				// first bucket-binned frame of this thread on this device: the table starts as "everything in slab 0" (all bounds 0xffffffff).
+				// Allocated and filled outside the rules of a capture that may be running on `stream` (see OrderHints::create)
+				hipStreamCaptureStatus csb = hipStreamCaptureStatusNone;
+				(void)hipStreamIsCapturing(stream, &csb);
+				hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+				if (csb == hipStreamCaptureStatusActive) (void)hipThreadExchangeStreamCaptureMode(&mode);
+				bool ok = hipMalloc((void**)&fc->slab_bounds, (size_t)MAX_CELLS * SLAB_ROW * sizeof(uint32_t)) == hipSuccess;
+				ok = ok && (fc->service || hipStreamCreateWithFlags(&fc->service, hipStreamNonBlocking) == hipSuccess);
+				ok = ok && hipMemsetAsync(fc->slab_bounds, 0xff, (size_t)MAX_CELLS * SLAB_ROW * sizeof(uint32_t), fc->service) == hipSuccess && hipStreamSynchronize(fc->service) == hipSuccess;
+				if (csb == hipStreamCaptureStatusActive) (void)hipThreadExchangeStreamCaptureMode(&mode);
+				if (!ok) { if (fc->slab_bounds) (void)hipFree(fc->slab_bounds); fc->slab_bounds = nullptr; (void)hipGetLastError(); }
+			}
+			if (!fc->slab_bounds) slab_lg = 0;      // no table: one slab per cell (merge-heavy, correct)
+			pro.zero = geom.counters; pro.n_zero = (int)(GeomStateV2::COUNTER_HEAD + (size_t)BIN_COPIES * align_up(ncells << slab_lg, 64));
+			if (slab_lg > 0) { pro.copy_dst = geom.bounds; pro.copy_src = fc->slab_bounds; pro.n_copy = (int)(ncells * SLAB_ROW); }
+			if (!sh_src && launch_bin_prepare(pro, stream) != 0) return -1;
+			pa.bucket = 1; pa.fine_total = geom.bucket_fine_total();
 		}
-		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream, zero_words, zero_words ? n_zero : 0) != 0) return -1; }
+		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream, buckets ? &pro : nullptr) != 0) return -1; }
 		if (const int evict_mb = env_int("ADGS_DBG_EVICT_MB", 0)) {
 			// measurement hook (tools/stage_cache_experiment.py): a fill of `evict_mb` MiB between the sh0 kernel and the preprocess pushes what
 			// the previous kernels wrote (deformed parameters, sh0) out of the 256 MiB Infinity Cache -- the state rocprofv3's serialised,
@@ -614,15 +681,18 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const size_t cap_fine = std::max<size_t>(fc->hint_fine, (size_t)8 * P + 4096);
 		mb->cap_cells = cap_cells; mb->cap_fine = cap_fine;
 		uint32_t* overflow_flag = geom.d_counts() + 3;         // written by cell_scan / publish_counts in every frame
+		const size_t ncols = ncells << slab_lg;
+		BinPairs bp;
+		bp.P = P; bp.dupinfo = geom.dupinfo; bp.cell_tiles = cell_tiles; bp.cgx = cgx; bp.ncells = (int)ncells; bp.lg = slab_lg; bp.bounds = geom.bounds; bp.cstride = (int)align_up(ncols, 64);
+		ColScanArgs sa;
+		sa.col_count = geom.col_count(); sa.col_cursor = geom.col_cursor; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells; sa.lg = slab_lg; sa.cstride = bp.cstride;
+		sa.chunks = geom.chunks; sa.max_chunks = buckets ? (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))) : 0u; sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
+		sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
+		sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
 		if (buckets) {
 			StageTimer t(ST_SCAN, stream);
-			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
-			CellScanArgs sa;
-			sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
-			sa.chunks = geom.chunks; sa.max_chunks = (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))); sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
-			sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
-			sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
-			if (launch_cell_scan(sa, stream) != 0) return -1;
+			if (launch_bin_count(bp, geom.col_count(), geom.offsets, stream) != 0) return -1;      // geom.offsets: free in a bucket-binned frame (the sort path's pair offsets)
+			if (launch_col_scan(sa, stream) != 0) return -1;
 		} else {
 			{
 				StageTimer t(ST_SCAN, stream);
@@ -648,14 +718,15 @@ static int raster_forward_impl(const ShSource* sh_src,
 				if (cells == 0) { ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream)); return 0; }     // cell_ranges: all (0, 0) from bucket_scan
 				const uint32_t cap = (uint32_t)std::min<size_t>(cells, 0xffffffffu);
 				{ StageTimer t(ST_DUPLICATE, stream);
-				  if (launch_cell_scatter(P, geom.dupinfo, geom.cell_start, geom.counts, bin.rec_unsorted, cap, cell_tiles, cgx, (int)ncells, bin.pool_cursor, stream) != 0) return -1; }
+				  if (launch_bin_scatter(bp, geom.col_cursor, geom.offsets, bin.rec_unsorted, cap, bin.pool_cursor, stream) != 0) return -1; }
 				ADGS_LAUNCH_CHECK(debug, stream);
 				ChunkSortArgs ga;
 				ga.chunks = geom.chunks; ga.d_counts = geom.d_counts(); ga.rec_u = bin.rec_unsorted; ga.key_s = bin.key_stage; ga.mask_s = bin.mask_stage;
-				ga.ent_f = bin.entries; ga.cap = cap;
-				const size_t grid = BinStateV2::max_chunks(cells, ncells);
+				ga.ent_f = bin.entries; ga.cap = cap; ga.bounds_out = fc->slab_bounds;
+				{ const char* cs = env_str("ADGS_CHUNK_SORT"); ga.flags = (cs && std::string(cs) == "radix") ? nullptr : geom.chunk_flags; }      // radix: every chunk through the LSD radix sort (A/B, tests)
+				const size_t grid = BinStateV2::max_chunks(cells, ncols);
 				{ StageTimer t(ST_SORT, stream); if (launch_chunk_sort(ga, (uint32_t)grid, stream) != 0) return -1; }
-				{ StageTimer t(ST_RANGES, stream); if (launch_chunk_merge(ga, (uint32_t)grid, stream) != 0) return -1; }      // "tile_ranges" slot: the merge of multi-chunk cells
+				{ StageTimer t(ST_RANGES, stream); if (launch_chunk_merge(ga, (uint32_t)grid, stream) != 0) return -1; }      // "tile_ranges" slot: the merge of multi-chunk columns
 				ADGS_LAUNCH_CHECK(debug, stream);
 				return 0;
 			}
@@ -708,7 +779,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 			if (order_tiles) {
 				StageTimer t(ST_RENDER_FWD, stream);
 				if (launch_tile_order((int)wtiles, img.tile_consumed, img.tile_order, stream, hint ? hint->buf : nullptr, viewmatrix) != 0) return -1;
-				if (hint) { hint->valid = true; hint_read = hint->buf; }      // (a second blend of this call -- the capacity re-run -- reads the order the first one left)
+				if (hint) hint->written = true;      // (a second blend of this call -- the capacity re-run -- reads the order the first one left)
 			}
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
@@ -732,6 +803,12 @@ static int raster_forward_impl(const ShSource* sh_src,
 			// the re-run fits by construction; the device word can also be set without speculation (cell_scan raises it when the chunk
 			// table is full), and a blend launched with it set renders nothing
 			ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream));
+			if (buckets && !chunk_table_full) {
+				// the first bin_scatter advanced the column cursors: col_scan again (same counts, same chunk table) puts them back on the column
+				// starts, this time against no capacity
+				sa.cap_cells = 0xffffffffu; sa.cap_fine = ~0ull;
+				if (launch_col_scan(sa, stream) != 0) return -1;
+			}
 			if (chunk_table_full) {
 				// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
 				// per-Gaussian pair offsets first
@@ -790,7 +867,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
 	pa.v2 = 0; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
-	pa.bucket_count = nullptr;
+	pa.bucket = 0;
 	pa.cfg_word = img.header; pa.cfg_value = frame_word; pa.ddir = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }

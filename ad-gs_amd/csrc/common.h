@@ -69,6 +69,18 @@ struct Carver {
 	size_t size() const { return align_up(off, 256) + 256; }
 };
 
+// What a frame's first kernel does for the binning kernels behind it, beside its own work (sh0 on the raw-SH path, bin_prepare otherwise):
+// zero the counters they accumulate into and take the frame's SNAPSHOT of the depth-slab bounds (the shared table is rewritten by every
+// frame's sort kernels -- possibly of another stream --, and the counting and the scattering pass of a frame must bin by the same bounds).
+struct FramePrologue { uint32_t* zero; int n_zero; uint32_t* copy_dst; const uint32_t* copy_src; int n_copy; };
+__device__ __forceinline__ void run_frame_prologue(const FramePrologue& p) {      // call from every thread of the grid
+	const int nb = min((int)gridDim.x, 8), b = (int)blockIdx.x;      // the first (up to) eight blocks share the work
+	if (b < nb) {
+		for (int i = b * (int)blockDim.x + threadIdx.x; i < p.n_zero; i += nb * (int)blockDim.x) p.zero[i] = 0u;
+		for (int i = b * (int)blockDim.x + threadIdx.x; i < p.n_copy; i += nb * (int)blockDim.x) p.copy_dst[i] = p.copy_src[i];
+	}
+}
+
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py; implemented in api.hip) ----
 enum Stage { ST_PREPROCESS = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM_FWD, ST_DEFORM_BWD,
 	ST_EXPAND, ST_COUNT };

@@ -916,9 +916,9 @@ namespace {
 // words -- consecutive threads own consecutive rows, so the loads are perfectly coalesced without any staging -- and dots
 // with the dense basis vector (zero where the family has no term).  General kernel: rows staged through LDS.
 template <int NV4>
-__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero, int ostride) {
+__global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float* __restrict__ out, FramePrologue pro, int ostride) {
 	__shared__ float s_w[NV4 * 4];
-	if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;      // counters the next kernel accumulates into (saves a memset launch)
+	run_frame_prologue(pro);      // counters the binning kernels accumulate into, the frame's snapshot of the slab bounds (saves a launch)
 	__shared__ float s_part[256 * NV4 + 4];
 	// The block owns 256 consecutive rows = 256 * NV4 consecutive 16-byte words of one segment (scene or object side).  Lane i of a
 	// load instruction reads word base + i -- 1 KiB of consecutive bytes per wave and instruction instead of 64 words 16 * NV4 bytes
@@ -983,9 +983,9 @@ __global__ void __launch_bounds__(256) sh0_rows_kernel(int N, ShSource s, float*
 	}
 	out[(size_t)n * ostride + (e - 3 * n)] = v;
 }
-__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out, uint32_t* __restrict__ zero_words, int n_zero, int ostride) {
+__global__ void __launch_bounds__(256) sh0_kernel(int N, ShSource s, float* __restrict__ out, FramePrologue pro, int ostride) {
 	extern __shared__ float s_rows[];
-	if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
+	run_frame_prologue(pro);
 	const int tid = threadIdx.x, B = blockDim.x, base = blockIdx.x * B, count = min(B, N - base);
 	const int np = s.f.n_params, L = 3 * np, stride = L | 1;
 	const bool lin = (s.scene_sp || s.obj_sp) && has_lin(s.f);
@@ -1018,22 +1018,23 @@ static int pick_block(int row_floats, size_t* lds) {
 	return 64;
 }
 
-int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words, int n_zero, int ostride) {
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, const FramePrologue* prologue, int ostride) {
 	if (N <= 0) return 0;
+	const FramePrologue pro = prologue ? *prologue : FramePrologue{ nullptr, 0, nullptr, nullptr, 0 };
 	const int np = s.f.n_params;
 	const bool lin = (s.scene_sp || s.obj_sp) && (s.f.n_terms[0] + s.f.n_terms[1] + s.f.n_terms[2]) > 0 && np > 0;
 	const bool aligned = ((reinterpret_cast<uintptr_t>(s.scene_sp) | reinterpret_cast<uintptr_t>(s.obj_sp)) & 15) == 0;
 	if (lin && np % 4 == 0 && np <= 32 && aligned) {
 		const unsigned blocks = (unsigned)(((size_t)N * 3 + 255) / 256);
 		switch (np / 4) {
-			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
-			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out, zero_words, n_zero, ostride); break;
+			case 1: hipLaunchKernelGGL(sh0_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			case 2: hipLaunchKernelGGL(sh0_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			case 3: hipLaunchKernelGGL(sh0_rows_kernel<3>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			case 4: hipLaunchKernelGGL(sh0_rows_kernel<4>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			case 5: hipLaunchKernelGGL(sh0_rows_kernel<5>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			case 6: hipLaunchKernelGGL(sh0_rows_kernel<6>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			case 7: hipLaunchKernelGGL(sh0_rows_kernel<7>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
+			default: hipLaunchKernelGGL(sh0_rows_kernel<8>, dim3(blocks), dim3(256), 0, stream, N, s, out, pro, ostride); break;
 		}
 		ADGS_HIP_CHECK(hipGetLastError());
 		return 0;
@@ -1042,7 +1043,7 @@ int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_
 	const int B = pick_block((3 * np) | 1, &lds);
 	if (lds > MAX_STAGING_LDS) { set_error("launch_sh0: SH deformation rows too large for the LDS staging buffer (more than 207 parameters per channel)"); return -1; }
 	if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sh0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out, zero_words, n_zero, ostride);
+	hipLaunchKernelGGL(sh0_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), lds, stream, N, s, out, pro, ostride);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -1168,7 +1169,7 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 			memset(&src, 0, sizeof(src));
 			src.Ns = sa.Ns; src.scene_dc = sa.scene_dc ? sa.scene_dc : sa.obj_dc; src.obj_dc = sa.obj_dc ? sa.obj_dc : sa.scene_dc;
 			src.scene_sp = sa.sp_scene; src.obj_sp = sa.sp_obj; src.f = fs;
-			if (launch_sh0(N, src, shs_out, stream, nullptr, 0, 48) != 0) return -1;
+			if (launch_sh0(N, src, shs_out, stream, nullptr, 48) != 0) return -1;
 			hipLaunchKernelGGL(shs_rest_interleave_kernel, dim3((unsigned)(((size_t)N * 12 + 255) / 256)), dim3(256), 0, stream, sa.Ns, N, sa.scene_rest, sa.obj_rest, shs_out);
 		} else {
 			hipLaunchKernelGGL(deform_shs_fwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, sa);

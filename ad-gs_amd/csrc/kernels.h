@@ -25,10 +25,9 @@ struct PreprocessArgs {
 	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
 	float* gacc;                     // v2: [P][GACC_STRIDE] accumulator lines, zeroed here for every visible Gaussian (nullptr: skip)
 	unsigned long long* fine_total;  // v2: reset here; the scan pass adds up fine_touched into it
-	// v2 bucket binning (binning.hip; bucket_count == nullptr: sort-based binning): every visible Gaussian is counted into the
-	// coarse cells it covers -- bucket_count[workgroup][cell], every entry written -- and fine_total is accumulated here (the host
-	// zeroed it)
-	uint32_t* bucket_count;
+	// v2 bucket binning (binning.hip; 0: sort-based binning): no scan pass runs over fine_touched, so fine_total is accumulated here
+	// (one atomic per workgroup; the frame's prologue zeroed it)
+	int bucket;
 	// the frame's configuration word, written into the header of the image state (api.hip: frame_cfg_word): a backward that cannot find
 	// its forward in the host-side frame table (cloned / offloaded state buffers) reads it back instead of consulting the environment
 	uint32_t* cfg_word; uint32_t cfg_value;
@@ -106,33 +105,55 @@ constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumula
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
 // ---- bucket binning (binning.hip) ----
-constexpr int MAX_CELLS = 1024;         // coarse cells one cell_scan workgroup (and one LDS histogram) handles
-constexpr int GS_NMAX = 8192;           // entries one chunk_sort workgroup sorts inside its CU
+constexpr int MAX_CELLS = 1024;         // coarse cells of a bucket-binned frame
+constexpr int SLAB_ROW = 32;            // words per cell in a table of depth-slab bounds: the 31 inner 32-quantiles of the cell's depth keys (+ 1 pad)
+constexpr int MAX_SLAB_LG = 5;          // a cell's list is built as 2^lg <= 32 independently sorted depth slabs ("columns")
+constexpr int MAX_COLS = 4096;          // (cell, slab) columns one col_scan workgroup (and one LDS histogram) handles
+constexpr int GS_NMAX = 4096;           // entries one chunk_sort workgroup sorts inside its CU
+#ifndef ADGS_BIN_COPIES
+#define ADGS_BIN_COPIES 1
+#endif
+constexpr int BIN_COPIES = ADGS_BIN_COPIES;      // privatised copies of the column counters / cursors (workgroup w of bin_count / bin_scatter uses copy w mod BIN_COPIES)
 constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
 // overflow: the totals exceed the capacity the frame's launches were enqueued against; overflow_count: such frames since the mailbox exists
-struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest cell's chunks
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest column's chunks
 	uint32_t cap_cells; unsigned long long cap_fine; };      // the capacity THIS frame was enqueued against, as its kernels saw it (a graph replay reports its capture's)
-struct CellScanArgs {
-	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
-	uint32_t* cell_start;               // [ncells + 1]
-	uint2* cell_ranges; int ncells;
-	uint4* chunks; uint32_t max_chunks; // sort chunks: (start, end, cell start, cell end) in list positions
-	uint32_t* d_counts;                 // [0] pairs, [1] chunks, [2] overflow flag (more chunks than the table holds)
+int launch_bin_prepare(const FramePrologue& p, hipStream_t stream);
+// A chunk of a column's range: what one chunk_sort workgroup sorts.  (col_start, col_end): the whole column -- the chunk IS the column
+// ("single": its sorted order is final) or one of several that chunk_merge ranks against each other; (cell_start, cell_n, cell): the cell
+// the column belongs to -- an entry whose final rank inside its cell is a 32-quantile position leaves its depth key as next frame's bound.
+struct BinChunk { uint32_t start, end, col_start, col_end, cell_start, cell_n, cell, pad; };
+static_assert(sizeof(BinChunk) == 32, "BinChunk is stored as two 16-byte words");
+// the (cell, Gaussian) pairs of a frame, as the counting and the scattering pass enumerate them (identically)
+struct BinPairs {
+	int P; const uint4* dupinfo;        // (shrunk tile rectangle min, max, depth bits, -) per Gaussian (preprocess_fwd)
+	int cell_tiles, cgx, ncells, lg;    // 2^lg depth slabs per cell: column = (cell << lg) + slab
+	int cstride;                        // words between two privatised copies of the column counters / cursors (>= columns, a multiple of 64)
+	const uint32_t* bounds;             // this frame's snapshot of the slab bounds [ncells][SLAB_ROW] (unused when lg == 0)
+};
+// slab_words[P]: the depth slabs (5 bits each) of every Gaussian's first six cells, bin_count -> bin_scatter
+int launch_bin_count(const BinPairs& b, uint32_t* col_count, uint32_t* slab_words, hipStream_t stream);
+int launch_bin_scatter(const BinPairs& b, uint32_t* col_cursor, uint32_t* slab_words, uint4* rec_u, uint32_t cap, uint32_t* pool_cursor, hipStream_t stream);
+struct ColScanArgs {
+	const uint32_t* col_count;          // [BIN_COPIES][cstride] pairs per column (bin_count)
+	uint32_t* col_cursor;               // [BIN_COPIES][cstride] <- column start + the pairs of the copies before: bin_scatter reserves its slices from them
+	uint2* cell_ranges; int ncells, lg, cstride;
+	BinChunk* chunks; uint32_t max_chunks;
+	uint32_t* d_counts;                 // [0] pairs, [1] chunks, [2] overflow flag (more chunks than the table holds), [3] the totals exceed the capacity
 	const unsigned long long* fine_total;
 	Mailbox* box; uint32_t seq;
 	uint32_t cap_cells; unsigned long long cap_fine;      // capacities of the launches that follow (d_counts[3] = the totals exceed them)
 };
-int launch_cell_scan(const CellScanArgs& a, hipStream_t stream);
-int launch_cell_colscan(uint32_t* counts, int nblocks, int ncells, uint32_t* cell_count, hipStream_t stream);
-int launch_cell_scatter(int P, const uint4* dupinfo, const uint32_t* cell_start, const uint32_t* counts, uint4* rec_u, uint32_t cap,
-	int cell_tiles, int cgx, int ncells, uint32_t* pool_cursor, hipStream_t stream);
+int launch_col_scan(const ColScanArgs& a, hipStream_t stream);
 struct ChunkSortArgs {
-	const uint4* chunks; const uint32_t* d_counts;
-	const uint4* rec_u;                 // unsorted (cell-grouped) records (depth bits, id, mask, -)
-	uint2* key_s; uint32_t* mask_s;     // chunk-sorted (depth, id) keys + masks of the multi-chunk cells
+	const BinChunk* chunks; const uint32_t* d_counts;
+	const uint4* rec_u;                 // unsorted (column-grouped) records (depth bits, id, mask, -)
+	uint2* key_s; uint32_t* mask_s;     // chunk-sorted (depth, id) keys + masks of the multi-chunk columns
 	uint2* ent_f;                       // final (id, mask) entries
 	uint32_t cap;
+	uint32_t* flags;                    // [MAX_CHUNKS] chunk_bsort -> chunk_sort: 1 = the chunk takes the radix sort (nullptr: the radix sort sorts every chunk, ADGS_CHUNK_SORT=radix)
+	uint32_t* bounds_out;               // the shared table of slab bounds [MAX_CELLS][SLAB_ROW]: this frame's 32-quantiles per cell, for the next frame (nullptr: none)
 };
 int launch_chunk_sort(const ChunkSortArgs& a, uint32_t grid, hipStream_t stream);
 int launch_chunk_merge(const ChunkSortArgs& a, uint32_t grid, hipStream_t stream);
@@ -198,8 +219,8 @@ int launch_lin_param_grad2(int count_a, const float* g_a, float* out_a, int coun
 	float eps = 0.f);
 // lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t), formed in double and rounded once (optim.hip)
 void adam_bias_terms(float lr, int step, float beta1, float beta2, float* step_size, float* inv_bc2_sqrt);
-// sh0[N,3] = dc + f_shs(t); optionally zeroes n_zero 32-bit words for the next kernel's counters
-int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, uint32_t* zero_words = nullptr, int n_zero = 0, int ostride = 3);      // ostride: floats per Gaussian in `out`
+// sh0[N,3] = dc + f_shs(t); optionally runs the frame's prologue (counters zeroed, slab bounds snapshot) for the binning kernels behind it
+int launch_sh0(int N, const ShSource& s, float* out, hipStream_t stream, const FramePrologue* prologue = nullptr, int ostride = 3);      // ostride: floats per Gaussian in `out`
 inline bool has_lin_host(const adgs_func_eval& f) { return (f.n_terms[0] + f.n_terms[1] + f.n_terms[2]) > 0 && f.n_params > 0; }
 
 int knn_run(int P, const float* points, float* meanDists, char* workspace, hipStream_t stream);

@@ -848,60 +848,42 @@ int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }
-// Longest-list-first order of the tiles for the backward (the forward recorded how many entries every tile consumed): one
-// workgroup, counting sort into 256 buckets of 8 entries.  9600 one-wave workgroups over 4096 wave slots are ~2.3 rounds;
-// without this the last round ends with whatever long tiles happen to sit at the end of the grid (backward 506 -> 466 us at C3).
-// Since round 5 the FORWARD launches it, right behind its blend kernel: the order serves this frame's backward (img.tile_order) and, as a copy in
-// the camera's hint buffer, the next forward of the same camera.  (Ordering the forward by the length of the tile's cell list was measured and does not help.)
+// Longest-list-first order of the tiles for the backward (the forward recorded how many entries every tile consumed).  9600 one-wave
+// workgroups over 4096 wave slots are ~2.3 rounds; without this the last round ends with whatever long tiles happen to sit at the end of
+// the grid (backward 506 -> 466 us at C3).  Since round 5 the FORWARD launches it, right behind its blend kernel: the order serves this
+// frame's backward (img.tile_order) and, as a copy in the camera's hint buffer, the next forward of the same camera.  (Ordering the forward by
+// the length of the tile's cell list was measured and does not help.)
+// Round 6: K workgroups instead of ONE (a 1024-bucket counting sort whose LDS atomics serialised on the hot buckets: 11.4 us alone on the
+// critical path between the two blend kernels).  Workgroup w owns the tiles t = w (mod K) -- a 1-in-K sample of the whole image, so all
+// slices have the same length distribution --, ranks them among each other by counting (<= 256 broadcast LDS reads per tile, no atomics),
+// and the slices are interleaved: slot = rank * K + w.  The result is the exact descending order within every slice and within a few
+// positions of it globally, which is all a dispatch order needs.
 namespace {
-__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy,
+constexpr int TO_THREADS = 256;
+__global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(int T, int K, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy,
 	const float* __restrict__ view) {
-	// 1024 buckets of one entry: the LDS atomics of the histogram and of the scatter are what this kernel costs, and they
-	// serialise per address -- with coarse buckets most tiles of a frame fall into a handful of them
-	constexpr int NB = 1024, PER = 16;            // tiles per thread kept in registers: one round of loads (T <= 16384), else the generic loops
-	__shared__ uint32_t hist[NB];
-	__shared__ uint32_t start[NB];
-	const int tid = threadIdx.x;
-	hist[tid] = 0;
-	if (order_copy && view && tid < 16) reinterpret_cast<float*>(order_copy + T)[tid] = view[tid];      // the pose this hint belongs to
+	__shared__ uint32_t s_key[TO_THREADS];
+	const int w = blockIdx.x, tid = threadIdx.x;
+	if (w == 0 && order_copy && view && tid < 16) reinterpret_cast<float*>(order_copy + T)[tid] = view[tid];      // the pose this hint belongs to
+	const int n = (T - w + K - 1) / K;             // tiles of this slice: w, w + K, ...  (n <= TO_THREADS: launch_tile_order)
+	const int t = w + tid * K;
+	const uint32_t mine = tid < n ? consumed[t] : 0u;
+	s_key[tid] = mine;
 	__syncthreads();
-	uint32_t b[PER];
-	const bool fits = T <= 1024 * PER;
-	if (fits) {
-#pragma unroll
-		for (int k = 0; k < PER; k++) b[k] = consumed[min(tid + k * 1024, T - 1)];      // unconditional, clamped: all loads in flight (a load under `t < T ?` waits at the end of its own exec-masked block)
-#pragma unroll
-		for (int k = 0; k < PER; k++) b[k] = tid + k * 1024 < T ? (uint32_t)(NB - 1) - min(b[k], (uint32_t)(NB - 1)) : 0xffffffffu;
-#pragma unroll
-		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) atomicAdd(&hist[b[k]], 1u);
-	} else {
-		for (int t = tid; t < T; t += 1024) atomicAdd(&hist[(uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1))], 1u);
-	}
-	__syncthreads();
-	if (tid < WAVE) {                                // exclusive scan of the buckets by one wave (16 buckets per lane)
-		uint32_t s16 = 0;
-		for (int q = 0; q < NB / WAVE; q++) s16 += hist[(NB / WAVE) * tid + q];
-		uint32_t incl = s16;
-#pragma unroll
-		for (int off = 1; off < WAVE; off <<= 1) { const uint32_t o = __shfl_up(incl, off, WAVE); if (tid >= off) incl += o; }
-		uint32_t run = incl - s16;
-		for (int q = 0; q < NB / WAVE; q++) { start[(NB / WAVE) * tid + q] = run; run += hist[(NB / WAVE) * tid + q]; }
-	}
-	__syncthreads();
-	if (fits) {
-#pragma unroll
-		for (int k = 0; k < PER; k++) if (b[k] != 0xffffffffu) { const uint32_t at = atomicAdd(&start[b[k]], 1u); order[at] = (uint32_t)(tid + k * 1024); if (order_copy) order_copy[at] = (uint32_t)(tid + k * 1024); }
-	} else {
-		for (int t = tid; t < T; t += 1024) {
-			const uint32_t at = atomicAdd(&start[(uint32_t)(NB - 1) - min(consumed[t], (uint32_t)(NB - 1))], 1u);
-			order[at] = (uint32_t)t; if (order_copy) order_copy[at] = (uint32_t)t;
-		}
-	}
+	if (tid >= n) return;
+	uint32_t rank = 0;
+#pragma unroll 8
+	for (int j = 0; j < n; j++) { const uint32_t o = s_key[j]; rank += (o > mine || (o == mine && j < tid)) ? 1u : 0u; }
+	// slot = rank * K + w < T: slices differ in length by at most one, and the longer ones are the first T mod K
+	const uint32_t at = rank * (uint32_t)K + (uint32_t)w;
+	order[at] = (uint32_t)t;
+	if (order_copy) order_copy[at] = (uint32_t)t;
 }
 } // namespace
 int launch_tile_order(int ntiles, const uint32_t* tile_consumed, uint32_t* order, hipStream_t stream, uint32_t* order_copy, const float* view) {
 	if (ntiles <= 0) return 0;
-	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_consumed, order, order_copy, view);
+	const int K = (ntiles + TO_THREADS - 1) / TO_THREADS;
+	hipLaunchKernelGGL(tile_order_kernel, dim3(K), dim3(TO_THREADS), 0, stream, ntiles, K, tile_consumed, order, order_copy, view);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -355,6 +355,27 @@ def frame_work_figures(frame, settings, use_fs, device, with_ref=True, full=Fals
     return chunks, r_ref, published, scanned
 
 
+HBM_FILL_GBS = 6900.0       # the fastest stream this box class delivers (write-only fill, profiles/r05/hbm_rates.txt): nothing can beat it
+
+
+def dominant_roofline(stage, stage_bytes_per_frame, mean_ms_per_bracket, brackets, frames):
+    """The `roofline` object of the bench line for `stage`: its algorithmic bytes per frame over its HIP-event time per FRAME.
+    `brackets` event brackets were recorded over `frames` rendered frames (a stage with two launch groups per frame has two per frame).
+    A figure above the box's fill rate is an instrument error, never a result: it is flagged and the fraction withheld."""
+    per_frame = max(brackets, 1) / max(frames, 1)
+    ms = mean_ms_per_bracket * per_frame
+    achieved = stage_bytes_per_frame / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "alg_bytes_per_launch": int(stage_bytes_per_frame), "avg_launch_ms": round(ms, 4),
+            "launch_groups_per_frame": round(per_frame, 3), "launches_timed": int(brackets)}
+    if achieved > HBM_FILL_GBS:
+        roof["instrument_error"] = "achieved %.0f GB/s exceeds the box's %.0f GB/s fill rate: bytes and time do not belong together" % (achieved, HBM_FILL_GBS)
+        roof["frac"] = None
+        print("bench: roofline instrument error for %s: %s" % (stage, roof["instrument_error"]), file=sys.stderr)
+    return roof
+
+
 def library_stamp():
     """First 16 hex digits of the SHA-256 of the loaded libadgs_hip.so: the committed counter files carry the stamp of the build
     they were collected on (tools/pmc_traffic.py, tools/pmc_blend.py), and are flagged stale when it differs."""
@@ -1159,16 +1180,19 @@ def main():
             if stages_all is None:
                 stages_all = stages
                 dom = max(stages, key=lambda k: stages[k][0] * max(stages[k][1], 1))
-            dom_ms = stages[dom][0]                   # HIP events on the launch stream, over the timed region
+            # HIP events on the launch stream, over the timed region.  A stage can hold several event brackets per frame (preprocess_fwd: the
+            # sh0 kernel and the preprocess kernel; render_fwd: the blend and the tile order) while `ab[dom]` is the stage's bytes per FRAME: the
+            # time that belongs to them is the stage's time per frame (mean per bracket x brackets per frame), not the mean per bracket
+            # (`bench_c5_1gpu.json` printed 7.1 TB/s = 0.89 for a two-launch stage).
+            roof_src = stages
             roof_timing = "HIP events around the kernel in every step of the timed region"
+            frames_timed = args.steps * max(len(frames), 1)
             if use_graph:                             # no event can be recorded inside a graph replay
-                dom_ms = stages_all[dom][0]
+                roof_src, frames_timed = stages_all, n_prof * max(len(frames), 1)
                 roof_timing = "HIP events around the kernel in the eager warm-up steps (the timed region replays HIP graphs)"
-            achieved = ab.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "alg_bytes_per_launch": int(ab.get(dom, 0)), "avg_launch_ms": round(dom_ms, 4),
-                    "launches_timed": int((stages_all if use_graph else stages)[dom][1]), "timing": roof_timing}
+            roof = dominant_roofline(dom, ab.get(dom, 0), roof_src[dom][0], roof_src[dom][1], frames_timed)
+            roof["timing"] = roof_timing
+            dom_ms = roof["avg_launch_ms"]
             roof.update(committed_pmc(dom, args.config, use_fs and v2))
             if world == 1 and not force_coll and not iteration_mode and not use_graph and args.config == "C3" and use_fs and v2:
                 live = measure_traffic_in_run(dom, args.config)

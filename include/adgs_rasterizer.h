@@ -237,8 +237,11 @@ typedef struct adgs_frame_status {
 	int64_t overflow_count;        /* frames that did not fit, since the mailbox exists */
 	int64_t eager_reruns;          /* eager forwards of this thread on this device that were enqueued twice */
 	int32_t overflow;              /* 1: this frame did not fit its capacity */
-	int32_t reserved;
+	int32_t order_hint;            /* 1: the forward was handed the longest-first tile order an earlier forward of the same camera (same matrix
+	                                  addresses, image shape) on the same stream left behind; 0: bottom-up (a camera's first render) */
 	int64_t unrepaired_overflow_count;      /* overflow_count minus the eager frames this library re-enqueued itself: overflows of graph replays */
+	int64_t order_hint_lookups;    /* forwards of this thread on this device that looked for a tile-order hint ... */
+	int64_t order_hint_hits;       /* ... and found one written by an earlier forward: the hit rate tells whether the caller's cameras keep their addresses */
 } adgs_frame_status;
 int adgs_get_frame_status(adgs_frame_status* out);
 

@@ -6,7 +6,8 @@ maximum alone lets every element far below the maximum pass with O(1) relative e
   1. element-wise: |got - ref| <= tol |ref| + tol max|ref| for EVERY element;
   2. relative L2: ||got - ref||_2 <= rel_l2 ||ref||_2 -- the whole tensor, tail included, weighted by energy;
   3. rows ([P, ...] tensors): the per-row error relative to the row's own norm, with a floor of `tol` x the RMS row norm (NOT the
-     maximum), may exceed 1e-3 on at most 1 % and 1e-2 on at most 0.1 % of the non-zero rows (`row_tol`).
+     maximum), may exceed 1e-3 on at most 1 % and 1e-2 on at most 0.1 % of the non-zero rows (`ROW_TOL`; the strict gradient pass:
+     0.45 % and 0.03 %, `STRICT_ROW_TOL` = twice the measured tails).
 
 Gate flips.  `alpha >= 1/255`, `power <= 0` and `T (1 - alpha) >= 1e-4` (forward.cu:345-361) are hard thresholds on computed values:
 two correct float32 evaluations of a frame take a gate differently where the gated value lies within their rounding error of the
@@ -106,7 +107,8 @@ def error_stats(got, ref, tol=TOL, slack=None):
             rms = float(np.sqrt((r[nz] ** 2).mean()))
             rel = e[nz] / (r[nz] + tol * rms)
             st.update(row_rms=rms, row_rel_p50=float(np.median(rel)), row_rel_p99=float(np.percentile(rel, 99)),
-                      row_rel_p9999=float(np.percentile(rel, 99.99)), row_rel_max=float(rel.max()), rows=int(nz.sum()))
+                      row_rel_p9999=float(np.percentile(rel, 99.99)), row_rel_max=float(rel.max()), rows=int(nz.sum()),
+                      row_frac_gt_1e3=float((rel > 1e-3).mean()), row_frac_gt_1e2=float((rel > 1e-2).mean()))
             st["_row_rel"] = rel
             st["_row_nz"] = nz
     return st
@@ -132,7 +134,16 @@ def mask_upstream(grads, pixel_mask):
     return out
 
 
-def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=1e-4, row_tol=((1e-3, 1e-2), (1e-2, 1e-3)), explained=None, slack=None,
+# Row rule (constraint 3): (relative row error, fraction of the non-zero rows that may exceed it).  The strict pass is held to 2 x the
+# measured tails of C2 / C3 (profiles/r06/parity_stats_strict.txt: the worst tensors -- the opacity and semantic gradients of C3 -- have
+# 0.216 % / 0.180 % of their rows above 1e-3 and 0.013 % / 0.014 % above 1e-2; p99 1 - 2.5e-4) -- until round 5 it shared the loose rule of the
+# masked comparisons, under which a regression that degraded 0.5 % of the rows to 5e-3 passed (its proposed 0.2 % / 0.02 % sit
+# BELOW the measured tails of those two tensors).
+ROW_TOL = ((1e-3, 1e-2), (1e-2, 1e-3))
+STRICT_ROW_TOL = ((1e-3, 4.5e-3), (1e-2, 3e-4))
+
+
+def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=1e-4, row_tol=ROW_TOL, explained=None, slack=None,
                  strict=False):
     """`slack` ([H, W] for images): per-element addition to the tolerance in units of the tensor's scale (explained_masks()["slack"]: the
     conditioning of the pixel's alphas).  `strict`: the gradient pass with the upstream gradients zeroed at the flagged pixels -- no
@@ -154,7 +165,7 @@ def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l
         if rel_l2 is not None and st["scale"] > 1e-30:
             assert st["rel_l2"] <= rel_l2, "%s [strict]: relative L2 error %.3g > %.3g" % (name, st["rel_l2"], rel_l2)
         if row_tol is not None and "_row_rel" in st:
-            for rt, rf in row_tol:
+            for rt, rf in (STRICT_ROW_TOL if row_tol is ROW_TOL else row_tol):
                 frac = float((st["_row_rel"] > rt).mean())
                 assert frac <= max(rf, 2.0 / st["rows"]), "%s [strict]: %.3g of the rows are off by more than %g of their own norm (p99 %.3g, max %.3g)" % (
                     name, frac, rt, st["row_rel_p99"], st["row_rel_max"])
@@ -216,5 +227,5 @@ def assert_rows_conditioned(name, got, f32_draws, exact, tol=TOL, factor=8.0, al
 
 
 def fmt_stats(name, st):
-    keys = ("scale", "max_err", "frac_bad", "rel_l2", "row_rel_p50", "row_rel_p99", "row_rel_p9999", "row_rel_max")
+    keys = ("scale", "max_err", "frac_bad", "rel_l2", "row_rel_p50", "row_rel_p99", "row_rel_p9999", "row_rel_max", "row_frac_gt_1e3", "row_frac_gt_1e2")
     return "%-28s " % name + " ".join("%s=%.3g" % (k, st[k]) for k in keys if k in st)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Per-kernel times (rocprofv3 kernel trace) of the binning kernels for several library builds: gpurun -- 'bash tools/gpu/r6_kab.sh default noslab ...'
+R=$GRAFT_REPO_ROOT; L=$R/ad-gs_amd/lib
+for v in "$@"; do
+  lib=$L/libadgs_hip_$v.so; [ $v = default ] && lib=$L/libadgs_hip.so
+  export ADGS_LIB=$lib
+  bash $R/tools/gpu/r6_kstats.sh kab_$v ${CFG:+--config $CFG} | grep -E "bin_pairs|col_scan|chunk_|tile_order" | sed "s/^/$v: /" | cut -c1-150
+done
