@@ -101,6 +101,7 @@ SIGNATURES = {
     "adgs_test_abi_sizeof": (ctypes.c_size_t, [c_i]),
     "adgs_test_set_capacity_hints": (None, [ctypes.c_longlong, ctypes.c_longlong]),
     "adgs_test_env_reads": (ctypes.c_ulonglong, []),
+    "adgs_test_scramble_slab_bounds": (c_i, [ctypes.c_uint]),
     "adgs_test_scan_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
     "adgs_test_exclusive_scan_u32": (c_i, [c_p, c_p, ctypes.c_size_t, c_p, c_p]),
     "adgs_test_sort_temp_bytes": (ctypes.c_size_t, [ctypes.c_size_t]),
@@ -119,7 +120,7 @@ class FrameStatus(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_int64), ("fine_pairs", ctypes.c_int64), ("capacity_pairs", ctypes.c_int64),
                 ("capacity_fine_pairs", ctypes.c_int64), ("overflow_count", ctypes.c_int64), ("eager_reruns", ctypes.c_int64),
                 ("overflow", ctypes.c_int32), ("order_hint", ctypes.c_int32), ("unrepaired_overflow_count", ctypes.c_int64),
-                ("order_hint_lookups", ctypes.c_int64), ("order_hint_hits", ctypes.c_int64)]
+                ("order_hint_lookups", ctypes.c_int64), ("order_hint_hits", ctypes.c_int64), ("fullest_slab_units", ctypes.c_int64)]
 
 
 def lib():

@@ -107,20 +107,18 @@ struct GeomStateV2 {
 	Splat* splats; uint8_t* clamped; uint32_t* cells_touched; uint32_t* offsets; uint32_t* fine_touched; uint4* dupinfo;
 	float* gacc; float* sh0; char* scan_temp; unsigned long long* fine_total;
 	float* ddir;      // [9][P]: d colour / d view direction of the raw-SH path (PreprocessArgs.ddir)
-	// bucket binning (binning.hip): ONE block of counters the frame's prologue zeroes -- the fine-tile total slots, the device-side
-	// (pairs, chunks, overflow) words, the pair counts per (cell, depth slab) column -- then the column cursors, the chunk table and the
-	// frame's snapshot of the slab bounds
-	uint32_t* counters; uint32_t* col_cursor; BinChunk* chunks; uint32_t* chunk_flags; uint32_t* bounds;      // bounds[ncells][SLAB_ROW]
-	static constexpr size_t COUNTER_HEAD = 256, COUNTER_WORDS = COUNTER_HEAD + (size_t)BIN_COPIES * MAX_COLS;      // (the head: 2 * SCAN_AUX_SLOTS + 8 words used; 256 keep the copies 16-byte aligned)
-	unsigned long long* bucket_fine_total() const { return reinterpret_cast<unsigned long long*>(counters); }
-	uint32_t* d_counts() const { return counters + 2 * SCAN_AUX_SLOTS; }
-	uint32_t* col_count() const { return counters + COUNTER_HEAD; }
+	// bucket binning (binning.hip): ONE block of counters the frame's prologue zeroes -- pair counts per cell, the fine-tile total slots,
+	// the device-side (pairs, overflow, ...) words -- then the cell starts, the frame's snapshot of the slab bounds and the counts matrix
+	uint32_t* counters; uint32_t* cell_start; uint2* cell_work; uint32_t* bounds; uint32_t* counts;      // counts[ceil(P / 256)][ncells]: pairs per (preprocess workgroup, cell); bounds[ncells][SLAB_ROW]; cell_work[ncells + 1]
+	static constexpr size_t COUNTER_WORDS = MAX_CELLS + 2 * SCAN_AUX_SLOTS + 8;
+	uint32_t* cell_count() const { return counters; }
+	unsigned long long* bucket_fine_total() const { return reinterpret_cast<unsigned long long*>(counters + MAX_CELLS); }
+	uint32_t* d_counts() const { return counters + MAX_CELLS + 2 * SCAN_AUX_SLOTS; }
 	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes, size_t ncells = 0) {
 		Carver c(chunk); GeomStateV2 g;
 		g.counters = c.take<uint32_t>(COUNTER_WORDS);
-		g.col_cursor = c.take<uint32_t>((size_t)BIN_COPIES * MAX_COLS);
-		g.chunks = c.take<BinChunk>(MAX_CHUNKS);
-		g.chunk_flags = c.take<uint32_t>(MAX_CHUNKS);
+		g.cell_start = c.take<uint32_t>(MAX_CELLS + 1);
+		g.cell_work = c.take<uint2>(MAX_CELLS + 1);
 		g.splats = c.take<Splat>(P);
 		g.gacc = c.take<float>(P * GACC_STRIDE);
 		g.dupinfo = c.take<uint4>(P);
@@ -132,7 +130,9 @@ struct GeomStateV2 {
 		g.fine_total = c.take<unsigned long long>(SCAN_AUX_SLOTS);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
 		g.ddir = c.take<float>(P * 9);
-		g.bounds = c.take<uint32_t>(std::min<size_t>(ncells, (size_t)MAX_CELLS) * SLAB_ROW);      // last: the backward carves without it
+		const size_t nc = std::min<size_t>(ncells, (size_t)MAX_CELLS + 1);      // last: the backward carves without them
+		g.bounds = c.take<uint32_t>(nc * SLAB_ROW);
+		g.counts = c.take<uint32_t>(((P + 255) / 256) * nc);
 		if (bytes) *bytes = c.size();
 		return g;
 	}
@@ -156,20 +156,21 @@ struct ImgStateV2 {
 struct BinStateV2 {
 	uint32_t* pool_cursor; uint32_t* pool;     // first, so that the backward finds them without knowing the sizes
 	uint64_t* keys_unsorted; uint64_t* keys; uint32_t* list_unsorted; uint32_t* list; char* sort_temp;
-	// bucket binning: unsorted (cell-grouped) 16-byte records, chunk-sorted (depth, id) keys + masks, final (id, mask) entries
-	uint4* rec_unsorted; uint2* key_stage; uint32_t* mask_stage; uint2* entries;
+	// bucket binning: unsorted (cell-grouped) records as two arrays -- depth keys; (id, mask) --, final (id, mask) entries
+	uint32_t* rec_key; uint2* rec_im; uint2* entries; uint32_t* slow_list;
+	// slab_sort workgroups a frame of R_cells pairs needs at most: a cell of n pairs has 2^lg <= max(1, 2 n / SLAB_TARGET) slabs
+	static size_t slab_grid(size_t R_cells, size_t ncells) { return std::max<size_t>(2 * R_cells / SLAB_TARGET + ncells + 1, ncells << forced_lg()); }
+	static int forced_lg() { const char* v = getenv("ADGS_SLABS_LG"); return (v && *v) ? std::min(std::max(atoi(v), 0), (int)MAX_SLAB_LG) : 0; }      // test hook: every cell gets 2^lg slabs (read by the FORWARD only)
 	// every tile's own block + blocks drawn from the cursor, each of which may end partly used
 	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + (2 * (size_t)POOL_BLOCK + 1) * ntiles + 1; }
-	// chunks of a frame: every column has full chunks + one partial
-	static size_t max_chunks(size_t R_cells, size_t ncols) { return std::min<size_t>((size_t)MAX_CHUNKS, ncols + R_cells / GS_NMAX + 1); }
-	static BinStateV2 carve_buckets(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes) {
+	static BinStateV2 carve_buckets(char* chunk, size_t R_cells, size_t R_fine, size_t ntiles, size_t* bytes, size_t ncells = 0) {
 		Carver c(chunk); BinStateV2 b;
 		b.pool_cursor = c.take<uint32_t>(64);
 		b.pool = c.take<uint32_t>(pool_chunks(R_fine, ntiles) * CHUNK_WORDS);
-		b.entries = c.take<uint2>(R_cells);
-		b.rec_unsorted = c.take<uint4>(R_cells);
-		b.key_stage = c.take<uint2>(R_cells);
-		b.mask_stage = c.take<uint32_t>(R_cells);
+		b.entries = c.take<uint2>(R_cells + 1);      // (+ 1: the blend forward's staged reads run one entry past a list, render_v2.hip)
+		b.rec_im = c.take<uint2>(R_cells);
+		b.rec_key = c.take<uint32_t>(R_cells);
+		b.slow_list = c.take<uint32_t>(1 + slab_grid(R_cells, ncells));
 		b.keys = nullptr; b.keys_unsorted = nullptr; b.sort_temp = nullptr; b.list = nullptr; b.list_unsorted = nullptr;
 		if (bytes) *bytes = c.size();
 		return b;
@@ -183,7 +184,7 @@ struct BinStateV2 {
 		b.keys = c.take<uint64_t>(R_cells);
 		b.keys_unsorted = c.take<uint64_t>(R_cells);
 		b.sort_temp = c.take<char>(sort_temp_bytes(R_cells));
-		b.rec_unsorted = nullptr; b.key_stage = nullptr; b.mask_stage = nullptr; b.entries = nullptr;
+		b.rec_key = nullptr; b.rec_im = nullptr; b.entries = nullptr; b.slow_list = nullptr;
 		if (bytes) *bytes = c.size();
 		return b;
 	}
@@ -307,7 +308,9 @@ static MailboxRef* mailbox() {
 // entry: replaying them concurrently on different streams is the caller's race, like replaying one graph twice at once.)
 // The table is bounded (OLDEST entry recycled: no hipFree / hipMalloc in steady state); under capture only existing entries are used.
 struct OrderHints {
-	struct Entry { const void* view; const void* proj; int W, H; size_t tiles; hipStream_t stream; bool captured; uint32_t* buf; unsigned long long used; bool written; };      // written: a tile_order launch has been enqueued into buf
+	struct Entry { const void* view; const void* proj; int W, H; size_t tiles; hipStream_t stream; bool captured; uint32_t* buf; unsigned long long used; bool written; size_t extra; };
+	// buf: [tiles] the order | [16] the pose it was made under | [extra] the camera's own depth-slab bounds (binning.hip), ncells x SLAB_ROW words
+	// written: a frame has been enqueued that fills buf (tile_order; slab_sort before it)
 	std::vector<Entry> entries;
 	unsigned long long clock = 0, lookups = 0, hits = 0;      // hits: forwards that found an entry (adgs_frame_status.order_hint: the last forward did)
 	hipStream_t service = nullptr;                            // a private non-blocking stream: buffer initialisation that is never part of a capture
@@ -319,12 +322,13 @@ struct OrderHints {
 	}
 	// A fresh buffer carries an all-zero pose signature (no view matrix is all zero: the kernel ignores the hint until tile_order has written
 	// one).  Zeroed on the service stream and waited for, so that it is neither captured nor ordered against the caller's stream by luck.
-	bool reset_signature(uint32_t* buf, size_t tiles) {
+	bool reset_signature(uint32_t* buf, size_t tiles, size_t extra) {      // ... and the bounds rows start as "everything in slab 0"
 		if (!service && hipStreamCreateWithFlags(&service, hipStreamNonBlocking) != hipSuccess) { service = nullptr; return false; }
-		return hipMemsetAsync(buf + tiles, 0, 16 * sizeof(uint32_t), service) == hipSuccess && hipStreamSynchronize(service) == hipSuccess;
+		return hipMemsetAsync(buf + tiles, 0, 16 * sizeof(uint32_t), service) == hipSuccess &&
+		       (extra == 0 || hipMemsetAsync(buf + tiles + 16, 0xff, extra * sizeof(uint32_t), service) == hipSuccess) && hipStreamSynchronize(service) == hipSuccess;
 	}
 	// capturing: the caller's stream is being captured into a graph (no synchronisation of it, no recycling of a live entry)
-	Entry* create(const void* view, const void* proj, int W, int H, size_t tiles, hipStream_t stream, bool captured) {
+	Entry* create(const void* view, const void* proj, int W, int H, size_t tiles, hipStream_t stream, bool captured, size_t extra) {
 		Entry* e = nullptr;
 		if (entries.size() >= MAX_ENTRIES) {      // recycle the least recently used entry that no graph holds
 			if (captured) return nullptr;
@@ -332,15 +336,15 @@ struct OrderHints {
 			if (!e) return nullptr;
 			// the old owner's stream may still have launches in flight that read or write the buffer: drain it before the buffer changes hands
 			(void)hipStreamSynchronize(e->stream);
-			if (e->tiles != tiles) { (void)hipFree(e->buf); e->buf = nullptr; e->tiles = 0; e->view = nullptr; if (hipMalloc((void**)&e->buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) { e->buf = nullptr; return nullptr; } }
+			if (e->tiles != tiles || e->extra != extra) { (void)hipFree(e->buf); e->buf = nullptr; e->tiles = 0; e->view = nullptr; if (hipMalloc((void**)&e->buf, (tiles + 16 + extra) * sizeof(uint32_t)) != hipSuccess) { e->buf = nullptr; return nullptr; } }
 		} else {
-			Entry fresh{ nullptr, nullptr, 0, 0, 0, nullptr, false, nullptr, 0, false };
-			if (hipMalloc((void**)&fresh.buf, (tiles + 16) * sizeof(uint32_t)) != hipSuccess) return nullptr;      // the permutation + the 16 floats of the view matrix it was made under
+			Entry fresh{ nullptr, nullptr, 0, 0, 0, nullptr, false, nullptr, 0, false, 0 };
+			if (hipMalloc((void**)&fresh.buf, (tiles + 16 + extra) * sizeof(uint32_t)) != hipSuccess) return nullptr;      // the permutation + the 16 floats of the view matrix it was made under + the bounds
 			entries.push_back(fresh);
 			e = &entries.back();
 		}
-		e->view = view; e->proj = proj; e->W = W; e->H = H; e->tiles = tiles; e->stream = stream; e->captured = captured; e->used = ++clock; e->written = false;
-		if (!reset_signature(e->buf, tiles)) { e->view = nullptr; e->tiles = 0; (void)hipFree(e->buf); e->buf = nullptr; return nullptr; }      // (an unusable slot: find() never matches tiles == 0 / buf == nullptr is never handed out)
+		e->view = view; e->proj = proj; e->W = W; e->H = H; e->tiles = tiles; e->stream = stream; e->captured = captured; e->used = ++clock; e->written = false; e->extra = extra;
+		if (!reset_signature(e->buf, tiles, extra)) { e->view = nullptr; e->tiles = 0; (void)hipFree(e->buf); e->buf = nullptr; return nullptr; }      // (an unusable slot: find() never matches tiles == 0 / buf == nullptr is never handed out)
 		return e;
 	}
 };
@@ -453,6 +457,7 @@ extern "C" int adgs_get_frame_status(adgs_frame_status* out) {
 	out->overflow = (int32_t)mb->host->overflow; out->overflow_count = (int64_t)mb->host->overflow_count;
 	out->eager_reruns = (int64_t)frame_context()->reruns;
 	out->order_hint = frame_context()->last_order_hint;
+	out->fullest_slab_units = (int64_t)mb->host->max_cell_chunks;
 	if (OrderHints* oh = order_hints()) { out->order_hint_lookups = (int64_t)oh->lookups; out->order_hint_hits = (int64_t)oh->hits; }
 	out->unrepaired_overflow_count = (int64_t)mb->host->overflow_count - (int64_t)mb->repaired;
 	return 0;
@@ -536,32 +541,24 @@ static int raster_forward_impl(const ShSource* sh_src,
 		size_t ncells = (size_t)cgx * cgy;
 		// Binning: bucket binning (binning.hip: per-cell lists built as independently sorted depth slabs, inside the CUs) unless the cell grid
 		// has more than MAX_CELLS cells, ADGS_BINNING=sort asks for the device-wide radix sort of (cell | depth) keys, the previous frames
-		// averaged more than ADGS_BUCKET_MAX_CHUNKS (4) chunks of GS_NMAX pairs per COLUMN at the largest slab count (tens of millions of
-		// pairs), or ONE column of the last bucket-binned frame held more than ADGS_BUCKET_MAX_CELL_CHUNKS (16) chunks (a column of k chunks
-		// pays k - 1 rank searches per entry in the merge).  Slabs per cell: the power of two that brings the previous frames' pairs per
-		// column to GS_NMAX / 2 or below (C3: 8 slabs of ~2.7 k, C5: 32 of ~2.1 k), so that a column stays one chunk when a camera's depths
-		// fit the bounds only roughly; ADGS_SLABS_LG overrides.  Until round 5 whole cells were sorted and merged, and C5 (9 chunks per
-		// cell) took the device-wide sort: EXPERIMENTS.md.
+		// held more pairs than the largest slab count can split into sortable pieces (hundreds of millions), or ONE slab of the last
+		// bucket-binned frame held more than ADGS_BUCKET_MAX_CELL_CHUNKS (16) x GS_NMAX entries (such a slab is bisected and its cell streamed
+		// again once per half: a cliff the average does not show; the figure decays, so the bucket path is tried again -- with the bounds the
+		// sorted frames have taught it in the meantime).  Slabs per cell: decided on the device from the cell's own pair count (cell_scan).
+		// Until round 5 whole cells were cut into position chunks, sorted and merged, and C5 (9 chunks per cell) took the device-wide sort:
+		// EXPERIMENTS.md.
 		const char* binning_env = env_str("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
-		const size_t max_cols = std::min<size_t>(ncells << MAX_SLAB_LG, (size_t)MAX_COLS);
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
-			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * max_cols &&
+			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * (ncells << MAX_SLAB_LG) &&
 			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));
-		int slab_lg = 0;
-		if (buckets) {
-			const size_t per_cell = fc->hint_cells / std::max<size_t>(ncells, 1);
-			while (slab_lg < MAX_SLAB_LG && (per_cell >> slab_lg) > (size_t)GS_NMAX / 2 && (ncells << (slab_lg + 1)) <= (size_t)MAX_COLS) slab_lg++;
-			const int lg_env = env_int("ADGS_SLABS_LG", -1);
-			if (lg_env >= 0) { slab_lg = std::min(lg_env, MAX_SLAB_LG); while (slab_lg > 0 && (ncells << slab_lg) > (size_t)MAX_COLS) slab_lg--; }
-		}
 		if (!buckets && !v2_keys_fit(gx, gy, cell_tiles)) {
 			cell_tiles = v2_cell_tiles(gx, gy, true);
 			cgx = (gx + cell_tiles - 1) / cell_tiles; cgy = (gy + cell_tiles - 1) / cell_tiles; ncells = (size_t)cgx * cgy;
 		}
 		const bool sort_fallback_fits = v2_keys_fit(gx, gy, cell_tiles);      // may this frame still fall back to the sort (chunk table full)?
 		size_t gb = 0, ib = 0;
-		const size_t count_cells = buckets ? ncells : 0;      // the snapshot of the slab bounds [ncells][SLAB_ROW] exists for bucket binning only
+		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] and the snapshot of the slab bounds exist for bucket binning only
 		GeomStateV2::carve(nullptr, P, &gb, count_cells);
 		char* gch = geometryBuffer(geometryUser, gb);
 		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
@@ -599,7 +596,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 					// unsafe" calls that a global-mode capture (torch.cuda.graph's default) forbids unless this thread switches to relaxed mode
 					hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
 					if (cap0) (void)hipThreadExchangeStreamCaptureMode(&mode);
-					hint = oh->create(viewmatrix, projmatrix, width, height, wtiles, stream, cap0);
+					hint = oh->create(viewmatrix, projmatrix, width, height, wtiles, stream, cap0, std::min<size_t>(ncells, (size_t)MAX_CELLS) * SLAB_ROW);
 					if (cap0) (void)hipThreadExchangeStreamCaptureMode(&mode);
 					(void)hipGetLastError();      // a failed allocation costs the hint, not the frame
 				}
@@ -622,11 +619,11 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.v2 = 1; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
 		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
-		pa.bucket = 0;
+		pa.bucket_count = nullptr;
 		pa.cfg_word = img.header; pa.cfg_value = frame_word;
 		pa.ddir = (sh_src && M == 16) ? geom.ddir : nullptr;      // raw-SH path: the backward will not read the `rest` rows a second time
-		// bucket binning accumulates the fine-tile total, a few device words and the pair counts per column, and bins by a snapshot of the
-		// thread's slab bounds: zeroed / copied by the sh0 kernel on the raw-SH path (no launch of its own), by bin_prepare otherwise
+		// bucket binning accumulates the fine-tile total and a few device words, and splits its cells by a snapshot of slab bounds (the
+		// camera's own, else the thread's latest): zeroed / copied by the sh0 kernel on the raw-SH path (no launch of its own), by bin_prepare otherwise
 		FramePrologue pro{ nullptr, 0, nullptr, nullptr, 0 };
 		if (buckets) {
 			if (!fc->slab_bounds) {
@@ -642,11 +639,14 @@ static int raster_forward_impl(const ShSource* sh_src,
 				if (csb == hipStreamCaptureStatusActive) (void)hipThreadExchangeStreamCaptureMode(&mode);
 				if (!ok) { if (fc->slab_bounds) (void)hipFree(fc->slab_bounds); fc->slab_bounds = nullptr; (void)hipGetLastError(); }
 			}
-			if (!fc->slab_bounds) slab_lg = 0;      // no table: one slab per cell (merge-heavy, correct)
-			pro.zero = geom.counters; pro.n_zero = (int)(GeomStateV2::COUNTER_HEAD + (size_t)BIN_COPIES * align_up(ncells << slab_lg, 64));
-			if (slab_lg > 0) { pro.copy_dst = geom.bounds; pro.copy_src = fc->slab_bounds; pro.n_copy = (int)(ncells * SLAB_ROW); }
+			pro.zero = reinterpret_cast<uint32_t*>(geom.bucket_fine_total()); pro.n_zero = 2 * SCAN_AUX_SLOTS + 8;
+			if (fc->slab_bounds) {
+				// the camera's own bounds (its previous render left them in its hint entry) fit best; a camera's first render takes the thread's latest
+				const bool own = hint && hint->written && hint->extra >= ncells * SLAB_ROW;
+				pro.copy_dst = geom.bounds; pro.copy_src = own ? hint->buf + wtiles + 16 : fc->slab_bounds; pro.n_copy = (int)(ncells * SLAB_ROW);
+			}
 			if (!sh_src && launch_bin_prepare(pro, stream) != 0) return -1;
-			pa.bucket = 1; pa.fine_total = geom.bucket_fine_total();
+			pa.bucket_count = geom.counts; pa.fine_total = geom.bucket_fine_total();
 		}
 		if (sh_src) { pa.sh_src = *sh_src; StageTimer t(ST_PREPROCESS, stream); if (launch_sh0(P, *sh_src, geom.sh0, stream, buckets ? &pro : nullptr) != 0) return -1; }
 		if (const int evict_mb = env_int("ADGS_DBG_EVICT_MB", 0)) {
@@ -681,18 +681,18 @@ static int raster_forward_impl(const ShSource* sh_src,
 		const size_t cap_fine = std::max<size_t>(fc->hint_fine, (size_t)8 * P + 4096);
 		mb->cap_cells = cap_cells; mb->cap_fine = cap_fine;
 		uint32_t* overflow_flag = geom.d_counts() + 3;         // written by cell_scan / publish_counts in every frame
-		const size_t ncols = ncells << slab_lg;
-		BinPairs bp;
-		bp.P = P; bp.dupinfo = geom.dupinfo; bp.cell_tiles = cell_tiles; bp.cgx = cgx; bp.ncells = (int)ncells; bp.lg = slab_lg; bp.bounds = geom.bounds; bp.cstride = (int)align_up(ncols, 64);
-		ColScanArgs sa;
-		sa.col_count = geom.col_count(); sa.col_cursor = geom.col_cursor; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells; sa.lg = slab_lg; sa.cstride = bp.cstride;
-		sa.chunks = geom.chunks; sa.max_chunks = buckets ? (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))) : 0u; sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
-		sa.fine_total = geom.bucket_fine_total(); sa.box = mb->dev; sa.seq = seq;
+		CellScanArgs sa;
+		sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
+		sa.max_chunks = (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))); sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
+		sa.fine_total = geom.bucket_fine_total(); sa.cell_work = geom.cell_work; sa.force_lg = buckets ? env_int("ADGS_SLABS_LG", -1) : -1;
 		sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
+		// who publishes the frame's totals to the host mailbox: slab_sort's last workgroup (it also knows the fullest slab) -- or, when the host
+		// waits for the totals BEFORE it enqueues the binning (ADGS_NO_SPECULATION), cell_scan
+		sa.box = speculate ? nullptr : mb->dev; sa.seq = seq;
 		if (buckets) {
 			StageTimer t(ST_SCAN, stream);
-			if (launch_bin_count(bp, geom.col_count(), geom.offsets, stream) != 0) return -1;      // geom.offsets: free in a bucket-binned frame (the sort path's pair offsets)
-			if (launch_col_scan(sa, stream) != 0) return -1;
+			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
+			if (launch_cell_scan(sa, stream) != 0) return -1;
 		} else {
 			{
 				StageTimer t(ST_SCAN, stream);
@@ -708,25 +708,26 @@ static int raster_forward_impl(const ShSource* sh_src,
 		BinStateV2 bin;
 		// rectangle-coverage masks in the key bits above (cell | depth): one bit per tile row and per tile column of a cell
 		const int mask_shift = 32 + bit;          // 2 * cell_tiles + bit <= 32: v2_cell_tiles
+		uint32_t seq_rerun = 0;
+		bool exact = false;      // the second enqueue of a frame (exact sizes: nothing is compared against a capacity any more)
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
 			if (buckets) {
-				BinStateV2::carve_buckets(nullptr, cells, fine * sub, wtiles, &bb);
+				BinStateV2::carve_buckets(nullptr, cells, fine * sub, wtiles, &bb, ncells);
 				char* bch = binningBuffer(binningUser, bb);
 				if (!bch) { set_error("binning allocator returned NULL"); return -1; }
-				bin = BinStateV2::carve_buckets(bch, cells, fine * sub, wtiles, nullptr);
+				bin = BinStateV2::carve_buckets(bch, cells, fine * sub, wtiles, nullptr, ncells);
 				if (cells == 0) { ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream)); return 0; }     // cell_ranges: all (0, 0) from bucket_scan
 				const uint32_t cap = (uint32_t)std::min<size_t>(cells, 0xffffffffu);
 				{ StageTimer t(ST_DUPLICATE, stream);
-				  if (launch_bin_scatter(bp, geom.col_cursor, geom.offsets, bin.rec_unsorted, cap, bin.pool_cursor, stream) != 0) return -1; }
+				  if (launch_cell_scatter(P, geom.dupinfo, geom.cell_start, geom.counts, bin.rec_key, bin.rec_im, cap, cell_tiles, cgx, (int)ncells, bin.pool_cursor, bin.slow_list, stream) != 0) return -1; }
 				ADGS_LAUNCH_CHECK(debug, stream);
-				ChunkSortArgs ga;
-				ga.chunks = geom.chunks; ga.d_counts = geom.d_counts(); ga.rec_u = bin.rec_unsorted; ga.key_s = bin.key_stage; ga.mask_s = bin.mask_stage;
-				ga.ent_f = bin.entries; ga.cap = cap; ga.bounds_out = fc->slab_bounds;
-				{ const char* cs = env_str("ADGS_CHUNK_SORT"); ga.flags = (cs && std::string(cs) == "radix") ? nullptr : geom.chunk_flags; }      // radix: every chunk through the LSD radix sort (A/B, tests)
-				const size_t grid = BinStateV2::max_chunks(cells, ncols);
-				{ StageTimer t(ST_SORT, stream); if (launch_chunk_sort(ga, (uint32_t)grid, stream) != 0) return -1; }
-				{ StageTimer t(ST_RANGES, stream); if (launch_chunk_merge(ga, (uint32_t)grid, stream) != 0) return -1; }      // "tile_ranges" slot: the merge of multi-chunk columns
+				SlabSortArgs ga;
+				ga.cell_ranges = img.cell_ranges; ga.ncells = (int)ncells; ga.cell_work = geom.cell_work; ga.grid = (uint32_t)BinStateV2::slab_grid(cells, ncells); ga.rec_key = bin.rec_key; ga.rec_im = bin.rec_im; ga.ent_f = bin.entries; ga.cap = cap;
+				ga.bounds = geom.bounds; ga.bounds_out = fc->slab_bounds; ga.d_counts = geom.d_counts(); ga.slow_list = bin.slow_list;
+				ga.bounds_out2 = (hint && hint->extra >= ncells * SLAB_ROW) ? hint->buf + wtiles + 16 : nullptr;
+				ga.box = mb->dev; ga.seq = exact ? seq_rerun : seq; ga.cap_cells = exact ? 0xffffffffu : sa.cap_cells; ga.cap_fine = exact ? ~0ull : sa.cap_fine;
+				{ StageTimer t(ST_SORT, stream); if (launch_slab_sort(ga, stream) != 0) return -1; }
 				ADGS_LAUNCH_CHECK(debug, stream);
 				return 0;
 			}
@@ -747,7 +748,10 @@ static int raster_forward_impl(const ShSource* sh_src,
 			  if (radix_sort_pairs_u64_dn(bin.keys_unsorted, bin.keys, bin.list_unsorted, bin.list, cells, d_count, 32 + bit, bin.sort_temp, stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			{ StageTimer t(ST_RANGES, stream);
-			  if (launch_tile_ranges((int)cells, d_count, bin.keys, img.cell_ranges, bit >= 32 ? 0xffffffffu : ((1u << bit) - 1u), stream) != 0) return -1; }
+			  if (launch_tile_ranges((int)cells, d_count, bin.keys, img.cell_ranges, bit >= 32 ? 0xffffffffu : ((1u << bit) - 1u), stream) != 0) return -1;
+			  // a sorted frame teaches the bucket path its depth-slab bounds too (the cells' 32-quantiles, read off the sorted keys)
+			  if (fc->slab_bounds && ncells <= (size_t)MAX_CELLS &&
+			      launch_bounds_from_sorted(bin.keys, img.cell_ranges, (int)ncells, d_count, (uint32_t)std::min<size_t>(cells, 0xffffffffu), fc->slab_bounds, stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);
 			return 0;
 		};
@@ -803,11 +807,9 @@ static int raster_forward_impl(const ShSource* sh_src,
 			// the re-run fits by construction; the device word can also be set without speculation (cell_scan raises it when the chunk
 			// table is full), and a blend launched with it set renders nothing
 			ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream));
-			if (buckets && !chunk_table_full) {
-				// the first bin_scatter advanced the column cursors: col_scan again (same counts, same chunk table) puts them back on the column
-				// starts, this time against no capacity
-				sa.cap_cells = 0xffffffffu; sa.cap_fine = ~0ull;
-				if (launch_col_scan(sa, stream) != 0) return -1;
+			exact = true;
+			if (buckets && !chunk_table_full) {      // slab_sort's completion counter / fullest slab / hand-over list
+				ADGS_HIP_CHECK(hipMemsetAsync(geom.d_counts() + 4, 0, 2 * sizeof(uint32_t), stream));
 			}
 			if (chunk_table_full) {
 				// more chunks than the chunk table holds (> 100 M pairs): this frame takes the device-wide radix sort, which needs the
@@ -818,8 +820,12 @@ static int raster_forward_impl(const ShSource* sh_src,
 				StageTimer t(ST_SCAN, stream);
 				if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
 			}
+			// slab_sort publishes once more (the fullest slab of the frame as it was really binned): under a sequence number of its own
+			uint32_t seq2 = 0;
+			if (buckets) { seq2 = mb->next_seq++; seq_rerun = seq2; }
 			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
 			if (launch_blend() != 0) return -1;
+			if (buckets && R_cells != 0 && wait_mailbox(mb, seq2, stream) != 0) return -1;      // (rare path: a frame that is enqueued twice)
 		}
 		{	// capacity hints for the next frame: 25% head-room over this frame, slow decay of older peaks
 			const size_t want_c = R_cells + R_cells / 4 + 4096, want_f = R_fine + R_fine / 4 + 4096;
@@ -867,7 +873,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 	pa.radii = radii; pa.splats = geom.splats; pa.cov3D = geom.cov3D; pa.clamped = geom.clamped; pa.tiles_touched = geom.tiles_touched;
 	pa.v2 = 0; pa.dupinfo = nullptr; pa.fine_touched = nullptr; pa.cell_tiles = 1; pa.cgx = gx; pa.cgy = gy;
 	memset(&pa.sh_src, 0, sizeof(pa.sh_src)); pa.sh0 = nullptr; pa.gacc = nullptr; pa.fine_total = nullptr;
-	pa.bucket = 0;
+	pa.bucket_count = nullptr;
 	pa.cfg_word = img.header; pa.cfg_value = frame_word; pa.ddir = nullptr;
 	if (sh_src) { set_error("the raw-SH entry points need the default (v2) pipeline (not ADGS_RASTER_MODE=classic, D_S <= ADGS_V2_MAX_SEMANTIC)"); return -1; }
 	{ StageTimer t(ST_PREPROCESS, stream); if (launch_preprocess_fwd(pa, stream) != 0) return -1; }
@@ -1308,6 +1314,23 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
 	FrameContext* fc = frame_context();
 	fc->hint_cells = (size_t)std::max(0ll, pairs); fc->hint_fine = (size_t)std::max(0ll, fine_pairs); fc->hint_max_cell_chunks = 0u;
+	// ... and what the binning has learned about depths: the thread's slab bounds back to "everything in slab 0", the cameras' own tables forgotten
+	(void)hipDeviceSynchronize();
+	if (fc->slab_bounds) (void)hipMemset(fc->slab_bounds, 0xff, (size_t)MAX_CELLS * SLAB_ROW * sizeof(uint32_t));
+	if (OrderHints* oh = order_hints()) for (auto& e : oh->entries) { e.written = false; if (e.buf) (void)oh->reset_signature(e.buf, e.tiles, e.extra); }
+}
+// fills the calling thread's table of depth-slab bounds with pseudo-random words (an LCG): ANY contents must give the same lists
+// (binning.hip: the slab of a depth is a monotone function of it whatever the row holds) -- returns 0, or -1 when no bucket-binned frame
+// has created the table yet
+extern "C" int adgs_test_scramble_slab_bounds(unsigned seed) {
+	FrameContext* fc = frame_context();
+	if (!fc->slab_bounds) return -1;
+	std::vector<uint32_t> h((size_t)MAX_CELLS * SLAB_ROW);
+	uint32_t x = seed * 2654435761u + 12345u;
+	for (auto& w : h) { x = x * 1664525u + 1013904223u; w = (x >> 3) ^ (x << 7); }
+	if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(fc->slab_bounds, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return -1;
+	if (OrderHints* oh = order_hints()) for (auto& e : oh->entries) e.written = false;      // the cameras' own tables are not consulted
+	return 0;
 }
 extern "C" size_t adgs_test_scan_temp_bytes(size_t n) { return scan_temp_bytes(n); }
 extern "C" int adgs_test_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream) {

@@ -25,9 +25,10 @@ struct PreprocessArgs {
 	const float* sh0;                // raw SH source: precomputed coefficient 0 [P,3] (launch_sh0)
 	float* gacc;                     // v2: [P][GACC_STRIDE] accumulator lines, zeroed here for every visible Gaussian (nullptr: skip)
 	unsigned long long* fine_total;  // v2: reset here; the scan pass adds up fine_touched into it
-	// v2 bucket binning (binning.hip; 0: sort-based binning): no scan pass runs over fine_touched, so fine_total is accumulated here
-	// (one atomic per workgroup; the frame's prologue zeroed it)
-	int bucket;
+	// v2 bucket binning (binning.hip; bucket_count == nullptr: sort-based binning): every visible Gaussian is counted into the
+	// coarse cells it covers -- bucket_count[workgroup][cell], every entry written -- and fine_total is accumulated here (the frame's
+	// prologue zeroed it)
+	uint32_t* bucket_count;
 	// the frame's configuration word, written into the header of the image state (api.hip: frame_cfg_word): a backward that cannot find
 	// its forward in the host-side frame table (cloned / offloaded state buffers) reads it back instead of consulting the environment
 	uint32_t* cfg_word; uint32_t cfg_value;
@@ -105,58 +106,53 @@ constexpr int GACC_STRIDE = 16;         // one 64-byte line of gradient accumula
 constexpr int GACC_USED = 14;           // S0 Sx Sy Sxx Sxy Syy c0 c1 c2 d f0 f1 f2 s0
 
 // ---- bucket binning (binning.hip) ----
-constexpr int MAX_CELLS = 1024;         // coarse cells of a bucket-binned frame
-constexpr int SLAB_ROW = 32;            // words per cell in a table of depth-slab bounds: the 31 inner 32-quantiles of the cell's depth keys (+ 1 pad)
-constexpr int MAX_SLAB_LG = 5;          // a cell's list is built as 2^lg <= 32 independently sorted depth slabs ("columns")
-constexpr int MAX_COLS = 4096;          // (cell, slab) columns one col_scan workgroup (and one LDS histogram) handles
-constexpr int GS_NMAX = 4096;           // entries one chunk_sort workgroup sorts inside its CU
-#ifndef ADGS_BIN_COPIES
-#define ADGS_BIN_COPIES 1
-#endif
-constexpr int BIN_COPIES = ADGS_BIN_COPIES;      // privatised copies of the column counters / cursors (workgroup w of bin_count / bin_scatter uses copy w mod BIN_COPIES)
-constexpr int MAX_CHUNKS = 16384;       // capacity of the chunk table
+constexpr int MAX_CELLS = 1024;         // coarse cells one cell_scan workgroup (and one LDS histogram) handles
+constexpr int SLAB_ROW = 128;           // words per cell in a table of depth-slab bounds: the 127 inner 128-quantiles of the cell's depth keys (+ 1 pad)
+constexpr int MAX_SLAB_LG = 7;          // a cell's list is built as 2^lg <= 128 independently sorted depth slabs; lg per cell, from the cell's pair count
+constexpr int SLAB_TARGET = 3072;       // ... the smallest lg that brings the cell's pairs per slab to this or below (3/4 of what one sort holds: with the camera's
+                                        // own bounds the slabs of a cell are equal to within its depth ties; 2048 made 1120 workgroups of C3's 70 cells: two rounds)
+constexpr int GS_NMAX = 4096;           // entries one slab_sort workgroup sorts at a time inside its CU
+constexpr int MAX_CHUNKS = 16384;       // a frame of more than MAX_CHUNKS x GS_NMAX pairs takes the device-wide sort
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
 // overflow: the totals exceed the capacity the frame's launches were enqueued against; overflow_count: such frames since the mailbox exists
-struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest column's chunks
+struct Mailbox { volatile uint32_t seq; uint32_t r_cells; unsigned long long r_fine; uint32_t oversize, n_groups, overflow, overflow_count, max_cell_chunks;      // max_cell_chunks: bucket binning, the fullest slab in units of GS_NMAX entries
 	uint32_t cap_cells; unsigned long long cap_fine; };      // the capacity THIS frame was enqueued against, as its kernels saw it (a graph replay reports its capture's)
 int launch_bin_prepare(const FramePrologue& p, hipStream_t stream);
-// A chunk of a column's range: what one chunk_sort workgroup sorts.  (col_start, col_end): the whole column -- the chunk IS the column
-// ("single": its sorted order is final) or one of several that chunk_merge ranks against each other; (cell_start, cell_n, cell): the cell
-// the column belongs to -- an entry whose final rank inside its cell is a 32-quantile position leaves its depth key as next frame's bound.
-struct BinChunk { uint32_t start, end, col_start, col_end, cell_start, cell_n, cell, pad; };
-static_assert(sizeof(BinChunk) == 32, "BinChunk is stored as two 16-byte words");
-// the (cell, Gaussian) pairs of a frame, as the counting and the scattering pass enumerate them (identically)
-struct BinPairs {
-	int P; const uint4* dupinfo;        // (shrunk tile rectangle min, max, depth bits, -) per Gaussian (preprocess_fwd)
-	int cell_tiles, cgx, ncells, lg;    // 2^lg depth slabs per cell: column = (cell << lg) + slab
-	int cstride;                        // words between two privatised copies of the column counters / cursors (>= columns, a multiple of 64)
-	const uint32_t* bounds;             // this frame's snapshot of the slab bounds [ncells][SLAB_ROW] (unused when lg == 0)
-};
-// slab_words[P]: the depth slabs (5 bits each) of every Gaussian's first six cells, bin_count -> bin_scatter
-int launch_bin_count(const BinPairs& b, uint32_t* col_count, uint32_t* slab_words, hipStream_t stream);
-int launch_bin_scatter(const BinPairs& b, uint32_t* col_cursor, uint32_t* slab_words, uint4* rec_u, uint32_t cap, uint32_t* pool_cursor, hipStream_t stream);
-struct ColScanArgs {
-	const uint32_t* col_count;          // [BIN_COPIES][cstride] pairs per column (bin_count)
-	uint32_t* col_cursor;               // [BIN_COPIES][cstride] <- column start + the pairs of the copies before: bin_scatter reserves its slices from them
-	uint2* cell_ranges; int ncells, lg, cstride;
-	BinChunk* chunks; uint32_t max_chunks;
-	uint32_t* d_counts;                 // [0] pairs, [1] chunks, [2] overflow flag (more chunks than the table holds), [3] the totals exceed the capacity
+struct CellScanArgs {
+	const uint32_t* cell_count;         // pairs per cell (cell_colscan)
+	uint32_t* cell_start;               // [ncells + 1]
+	uint2* cell_ranges; int ncells;
+	uint32_t max_chunks;                // more GS_NMAX-entry units than this: d_counts[2] (the host re-bins with the device-wide sort)
+	uint2* cell_work;                   // [ncells + 1] <- (first slab_sort workgroup of the cell, its lg); [ncells] = (workgroups in all, 0)
+	int force_lg;                       // >= 0: every cell gets 2^force_lg slabs (ADGS_SLABS_LG: tests)
+	uint32_t* d_counts;                 // [0] pairs, [1] slab_sort workgroups, [2] more than max_chunks x GS_NMAX pairs, [3] the totals exceed the capacity,
+	                                    // [4] slab_sort workgroups done, [5] the fullest slab (GS_NMAX units), [6..7] fine-tile total
 	const unsigned long long* fine_total;
-	Mailbox* box; uint32_t seq;
-	uint32_t cap_cells; unsigned long long cap_fine;      // capacities of the launches that follow (d_counts[3] = the totals exceed them)
+	uint32_t cap_cells; unsigned long long cap_fine;      // capacities of the launches that follow
+	Mailbox* box; uint32_t seq;         // non-null: publish the totals here (a host that waits for them before it enqueues the binning)
 };
-int launch_col_scan(const ColScanArgs& a, hipStream_t stream);
-struct ChunkSortArgs {
-	const BinChunk* chunks; const uint32_t* d_counts;
-	const uint4* rec_u;                 // unsorted (column-grouped) records (depth bits, id, mask, -)
-	uint2* key_s; uint32_t* mask_s;     // chunk-sorted (depth, id) keys + masks of the multi-chunk columns
+int launch_cell_scan(const CellScanArgs& a, hipStream_t stream);
+int launch_cell_colscan(uint32_t* counts, int nblocks, int ncells, uint32_t* cell_count, hipStream_t stream);
+// rec_key[pos] = depth bits, rec_im[pos] = (Gaussian id, rectangle mask): a cell's unsorted records, struct-of-arrays (slab_sort streams the keys alone)
+int launch_cell_scatter(int P, const uint4* dupinfo, const uint32_t* cell_start, const uint32_t* counts, uint32_t* rec_key, uint2* rec_im, uint32_t cap,
+	int cell_tiles, int cgx, int ncells, uint32_t* pool_cursor, uint32_t* slow_list, hipStream_t stream);      // slow_list[0] <- 0
+struct SlabSortArgs {
+	const uint2* cell_ranges; int ncells;
+	const uint2* cell_work;             // (first workgroup, lg) per cell (cell_scan): 2^lg depth slabs, one workgroup each
+	uint32_t grid;                      // workgroups launched (>= d_counts[1] whenever the frame fits its capacity)
+	const uint32_t* rec_key; const uint2* rec_im;  // the cells' unsorted records (cell_scatter)
 	uint2* ent_f;                       // final (id, mask) entries
-	uint32_t cap;
-	uint32_t* flags;                    // [MAX_CHUNKS] chunk_bsort -> chunk_sort: 1 = the chunk takes the radix sort (nullptr: the radix sort sorts every chunk, ADGS_CHUNK_SORT=radix)
-	uint32_t* bounds_out;               // the shared table of slab bounds [MAX_CELLS][SLAB_ROW]: this frame's 32-quantiles per cell, for the next frame (nullptr: none)
+	uint32_t cap;                       // records the binning buffer holds
+	const uint32_t* bounds;             // this frame's snapshot of the slab bounds [ncells][SLAB_ROW]
+	uint32_t* bounds_out;               // the thread's table [MAX_CELLS][SLAB_ROW]: this frame's 32-quantiles per cell, for the next frame (nullptr: none)
+	uint32_t* bounds_out2;              // ... and the camera's own table (api.hip: OrderHints), for its next render (nullptr: none)
+	uint32_t* slow_list;                // [1 + grid] slabs slab_sort hands to slab_sort_slow, (cell << 8) | slab: [0] = count (zeroed by cell_scatter)
+	uint32_t* d_counts;
+	Mailbox* box; uint32_t seq; uint32_t cap_cells; unsigned long long cap_fine;      // the last workgroup to finish publishes the frame's totals
 };
-int launch_chunk_sort(const ChunkSortArgs& a, uint32_t grid, hipStream_t stream);
-int launch_chunk_merge(const ChunkSortArgs& a, uint32_t grid, hipStream_t stream);
+int launch_slab_sort(const SlabSortArgs& a, hipStream_t stream);
+// sorted frames (device-wide radix sort): the 32-quantiles of every cell from the sorted (cell | depth) keys
+int launch_bounds_from_sorted(const uint64_t* keys, const uint2* cell_ranges, int ncells, const uint32_t* d_total, uint32_t cap, uint32_t* bounds_out, hipStream_t stream);
 
 int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
 	uint32_t cap, int cell_tiles, int cgx, uint2* cell_ranges, int ncells, uint32_t* pool_cursor, int mask_shift, hipStream_t stream);

@@ -149,12 +149,14 @@ __device__ __forceinline__ PreIn load_pre_in(const PreprocessArgs& a, const int 
 }
 
 template <bool STAGED>
-__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, const PreIn& in);
+__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell, const PreIn& in);
 
 template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 	extern __shared__ float s_sh[];
+	__shared__ uint32_t s_cell[MAX_CELLS];     // bucket binning: this workgroup's (cell, Gaussian) pair count per coarse cell
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a.bucket_count) for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) s_cell[c] = 0u;
 	if (idx == 0 && a.cfg_word) *a.cfg_word = a.cfg_value;
 	PreIn in;
 	if (STAGED) {
@@ -182,19 +184,21 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 			}
 		}
 	}
-	if (STAGED) __syncthreads();
-	if (a.v2 && !a.bucket && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
+	if (STAGED || a.bucket_count) __syncthreads();
+	if (a.v2 && !a.bucket_count && idx < SCAN_AUX_SLOTS) a.fine_total[idx] = 0ull;     // counters of the scan's side sum (P >= 1 block: always covered)
 	PreOut o = { 0u, 0u };
-	if (idx < a.P) o = preprocess_one<STAGED>(a, idx, s_sh, in);
-	if (a.bucket) {
-		// bucket binning (binning.hip): no scan pass runs over fine_touched; the fine-tile total (capacity bound of the chunk pool) is one
-		// atomic per workgroup.  (The (cell, Gaussian) pairs are counted by bin_count from the 16-byte records written below.)
+	if (idx < a.P) o = preprocess_one<STAGED>(a, idx, s_sh, s_cell, in);
+	if (a.bucket_count) {
+		// bucket binning (binning.hip): no scan pass runs.  The pair counts per coarse cell were summed in LDS (the Gaussians of an
+		// object are neighbours in index AND on the screen: global atomics serialise on a few hot cells) and go out as this
+		// workgroup's row of the counts matrix; the fine-tile total (capacity bound of the chunk pool) is one atomic per workgroup.
 		__shared__ uint32_t s_red[256 / WAVE];
 		uint32_t nf = o.nfine;
 #pragma unroll
 		for (int off = WAVE / 2; off > 0; off >>= 1) nf += __shfl_xor(nf, off, WAVE);
 		if ((threadIdx.x & (WAVE - 1)) == 0) s_red[threadIdx.x / WAVE] = nf;
 		__syncthreads();
+		for (int c = threadIdx.x; c < a.cgx * a.cgy; c += 256) a.bucket_count[(size_t)blockIdx.x * (a.cgx * a.cgy) + c] = s_cell[c];
 		if (threadIdx.x == 0) {
 			uint32_t n = 0;
 #pragma unroll
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 }
 
 template <bool STAGED>
-__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, const PreIn& in) {
+__device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const int idx, const float* s_sh, uint32_t* s_cell, const PreIn& in) {
 	const PreOut none = { 0u, 0u };
 	if (idx == 0) {       // sentinels: the exclusive scans over P + 1 entries leave the totals at [P]
 		a.tiles_touched[a.P] = 0;
@@ -379,6 +383,10 @@ __device__ __forceinline__ PreOut preprocess_one(const PreprocessArgs& a, const 
 	if (nfine) {
 		const uint32_t c0x = sminx / a.cell_tiles, c1x = (smaxx - 1) / a.cell_tiles, c0y = sminy / a.cell_tiles, c1y = (smaxy - 1) / a.cell_tiles;
 		ncell = (c1x - c0x + 1) * (c1y - c0y + 1);
+		if (a.bucket_count) {       // bucket binning: count this Gaussian into every coarse cell it covers
+			for (uint32_t y = c0y; y <= c1y; y++)
+				for (uint32_t x = c0x; x <= c1x; x++) atomicAdd(s_cell + y * a.cgx + x, 1u);
+		}
 	}
 	a.dupinfo[idx] = make_uint4(sminx | (sminy << 16), smaxx | (smaxy << 16), __float_as_uint(vz), 0u);   // all the binning kernel needs, 16 B
 	a.tiles_touched[idx] = ncell;

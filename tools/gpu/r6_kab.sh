@@ -4,5 +4,5 @@ R=$GRAFT_REPO_ROOT; L=$R/ad-gs_amd/lib
 for v in "$@"; do
   lib=$L/libadgs_hip_$v.so; [ $v = default ] && lib=$L/libadgs_hip.so
   export ADGS_LIB=$lib
-  bash $R/tools/gpu/r6_kstats.sh kab_$v ${CFG:+--config $CFG} | grep -E "bin_pairs|col_scan|chunk_|tile_order" | sed "s/^/$v: /" | cut -c1-150
+  bash $R/tools/gpu/r6_kstats.sh kab_$v ${CFG:+--config $CFG} | grep -E "cell_|slab_sort|tile_order|bin_prepare" | sed "s/^/$v: /" | cut -c1-150
 done
