@@ -28,6 +28,12 @@ SIGNATURES = {
     "adgs_raster_forward": (c_i, [ALLOC_FN, c_p, ALLOC_FN, c_p, ALLOC_FN, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i,
                                   c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
                                   c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "adgs_raster_render": (c_i, [ALLOC_FN, c_p, ALLOC_FN, c_p, ALLOC_FN, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i,
+                                 c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
+                                 c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "adgs_raster_render_rawsh": (c_i, [ALLOC_FN, c_p, ALLOC_FN, c_p, ALLOC_FN, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i,
+                                       c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_f, c_f,
+                                       c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "adgs_raster_backward": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
                                    c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),

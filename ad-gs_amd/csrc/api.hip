@@ -512,7 +512,8 @@ extern "C" int adgs_device_check(void) {
 	return 0;
 }
 
-static int raster_forward_impl(const ShSource* sh_src,
+// training = false: the forward-only render (adgs_raster_render*): nothing is kept for a backward
+static int raster_forward_impl(const ShSource* sh_src, bool training,
 	adgs_alloc_fn geometryBuffer, void* geometryUser,
 	adgs_alloc_fn binningBuffer, void* binningUser,
 	adgs_alloc_fn imageBuffer, void* imageUser,
@@ -534,6 +535,8 @@ static int raster_forward_impl(const ShSource* sh_src,
 	if (gx > 65535 || gy > 65535) { set_error("image too large"); return -1; }
 	if (ntiles * 4 * (2 * (size_t)POOL_BLOCK + 1) > 0xffffffffull) { set_error("image too large: chunk slots are 32-bit"); return -1; }      // 4: wave tiles per 16x16 tile at most
 
+	// semantic channels beyond the first are blended by a replay of the published lists: such a frame publishes them whatever it is for
+	if (D_S > 1) training = true;
 	if (use_v2(D_S)) {
 		// the cell edge as asked for; a frame that takes the sorted path shrinks it until the mask bits fit its keys (decided below)
 		int cell_tiles = v2_cell_tiles(gx, gy, false);
@@ -575,15 +578,17 @@ static int raster_forward_impl(const ShSource* sh_src,
 			fcfg.tile_order = env_int("ADGS_TILE_ORDER", 1) != 0; fcfg.sh_staging = env_str("ADGS_NO_SH_STAGING") == nullptr; fcfg.timeline = env_int("ADGS_TIMELINE_BWD", 0) != 0;
 			// fewer tiles than wave slots: nothing to balance, neither in the backward nor in the forward
 			order_tiles = wtiles >= 2048 && fcfg.tile_order;
+			if (!training) order_tiles = false;      // no backward to balance, and an evaluation render does not come back to its camera
 			fcfg.order_ready = order_tiles ? 1 : 0;
-			remember_frame(FrameKey{ ich, gch, width, height, P }, fcfg);
+			if (training) remember_frame(FrameKey{ ich, gch, width, height, P }, fcfg);
 			frame_word = frame_cfg_word(fcfg);
 		}
 		// ADGS_FWD_ORDER: 2 (default) = this camera's previous render decides the forward's tile order (bottom-up without one), 1 = bottom-up, 0 = top-down
 		const int fwd_order_mode = env_int("ADGS_FWD_ORDER", 2);
 		OrderHints::Entry* hint = nullptr;
 		const uint32_t* hint_read = nullptr;
-		if (order_tiles && fwd_order_mode == 2) {
+		const bool fwd_hint_wanted = wtiles >= 2048 && env_int("ADGS_TILE_ORDER", 1) != 0 && fwd_order_mode == 2;
+		if (fwd_hint_wanted) {
 			hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
 			(void)hipStreamIsCapturing(stream, &cs0);
 			if (OrderHints* oh = order_hints()) {
@@ -591,7 +596,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 				hint = oh->find(viewmatrix, projmatrix, width, height, wtiles, stream, cap0);
 				// a camera's first render has no hint (bottom-up).  Another camera's order is no substitute: measured with the bench's jittered
 				// cameras (0.04 rad of yaw: the image shifts by a few tiles) it is WORSE than bottom-up, 910 - 920 against 928 frames/s.
-				if (!hint) {
+				if (!hint && training) {
 					// an entry is allocated outside the capture's rules: hipMalloc and the service stream's memset + wait are "potentially
 					// unsafe" calls that a global-mode capture (torch.cuda.graph's default) forbids unless this thread switches to relaxed mode
 					hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
@@ -618,10 +623,10 @@ static int raster_forward_impl(const ShSource* sh_src,
 		pa.radii = radii; pa.splats = geom.splats; pa.cov3D = nullptr; pa.clamped = geom.clamped; pa.tiles_touched = geom.cells_touched;     // cov3D: recomputed by the backward
 		pa.v2 = 1; pa.dupinfo = geom.dupinfo; pa.fine_touched = geom.fine_touched; pa.cell_tiles = cell_tiles; pa.cgx = cgx; pa.cgy = cgy;
 		memset(&pa.sh_src, 0, sizeof(pa.sh_src));
-		pa.sh0 = geom.sh0; pa.gacc = geom.gacc; pa.fine_total = geom.fine_total;
+		pa.sh0 = geom.sh0; pa.gacc = training ? geom.gacc : nullptr; pa.fine_total = geom.fine_total;      // forward-only: no accumulator lines to zero
 		pa.bucket_count = nullptr;
 		pa.cfg_word = img.header; pa.cfg_value = frame_word;
-		pa.ddir = (sh_src && M == 16) ? geom.ddir : nullptr;      // raw-SH path: the backward will not read the `rest` rows a second time
+		pa.ddir = (training && sh_src && M == 16) ? geom.ddir : nullptr;      // raw-SH path: the backward will not read the `rest` rows a second time
 		// bucket binning accumulates the fine-tile total and a few device words, and splits its cells by a snapshot of slab bounds (the
 		// camera's own, else the thread's latest): zeroed / copied by the sh0 kernel on the raw-SH path (no launch of its own), by bin_prepare otherwise
 		FramePrologue pro{ nullptr, 0, nullptr, nullptr, 0 };
@@ -713,10 +718,10 @@ static int raster_forward_impl(const ShSource* sh_src,
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
 			if (buckets) {
-				BinStateV2::carve_buckets(nullptr, cells, fine * sub, wtiles, &bb, ncells);
+				BinStateV2::carve_buckets(nullptr, cells, training ? fine * sub : 0, training ? wtiles : 0, &bb, ncells);      // forward-only: no chunk pool
 				char* bch = binningBuffer(binningUser, bb);
 				if (!bch) { set_error("binning allocator returned NULL"); return -1; }
-				bin = BinStateV2::carve_buckets(bch, cells, fine * sub, wtiles, nullptr, ncells);
+				bin = BinStateV2::carve_buckets(bch, cells, training ? fine * sub : 0, training ? wtiles : 0, nullptr, ncells);
 				if (cells == 0) { ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream)); return 0; }     // cell_ranges: all (0, 0) from bucket_scan
 				const uint32_t cap = (uint32_t)std::min<size_t>(cells, 0xffffffffu);
 				{ StageTimer t(ST_DUPLICATE, stream);
@@ -725,16 +730,16 @@ static int raster_forward_impl(const ShSource* sh_src,
 				SlabSortArgs ga;
 				ga.cell_ranges = img.cell_ranges; ga.ncells = (int)ncells; ga.cell_work = geom.cell_work; ga.grid = (uint32_t)BinStateV2::slab_grid(cells, ncells); ga.rec_key = bin.rec_key; ga.rec_im = bin.rec_im; ga.ent_f = bin.entries; ga.cap = cap;
 				ga.bounds = geom.bounds; ga.bounds_out = fc->slab_bounds; ga.d_counts = geom.d_counts(); ga.slow_list = bin.slow_list;
-				ga.bounds_out2 = (hint && hint->extra >= ncells * SLAB_ROW) ? hint->buf + wtiles + 16 : nullptr;
+				ga.bounds_out2 = (training && hint && hint->extra >= ncells * SLAB_ROW) ? hint->buf + wtiles + 16 : nullptr;
 				ga.box = mb->dev; ga.seq = exact ? seq_rerun : seq; ga.cap_cells = exact ? 0xffffffffu : sa.cap_cells; ga.cap_fine = exact ? ~0ull : sa.cap_fine;
 				{ StageTimer t(ST_SORT, stream); if (launch_slab_sort(ga, stream) != 0) return -1; }
 				ADGS_LAUNCH_CHECK(debug, stream);
 				return 0;
 			}
-			BinStateV2::carve(nullptr, cells, fine * sub, wtiles, &bb);        // a Gaussian can enter both halves of a tile
+			BinStateV2::carve(nullptr, cells, training ? fine * sub : 0, training ? wtiles : 0, &bb);        // a Gaussian can enter both halves of a tile
 			char* bch = binningBuffer(binningUser, bb);
 			if (!bch) { set_error("binning allocator returned NULL"); return -1; }
-			bin = BinStateV2::carve(bch, cells, fine * sub, wtiles, nullptr);
+			bin = BinStateV2::carve(bch, cells, training ? fine * sub : 0, training ? wtiles : 0, nullptr);
 			if (cells == 0) {
 				ADGS_HIP_CHECK(hipMemsetAsync(img.cell_ranges, 0, ncells * sizeof(uint2), stream));
 				ADGS_HIP_CHECK(hipMemsetAsync(bin.pool_cursor, 0, sizeof(uint32_t), stream));
@@ -769,7 +774,7 @@ static int raster_forward_impl(const ShSource* sh_src,
 			ra.order_mode = fwd_order_mode == 2 ? 1 : fwd_order_mode; ra.fwd_order = nullptr;
 			ra.fwd_view = viewmatrix; ra.fwd_sig = nullptr;
 			if (hint_read) { ra.order_mode = 2; ra.fwd_order = hint_read; ra.fwd_sig = reinterpret_cast<const float*>(hint_read + wtiles); }
-			ra.overflow_flag = overflow_flag;
+			ra.overflow_flag = overflow_flag; ra.publish = training;
 			{ StageTimer t(ST_RENDER_FWD, stream);
 			  if (launch_render_fwd_v2(ra, stream) != 0) return -1;
 			  for (int c0 = 1; ra.has_sem && c0 < D_S; c0 += 4) {      // semantic channels beyond the Splat's slot: a replay of the published lists
@@ -1085,7 +1090,22 @@ extern "C" int adgs_raster_forward(
 	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
 	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
 	int inv_depth, int* radii, int debug, void* stream) {
-	return raster_forward_impl(nullptr, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
+	return raster_forward_impl(nullptr, true, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
+		width, height, means3D, shs, colors_precomp, flow_points, semantic, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+		viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, img_opacity, img_flow, img_semantic,
+		inv_depth, radii, debug, stream);
+}
+
+// The forward-only render: adgs_raster_forward's arguments and images, nothing kept for a backward (include/adgs_rasterizer.h)
+extern "C" int adgs_raster_render(
+	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser, adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S, const float* background, int width, int height,
+	const float* means3D, const float* shs, const float* colors_precomp, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream) {
+	return raster_forward_impl(nullptr, false, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
 		width, height, means3D, shs, colors_precomp, flow_points, semantic, opacities, scales, scale_modifier, rotations, cov3D_precomp,
 		viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, img_opacity, img_flow, img_semantic,
 		inv_depth, radii, debug, stream);
@@ -1144,7 +1164,24 @@ extern "C" int adgs_raster_forward_rawsh(
 	if (P > 0 && check_sh_source(sh, P, M, "adgs_raster_forward_rawsh") != 0) return -1;
 	if (P <= 0) return 0;
 	const ShSource src = to_sh_source(sh);
-	return raster_forward_impl(&src, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
+	return raster_forward_impl(&src, true, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
+		width, height, means3D, nullptr, nullptr, flow_points, semantic, opacities, scales, scale_modifier, rotations, nullptr,
+		viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, img_opacity, img_flow, img_semantic,
+		inv_depth, radii, debug, stream);
+}
+
+extern "C" int adgs_raster_render_rawsh(
+	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser, adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S, const float* background, int width, int height,
+	const float* means3D, const adgs_sh_source* sh, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream) {
+	if (P > 0 && check_sh_source(sh, P, M, "adgs_raster_render_rawsh") != 0) return -1;
+	if (P <= 0) return 0;
+	const ShSource src = to_sh_source(sh);
+	return raster_forward_impl(&src, false, geometryBuffer, geometryUser, binningBuffer, binningUser, imageBuffer, imageUser, P, D, M, D_S, background,
 		width, height, means3D, nullptr, nullptr, flow_points, semantic, opacities, scales, scale_modifier, rotations, nullptr,
 		viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, img_opacity, img_flow, img_semantic,
 		inv_depth, radii, debug, stream);

@@ -173,6 +173,7 @@ struct RenderV2FwdArgs {
 	const uint32_t* fwd_order;              // order_mode 2: workgroup -> tile, the longest-first order of THIS CAMERA'S PREVIOUS render (api.hip: OrderHints)
 	const float* fwd_view; const float* fwd_sig;      // this frame's view matrix / the one the hint was made under (16 floats each): a hint of another pose is ignored
 	const uint32_t* overflow_flag;          // device word: != 0 = the frame does not fit the capacity of this launch (blend nothing)
+	bool publish;                           // true: the training forward; false: nothing is kept for a backward (pool / tile_* / n_contrib are not touched, may be NULL)
 };
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream);
 

@@ -125,14 +125,17 @@ __device__ __forceinline__ uint64_t eval_entry_fwd(const EntryGeom& eg, const fl
 	return any_m;
 }
 
-template <int PPL>
+// PUBLISH: the training forward (the consumed (tile, Gaussian) sequence goes to the chunk pool, per-pixel contributor counts and per-tile
+// bookkeeping are written for the backward).  false: the forward-only render (adgs_raster_render: evaluation under torch.no_grad(),
+// /root/reference/render.py:52-55,156) -- same pixels bit for bit, nothing kept for a backward that will not come.
+template <int PPL, bool PUBLISH>
 __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) {
 	constexpr int ROWS = 4 * PPL, SUB = TILE_Y / ROWS;       // rows per wave tile; wave tiles per 16x16 tile
 	// Gathered Splat lines, one ROW per candidate.  Rows are SPLAT_ROW = 5 quads apart (80 bytes), not 4: lane l stores its line with four
 	// ds_write_b128 at l * 64 bytes otherwise, and the sixteen lanes of a pass land on four bank quads (round 4: SQ_LDS_BANK_CONFLICT = 23 % of
 	// the kernel's LDS-active cycles); at 80 bytes the sixteen start banks 20 l mod 64 are all different.  The fifth quad of the 64 rows is
 	// exactly the 256-entry candidate ring (s_cand): the kernel's LDS footprint stays 7680 bytes = 21 workgroups per CU.
-	__shared__ uint32_t s_pub[2 * WAVE];         // live ids waiting to leave as a full chunk
+	__shared__ uint32_t s_pub[PUBLISH ? 2 * WAVE : 1];         // live ids waiting to leave as a full chunk
 	// key-stream scan: SCAN_ROUNDS x 64 list entries per step; ring: < 64 waiting + one step's survivors, power of two.  With the
 	// staged key stream (below) a step is half a staged block: 4096 + 512 + 1024 + 2048 bytes of LDS = 21 workgroups per CU.
 	constexpr int SCAN_ROUNDS = 2, CAND_RING = 2 * WAVE * SCAN_ROUNDS;
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		// no contributors: a graph replay that overflowed hands these to the caller, whose loss and optimizer step must not see stale
 		// pool memory -- a NaN that has reached the Adam moments cannot be redone); the host enqueues binning and blend again with
 		// exact sizes (or, under stream capture, reports the overflow through adgs_get_frame_status).
-		if (lane == 0) { a.tile_last_chunk[tile] = NO_CHUNK; a.tile_consumed[tile] = 0u; a.tile_scanned[tile] = 0u; a.tile_batches[tile] = 0u; }
+		if (PUBLISH && lane == 0) { a.tile_last_chunk[tile] = NO_CHUNK; a.tile_consumed[tile] = 0u; a.tile_scanned[tile] = 0u; a.tile_batches[tile] = 0u; }
 		const uint32_t ex = tx * TILE_X + (lane & 15);
 		const size_t eHW = (size_t)a.H * a.W;
 #pragma unroll
@@ -258,6 +261,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 	// batch that may need it, so that the atomic's round trip hides behind the loop.
 	uint32_t pub_n = 0, pre_block = 0; bool pre_drawn = false;
 	auto flush_chunk = [&](uint32_t cnt) {       // wave-uniform cnt in [1, 64]: the first cnt ids of s_pub become a chunk, the rest moves down
+		if (!PUBLISH) return;
 		if (blk_left == 0) {
 			if (!pre_drawn) { uint32_t nb = 0; if (lane == 0) nb = atomicAdd(a.pool_cursor, (uint32_t)POOL_BLOCK); pre_block = nb; }
 			blk_next = gridDim.x * (uint32_t)POOL_BLOCK + __shfl(pre_block, 0, WAVE); blk_left = POOL_BLOCK; pre_drawn = false;
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		PT(t_g0);
 		__syncthreads();
 		entries_in += n;
-		if (blk_left == 0 && !pre_drawn && pub_n + n >= (uint32_t)WAVE) {      // this batch may complete a chunk and the block is used up
+		if (PUBLISH && blk_left == 0 && !pre_drawn && pub_n + n >= (uint32_t)WAVE) {      // this batch may complete a chunk and the block is used up
 			uint32_t nb = 0;
 			if (lane == 0) nb = atomicAdd(a.pool_cursor, (uint32_t)POOL_BLOCK);
 			pre_block = nb; pre_drawn = true;
@@ -395,8 +399,11 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 			if (any_m == 0ull) continue;
 
 			PROBE_LIVE(actm, PPL);
-			uint32_t position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
-			asm volatile("" : "+v"(position));        // one copy into a vector register per entry (else: one v_mov per strip)
+			uint32_t position = 0u;
+			if (PUBLISH) {
+				position = consumed + (uint32_t)__popcll(live) + 1u;      // 1-based position in the published sequence
+				asm volatile("" : "+v"(position));        // one copy into a vector register per entry (else: one v_mov per strip)
+			}
 			live |= 1ull << j;
 			const float4 q2 = s_splat[j * SPLAT_ROW + 2];      // b dval fx fy
 			const float4 q3 = s_splat[j * SPLAT_ROW + 3];      // fz sem0 zview lean
@@ -413,19 +420,22 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 				F0[k] = fmaf(q2.z, w, F0[k]); F1[k] = fmaf(q2.w, w, F1[k]); F2[k] = fmaf(q3.x, w, F2[k]);
 				Dp[k] = fmaf(q2.y, w, Dp[k]); S0[k] = fmaf(q3.y, w, S0[k]);
 				T[k] = up ? test_T : T[k];
-				last_contrib[k] = up ? position : last_contrib[k];
+				if (PUBLISH) last_contrib[k] = up ? position : last_contrib[k];
 			}
 		}
 		PT(t_b1); PT_ACC(3, t_b0, t_b1);
 		// ---- the live entries of this batch join the pending chunk, in order
 		const uint32_t nlive = (uint32_t)__popcll(live);
-		if ((live >> lane) & 1ull) s_pub[pub_n + (uint32_t)__popcll(live & lt_mask)] = myid;
-		pub_n += nlive; consumed += nlive;
-		if (pub_n >= (uint32_t)WAVE) flush_chunk(WAVE);
+		if (PUBLISH) {
+			if ((live >> lane) & 1ull) s_pub[pub_n + (uint32_t)__popcll(live & lt_mask)] = myid;
+			pub_n += nlive;
+		}
+		consumed += nlive;
+		if (PUBLISH && pub_n >= (uint32_t)WAVE) flush_chunk(WAVE);
 	}
-	if (pub_n > 0) flush_chunk(pub_n);
+	if (PUBLISH && pub_n > 0) flush_chunk(pub_n);
 
-	if (lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = entries_in; }
+	if (PUBLISH && lane == 0) { a.tile_last_chunk[tile] = prev_chunk; a.tile_consumed[tile] = consumed; a.tile_scanned[tile] = min(pos, range.y) - range.x; a.tile_batches[tile] = entries_in; }
 	TL_STORE(lane, a.tile_scanned, a.tile_batches, tile);      // timeline build: the wave's life instead of the statistics
 	PROBE_FLUSH(0, lane);
 	{ PT(t_wave1); PT_ACC(4, t_wave0, t_wave1); PT_ADD(5, 1ull); PT_FLUSH(0, 10, lane); }
@@ -435,7 +445,7 @@ __global__ void __launch_bounds__(WAVE) render_fwd_v2_kernel(RenderV2FwdArgs a) 
 		if (inside[k]) {
 			const size_t pix_id = (size_t)a.W * (py0 + 4 * k) + px;
 			a.final_T[pix_id] = (float)(1.0 - (double)T[k]);
-			a.n_contrib[pix_id] = last_contrib[k];
+			if (PUBLISH) a.n_contrib[pix_id] = last_contrib[k];
 			if (a.has_color) {
 				// background composite in the epilogue: constant colour (forward.cu:392-394) or, with an environment map, the per-pixel
 				// background of gaussian_renderer/__init__.py:93-94 (render = foreground + (1 - O) * background, T = 1 - O)
@@ -842,9 +852,13 @@ __global__ void __launch_bounds__(256) reset_tiles_kernel(uint32_t T, uint32_t* 
 
 int launch_render_fwd_v2(const RenderV2FwdArgs& a, hipStream_t stream) {
 	const uint32_t T = (uint32_t)a.gx * a.gy;           // a.gy counts WAVE tiles (16 x 4*ppl pixels)
-	if (a.ppl == 1) hipLaunchKernelGGL(render_fwd_v2_kernel<1>, dim3(T), dim3(WAVE), 0, stream, a);
-	else if (a.ppl == 2) hipLaunchKernelGGL(render_fwd_v2_kernel<2>, dim3(T), dim3(WAVE), 0, stream, a);
-	else hipLaunchKernelGGL(render_fwd_v2_kernel<4>, dim3(T), dim3(WAVE), 0, stream, a);
+	if (!a.publish) {
+		if (a.ppl == 1) hipLaunchKernelGGL((render_fwd_v2_kernel<1, false>), dim3(T), dim3(WAVE), 0, stream, a);
+		else if (a.ppl == 2) hipLaunchKernelGGL((render_fwd_v2_kernel<2, false>), dim3(T), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL((render_fwd_v2_kernel<4, false>), dim3(T), dim3(WAVE), 0, stream, a);
+	} else if (a.ppl == 1) hipLaunchKernelGGL((render_fwd_v2_kernel<1, true>), dim3(T), dim3(WAVE), 0, stream, a);
+	else if (a.ppl == 2) hipLaunchKernelGGL((render_fwd_v2_kernel<2, true>), dim3(T), dim3(WAVE), 0, stream, a);
+	else hipLaunchKernelGGL((render_fwd_v2_kernel<4, true>), dim3(T), dim3(WAVE), 0, stream, a);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -72,7 +72,9 @@ def _stream_ptr(device):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, flow_points, semantic,
-                        degree, campos, prefiltered, inv_depth, debug):
+                        degree, campos, prefiltered, inv_depth, debug, training=True):
+    """training=False (extension): the forward-only render, adgs_raster_render -- the same images and radii bit for bit, the three
+    state buffers come back as scratch no backward may be run over."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -107,12 +109,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         bg_, m3_, sh_, col_, fl_, sem_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
         try:
             with _on(dev):
-                rendered = _lib.check(lib.adgs_raster_forward(
+                rendered = _lib.check((lib.adgs_raster_forward if training else lib.adgs_raster_render)(
                     geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, D_S, _ptr(bg_), W, H,
                     _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
                     _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                     _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic), int(bool(inv_depth)),
-                    _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward")
+                    _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward" if training else "adgs_raster_render")
         finally:
             for b in (geom, binning, img):
                 b.release()
@@ -228,7 +230,7 @@ def _sh_source(raw, dev):
 
 
 def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                              image_height, image_width, sh_raw, flow_points, semantic, degree, campos, inv_depth, debug):
+                              image_height, image_width, sh_raw, flow_points, semantic, degree, campos, inv_depth, debug, training=True):
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be on a HIP device; there is no CPU rasterizer")
     lib = _lib.lib()
@@ -260,11 +262,11 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
         bg_, m3_, fl_, sem_, op_, sc_, rot_, view_, proj_, cam_ = keep
         try:
             with _on(dev):
-                rendered = _lib.check(lib.adgs_raster_forward_rawsh(
+                rendered = _lib.check((lib.adgs_raster_forward_rawsh if training else lib.adgs_raster_render_rawsh)(
                     geom.cb, geom.user, binning.cb, binning.user, img.cb, img.user, P, int(degree), M, D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src),
                     _ptr(fl_), _ptr(sem_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_),
                     float(tan_fovx), float(tan_fovy), _ptr(out_color), _ptr(out_depth), _ptr(img_opacity), _ptr(img_flow), _ptr(img_semantic),
-                    int(bool(inv_depth)), _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward_rawsh")
+                    int(bool(inv_depth)), _ptr(radii), int(bool(debug)), _stream_ptr(dev)), "adgs_raster_forward_rawsh" if training else "adgs_raster_render_rawsh")
         finally:
             for b in (geom, binning, img):
                 b.release()

@@ -167,8 +167,22 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         return (g_means3D, g_means2D, g_opac, g_scales, g_rot, g_flow, g_sem) + tuple(g_sh) + (None, None, None) + g_geo + (None, g_bg, None)
 
 
+def _no_backward_can_follow(*tensors):
+    """True when autograd will never ask for a backward of this call: gradients are switched off (the reference's evaluation path,
+    render.py:156 `with torch.no_grad()`), or no input requires one."""
+    return not torch.is_grad_enabled() or not any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points,
                         semantic, raster_settings):
+    if _no_backward_can_follow(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, flow_points, semantic):
+        # the forward-only render (adgs_raster_render): the same six outputs bit for bit, nothing published for a backward
+        s = raster_settings
+        args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx,
+                s.tanfovy, s.image_height, s.image_width, sh, flow_points, semantic, s.sh_degree, s.campos, s.prefiltered, s.inv_depth, s.debug)
+        with torch.no_grad():
+            r = _call_with_dump(lambda *a: _C.rasterize_gaussians(*a, training=False), args, s.debug, "snapshot_fw.dump", "forward")
+        return r[1], r[4], r[2], r[3], r[8], r[9]
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      flow_points, semantic, raster_settings)
 
@@ -190,6 +204,17 @@ class GaussianRasterizer(nn.Module):
         bg_image [3,H,W]: per-pixel background composited in the blend epilogue -- the first output is then
         `foreground + (1 - img_opacity) * bg_image` (gaussian_renderer/__init__.py:93-94) and bg_image receives a gradient."""
         empty = lambda t: torch.Tensor([]) if t is None else t
+        geo4 = [getattr(sh_raw, n, None) for n in ("scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity")]
+        if _no_backward_can_follow(means3D, means2D, opacities, scales, rotations, flow_points, semantic, sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest,
+                                   sh_raw.obj_rest, sh_raw.scene_deform, sh_raw.obj_deform, bg_image, *geo4):
+            s = self.raster_settings
+            raw = (sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest, sh_raw.obj_rest, sh_raw.scene_deform, sh_raw.obj_deform, sh_raw.func_eval,
+                   tuple(geo4) if geo4[0] is not None else None, bg_image)
+            with torch.no_grad():
+                r = _C.rasterize_gaussians_rawsh(s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+                                                 s.image_height, s.image_width, raw, empty(flow_points), empty(semantic), s.sh_degree, s.campos, s.inv_depth,
+                                                 s.debug, training=False)
+            return r[1], r[4], r[2], r[3], r[8], r[9]
         return _RasterizeGaussiansRawSH.apply(means3D, means2D, opacities, scales, rotations, empty(flow_points), empty(semantic),
                                               sh_raw.scene_dc, sh_raw.obj_dc, sh_raw.scene_rest, sh_raw.obj_rest, sh_raw.scene_deform,
                                               sh_raw.obj_deform, sh_raw.func_eval, self.raster_settings, factor_sink,

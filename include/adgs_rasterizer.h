@@ -71,6 +71,42 @@ int adgs_raster_forward(
 	int debug,
 	void* stream);
 
+/* The forward-only render: adgs_raster_forward's arguments, images and radii -- bit for bit -- with nothing kept for a backward: no replay
+ * lists, no per-pixel contributor counts, no accumulator lines, no tile order; the three buffers are scratch.  What the reference runs under
+ * torch.no_grad() for evaluation and reports as its render FPS (render.py:52-55,86,156) -- there through the same forward() as training.
+ * Frames with more than one semantic channel publish their lists all the same (channels 1.. are blended by a replay of them). */
+int adgs_raster_render(
+	adgs_alloc_fn geometryBuffer, void* geometryUser,
+	adgs_alloc_fn binningBuffer, void* binningUser,
+	adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S,
+	const float* background,
+	int width, int height,
+	const float* means3D,
+	const float* shs,
+	const float* colors_precomp,
+	const float* flow_points,
+	const float* semantic,
+	const float* opacities,
+	const float* scales,
+	float scale_modifier,
+	const float* rotations,
+	const float* cov3D_precomp,
+	const float* viewmatrix,
+	const float* projmatrix,
+	const float* cam_pos,
+	float tan_fovx, float tan_fovy,
+	int prefiltered,
+	float* out_color,
+	float* out_depth,
+	float* img_opacity,
+	float* img_flow,
+	float* img_semantic,
+	int inv_depth,
+	int* radii,
+	int debug,
+	void* stream);
+
 /* CudaRasterizer::Rasterizer::backward  (RAST/cuda_rasterizer/rasterizer.h:64-103,
  * rasterizer_impl.cu:356-476).  All dL_* outputs must be zero-initialised by the
  * caller (RAST/rasterize_points.cu:195-206) unless adgs_raster_needs_zero_init() says
@@ -162,6 +198,17 @@ typedef struct adgs_sh_grads {
 } adgs_sh_grads;
 
 int adgs_raster_forward_rawsh(
+	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser,
+	adgs_alloc_fn imageBuffer, void* imageUser,
+	int P, int D, int M, int D_S, const float* background, int width, int height,
+	const float* means3D, const adgs_sh_source* sh, const float* flow_points, const float* semantic,
+	const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+	float* out_color, float* out_depth, float* img_opacity, float* img_flow, float* img_semantic,
+	int inv_depth, int* radii, int debug, void* stream);
+
+/* ... and its forward-only form (see adgs_raster_render) */
+int adgs_raster_render_rawsh(
 	adgs_alloc_fn geometryBuffer, void* geometryUser, adgs_alloc_fn binningBuffer, void* binningUser,
 	adgs_alloc_fn imageBuffer, void* imageUser,
 	int P, int D, int M, int D_S, const float* background, int width, int height,

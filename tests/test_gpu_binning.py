@@ -186,18 +186,20 @@ def test_c5_size_bucket_binning_equals_sort_binning_bit_for_bit(monkeypatch):
 
 
 # ---- round 6: depth slabs (binning.hip: slab_sort / slab_sort_slow)
-def _forward_only(sc, cam=None):
-    """One forward through the drop-in API with FIXED camera tensors (a camera's own slab bounds live under the addresses of its matrices)."""
+def _forward_only(sc, cam=None, train=False):
+    """One forward through the drop-in API with FIXED camera tensors (a camera's own slab bounds live under the addresses of its matrices).
+    train: the training forward (inputs that require gradients; only a training frame leaves a camera its own bounds and tile order) --
+    else the forward-only render of an evaluation."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     cam = cam or {k: sc[k].cuda() for k in ("viewmatrix", "projmatrix", "campos", "bg")}
     s = GaussianRasterizationSettings(sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], cam["bg"], 1.0, cam["viewmatrix"], cam["projmatrix"], sc["sh_degree"],
                                       cam["campos"], False, True, False)
     d = lambda t: t.cuda()
-    with torch.no_grad():
-        out = GaussianRasterizer(s)(means3D=d(sc["means3D"]), means2D=torch.zeros(sc["P"], 3, device="cuda"), opacities=d(sc["opacities"]), shs=d(sc["shs"]),
-                                    scales=d(sc["scales"]), rotations=d(sc["rotations"]), flow_points=d(sc["flow_points"]), semantic=d(sc["semantic"]))
+    with torch.set_grad_enabled(train):
+        out = GaussianRasterizer(s)(means3D=d(sc["means3D"]).requires_grad_(train), means2D=torch.zeros(sc["P"], 3, device="cuda"), opacities=d(sc["opacities"]),
+                                    shs=d(sc["shs"]), scales=d(sc["scales"]), rotations=d(sc["rotations"]), flow_points=d(sc["flow_points"]), semantic=d(sc["semantic"]))
     torch.cuda.synchronize()
-    return [o.clone() for o in out], cam
+    return [o.detach().clone() for o in out], cam
 
 
 def _translucent(P, W, H, focal, seed, scale_mult=0.004):
@@ -264,7 +266,7 @@ def test_a_cameras_own_bounds_and_another_cameras(monkeypatch):
     ref_b, cam_b = _forward_only(b)
     monkeypatch.setenv("ADGS_BINNING", "bucket")
     for scene, cam, ref in ((a, cam_a, ref_a), (a, cam_a, ref_a), (b, cam_b, ref_b), (a, cam_a, ref_a), (b, cam_b, ref_b)):
-        out, _c = _forward_only(scene, cam)
+        out, _c = _forward_only(scene, cam, train=True)
         assert _stats()["tiles"] >= 2048 and _stats()["bucket_binning"] == 1
         for x, y in zip(out, ref):
             assert torch.equal(x, y)

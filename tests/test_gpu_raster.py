@@ -628,9 +628,8 @@ def test_repeated_backward_over_one_forward_state():
     assert float(runs[0][0].abs().sum()) > 0
     # more forwards than the frame table holds in between: the backward of the first one no longer finds its entry
     loss0 = forward()
-    with torch.no_grad():
-        for _ in range(260):
-            forward()
+    for _ in range(260):                      # (training forwards: under no_grad they would be forward-only renders, which leave the table alone)
+        forward()
     late = torch.autograd.grad(loss0, L)
     for a, b in zip(runs[0], late):
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), float((a - b).abs().max())
