@@ -159,7 +159,7 @@ struct BinStateV2 {
 	// bucket binning: unsorted (cell-grouped) records as two arrays -- depth keys; (id, mask) --, final (id, mask) entries
 	uint32_t* rec_key; uint2* rec_im; uint2* entries; uint32_t* slow_list;
 	// slab_sort workgroups a frame of R_cells pairs needs at most: a cell of n pairs has 2^lg <= max(1, 2 n / SLAB_TARGET) slabs
-	static size_t slab_grid(size_t R_cells, size_t ncells) { return std::max<size_t>(2 * R_cells / SLAB_TARGET + ncells + 1, ncells << forced_lg()); }
+	static size_t slab_grid(size_t R_cells, size_t ncells) { return std::max<size_t>(2 * R_cells / SLAB_TARGET_FOREIGN + ncells + 1, ncells << forced_lg()); }
 	static int forced_lg() { const char* v = getenv("ADGS_SLABS_LG"); return (v && *v) ? std::min(std::max(atoi(v), 0), (int)MAX_SLAB_LG) : 0; }      // test hook: every cell gets 2^lg slabs (read by the FORWARD only)
 	// every tile's own block + blocks drawn from the cursor, each of which may end partly used
 	static size_t pool_chunks(size_t R_fine, size_t ntiles) { return R_fine / WAVE + (2 * (size_t)POOL_BLOCK + 1) * ntiles + 1; }
@@ -630,6 +630,7 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		// bucket binning accumulates the fine-tile total and a few device words, and splits its cells by a snapshot of slab bounds (the
 		// camera's own, else the thread's latest): zeroed / copied by the sh0 kernel on the raw-SH path (no launch of its own), by bin_prepare otherwise
 		FramePrologue pro{ nullptr, 0, nullptr, nullptr, 0 };
+		bool own_bounds = false, sample_bounds = false;
 		if (buckets) {
 			if (!fc->slab_bounds) {
 				// first bucket-binned frame of this thread on this device: the table starts as "everything in slab 0" (all bounds 0xffffffff).
@@ -647,7 +648,10 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 			pro.zero = reinterpret_cast<uint32_t*>(geom.bucket_fine_total()); pro.n_zero = 2 * SCAN_AUX_SLOTS + 8;
 			if (fc->slab_bounds) {
 				// the camera's own bounds (its previous render left them in its hint entry) fit best; a camera's first render takes the thread's latest
+				// ... the thread's latest on images too small for camera entries; else the frame samples its own (cell_sample)
 				const bool own = hint && hint->written && hint->extra >= ncells * SLAB_ROW;
+				own_bounds = own;
+				sample_bounds = !own && fwd_hint_wanted && env_int("ADGS_SLAB_SAMPLE", 1) != 0;
 				pro.copy_dst = geom.bounds; pro.copy_src = own ? hint->buf + wtiles + 16 : fc->slab_bounds; pro.n_copy = (int)(ncells * SLAB_ROW);
 			}
 			if (!sh_src && launch_bin_prepare(pro, stream) != 0) return -1;
@@ -690,6 +694,7 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		sa.cell_count = geom.cell_count(); sa.cell_start = geom.cell_start; sa.cell_ranges = img.cell_ranges; sa.ncells = (int)ncells;
 		sa.max_chunks = (uint32_t)std::min(MAX_CHUNKS, std::max(1, env_int("ADGS_MAX_CHUNKS", MAX_CHUNKS))); sa.d_counts = geom.d_counts();      // ADGS_MAX_CHUNKS: test hook for the overflow fallback
 		sa.fine_total = geom.bucket_fine_total(); sa.cell_work = geom.cell_work; sa.force_lg = buckets ? env_int("ADGS_SLABS_LG", -1) : -1;
+		sa.slab_target = own_bounds ? (uint32_t)SLAB_TARGET : (uint32_t)SLAB_TARGET_FOREIGN;      // sampled bounds carry sampling noise: measured, a 3072 target overflows a slab in one view of a few
 		sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
 		// who publishes the frame's totals to the host mailbox: slab_sort's last workgroup (it also knows the fullest slab) -- or, when the host
 		// waits for the totals BEFORE it enqueues the binning (ADGS_NO_SPECULATION), cell_scan
@@ -732,7 +737,9 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 				ga.bounds = geom.bounds; ga.bounds_out = fc->slab_bounds; ga.d_counts = geom.d_counts(); ga.slow_list = bin.slow_list;
 				ga.bounds_out2 = (training && hint && hint->extra >= ncells * SLAB_ROW) ? hint->buf + wtiles + 16 : nullptr;
 				ga.box = mb->dev; ga.seq = exact ? seq_rerun : seq; ga.cap_cells = exact ? 0xffffffffu : sa.cap_cells; ga.cap_fine = exact ? ~0ull : sa.cap_fine;
-				{ StageTimer t(ST_SORT, stream); if (launch_slab_sort(ga, stream) != 0) return -1; }
+				{ StageTimer t(ST_SORT, stream);
+				  if (sample_bounds && launch_cell_sample(ga, geom.bounds, stream) != 0) return -1;
+				  if (launch_slab_sort(ga, stream) != 0) return -1; }
 				ADGS_LAUNCH_CHECK(debug, stream);
 				return 0;
 			}

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 	(void)block_excl_scan_1024(nch, s_wave, &nchunks_total);
 	// depth slabs of the cell: the smallest power of two that brings its pairs per slab to SLAB_TARGET or below -- one slab_sort workgroup each
 	uint32_t lg = 0;
-	while (lg < (uint32_t)MAX_SLAB_LG && (n >> lg) > (uint32_t)SLAB_TARGET) lg++;
+	while (lg < (uint32_t)MAX_SLAB_LG && (n >> lg) > a.slab_target) lg++;
 	if (a.force_lg >= 0) lg = min((uint32_t)a.force_lg, (uint32_t)MAX_SLAB_LG);
 	const uint32_t m = (c < a.ncells && n) ? 1u << lg : 0u;
 	const uint32_t w0 = block_excl_scan_1024(m, s_wave, &work_total);
@@ -411,6 +411,39 @@ __device__ __forceinline__ void radix_rank(SlabLds& s, uint32_t n, uint32_t (&ke
 	}
 }
 
+// This frame's own slab bounds from a SAMPLE of every cell's depth keys, for frames that have no bounds of their camera's previous render
+// (a camera's first render, an evaluation view): the bounds of ANOTHER camera's render misfit narrow slabs by factors -- a cluster of object
+// Gaussians that moves across a bound doubles a slab -- and an oversized slab costs slab_sort_slow three streams of its cell (measured: 350 us
+// of a 750 us forward-only C3 frame).  One workgroup per cell: up to GS_NMAX keys at equal strides through the cell's unsorted records (their
+// order is the Gaussians' index order interleaved over the scatter workgroups: a stride sees scene and object Gaussians in proportion), ranked
+// like a slab, and the sample of rank floor(q S / 128) is bound q - 1.  With S = 4096 samples a slab of 1/16 of the cell is hit 256 +- 15 times:
+// slab sizes within ~20 % (3 sigma) of their target.  Cells of one slab are skipped.
+__global__ void __launch_bounds__(GS_THREADS, 4) cell_sample_kernel(SlabSortArgs a, uint32_t* __restrict__ bounds /* this frame's [ncells][SLAB_ROW] */) {
+	__shared__ __attribute__((aligned(16))) SlabLds s;
+	const int tid = threadIdx.x;
+	const uint32_t cell = blockIdx.x;
+	if (!(a.d_counts[2] == 0u && a.d_counts[3] == 0u && a.d_counts[0] <= a.cap)) return;
+	const uint2 range = a.cell_ranges[cell];
+	const uint32_t n_c = range.y - range.x;
+	if (n_c == 0u || a.cell_work[cell].y == 0u) return;      // empty, or one slab: no bounds needed
+	const uint32_t S = min(n_c, (uint32_t)GS_NMAX);
+	uint32_t key[GS_ITEMS], id[GS_ITEMS], rank[GS_ITEMS], src[GS_ITEMS];
+#pragma unroll
+	for (int r = 0; r < GS_ITEMS; r++) {
+		const uint32_t i = r * GS_THREADS + tid;
+		id[r] = i; src[r] = 0u;
+		key[r] = a.rec_key[range.x + min((uint32_t)(((unsigned long long)(2u * i + 1u) * n_c) / (2ull * S)), n_c - 1u)];      // clamped: all loads in flight
+	}
+	bool radix = false;
+	if (!bucket_rank(s, S, key, id, rank)) { radix = true; radix_rank(s, S, key, id, src, rank); }
+#pragma unroll
+	for (int r = 0; r < GS_ITEMS; r++) {
+		const bool have = radix ? rank[r] != 0xffffffffu : (uint32_t)(r * GS_THREADS + tid) < S;
+		if (have) publish_bound(bounds, cell, rank[r], S, key[r]);
+	}
+	// (a cell of fewer than 128 samples leaves some bounds unwritten: stale words -> the row may be unsorted -> the generic kernel; it has one slab anyway)
+}
+
 // One workgroup per (cell, slab): see the file header.  The common case only: a sorted bounds row (the slab is then a
 // key RANGE: two compares per streamed key), a selection of at most GS_NMAX entries, a bucket sort that succeeds; anything else is appended
 // to a.slow_list for slab_sort_slow (which needs twice the registers: kept out of this kernel, three workgroups of which share a CU).
@@ -715,6 +748,12 @@ int launch_slab_sort(const SlabSortArgs& a, hipStream_t stream) {
 	if (a.ncells <= 0) return 0;
 	hipLaunchKernelGGL(slab_sort_kernel, dim3(a.grid), dim3(GS_THREADS), 0, stream, a);
 	hipLaunchKernelGGL(slab_sort_slow_kernel, dim3(128), dim3(GS_THREADS), 0, stream, a);      // the handed-over slabs + the mailbox (its last workgroup)
+	ADGS_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+int launch_cell_sample(const SlabSortArgs& a, uint32_t* bounds, hipStream_t stream) {
+	if (a.ncells <= 0) return 0;
+	hipLaunchKernelGGL(cell_sample_kernel, dim3((unsigned)a.ncells), dim3(GS_THREADS), 0, stream, a, bounds);
 	ADGS_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -1151,7 +1151,8 @@ extern "C" int adgs_deform_forward_flow(const adgs_deform_params* p, const adgs_
 			const int nb_rot = (a.o.rotation || a.o.opacity || a.o.scales) ? nb_o : 0;
 			const int nb_xyz = (a.o.xyz || a.flow_xyz) ? (a.xyz_rows ? (int)((3 * (size_t)p->No + B - 1) / B) : nb_o) : 0;
 			a.n_begin = 0; a.n_end = N;
-#define ADGS_CALL(NQ) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define ADGS_CALL(NQ) do { if (nb_rot + nb_xyz + nb_scene == 0) break;      /* a model without objects on the raw-scene path: nothing to deform */ \
+				if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 				hipLaunchKernelGGL((deform_fwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz); } while (0)
 			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
 #undef ADGS_CALL
@@ -1221,7 +1222,7 @@ extern "C" int adgs_deform_backward_flow(const adgs_deform_params* p, const adgs
 				nb_scene = (p->use_time_mask & ADGS_DEFORM_SKIP_SCENE) ? 0 : (a.scene4 ? ((p->Ns + 3) / 4 + B - 1) / B : (p->Ns + B - 1) / B);
 			a.n_begin = 0; a.n_end = N;
 #define ADGS_CALL(NQ) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_bwd_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-				hipLaunchKernelGGL((deform_bwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz); } while (0)
+				if (nb_rot + nb_xyz + nb_scene != 0) hipLaunchKernelGGL((deform_bwd_kernel<NQ>), dim3(nb_rot + nb_xyz + nb_scene), dim3(B), lds, stream, a, nb_rot, nb_xyz); } while (0)
 			ADGS_NQ_SWITCH(a.fr, ADGS_CALL)
 #undef ADGS_CALL
 			ADGS_HIP_CHECK(hipGetLastError());

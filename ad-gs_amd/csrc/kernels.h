@@ -111,6 +111,7 @@ constexpr int SLAB_ROW = 128;           // words per cell in a table of depth-sl
 constexpr int MAX_SLAB_LG = 7;          // a cell's list is built as 2^lg <= 128 independently sorted depth slabs; lg per cell, from the cell's pair count
 constexpr int SLAB_TARGET = 3072;       // ... the smallest lg that brings the cell's pairs per slab to this or below (3/4 of what one sort holds: with the camera's
                                         // own bounds the slabs of a cell are equal to within its depth ties; 2048 made 1120 workgroups of C3's 70 cells: two rounds)
+constexpr int SLAB_TARGET_FOREIGN = 2048;      // ... when the bounds are not the camera's own (sampled by cell_sample; another render's on small images): room for a 2 x misfit
 constexpr int GS_NMAX = 4096;           // entries one slab_sort workgroup sorts at a time inside its CU
 constexpr int MAX_CHUNKS = 16384;       // a frame of more than MAX_CHUNKS x GS_NMAX pairs takes the device-wide sort
 // pinned host mailbox the device publishes the frame totals to (api.hip: the host polls `seq`)
@@ -125,6 +126,7 @@ struct CellScanArgs {
 	uint32_t max_chunks;                // more GS_NMAX-entry units than this: d_counts[2] (the host re-bins with the device-wide sort)
 	uint2* cell_work;                   // [ncells + 1] <- (first slab_sort workgroup of the cell, its lg); [ncells] = (workgroups in all, 0)
 	int force_lg;                       // >= 0: every cell gets 2^force_lg slabs (ADGS_SLABS_LG: tests)
+	uint32_t slab_target;               // the smallest lg that brings a cell's pairs per slab to this or below
 	uint32_t* d_counts;                 // [0] pairs, [1] slab_sort workgroups, [2] more than max_chunks x GS_NMAX pairs, [3] the totals exceed the capacity,
 	                                    // [4] slab_sort workgroups done, [5] the fullest slab (GS_NMAX units), [6..7] fine-tile total
 	const unsigned long long* fine_total;
@@ -151,6 +153,8 @@ struct SlabSortArgs {
 	Mailbox* box; uint32_t seq; uint32_t cap_cells; unsigned long long cap_fine;      // the last workgroup to finish publishes the frame's totals
 };
 int launch_slab_sort(const SlabSortArgs& a, hipStream_t stream);
+// this frame's bounds [ncells][SLAB_ROW] from a sample of every cell's keys (frames without bounds of their camera's previous render)
+int launch_cell_sample(const SlabSortArgs& a, uint32_t* bounds, hipStream_t stream);
 // sorted frames (device-wide radix sort): the 32-quantiles of every cell from the sorted (cell | depth) keys
 int launch_bounds_from_sorted(const uint64_t* keys, const uint2* cell_ranges, int ncells, const uint32_t* d_total, uint32_t cap, uint32_t* bounds_out, hipStream_t stream);
 

@@ -243,7 +243,10 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
     if sh_raw[0].size(0) + sh_raw[1].size(0) != P:
         raise RuntimeError("raw SH tensors do not match the number of Gaussians")
     f32 = dict(dtype=torch.float32, device=dev)
-    alloc = lambda written, *shape: (torch.empty if (written and P != 0) else torch.zeros)(shape, **f32)
+    # an output no kernel writes (absent input) is a zero image: materialised for the training forward (autograd hands it on), a broadcast
+    # view of one zero for the forward-only render (29 MB of fill per 1920x1280 frame for an image nobody asked for)
+    zero_img = (lambda *shape: torch.zeros((), **f32).expand(shape)) if not training else (lambda *shape: torch.zeros(shape, **f32))
+    alloc = lambda written, *shape: torch.empty(shape, **f32) if (written and P != 0) else zero_img(*shape)
     out_color, out_depth, img_opacity = alloc(True, NUM_CHANNELS, H, W), alloc(True, 1, H, W), alloc(True, 1, H, W)
     img_flow, img_semantic = alloc(flow_points.size(0) != 0, FLOW_CHANNELS, H, W), alloc(D_S > 0, D_S, H, W)
     radii = (torch.empty if P != 0 else torch.zeros)((P,), dtype=torch.int32, device=dev)

@@ -36,7 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "ad-gs_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")
 ITERATION_CONFIGS = {"C4": dict(cams=3, densify_every=0), "C5": dict(cams=5, densify_every=10)}
 
 
@@ -753,6 +753,62 @@ def quick_measure(config, steps, device, use_fs, variant="default", mode=None, w
                 os.environ[k] = v
 
 
+def inference_measure(config, steps, device, cameras=16, graph=False, env_res=1024, warm=None):
+    """Forward-only frames/s: the number the reference itself reports (render.py:52-55,86: `render(view, gaussians, env_map, pipeline)["render"]`
+    clipped to [0, 1], under torch.no_grad() :156, FPS over the evaluation views) -- gaussian_renderer.render() on the HIP path: per-frame
+    deformation, the forward-only rasterizer entry (adgs_raster_render_rawsh: no replay lists, no accumulator lines, no tile order), the
+    environment map composited in the blend epilogue.  Every step renders another view of the pool (an evaluation renders every view once:
+    the views' first renders are part of the warm-up only because the pool is cycled).  graph: one HIP graph per view (adgs.graph)."""
+    import types
+    import torch
+    from adgs import synthetic, _lib, graph as adgs_graph
+    from adgs.env import EnvironmentMap
+    from adgs.model import SyntheticGaussianModel
+    from gaussian_renderer import render
+    cfg = synthetic.CONFIGS[config]
+    sc = synthetic.to_z_up_world(build_scene(config))          # driving-dataset world frame: cameras look horizontally (examples/train_iteration.py)
+    model = SyntheticGaussianModel.from_scene(sc, device=device, seed=0)
+    model.raw_sh, model.raw_scene = True, True
+    env_map = EnvironmentMap(env_res, 3, device=device)
+    with torch.no_grad():
+        env_map.grid_map.copy_(torch.rand(env_map.grid_map.shape, generator=torch.Generator().manual_seed(3)).to(device))
+    pipe = types.SimpleNamespace(inv_depth=True, debug=False)
+    cams = []
+    for cam, t in camera_pool(cfg, cameras):
+        c = synthetic.camera_object(synthetic.camera_to_z_up(cam), time=t)
+        for name in ("world_view_transform", "full_proj_transform", "camera_center"):      # scene/cameras.py:77-80: the matrices live on the GPU
+            setattr(c, name, getattr(c, name).to(device))
+        c.cam_id = len(cams)          # scene/env.py:44-76 caches a camera's rays under its id
+        cams.append(c)
+
+    def view(k):
+        def fn():
+            with torch.no_grad():
+                return torch.clip(render(cams[k], model, env_map, pipe)["render"], 0.0, 1.0)
+        return fn
+    fns = [view(k) for k in range(len(cams))]
+    reruns0 = _lib.frame_status()["eager_reruns"]
+    if graph:
+        cache = adgs_graph.GraphCache(lambda k: fns[k], warmup=2)
+        step = lambda i=0: cache(i % len(fns))
+    else:
+        step = lambda i=0: fns[i % len(fns)]()
+    for i in range(warm if warm is not None else max(15, 2 * len(fns))):
+        step(i)
+    elapsed, ms = timed_loop(step, steps, torch.cuda.synchronize)
+    res = {"workload": "%s forward-only: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects, deformation + rasterizer + %d^2 x 6 environment map" % (
+               config, cfg["P"], cfg["W"], cfg["H"], cfg["sh_degree"], cfg["n_objects"], env_res),
+           "frames_per_s": round(steps / elapsed, 1), "ms_per_frame": round(elapsed / steps * 1e3, 4), "steps": steps, "views": len(fns),
+           "launch": "HIP graph replay (one graph per view)" if graph else "eager", "step_ms": step_stats(ms)}
+    if graph:
+        res["graph_replays_fitted_their_capacity"] = bool(cache.validate(repair=False))
+    else:
+        res["capacity_reruns"] = _lib.frame_status()["eager_reruns"] - reruns0
+    st = _lib.frame_status()
+    res["fullest_slab_units"] = st["fullest_slab_units"]
+    return res
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks from here (this process has not touched the GPU), relay
     their output and exit with their status."""
@@ -1269,6 +1325,19 @@ def main():
                     gc.collect(); torch.cuda.empty_cache()
                 except Exception as exc:
                     result["reference_api_path"] = "failed: %r" % (exc,)
+                # forward-only frames/s: the reference's own reported number (eval render FPS, render.py:52-55,86 under no_grad :156)
+                try:
+                    inf = []
+                    for c, n in (("C3", 200), ("C2", 300), ("C1", 300)):
+                        for g in (False, True):
+                            try:
+                                inf.append(inference_measure(c, n, device, cameras=K, graph=g))
+                            except Exception as exc:
+                                inf.append({"workload": c + " forward-only", "launch": "HIP graph replay" if g else "eager", "failed": repr(exc)})
+                            gc.collect(); torch.cuda.empty_cache()
+                    result["inference"] = inf
+                except Exception as exc:
+                    result["inference"] = "failed: %r" % (exc,)
                 # a whole training iteration (train.py:47-167) at C3: render + every loss and regulariser + both Adam steps + the
                 # amortised neighbour-index / densification work, with per-stage HIP-event times (examples/train_iteration.py)
                 try:
