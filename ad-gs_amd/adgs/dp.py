@@ -150,7 +150,9 @@ def _expand_grads():
     """adgs_sh_grads (include/adgs_rasterizer.h): ONE ctypes mirror for both users of the struct (the rasterizer backward and the
     expansion), so that its size cannot drift from the C side again; tests/test_abi_and_oracle_knn.py checks sizeof against the library."""
     from diff_gaussian_rasterization._C import ShGrads
-    return ShGrads()
+    g = ShGrads()
+    g.struct_bytes = ctypes.sizeof(ShGrads)
+    return g
 
 
 def hip_sh_grad_expand(cams, W, C, P, Ns, row0, xyz_head, D, M, outs, _cache=None):

@@ -82,8 +82,15 @@ class BackwardClaim:
     """What one rasterizer backward was granted by BackwardEpilogue.claim: the adgs_sh_adam block, which tensors it covers (`fused`:
     name -> True) and the tensors that must stay alive until the kernels have been enqueued."""
 
-    def __init__(self, struct, fused, keep):
-        self.struct, self.fused, self.keep = struct, fused, keep
+    def __init__(self, struct, fused, keep, undo=None):
+        self.struct, self.fused, self.keep, self._undo = struct, fused, keep, undo
+
+    def rollback(self):
+        """The backward the claim was made for did not run (the native call raised before any kernel was enqueued): the step counters go
+        back, the tensors are not "already stepped" any more, and the optimizer is armed again as it was."""
+        if self._undo is not None:
+            self._undo()
+            self._undo = None
 
 
 class BackwardEpilogue:
@@ -149,7 +156,14 @@ class BackwardEpilogue:
             return None
         (b1, b2), eps = betas_eps
         st_block.beta1, st_block.beta2, st_block.eps = float(b1), float(b2), float(eps)
-        return BackwardClaim(st_block, fused, keep)
+        stepped = list(self.claimed)
+
+        def undo():
+            for t in stepped:
+                opt.state[t]["step"] -= 1
+            self.claimed = [t for t in self.claimed if not any(t is u for u in stepped)]
+            self.armed = True
+        return BackwardClaim(st_block, fused, keep, undo)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -160,6 +174,10 @@ class FusedAdam(torch.optim.Optimizer):
         environment map).  Only valid while nothing but this optimizer writes the moments: moments that arrive from elsewhere
         (a loaded or edited state) are detected by their address and size and treated as active everywhere."""
         self.skip_dormant_tiles = bool(skip_dormant_tiles)
+        if skip_dormant_tiles and in_backward:
+            # the in-backward kernels update moments without marking tiles: a later ordinary step() would take every tile of such a tensor
+            # for dormant and skip tiles whose moments are not zero (round-5 advisor finding)
+            raise ValueError("FusedAdam: skip_dormant_tiles and in_backward cannot be combined (the in-backward step does not keep the tile map)")
         if weight_decay != 0 or amsgrad:
             raise ValueError("FusedAdam implements the configuration the reference uses: no weight decay, no amsgrad")
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):

@@ -1205,6 +1205,14 @@ extern "C" int adgs_raster_backward_rawsh(
 	float* dL_dcov3D, const adgs_sh_grads* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dflow, float* dL_dsemantic,
 	const float* grad_img_opacity, const float* img_opacity, int inv_depth, int debug, void* stream) {
 	if (!sh || !dL_dsh) { set_error("adgs_raster_backward_rawsh: NULL SH source / gradients"); return -1; }
+	// the gradient block is versioned by its size: what the caller's header did not know yet is absent (NULL)
+	adgs_sh_grads grads_full;
+	memset(&grads_full, 0, sizeof(grads_full));
+	if (dL_dsh->struct_bytes < offsetof(adgs_sh_grads, scene_xyz) || dL_dsh->struct_bytes > 4096) {
+		set_error("adgs_raster_backward_rawsh: adgs_sh_grads.struct_bytes must be sizeof(adgs_sh_grads) of the caller's header"); return -1;
+	}
+	memcpy(&grads_full, dL_dsh, std::min<size_t>((size_t)dL_dsh->struct_bytes, sizeof(grads_full)));
+	dL_dsh = &grads_full;
 	if (P > 0 && check_sh_source(sh, P, M, "adgs_raster_backward_rawsh") != 0) return -1;
 	const ShSource src = to_sh_source(sh);
 	ShGradDst dst;

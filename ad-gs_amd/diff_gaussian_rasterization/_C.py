@@ -196,8 +196,9 @@ class ShSource(ctypes.Structure):
 
 class ShGrads(ctypes.Structure):
     """adgs_sh_grads (include/adgs_rasterizer.h)."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor",
-                                               "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity", "bg_image", "adam")]
+    _fields_ = [("struct_bytes", ctypes.c_uint64)] + [(n, ctypes.c_void_p) for n in (
+        "scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform", "rgb_factor",
+        "scene_xyz", "scene_scaling", "scene_rotation", "scene_opacity", "bg_image", "adam")]
 
 
 def _sh_source(raw, dev):
@@ -324,6 +325,7 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     if P != 0:
         src, keep_sh = _sh_source(sh_raw, dev)
         gs = ShGrads()
+        gs.struct_bytes = ctypes.sizeof(ShGrads)
         for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
             setattr(gs, name, _ptr(t))
         gs.rgb_factor = _ptr(rgb_factor)

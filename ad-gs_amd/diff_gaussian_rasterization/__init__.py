@@ -154,12 +154,17 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         # FusedAdam(in_backward=True), armed for this backward: the step is applied where the gradient rows are produced
         claim = ctx.adam.claim(dict(scene_rest=scene_rest, obj_rest=obj_rest, scene_deform=scene_deform, obj_deform=obj_deform),
                                dict(zip(("scene_rest", "obj_rest", "scene_deform", "obj_deform"), need[2:6])), factored) if ctx.adam is not None else None
-        res = _C.rasterize_gaussians_backward_rawsh(
-            s.bg, means3D, radii, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
-            grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, need, s.sh_degree, s.campos,
-            geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
-            want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False,
-            geo_grad_alloc=(arena.take if arena is not None else None), adam=claim)
+        try:
+            res = _C.rasterize_gaussians_backward_rawsh(
+                s.bg, means3D, radii, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
+                grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, need, s.sh_degree, s.campos,
+                geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
+                want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False,
+                geo_grad_alloc=(arena.take if arena is not None else None), adam=claim)
+        except Exception:
+            if claim is not None:          # the native call validates everything before its first launch: nothing was stepped
+                claim.rollback()
+            raise
         (g_means2D, g_opac, g_means3D, g_sh, g_scales, g_rot, g_flow, g_sem, g_factor, g_geo, g_bg) = res
         if factored:
             ctx.factor_sink.append(g_factor)

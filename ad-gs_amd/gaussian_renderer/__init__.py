@@ -19,18 +19,36 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 _BLACK = {}
 
 
+def _camera_matrices(cam, device):
+    """The camera's view / projection matrices and centre as CONTIGUOUS tensors on `device`, the same three tensors at every call while the
+    camera does not change.  The reference's Camera builds world_view_transform as a transposed (non-contiguous) tensor (scene/cameras.py:76-82):
+    taking `.contiguous()` per render would hand the library a fresh temporary each time -- and the library recognises a camera by the
+    addresses of its matrices (the tile order and the depth-slab bounds of its previous render: include/adgs_rasterizer.h,
+    adgs_frame_status.order_hint).  Kept on the camera object itself; rebuilt when a matrix is replaced or written in place."""
+    src = (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+    sig = tuple((t.data_ptr(), t._version, str(t.device)) for t in src) + (str(device),)
+    ent = getattr(cam, "_adgs_matrices", None)
+    if ent is not None and ent[0] == sig:
+        return ent[1]
+    mats = tuple((t if t.device == device else t.to(device)).contiguous() for t in src)
+    try:
+        cam._adgs_matrices = (sig, mats)
+    except AttributeError:              # a camera type without instance attributes: per-call temporaries (no hints)
+        pass
+    return mats
+
+
 def _camera_settings(cam, pc, pipe, scale_modifier, device):
     """Everything the rasterizer needs to know about the view (the background colour is black: the sky comes from env_map).
     The reference's Camera keeps its matrices on the GPU (scene/cameras.py:77-80); a camera object that holds host tensors costs
-    three blocking uploads per render here -- each one a stream synchronisation."""
-    on = lambda t: t if t.device == device else t.to(device)
+    three blocking uploads at its first render here (kept on the camera afterwards: _camera_matrices)."""
     black = _BLACK.get(device)
     if black is None:
         black = _BLACK[device] = torch.zeros(3, dtype=torch.float32, device=device)
+    view, proj, center = _camera_matrices(cam, device)
     return GaussianRasterizationSettings(
         int(cam.image_height), int(cam.image_width), math.tan(0.5 * cam.FoVx), math.tan(0.5 * cam.FoVy),
-        black, scale_modifier, on(cam.world_view_transform), on(cam.full_proj_transform),
-        pc.active_sh_degree, on(cam.camera_center), False, pipe.inv_depth, pipe.debug)
+        black, scale_modifier, view, proj, pc.active_sh_degree, center, False, pipe.inv_depth, pipe.debug)
 
 
 def _deformed_state(pc, t, flow_pkg, full_rows=False):

@@ -183,6 +183,8 @@ typedef struct adgs_sh_source {
 } adgs_sh_source;
 struct adgs_sh_adam;      /* adgs_optim.h */
 typedef struct adgs_sh_grads {
+	uint64_t struct_bytes;   /* sizeof(adgs_sh_grads) as the CALLER was compiled: members beyond it are taken as NULL, so a caller built against an
+	                            older header (before `adam`) keeps working; 0 or less than the first seven pointers is an error */
 	float *scene_dc, *obj_dc, *scene_rest, *obj_rest, *scene_deform, *obj_deform;   /* NULL = not wanted */
 	float *rgb_factor;   /* [P,3] or NULL: the clamp-masked colour gradient dL/dRGB * (1 - clamped) (backward.cu:20-139), 0 for
 	                        Gaussians with radii == 0 -- the one per-camera vector every SH gradient row above is a multiple of
