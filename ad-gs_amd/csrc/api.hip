@@ -649,7 +649,9 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 			if (fc->slab_bounds) {
 				// the camera's own bounds (its previous render left them in its hint entry) fit best; a camera's first render takes the thread's latest
 				// ... the thread's latest on images too small for camera entries; else the frame samples its own (cell_sample)
-				const bool own = hint && hint->written && hint->extra >= ncells * SLAB_ROW;
+				// (a frame being captured into a graph: its entry belongs to the graph, starts as "everything in slab 0" and is rewritten by every
+				// replay -- the first replay bisects, the others split by their own previous bounds; baking "sample" in would cost every replay the pass)
+				const bool own = hint && (hint->written || hint->captured) && hint->extra >= ncells * SLAB_ROW;
 				own_bounds = own;
 				sample_bounds = !own && fwd_hint_wanted && env_int("ADGS_SLAB_SAMPLE", 1) != 0;
 				pro.copy_dst = geom.bounds; pro.copy_src = own ? hint->buf + wtiles + 16 : fc->slab_bounds; pro.n_copy = (int)(ncells * SLAB_ROW);

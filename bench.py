@@ -828,6 +828,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="C3", help="BASELINE.json config: C1, C2, C3 (default), C4, C5")
     ap.add_argument("--cams-per-iter", type=int, default=0, help="iteration mode: cameras per iteration, dealt round-robin to the ranks (default: C4 3, C5 5)")
+    ap.add_argument("--cams-per-rank", type=int, default=0, help="k cameras per GPU and step with ONE gradient exchange behind them (k x N cameras per iteration, dealt "
+                    "round-robin: weak scaling with the exchange amortised over k renders; DESIGN.md section 6)")
     ap.add_argument("--densify-every", type=int, default=-1, help="iteration mode: densify/prune every k iterations inside the timed loop (default: C5 10, else off)")
     ap.add_argument("--cameras", type=int, default=int(os.environ.get("ADGS_BENCH_CAMERAS", "16")),
                     help="cameras / time stamps in the pool every GPU cycles through, one per step (train.py:55-61 draws a random camera per iteration); "
@@ -882,6 +884,11 @@ def main():
     barrier = dist.barrier if world > 1 else None
 
     # ---- which cameras does a step render?
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.cams_per_rank > 0:
+        if args.cams_per_iter > 0 or args.config in ITERATION_CONFIGS:
+            raise SystemExit("--cams-per-rank is the weak-scaling form of --cams-per-iter: give one of them, on C3")
+        args.cams_per_iter = args.cams_per_rank * world_env
     iteration_mode = args.config in ITERATION_CONFIGS or args.cams_per_iter > 0
     if iteration_mode and cfg["n_objects"] == 0:
         raise SystemExit("--cams-per-iter needs a dynamic config (C3, C4, C5)")
@@ -955,6 +962,8 @@ def main():
             ex._arena_setup()
     densify_thr = [None]
 
+    # ADGS_BENCH_STREAMS=S (default 1): the cameras of an iteration on S side streams (step() below)
+    side_streams = [torch.cuda.Stream(device) for _ in range(int(os.environ.get("ADGS_BENCH_STREAMS", "1")))] if int(os.environ.get("ADGS_BENCH_STREAMS", "1")) > 1 else None
     use_graph = args.graph == "on"
     if use_graph and (world > 1 or force_coll or iteration_mode or factored):
         raise SystemExit("--graph on: single GPU, one camera per step (the exchange of the multi-GPU step is issued eagerly)")
@@ -966,12 +975,29 @@ def main():
             return
         if factored:
             ex.begin(n_cams)                     # the all-gather starts from inside the backward, as soon as the last factor exists
-        for f in (frames if iteration_mode else [my_pool[it % pool_k]]):
+        def one_camera(f):
             outs = f.forward(sink_for=ex.sink_for if factored else None)
             torch.autograd.backward(outs, up_list)
             if densify_every:
                 with torch.no_grad():
                     model.add_densification_stats(dict(viewspace_points=f.last_means2D, radii=f.last_radii))
+        if side_streams and iteration_mode and len(frames) > 1:
+            # The cameras of an iteration are independent until the gradient sum (train.py:55-61,74): camera i runs on side stream i mod S,
+            # forward and backward (autograd runs a backward on its forward's stream).  The host enqueues them in order -- a forward returns
+            # once its binning totals are known -- so what overlaps on the GPU is one camera's blend tail / backward with the next camera's
+            # deformation, preprocess and binning.  Gradients accumulate into the shared .grad tensors: autograd
+            # orders the accumulation across streams; the exchange / optimizer wait for both streams.
+            main = torch.cuda.current_stream()
+            for s_ in side_streams:
+                s_.wait_stream(main)
+            for i, f in enumerate(frames):
+                with torch.cuda.stream(side_streams[i % len(side_streams)]):
+                    one_camera(f)
+            for s_ in side_streams:
+                main.wait_stream(s_)
+        else:
+            for f in (frames if iteration_mode else [my_pool[it % pool_k]]):
+                one_camera(f)
         if factored:
             ct, cp, ft = ex_args[0 if iteration_mode else it % pool_k]
             ex.reduce(ct, cp, flow_times=ft)
@@ -1143,7 +1169,7 @@ def main():
         result = {
             "metric": "fwd+bwd frames/s",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if iteration_mode else "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (iteration_mode and not args.cams_per_rank) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         }
         config = {"workload": "%s: %d Gaussians, %dx%d, SH deg %d, %d dynamic objects%s, %s" % (
@@ -1158,6 +1184,7 @@ def main():
                                                                           "the pool's cameras return every %d steps with unchanged parameters, a training run returns once per epoch" % pool_k),
             "launch": ("HIP graph replay, one graph per camera (adgs.graph); every replay fitted its capacity: %s" % graph_ok) if use_graph else "eager",
             "parallelism": "dp%d (camera-parallel over RCCL)" % world if world > 1 else "single GPU", "gradient_exchange": exchange,
+            "camera_streams": len(side_streams) if (side_streams and iteration_mode) else 1,
             "step_ms_hip_events": dict(step_stats(step_ms), first=round(step_ms[0], 4))}
         if os.environ.get("ADGS_BENCH_DUMP_STEPS"):
             config["step_ms_series"] = [round(x, 4) for x in step_ms[:int(os.environ["ADGS_BENCH_DUMP_STEPS"])]]

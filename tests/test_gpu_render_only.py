@@ -114,3 +114,4 @@ def test_render_path_replayed_as_a_hip_graph():
 def test_the_c_abi_exports_the_render_entry_points():
     lib = _lib.lib()
     assert hasattr(lib, "adgs_raster_render") and hasattr(lib, "adgs_raster_render_rawsh")
+
