@@ -27,7 +27,8 @@ static thread_local std::string g_last_error;
 struct FrameContext {
 	adgs_frame_stats stats;
 	size_t hint_cells, hint_fine;          // speculative binning capacities (v2 forward): previous frames' counts + 25 %
-	unsigned hint_max_cell_chunks;         // chunks of the fullest cell of the last bucket-binned frame
+	unsigned hint_max_cell_chunks;         // the fullest slab (GS_NMAX units) of the last bucket-binned frames, decaying
+	bool bucket_frame_pending;             // the last forward was bucket-binned: its fullest slab is (or will be) in the mailbox
 	long long reruns;                      // forwards whose capacity was too small (binning + blend enqueued twice)
 	int last_order_hint;                   // the last forward was handed a tile order an earlier forward of the same camera and stream left (OrderHints)
 	// Depth-slab bounds of the bucket binning (binning.hip): [MAX_CELLS][SLAB_ROW] device words, the 32-quantiles of every cell's depth keys
@@ -552,6 +553,13 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		// EXPERIMENTS.md.
 		const char* binning_env = env_str("ADGS_BINNING");
 		const std::string binning_mode = binning_env ? binning_env : "";
+		{	// the hot-slab hint: what the device last reported (see the end of this block), decaying
+			const MailboxRef* mbp = mailbox();
+			const unsigned old_m = fc->hint_max_cell_chunks;
+			const unsigned seen = (mbp && fc->bucket_frame_pending) ? mbp->host->max_cell_chunks : 0u;
+			fc->hint_max_cell_chunks = std::max(seen, old_m - std::max(1u, old_m / 16) * (old_m ? 1u : 0u));
+			fc->bucket_frame_pending = false;
+		}
 		bool buckets = ncells <= (size_t)MAX_CELLS && cell_tiles <= 16 && binning_mode != "sort" &&
 			(binning_mode == "bucket" || (fc->hint_cells <= (size_t)std::max(1, env_int("ADGS_BUCKET_MAX_CHUNKS", 4)) * GS_NMAX * (ncells << MAX_SLAB_LG) &&
 			                              fc->hint_max_cell_chunks <= (unsigned)std::max(1, env_int("ADGS_BUCKET_MAX_CELL_CHUNKS", 16))));
@@ -651,7 +659,10 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 				// ... the thread's latest on images too small for camera entries; else the frame samples its own (cell_sample)
 				// (a frame being captured into a graph: its entry belongs to the graph, starts as "everything in slab 0" and is rewritten by every
 				// replay -- the first replay bisects, the others split by their own previous bounds; baking "sample" in would cost every replay the pass)
-				const bool own = hint && (hint->written || hint->captured) && hint->extra >= ncells * SLAB_ROW;
+				// A forward-only render never takes an entry's bounds: it does not rewrite them, so an entry found under RECYCLED matrix addresses
+				// (another camera's, freed since) would misfit every render of the view -- a training frame heals such an entry with its first
+				// render (measured: the bench's forward-only line at 1 585 instead of 1 980 frames/s behind the training lines of the same process).
+				const bool own = training && hint && (hint->written || hint->captured) && hint->extra >= ncells * SLAB_ROW;
 				own_bounds = own;
 				sample_bounds = !own && fwd_hint_wanted && env_int("ADGS_SLAB_SAMPLE", 1) != 0;
 				pro.copy_dst = geom.bounds; pro.copy_src = own ? hint->buf + wtiles + 16 : fc->slab_bounds; pro.n_copy = (int)(ncells * SLAB_ROW);
@@ -698,9 +709,10 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		sa.fine_total = geom.bucket_fine_total(); sa.cell_work = geom.cell_work; sa.force_lg = buckets ? env_int("ADGS_SLABS_LG", -1) : -1;
 		sa.slab_target = own_bounds ? (uint32_t)SLAB_TARGET : (uint32_t)SLAB_TARGET_FOREIGN;      // sampled bounds carry sampling noise: measured, a 3072 target overflows a slab in one view of a few
 		sa.cap_cells = speculate ? (uint32_t)cap_cells : 0xffffffffu; sa.cap_fine = speculate ? (unsigned long long)cap_fine : ~0ull;
-		// who publishes the frame's totals to the host mailbox: slab_sort's last workgroup (it also knows the fullest slab) -- or, when the host
-		// waits for the totals BEFORE it enqueues the binning (ADGS_NO_SPECULATION), cell_scan
-		sa.box = speculate ? nullptr : mb->dev; sa.seq = seq;
+		// cell_scan publishes the frame's totals to the host mailbox (the first kernel that knows them: until the middle of round 6 the LAST
+		// kernel of the binning did, and the host came back from its wait with only the blend left in the queue -- 0.2 ms to get the backward's
+		// first kernel enqueued, which a slow host misses: C3 at 1.01 ms per step against 0.96 ms of kernels on such a box)
+		sa.box = mb->dev; sa.seq = seq;
 		if (buckets) {
 			StageTimer t(ST_SCAN, stream);
 			if (launch_cell_colscan(geom.counts, (P + 255) / 256, (int)ncells, geom.cell_count(), stream) != 0) return -1;
@@ -720,8 +732,6 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		BinStateV2 bin;
 		// rectangle-coverage masks in the key bits above (cell | depth): one bit per tile row and per tile column of a cell
 		const int mask_shift = 32 + bit;          // 2 * cell_tiles + bit <= 32: v2_cell_tiles
-		uint32_t seq_rerun = 0;
-		bool exact = false;      // the second enqueue of a frame (exact sizes: nothing is compared against a capacity any more)
 		auto enqueue_binning = [&](size_t cells, size_t fine, const uint32_t* d_count) -> int {
 			size_t bb = 0;
 			if (buckets) {
@@ -738,7 +748,7 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 				ga.cell_ranges = img.cell_ranges; ga.ncells = (int)ncells; ga.cell_work = geom.cell_work; ga.grid = (uint32_t)BinStateV2::slab_grid(cells, ncells); ga.rec_key = bin.rec_key; ga.rec_im = bin.rec_im; ga.ent_f = bin.entries; ga.cap = cap;
 				ga.bounds = geom.bounds; ga.bounds_out = fc->slab_bounds; ga.d_counts = geom.d_counts(); ga.slow_list = bin.slow_list;
 				ga.bounds_out2 = (training && hint && hint->extra >= ncells * SLAB_ROW) ? hint->buf + wtiles + 16 : nullptr;
-				ga.box = mb->dev; ga.seq = exact ? seq_rerun : seq; ga.cap_cells = exact ? 0xffffffffu : sa.cap_cells; ga.cap_fine = exact ? ~0ull : sa.cap_fine;
+				ga.box = mb->dev;
 				{ StageTimer t(ST_SORT, stream);
 				  if (sample_bounds && launch_cell_sample(ga, geom.bounds, stream) != 0) return -1;
 				  if (launch_slab_sort(ga, stream) != 0) return -1; }
@@ -821,7 +831,6 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 			// the re-run fits by construction; the device word can also be set without speculation (cell_scan raises it when the chunk
 			// table is full), and a blend launched with it set renders nothing
 			ADGS_HIP_CHECK(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), stream));
-			exact = true;
 			if (buckets && !chunk_table_full) {      // slab_sort's completion counter / fullest slab / hand-over list
 				ADGS_HIP_CHECK(hipMemsetAsync(geom.d_counts() + 4, 0, 2 * sizeof(uint32_t), stream));
 			}
@@ -834,22 +843,19 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 				StageTimer t(ST_SCAN, stream);
 				if (exclusive_scan_u32_sum(geom.cells_touched, geom.offsets, (size_t)P + 1, geom.scan_temp, geom.fine_touched, geom.fine_total, stream) != 0) return -1;
 			}
-			// slab_sort publishes once more (the fullest slab of the frame as it was really binned): under a sequence number of its own
-			uint32_t seq2 = 0;
-			if (buckets) { seq2 = mb->next_seq++; seq_rerun = seq2; }
 			if (enqueue_binning(R_cells, R_fine, nullptr) != 0) return -1;
 			if (launch_blend() != 0) return -1;
-			if (buckets && R_cells != 0 && wait_mailbox(mb, seq2, stream) != 0) return -1;      // (rare path: a frame that is enqueued twice)
 		}
 		{	// capacity hints for the next frame: 25% head-room over this frame, slow decay of older peaks
 			const size_t want_c = R_cells + R_cells / 4 + 4096, want_f = R_fine + R_fine / 4 + 4096;
 			const size_t old_c = fc->hint_cells, old_f = fc->hint_fine;
 			fc->hint_cells = std::max(want_c, old_c - old_c / 16);
 			fc->hint_fine = std::max(want_f, old_f - old_f / 16);
-			// the fullest cell of a bucket-binned frame; a sorted frame does not report one: the old figure decays, so that a scene
-			// with a persistent hot cell re-tries the bucket path once in a few dozen frames instead of every other frame
-			const unsigned old_m = fc->hint_max_cell_chunks;
-			fc->hint_max_cell_chunks = std::max(buckets ? mb->host->max_cell_chunks : 0u, old_m - std::max(1u, old_m / 16) * (old_m ? 1u : 0u));
+			// the fullest slab of a bucket-binned frame: the LATEST figure the device has reported (slab_sort_slow writes it when the frame's
+			// binning is through -- this frame's if the caller drains the stream between frames, an earlier one in a free-running loop: it is a
+			// policy hint); a sorted frame does not report one: the old figure decays, so that a scene with a persistent hot cell re-tries
+			// the bucket path once in a few dozen frames instead of every other frame
+			fc->bucket_frame_pending = buckets;
 		}
 		fc->stats.num_rendered = (int64_t)R_cells; fc->stats.tiles = (int32_t)ntiles; fc->stats.sort_bits = buckets ? 32 : 32 + bit;
 		fc->stats.sort_passes = buckets ? 4 : (32 + bit + 7) / 8;
@@ -1367,7 +1373,7 @@ extern "C" size_t adgs_test_abi_sizeof(int which) {
 }
 extern "C" void adgs_test_set_capacity_hints(long long pairs, long long fine_pairs) {
 	FrameContext* fc = frame_context();
-	fc->hint_cells = (size_t)std::max(0ll, pairs); fc->hint_fine = (size_t)std::max(0ll, fine_pairs); fc->hint_max_cell_chunks = 0u;
+	fc->hint_cells = (size_t)std::max(0ll, pairs); fc->hint_fine = (size_t)std::max(0ll, fine_pairs); fc->hint_max_cell_chunks = 0u; fc->bucket_frame_pending = false;
 	// ... and what the binning has learned about depths: the thread's slab bounds back to "everything in slab 0", the cameras' own tables forgotten
 	(void)hipDeviceSynchronize();
 	if (fc->slab_bounds) (void)hipMemset(fc->slab_bounds, 0xff, (size_t)MAX_CELLS * SLAB_ROW * sizeof(uint32_t));

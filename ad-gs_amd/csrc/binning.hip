@@ -118,8 +118,11 @@ __global__ void __launch_bounds__(CS_THREADS) cell_scan_kernel(CellScanArgs a) {
 		a.d_counts[0] = total; a.d_counts[1] = work_total; a.d_counts[2] = over; a.d_counts[3] = nofit;
 		a.d_counts[4] = 0u; a.d_counts[5] = 0u;      // slab_sort: workgroups done, the fullest slab (in units of GS_NMAX entries)
 		a.d_counts[6] = (uint32_t)fine; a.d_counts[7] = (uint32_t)(fine >> 32);
+		// the totals go to the host mailbox HERE, before the scatter and the slab sorts run: the host (which has the rest of the forward enqueued
+		// by now) learns whether the frame fitted its capacity while ~270 us of this frame's work are still queued, and spends them enqueueing
+		// the backward.  (The fullest slab -- a statistic and a policy hint -- follows from slab_sort_slow, unsequenced.)
 		if (a.box) {
-			a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit; a.box->max_cell_chunks = 0u;
+			a.box->r_cells = total; a.box->r_fine = fine; a.box->oversize = over; a.box->n_groups = nchunks_total; a.box->overflow = nofit;
 			if (nofit) a.box->overflow_count = a.box->overflow_count + 1u;
 			a.box->cap_cells = a.cap_cells; a.box->cap_fine = a.cap_fine;
 			__threadfence_system();
@@ -568,7 +571,7 @@ __global__ void __launch_bounds__(GS_THREADS, 6) slab_sort_kernel(SlabSortArgs a
 // entries (a thread's first frame, a camera the bounds do not fit), long runs of equal depths, a bounds row that is not sorted.  The
 // generic form of everything: the slab of a key by slab128_of (any row), a selection that does not fit is bisected at the median of the
 // first GS_NMAX entries it collected and both halves are streamed again, the bucket sort falls back to the radix sort.  A few workgroups
-// walk the list; the last one to finish publishes the frame's totals to the host mailbox.
+// walk the list; the last one to finish reports the frame's fullest slab to the host mailbox.
 __global__ void __launch_bounds__(GS_THREADS, 4) slab_sort_slow_kernel(SlabSortArgs a) {
 	__shared__ __attribute__((aligned(16))) SlabLds s;
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -684,8 +687,8 @@ __global__ void __launch_bounds__(GS_THREADS, 4) slab_sort_slow_kernel(SlabSortA
 		}
 	}
 	}
-	// the last workgroup to finish publishes the frame's totals to the host mailbox (the host sizes the binning buffer from them and learns
-	// here whether the frame fitted its capacity)
+	// the last workgroup to finish leaves the fullest slab of the frame (in units of GS_NMAX entries) in the host mailbox: a statistic
+	// (adgs_get_frame_status) and the hot-cell hint of the next frames' binning policy; the totals went out with cell_scan
 	__syncthreads();
 	if (tid == 0) {
 		if (max_rounds) atomicMax(a.d_counts + 5, max_rounds);
@@ -693,16 +696,10 @@ __global__ void __launch_bounds__(GS_THREADS, 4) slab_sort_slow_kernel(SlabSortA
 		s.last = atomicAdd(a.d_counts + 4, 1u) == gridDim.x - 1u ? 1u : 0u;
 	}
 	__syncthreads();
-	if (s.last && tid == 0) {
+	if (s.last && tid == 0 && a.box) {
 		__threadfence();
-		const uint32_t over = a.d_counts[2], nofit = a.d_counts[3];
-		a.box->r_cells = total; a.box->r_fine = (unsigned long long)a.d_counts[6] | ((unsigned long long)a.d_counts[7] << 32);
-		a.box->oversize = over; a.box->n_groups = a.d_counts[1]; a.box->overflow = nofit;
 		a.box->max_cell_chunks = *(volatile uint32_t*)(a.d_counts + 5);
-		if (nofit) a.box->overflow_count = a.box->overflow_count + 1u;
-		a.box->cap_cells = a.cap_cells; a.box->cap_fine = a.cap_fine;
 		__threadfence_system();
-		a.box->seq = a.seq;                       // published last: the host spins on it
 	}
 }
 

@@ -150,7 +150,7 @@ struct SlabSortArgs {
 	uint32_t* bounds_out2;              // ... and the camera's own table (api.hip: OrderHints), for its next render (nullptr: none)
 	uint32_t* slow_list;                // [1 + grid] slabs slab_sort hands to slab_sort_slow, (cell << 8) | slab: [0] = count (zeroed by cell_scatter)
 	uint32_t* d_counts;
-	Mailbox* box; uint32_t seq; uint32_t cap_cells; unsigned long long cap_fine;      // the last workgroup to finish publishes the frame's totals
+	Mailbox* box;                       // the last workgroup to finish reports the fullest slab (max_cell_chunks)
 };
 int launch_slab_sort(const SlabSortArgs& a, hipStream_t stream);
 // this frame's bounds [ncells][SLAB_ROW] from a sample of every cell's keys (frames without bounds of their camera's previous render)

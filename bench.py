@@ -70,13 +70,14 @@ def alg_bytes(P, V, R, X, T, M, F, D_S, passes):
 def alg_bytes_v2(P, V, Rc, E, X, T, M, F, D_S, passes, E_pub=None, bucket=False, ddir=True):
     """Algorithmic bytes per launch of the default (v2, coarse-binned) pipeline -- DESIGN.md section 5.
     Rc = (cell, Gaussian) pairs that are sorted, E = (tile, Gaussian) entries blended, E_pub = entries the backward replays.
-    bucket: bucket binning (binning.hip) -- "scan" = the one-workgroup bucket scan (16384 counters in, starts + groups out),
-    "duplicate_keys" = the scatter (16 B per Gaussian in, 12 B per pair out), "radix_sort" = the in-CU group sort (12 B per pair
-    in, 8 B out: the radix passes never leave the CU), no range pass.
+    bucket: bucket binning (binning.hip) -- "scan" = the column scan of the counts matrix [P / 256][cells] (read + written once) + the cell scan,
+    "duplicate_keys" = the scatter (16 B per Gaussian in, its counts row, 12 B per pair out), "radix_sort" = the depth-slab sort (a cell's
+    4-byte keys streamed once per slab of the cell -- ~8 slabs at C3 --, 8 B per pair gathered, 8 B out: the sort never leaves the CU), no range pass.
     ddir: the preprocess forward stores d colour / d view direction (36 B per visible Gaussian) and the backward reads those instead of
     the SH row a second time (raw-SH path, 16 coefficients: round 5)."""
     out = X * (12 + 4 + 4 + 12 * F + 4 * D_S + 4)
-    binning = ({"scan": 16384 * 4 * 3, "duplicate_keys": P * 16 + Rc * 12, "radix_sort": Rc * 20, "tile_ranges": 0} if bucket else
+    ncells, slabs = 70, 8
+    binning = ({"scan": ((P + 255) // 256) * ncells * 8, "duplicate_keys": P * 16 + ((P + 255) // 256) * ncells * 4 + Rc * 12, "radix_sort": Rc * (4 * slabs + 8 + 8), "tile_ranges": 0} if bucket else
                {"scan": P * 12, "duplicate_keys": V * (8 + 4) + Rc * 12, "radix_sort": passes * Rc * 24 + Rc * 8, "tile_ranges": Rc * 8})
     return {
         "preprocess_fwd": P * (12 + 12 + 16 + 4 + 12 * M) + P * 12 + V * (64 + 24 + 1 + 64) + (V * 36 if ddir else 0),      # Splat line, binning words, clamp byte, zeroed accumulator line (no filter record since round 4)
@@ -355,7 +356,7 @@ def frame_work_figures(frame, settings, use_fs, device, with_ref=True, full=Fals
     return chunks, r_ref, published, scanned
 
 
-HBM_FILL_GBS = 6900.0       # the fastest stream this box class delivers (write-only fill, profiles/r05/hbm_rates.txt): nothing can beat it
+HBM_FILL_GBS = 6900.0       # the fastest stream this box class delivers (write-only fill, profiles/r06/hbm_rates.txt): nothing can beat it
 
 
 def dominant_roofline(stage, stage_bytes_per_frame, mean_ms_per_bracket, brackets, frames):
@@ -389,7 +390,7 @@ def library_stamp():
 
 def committed_pmc(stage, config, measured_case):
     """HBM traffic / VALU issue rate of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's build
-    (profiles/r05/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
+    (profiles/r06/, collected with this same command line; counters cannot be read from inside the process).  Only attached for
     the case they were measured on (C3, flow+semantic, default pipeline); absent files leave `traffic` null; counters collected on
     another build of the library are flagged (`counters_stale`)."""
     if config != "C3" or not measured_case:
@@ -403,7 +404,7 @@ def committed_pmc(stage, config, measured_case):
         for k, v in tr.items():
             if kname and kname in k:
                 out["traffic"] = v["hbm_bytes_per_launch"]
-                out["traffic_source"] = ("profiles/r05/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
+                out["traffic_source"] = ("profiles/r06/hbm_traffic_per_kernel.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of this command; "
                                          "FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, per launch)")
                 break
         pmf = json.load(open(os.path.join(PROFILE_DIR, "pmc_blend_kernels.json")))
@@ -414,7 +415,7 @@ def committed_pmc(stage, config, measured_case):
             out["wave_state_shares"] = pm.get("wave_state_shares")
             out["waves_per_simd_mean"] = pm.get("waves_per_simd_mean")
             out["valu_note"] = ("the blend kernels are far from the HBM roof by construction (SURVEY.md 8(d)): wave64 VALU instructions per SIMD and cycle "
-                                "(rocprofv3 --pmc, profiles/r05/pmc_blend_kernels.json; normalisation: tools/pmc_blend.py) against the full-rate fp32 issue rate "
+                                "(rocprofv3 --pmc, profiles/r06/pmc_blend_kernels.json; normalisation: tools/pmc_blend.py) against the full-rate fp32 issue rate "
                                 "0.5 x the sustained shader clock over the nominal 2.4 GHz = %.3f -- a ceiling the kernels' instruction mixes cannot reach (half-rate "
                                 "compares / selects, quarter-rate exp / rcp: tools/isa_mix.py, tools/microbench/issue_hazards.hip); wave_state_shares: where the "
                                 "resident waves' cycles go (issuing / parked at s_waitcnt / ready but not issued)" % VALU_PEAK_PER_SIMD_CYCLE)
@@ -476,11 +477,11 @@ STAGE_KERNELS = {"preprocess_fwd": (("sh0_rows_kernel", "sh0_kernel", "preproces
                  "preprocess_bwd": (("preprocess_bwd_kernel", "deform_lin_param_grad_kernel"), "b"),      # + the SH-deformation gradient rows of the raw-SH path (launched by the raster backward)
                  "deform_fwd": (("deform_fwd_kernel",), "f"), "deform_bwd": (("deform_bwd_kernel",), "b"),
                  "scan": (("cell_colscan_kernel", "cell_scan_kernel"), "f"), "duplicate_keys": (("cell_scatter_kernel",), "f"),
-                 "radix_sort": (("chunk_sort_kernel",), "f"), "tile_ranges": (("chunk_merge_kernel",), "f")}
+                 "radix_sort": (("cell_sample_kernel", "slab_sort_kernel", "slab_sort_slow_kernel"), "f")}      # the "radix_sort" slot of a bucket-binned frame: the depth-slab sort
 
 
 def committed_kernel_stats():
-    """Per-stage kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this round (profiles/r05/kernel_stats.csv):
+    """Per-stage kernel time per step from the committed rocprofv3 --kernel-trace --stats summary of this round (profiles/r06/kernel_stats.csv):
     total duration of the stage's kernels over the number of forwards / backwards in the profiled run (= the calls of the blend kernel of that
     direction).  Empty when the file is absent."""
     import csv

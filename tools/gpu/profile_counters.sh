@@ -1,9 +1,9 @@
 #!/bin/bash
-# profiles of `bench.py` (C3, driver settings) for profiles/r05: rocprofv3 kernel stats, HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes),
+# profiles of `bench.py` (C3, driver settings) for profiles/r06: rocprofv3 kernel stats, HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes),
 # SQ counters of the blend kernels (wave states, LDS bank conflicts), the training iteration.  Counter passes never share a run with a trace
 # domain; the program itself follows `--`.
 R=$GRAFT_REPO_ROOT
-o=$R/gpurun_out/${1:-r05_prof}; mkdir -p $o
+o=$R/gpurun_out/${1:-r06_prof}; mkdir -p $o
 cd /tmp && export TMPDIR=/tmp
 export ADGS_BENCH_PMC=0
 B="python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
