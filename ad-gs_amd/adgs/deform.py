@@ -140,7 +140,7 @@ def _make_func_eval_cached(v, order_args, n_params):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.stream_ptr(dev)
 
 
 def _dp(t):

@@ -35,7 +35,7 @@ class DensifySide(ctypes.Structure):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.stream_ptr(dev)
 
 
 def _ptr(t):

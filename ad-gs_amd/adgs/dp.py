@@ -181,7 +181,7 @@ def hip_sh_grad_expand(cams, W, C, P, Ns, row0, xyz_head, D, M, outs, _cache=Non
         setattr(g, n, ptr(t))
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().adgs_sh_grad_expand(len(cams), arr, ptr(W), int(C), int(P), int(Ns), int(row0), ptr(xyz_head), int(D), int(M),
-                                                  ctypes.byref(g), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                                  ctypes.byref(g), _lib.stream_ptr(dev)),
                    "adgs_sh_grad_expand")
 
 
@@ -279,7 +279,7 @@ def hip_lin_grad_expand(terms, W, C, count, scale, out):
             raise RuntimeError("adgs_lin_grad_expand: factors must be contiguous float32 [count,3]")
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().adgs_lin_grad_expand(len(terms), arr, W.data_ptr(), int(C), int(count), float(scale), out.data_ptr(),
-                                                   ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), "adgs_lin_grad_expand")
+                                                   _lib.stream_ptr(out.device)), "adgs_lin_grad_expand")
 
 
 class _FactorSink(list):

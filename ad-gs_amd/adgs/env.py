@@ -32,7 +32,7 @@ class _EnvBackground(torch.autograd.Function):
         Rarr = (ctypes.c_float * 9)(*R9)
         with torch.cuda.device(gm.device):
             _lib.check(_lib.lib().adgs_envmap_forward(C, Hm, Wm, gm.data_ptr(), H, W, float(focal), Rarr, out.data_ptr(),
-                                                      ctypes.c_void_p(torch.cuda.current_stream(gm.device).cuda_stream)), "adgs_envmap_forward")
+                                                      _lib.stream_ptr(gm.device)), "adgs_envmap_forward")
         ctx.save_for_backward(out)
         ctx.meta = (tuple(grid_map.shape), C, Hm, Wm, H, W, float(focal), Rarr)
         ctx.marked = marked
@@ -50,7 +50,7 @@ class _EnvBackground(torch.autograd.Function):
         with torch.cuda.device(out.device):
             _lib.check(_lib.lib().adgs_envmap_backward_marked(C, Hm, Wm, H, W, focal, Rarr, out.data_ptr(), g.data_ptr(), gg.data_ptr(),
                                                               mk.marks.data_ptr() if mk is not None else None, ADAM_TILE,
-                                                              ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), "adgs_envmap_backward")
+                                                              _lib.stream_ptr(out.device)), "adgs_envmap_backward")
         if mk is not None:
             mk.issued(gg)
         return gg, None, None, None, None, None

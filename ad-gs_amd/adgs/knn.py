@@ -26,7 +26,7 @@ def knn_points(p1, p2, K=1):
         with torch.cuda.device(p1.device):
             ws = torch.empty(int(lib.adgs_knn_points_workspace_bytes(A, N, K)), dtype=torch.uint8, device=p1.device)
             _lib.check(lib.adgs_knn_points(A, a.data_ptr(), N, p.data_ptr(), D, K, idx.data_ptr(), dists.data_ptr(), ws.data_ptr(),
-                                           ctypes.c_void_p(torch.cuda.current_stream(p1.device).cuda_stream)), "adgs_knn_points")
+                                           _lib.stream_ptr(p1.device)), "adgs_knn_points")
     return _KNN(dists[None], idx[None], None)
 
 

@@ -17,7 +17,7 @@ SLOTS = 256        # ADGS_LOSS_SLOTS
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.stream_ptr(dev)
 
 
 class _Slice:
@@ -80,7 +80,7 @@ _ARENAS = {}
 def _work(device, doubles):
     """(zeroed work buffer of `doubles` doubles for one loss term, its _Slice token: call done() after the term's launches)"""
     if not torch.cuda.is_current_stream_capturing():
-        key = (device, torch.cuda.current_stream(device).cuda_stream, doubles)
+        key = (device, _lib.stream_ptr(device).value, doubles)
         a = _ARENAS.get(key)
         if a is None:
             if len(_ARENAS) > 48:

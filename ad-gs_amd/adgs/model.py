@@ -66,8 +66,11 @@ class SyntheticGaussianModel:
         return [getattr(self, n) for n in _RAW if getattr(self, n, None) is not None and getattr(self, n).numel() > 0]
 
     def zero_grad(self):
-        for p in self.parameters():
-            p.grad = None
+        d = self.__dict__
+        for n in _RAW:
+            p = d.get(n)
+            if p is not None:
+                p.grad = None
 
     @property
     def get_scene_pts_num(self):

@@ -294,7 +294,7 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.lib()
         for (dev, b1, b2, eps), items in batches.items():
             with torch.cuda.device(dev):
-                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                stream = _lib.stream_ptr(dev)
                 for i in range(0, len(items), MAX_GROUPS):
                     chunk = items[i:i + MAX_GROUPS]
                     arr = (AdamGroup * len(chunk))(*[c[0] for c in chunk])
@@ -324,4 +324,4 @@ def add_densification_stats(xyz_gradient_accum, denom, max_radii2D, viewspace_gr
     with torch.cuda.device(radii.device):
         _lib.check(_lib.lib().adgs_densification_stats(N, radii.data_ptr(), viewspace_grad.data_ptr(), xyz_gradient_accum.data_ptr(), denom.data_ptr(),
                                                        max_radii2D.data_ptr() if max_radii2D is not None else None,
-                                                       ctypes.c_void_p(torch.cuda.current_stream(radii.device).cuda_stream)), "adgs_densification_stats")
+                                                       _lib.stream_ptr(radii.device)), "adgs_densification_stats")

@@ -67,7 +67,7 @@ _on = _lib.on_device
 
 
 def _stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return _lib.stream_ptr(device)
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -145,8 +145,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     has_sr = scales.size(0) != 0
     has_flow = flow_points.size(0) != 0 and dL_dout_flow is not None and dL_dout_flow.numel() != 0
     has_sem = D_S > 0 and dL_dout_semantic is not None and dL_dout_semantic.numel() != 0
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = z(True, P, 3), z(True, P, 3), z(True, P, NUM_CHANNELS), z(True, P, 1)
-    dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = z(True, P, 2, 2), z(True, P, 1), z(True, P, 6), z(True, P, M, 3)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(True, P, 3), z(True, P, 3), z(True, P, NUM_CHANNELS)
+    dL_dopacity, dL_dcov3D, dL_dsh = z(True, P, 1), z(True, P, 6), z(True, P, M, 3)
+    # dL_ddepths / dL_dconic never leave this function (the reference allocates them as scratch, rasterize_points.cu:195-206): the default
+    # pipeline keeps them inside its fused preprocess backward (NULL = not wanted, include/adgs_rasterizer.h)
+    dL_ddepths, dL_dconic = (None, None) if lazy else (z(True, P, 1), z(True, P, 2, 2))
     dL_dscales, dL_drotations = z(has_sr, P, 3), z(has_sr, P, 4)
     dL_dflow_points, dL_dsemantic = z(has_flow, P, FLOW_CHANNELS), z(has_sem, P, D_S)
     if P != 0:

@@ -21,6 +21,6 @@ def distCUDA2(points):
         return means
     with torch.cuda.device(points.device):
         ws = torch.empty((int(lib.adgs_knn_workspace_bytes(P)),), dtype=torch.uint8, device=points.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(points.device).cuda_stream)
+        stream = _lib.stream_ptr(points.device)
         _lib.check(lib.adgs_knn_dist2(P, pts.data_ptr(), means.data_ptr(), ws.data_ptr(), stream), "adgs_knn_dist2")
     return means

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("N,A,D,K", [(20000, 2500, 3, 8), (20000, 2500, 4, 8), (1000, 1000, 3, 1), (5000, 77, 4, 16), (3000, 300, 3, 32), (64, 8, 3, 8),
-                                     (100_000, 12_500, 4, 8)])
+                                     (100_000, 2_500, 4, 8)])      # (the oracle's cost is A x N: 12 500 anchors took 79 s of the suite's 1200 s limit)
 def test_knn_points_vs_oracle(N, A, D, K):
     from adgs.knn import knn_points
     rng = np.random.default_rng(N + A + D + K)
