@@ -26,10 +26,13 @@ json.dump(dict(out, _library_sha256_16=lib_stamp()), open(sys.argv[3], "w"), ind
 if len(sys.argv) > 4:
     # per-frame total: all launches of the run (bench.py with ADGS_BENCH_SKIP_STATS=1) divided by the number of frames
     # = launches of the blend backward (exactly one per frame)
-    frames = max(cf.get(next(k for k in cf if "render_bwd_v2_kernel" in k), 1), 1)
-    tot = sum((2.0 * fetch.get(k, 0.0) * cf.get(k, 0) + write.get(k, 0.0) * cw.get(k, 0)) * 1024 for k in set(fetch) | set(write))
-    json.dump({"frames": int(frames), "hbm_bytes_per_frame": int(tot / frames), "_library_sha256_16": lib_stamp(),
-               "note": "sum over ALL kernels of the run of 2*FETCH_SIZE + WRITE_SIZE (KiB), divided by the number of frames"}, open(sys.argv[4], "w"), indent=1)
-    print("frames", frames, "HBM bytes per frame %.1f MB" % (tot / frames / 1e6))
+    # (each pass by ITS OWN frame count: the two passes are two runs, and until round 6 both were divided by the fetch pass's count --
+    # a first r06 profile whose passes differed in length (217 / 117 frames) reported 1.91 GB where the kernels sum to 2.33)
+    bwd = lambda c: max(c.get(next((k for k in c if "render_bwd_v2_kernel" in k), ""), 1), 1)
+    frames, frames_w = bwd(cf), bwd(cw)
+    tot = sum(2.0 * fetch.get(k, 0.0) * cf.get(k, 0) * 1024 for k in fetch) / frames + sum(write.get(k, 0.0) * cw.get(k, 0) * 1024 for k in write) / frames_w
+    json.dump({"frames": int(frames), "frames_write_pass": int(frames_w), "hbm_bytes_per_frame": int(tot), "_library_sha256_16": lib_stamp(),
+               "note": "sum over ALL kernels of a run of 2*FETCH_SIZE (KiB) / its frames + WRITE_SIZE (KiB) / its frames"}, open(sys.argv[4], "w"), indent=1)
+    print("frames", frames, frames_w, "HBM bytes per frame %.1f MB" % (tot / 1e6))
 for k, v in list(out.items())[:24]:
     print(f"{k[:70]:70s} rd {v['read_bytes_per_launch']/1e6:9.1f} MB  wr {v['write_bytes_per_launch']/1e6:9.1f} MB")
