@@ -687,8 +687,15 @@ def timed_loop(step, steps, sync, barrier=None):
 
 
 def step_stats(ms):
-    return {"median": round(percentile(ms, 0.5), 4), "p10": round(percentile(ms, 0.1), 4), "p90": round(percentile(ms, 0.9), 4),
-            "min": round(min(ms), 4), "max": round(max(ms), 4)} if ms else {}
+    """Per-step times of a secondary line.  `outlier_steps`: steps of more than three medians (a shared box now and then stalls one step
+    of a run for 20 - 60 ms -- seen on three of this round's boxes, on a different line each time; `frames_per_s` of the line is the plain
+    mean and carries it, `frames_per_s_at_median_step` does not)."""
+    if not ms:
+        return {}
+    med = percentile(ms, 0.5)
+    return {"median": round(med, 4), "p10": round(percentile(ms, 0.1), 4), "p90": round(percentile(ms, 0.9), 4),
+            "min": round(min(ms), 4), "max": round(max(ms), 4), "outlier_steps": sum(1 for x in ms if x > 3.0 * med),
+            "frames_per_s_at_median_step": round(1e3 / med, 1) if med > 0 else None}
 
 
 def quick_measure(config, steps, device, use_fs, variant="default", mode=None, with_stats=False, warm=15, cameras=1, graph=False, env=None):
