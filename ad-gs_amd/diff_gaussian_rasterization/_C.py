@@ -72,9 +72,10 @@ def _stream_ptr(device):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, flow_points, semantic,
-                        degree, campos, prefiltered, inv_depth, debug, training=True):
+                        degree, campos, prefiltered, inv_depth, debug, training=True, plan=None):
     """training=False (extension): the forward-only render, adgs_raster_render -- the same images and radii bit for bit, the three
-    state buffers come back as scratch no backward may be run over."""
+    state buffers come back as scratch no backward may be run over.  plan (a dict, extension): filled with the validated inputs of this call
+    and their pointers, for rasterize_gaussians_backward(plan=...) of the same call pair (see rasterize_gaussians_rawsh)."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -107,6 +108,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             (semantic, "semantic"), (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"),
             (cov3D_precomp, "cov3D_precomp"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"))]
         bg_, m3_, sh_, col_, fl_, sem_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
+        if plan is not None:
+            plan["keep"] = keep
+            plan["ptrs"] = tuple(_ptr(t) for t in (bg_, m3_, sh_, col_, fl_, sem_, sc_, rot_, cov_, view_, proj_, cam_))
         try:
             with _on(dev):
                 rendered = _lib.check((lib.adgs_raster_forward if training else lib.adgs_raster_render)(
@@ -127,7 +131,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, dL_dout_flow,
                                  dL_dout_semantic, semantic, flow_points, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, img_opacity, grad_img_opacity, inv_depth, debug):
+                                 imageBuffer, img_opacity, grad_img_opacity, inv_depth, debug, plan=None):
     lib = _lib.lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -154,17 +158,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dflow_points, dL_dsemantic = z(has_flow, P, FLOW_CHANNELS), z(has_sem, P, D_S)
     if P != 0:
         keep = [_prep(t, dev, n) for t, n in (
-            (background, "bg"), (means3D, "means3D"), (sh, "sh"), (colors, "colors_precomp"), (flow_points, "flow_points"),
-            (semantic, "semantic"), (scales, "scales"), (rotations, "rotations"), (cov3D_precomp, "cov3D_precomp"),
-            (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"), (dL_dout_color, "dL_dout_color"),
-            (dL_dout_depth, "dL_dout_depth"), (dL_dout_flow, "dL_dout_flow"), (dL_dout_semantic, "dL_dout_semantic"),
+            (dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"), (dL_dout_flow, "dL_dout_flow"), (dL_dout_semantic, "dL_dout_semantic"),
             (grad_img_opacity, "grad_img_opacity"), (img_opacity, "img_opacity"))]
-        bg_, m3_, sh_, col_, fl_, sem_, sc_, rot_, cov_, view_, proj_, cam_, gc_, gd_, gf_, gs_, go_, io_ = keep
+        gc_, gd_, gf_, gs_, go_, io_ = keep
+        if plan is not None and "ptrs" in plan:      # validated and marshalled by the forward of this call pair
+            p_bg, p_m3, p_sh, p_col, p_fl, p_sem, p_sc, p_rot, p_cov, p_view, p_proj, p_cam = plan["ptrs"]
+        else:
+            keep2 = [_prep(t, dev, n) for t, n in (
+                (background, "bg"), (means3D, "means3D"), (sh, "sh"), (colors, "colors_precomp"), (flow_points, "flow_points"),
+                (semantic, "semantic"), (scales, "scales"), (rotations, "rotations"), (cov3D_precomp, "cov3D_precomp"),
+                (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"))]
+            p_bg, p_m3, p_sh, p_col, p_fl, p_sem, p_sc, p_rot, p_cov, p_view, p_proj, p_cam = (_ptr(t) for t in keep2)
         radii_ = _prep(radii, dev, "radii", torch.int32)
         with _on(dev):
             _lib.check(lib.adgs_raster_backward(
-                P, int(degree), M, int(R), D_S, _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(fl_), _ptr(sem_),
-                _ptr(sc_), float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(view_), _ptr(proj_), _ptr(cam_),
+                P, int(degree), M, int(R), D_S, p_bg, W, H, p_m3, p_sh, p_col, p_fl, p_sem,
+                p_sc, float(scale_modifier), p_rot, p_cov, p_view, p_proj, p_cam,
                 float(tan_fovx), float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
                 _ptr(gc_), _ptr(gd_), _ptr(gf_), _ptr(gs_),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
@@ -234,7 +243,10 @@ def _sh_source(raw, dev):
 
 
 def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                              image_height, image_width, sh_raw, flow_points, semantic, degree, campos, inv_depth, debug, training=True):
+                              image_height, image_width, sh_raw, flow_points, semantic, degree, campos, inv_depth, debug, training=True, plan=None):
+    """plan (a dict, extension): filled with what the backward of this very call needs again -- the adgs_sh_source struct, the validated
+    (contiguous) inputs and their pointers -- so that rasterize_gaussians_backward_rawsh(plan=...) does not validate and marshal them a
+    second time (the Python between the loss kernels and the backward's first launch is GPU idle time on a slow host)."""
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be on a HIP device; there is no CPU rasterizer")
     lib = _lib.lib()
@@ -267,6 +279,9 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
                                               (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"), (viewmatrix, "viewmatrix"),
                                               (projmatrix, "projmatrix"), (campos, "campos"))]
         bg_, m3_, fl_, sem_, op_, sc_, rot_, view_, proj_, cam_ = keep
+        if plan is not None:
+            plan["src"], plan["keep"] = src, (keep_sh, keep)
+            plan["ptrs"] = (_ptr(bg_), _ptr(m3_), _ptr(fl_), _ptr(sem_), _ptr(sc_), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_))
         try:
             with _on(dev):
                 rendered = _lib.check((lib.adgs_raster_forward_rawsh if training else lib.adgs_raster_render_rawsh)(
@@ -286,7 +301,7 @@ def rasterize_gaussians_rawsh(background, means3D, opacity, scales, rotations, s
 def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotations, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_semantic, semantic, flow_points, sh_raw,
                                        sh_needs_grad, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, img_opacity, grad_img_opacity,
-                                       inv_depth, debug, want_rgb_factor=False, geo_grad_alloc=None, adam=None):
+                                       inv_depth, debug, want_rgb_factor=False, geo_grad_alloc=None, adam=None, plan=None, want_sem_grad=True):
     """With want_rgb_factor the result carries one more entry: the [P,3] clamp-masked colour gradient every SH gradient row is a
     multiple of (include/adgs_exchange.h); combined with sh_needs_grad all False the SH rows are not materialised at all.
     adam: an adgs.optim.BackwardClaim (FusedAdam(in_backward=True)) -- the tensors it names take the Adam step inside the backward
@@ -305,7 +320,10 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     # preprocess backward here): not materialised on this path (NULL = not wanted, include/adgs_rasterizer.h)
     dL_dcolors = dL_ddepths = dL_dconic = dL_dcov3D = None
     dL_dflow_points = e(P, FLOW_CHANNELS) if has_flow else torch.zeros((P, FLOW_CHANNELS), dtype=torch.float32, device=dev)
-    dL_dsemantic = e(P, D_S) if has_sem else torch.zeros((P, D_S), dtype=torch.float32, device=dev)
+    if not want_sem_grad and D_S == 1:
+        dL_dsemantic = None        # a constant semantic input (the object mask of gaussian_renderer.render()): NULL = not wanted (channel 0 is a row of the preprocess backward)
+    else:
+        dL_dsemantic = e(P, D_S) if has_sem else torch.zeros((P, D_S), dtype=torch.float32, device=dev)
     sh_needs_grad = list(sh_needs_grad)
     fused = adam.fused if (adam is not None and P != 0) else {}
     for i, name in enumerate(("scene_rest", "obj_rest", "scene_deform", "obj_deform")):
@@ -326,7 +344,10 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
     if P == 0 and len(sh_raw) > 8 and sh_raw[8] is not None:
         bg_grad = dL_dout_color.clone()                # T = 1 everywhere
     if P != 0:
-        src, keep_sh = _sh_source(sh_raw, dev)
+        if plan is not None and "src" in plan:       # the forward of this call pair validated and marshalled these already
+            src = plan["src"]
+        else:
+            src, keep_sh = _sh_source(sh_raw, dev)
         gs = ShGrads()
         gs.struct_bytes = ctypes.sizeof(ShGrads)
         for name, t in zip(("scene_dc", "obj_dc", "scene_rest", "obj_rest", "scene_deform", "obj_deform"), sh_grads):
@@ -346,16 +367,21 @@ def rasterize_gaussians_backward_rawsh(background, means3D, radii, scales, rotat
             for n, g in zip(names, geo_grads):
                 setattr(gs, n, _ptr(g))
         keep = [_prep(t, dev, n) for t, n in (
-            (background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"), (scales, "scales"),
-            (rotations, "rotations"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"),
             (dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"), (dL_dout_flow, "dL_dout_flow"),
             (dL_dout_semantic, "dL_dout_semantic"), (grad_img_opacity, "grad_img_opacity"), (img_opacity, "img_opacity"))]
-        bg_, m3_, fl_, sem_, sc_, rot_, view_, proj_, cam_, gc_, gd_, gf_, gs_, go_, io_ = keep
+        gc_, gd_, gf_, gs_, go_, io_ = keep
+        if plan is not None and "ptrs" in plan:
+            p_bg, p_m3, p_fl, p_sem, p_sc, p_rot, p_view, p_proj, p_cam = plan["ptrs"]
+        else:
+            keep2 = [_prep(t, dev, n) for t, n in (
+                (background, "bg"), (means3D, "means3D"), (flow_points, "flow_points"), (semantic, "semantic"), (scales, "scales"),
+                (rotations, "rotations"), (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"))]
+            p_bg, p_m3, p_fl, p_sem, p_sc, p_rot, p_view, p_proj, p_cam = (_ptr(t) for t in keep2)
         radii_ = _prep(radii, dev, "radii", torch.int32)
         with _on(dev):
             _lib.check(lib.adgs_raster_backward_rawsh(
-                P, int(degree), M, int(R), D_S, _ptr(bg_), W, H, _ptr(m3_), ctypes.byref(src), _ptr(fl_), _ptr(sem_), _ptr(sc_),
-                float(scale_modifier), _ptr(rot_), _ptr(view_), _ptr(proj_), _ptr(cam_), float(tan_fovx), float(tan_fovy), _ptr(radii_),
+                P, int(degree), M, int(R), D_S, p_bg, W, H, p_m3, ctypes.byref(src), p_fl, p_sem, p_sc,
+                float(scale_modifier), p_rot, p_view, p_proj, p_cam, float(tan_fovx), float(tan_fovy), _ptr(radii_),
                 _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc_), _ptr(gd_), _ptr(gf_), _ptr(gs_),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                 ctypes.byref(gs), _ptr(dL_dscales), _ptr(dL_drotations), _ptr(dL_dflow_points), _ptr(dL_dsemantic), _ptr(go_), _ptr(io_),

@@ -64,9 +64,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, flow_points,
                        semantic, s.sh_degree, s.campos, s.prefiltered, s.inv_depth, s.debug)
+        plan = {}      # the validated inputs / pointers of this call, for its backward (_C.rasterize_gaussians)
         (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow,
-         img_semantic) = _call_with_dump(_C.rasterize_gaussians, native_args, s.debug, "snapshot_fw.dump", "forward")
-        ctx.raster_settings = s
+         img_semantic) = _call_with_dump(lambda *a: _C.rasterize_gaussians(*a, plan=plan), native_args, s.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings, ctx.plan = s, plan
         ctx.num_rendered = num_rendered
         ctx.set_materialize_grads(False)     # outputs the loss does not use arrive as None (NULL for the kernels), not as zero fills
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
@@ -86,7 +87,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                        binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_flow_points, grad_semantic) = _call_with_dump(
-            _C.rasterize_gaussians_backward, native_args, s.debug, "snapshot_bw.dump", "backward")
+            lambda *a: _C.rasterize_gaussians_backward(*a, plan=ctx.plan), native_args, s.debug, "snapshot_bw.dump", "backward")
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, grad_flow_points, grad_semantic, None)
 
@@ -127,10 +128,11 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
         s = raster_settings
         geo = (scene_xyz, scene_scaling, scene_rotation, scene_opacity) if scene_xyz is not None else None
         raw = (scene_dc, obj_dc, scene_rest, obj_rest, scene_deform, obj_deform, func_eval, geo, bg_image)
+        plan = {}      # the validated inputs / pointers / adgs_sh_source of this call, for its backward (_C.rasterize_gaussians_rawsh)
         (num_rendered, color, depth, img_opacity, radii, geom_buf, binning_buf, img_buf, img_flow, img_semantic) = _C.rasterize_gaussians_rawsh(
             s.bg, means3D, opacities, scales, rotations, s.scale_modifier, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height,
-            s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug)
-        ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink = s, num_rendered, func_eval, factor_sink
+            s.image_width, raw, flow_points, semantic, s.sh_degree, s.campos, s.inv_depth, s.debug, plan=plan)
+        ctx.raster_settings, ctx.num_rendered, ctx.func_eval, ctx.factor_sink, ctx.plan = s, num_rendered, func_eval, factor_sink, plan
         ctx.has_geo, ctx.grad_arena, ctx.has_bg, ctx.adam = geo is not None, grad_arena, bg_image is not None, adam
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means3D, scales, rotations, radii, geom_buf, binning_buf, img_buf, img_opacity, flow_points, semantic,
@@ -160,7 +162,7 @@ class _RasterizeGaussiansRawSH(torch.autograd.Function):
                 grad_depth, grad_img_flow, grad_img_semantic, semantic, flow_points, raw, need, s.sh_degree, s.campos,
                 geom_buf, ctx.num_rendered, binning_buf, img_buf, img_opacity, grad_img_opacity, s.inv_depth, s.debug,
                 want_rgb_factor=(ctx.factor_sink.next_target(means3D.size(0)) if hasattr(ctx.factor_sink, "next_target") else True) if factored else False,
-                geo_grad_alloc=(arena.take if arena is not None else None), adam=claim)
+                geo_grad_alloc=(arena.take if arena is not None else None), adam=claim, plan=ctx.plan, want_sem_grad=ctx.needs_input_grad[6])
         except Exception:
             if claim is not None:          # the native call validates everything before its first launch: nothing was stepped
                 claim.rollback()
