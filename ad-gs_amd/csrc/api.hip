@@ -115,7 +115,9 @@ struct GeomStateV2 {
 	uint32_t* cell_count() const { return counters; }
 	unsigned long long* bucket_fine_total() const { return reinterpret_cast<unsigned long long*>(counters + MAX_CELLS); }
 	uint32_t* d_counts() const { return counters + MAX_CELLS + 2 * SCAN_AUX_SLOTS; }
-	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes, size_t ncells = 0) {
+	// with_ddir: the frame hands d colour / d direction from its forward to its backward (raw-SH path, degree 3, a training frame) -- both
+	// sides derive the flag from the same arguments; ncells: forward only
+	static GeomStateV2 carve(char* chunk, size_t P, size_t* bytes, bool with_ddir, size_t ncells = 0) {
 		Carver c(chunk); GeomStateV2 g;
 		g.counters = c.take<uint32_t>(COUNTER_WORDS);
 		g.cell_start = c.take<uint32_t>(MAX_CELLS + 1);
@@ -130,7 +132,7 @@ struct GeomStateV2 {
 		g.sh0 = c.take<float>(P * 3);
 		g.fine_total = c.take<unsigned long long>(SCAN_AUX_SLOTS);
 		g.scan_temp = c.take<char>(scan_temp_bytes(P + 1));
-		g.ddir = c.take<float>(P * 9);
+		g.ddir = with_ddir ? c.take<float>(P * 9) : nullptr;
 		const size_t nc = std::min<size_t>(ncells, (size_t)MAX_CELLS + 1);      // last: the backward carves without them
 		g.bounds = c.take<uint32_t>(nc * SLAB_ROW);
 		g.counts = c.take<uint32_t>(((P + 255) / 256) * nc);
@@ -570,7 +572,8 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		const bool sort_fallback_fits = v2_keys_fit(gx, gy, cell_tiles);      // may this frame still fall back to the sort (chunk table full)?
 		size_t gb = 0, ib = 0;
 		const size_t count_cells = buckets ? ncells : 0;      // the counts matrix [ceil(P / 256)][ncells] and the snapshot of the slab bounds exist for bucket binning only
-		GeomStateV2::carve(nullptr, P, &gb, count_cells);
+		const bool with_ddir = training && sh_src && M == 16;
+		GeomStateV2::carve(nullptr, P, &gb, with_ddir, count_cells);
 		char* gch = geometryBuffer(geometryUser, gb);
 		const int ppl = v2_pixels_per_lane(ntiles), sub = TILE_Y / (4 * ppl);
 		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);                    // rows of wave tiles
@@ -578,7 +581,7 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		ImgStateV2::carve(nullptr, npix, wtiles, ncells, &ib);
 		char* ich = imageBuffer(imageUser, ib);
 		if (!gch || !ich) { set_error("buffer allocator returned NULL"); return -1; }
-		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, count_cells);
+		GeomStateV2 geom = GeomStateV2::carve(gch, P, nullptr, with_ddir, count_cells);
 		ImgStateV2 img = ImgStateV2::carve(ich, npix, wtiles, ncells, nullptr);
 		uint32_t frame_word = 0; bool order_tiles = false;
 		{
@@ -634,7 +637,7 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 		pa.sh0 = geom.sh0; pa.gacc = training ? geom.gacc : nullptr; pa.fine_total = geom.fine_total;      // forward-only: no accumulator lines to zero
 		pa.bucket_count = nullptr;
 		pa.cfg_word = img.header; pa.cfg_value = frame_word;
-		pa.ddir = (training && sh_src && M == 16) ? geom.ddir : nullptr;      // raw-SH path: the backward will not read the `rest` rows a second time
+		pa.ddir = geom.ddir;      // raw-SH path: the backward will not read the `rest` rows a second time
 		// bucket binning accumulates the fine-tile total and a few device words, and splits its cells by a snapshot of slab bounds (the
 		// camera's own, else the thread's latest): zeroed / copied by the sh0 kernel on the raw-SH path (no launch of its own), by bin_prepare otherwise
 		FramePrologue pro{ nullptr, 0, nullptr, nullptr, 0 };
@@ -979,7 +982,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 	if (cfg.v2) {
 		const int cell_tiles = cfg.cell_tiles;
 		const size_t ncells = (size_t)((gx + cell_tiles - 1) / cell_tiles) * ((gy + cell_tiles - 1) / cell_tiles);
-		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr);
+		GeomStateV2 geom = GeomStateV2::carve(geom_buffer, P, nullptr, sh_src && M == 16);
 		const int ppl = cfg.ppl;
 		const int wgy = (height + 4 * ppl - 1) / (4 * ppl);
 		const size_t wtiles = (size_t)gx * wgy;
@@ -1047,7 +1050,7 @@ static int raster_backward_impl(const ShSource* sh_src, const ShGradDst* sh_dst,
 		pa.out_mean2D = dL_dmean2D; pa.out_conic = dL_dconic; pa.out_opacity = dL_dopacity; pa.out_color = dL_dcolor; pa.out_depth = dL_ddepth;
 		pa.out_flow = ra.do_flow ? dL_dflow : nullptr; pa.out_sem = ra.do_sem ? dL_dsemantic : nullptr; pa.D_S = D_S;
 		pa.sh_staging = cfg.sh_staging;
-		pa.ddir = (sh_src && M == 16) ? geom.ddir : nullptr;
+		pa.ddir = geom.ddir;
 		{ StageTimer t(ST_PREPROCESS_BWD, stream); if (launch_preprocess_bwd(pa, stream) != 0) return -1; }
 		ADGS_LAUNCH_CHECK(debug, stream);
 		return 0;

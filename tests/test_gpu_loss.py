@@ -153,14 +153,15 @@ def test_flow_camera_reallocated_every_iteration_is_never_stale():
     flow = np.stack([rng.random((H, W)) * (W - 1), rng.random((H, W)) * (H - 1)]).astype(np.float32)
     vis, op = (rng.random((H, W)) * 0.5 + 0.5).astype(np.float32), rng.random((H, W)).astype(np.float32)
     d = lambda a: torch.tensor(a, device="cuda")
-    seen = set()
-    for it in range(6):
+    seen = []
+
+    def iteration(it):      # a function: every temporary is gone when it returns, only the allocator's free lists remember it
         K = np.array([[300.0 + 37 * it, 0, W / 2], [0, 310.0 - 11 * it, H / 2], [0, 0, 1]], np.float32)
         a = 0.1 * it
         R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
         T = np.array([0.2 - 0.1 * it, 0.05 * it, 0.1], np.float32)
         Kd, Rd, Td = d(K), d(R), d(T)                         # fresh allocations, freed at the end of the iteration
-        seen.add((Kd.data_ptr(), Rd.data_ptr(), Td.data_ptr()))
+        seen.append(Kd.data_ptr())
         want, g_f, g_o = lo.flow_loss(pts, flow, vis, op, K, R, T, 0.02)
         res = []
         for cam in ((Kd, Rd, Td), (torch.tensor(K), torch.tensor(R), torch.tensor(T))):
@@ -179,8 +180,16 @@ def test_flow_camera_reallocated_every_iteration_is_never_stale():
         assert torch.equal(terms[3], res[0][0])
         terms[3].backward()
         assert torch.equal(f.grad, res[0][1])
-        del Kd, Rd, Td
-    assert len({k for k, _, _ in seen}) < 6, "the allocator did not re-issue an address: the test does not exercise the stale-cache case"
+
+    # at least six cameras, and on until the allocator has re-issued an address at least twice (which address a fresh tensor gets depends on
+    # what the tests before this one left in the allocator's free lists: with six iterations flat the suite once saw six different ones)
+    it = 0
+    while it < 6 or (len(seen) - len(set(seen)) < 2 and it < 24):
+        iteration(it)
+        torch.cuda.synchronize()
+        it += 1
+    if len(set(seen)) == len(seen):
+        pytest.skip("every camera was correct, but the allocator re-issued no address in %d iterations: the stale-cache case was not exercised" % it)
     assert not hasattr(loss, "_HOST_FLOATS")
 
 
