@@ -689,13 +689,13 @@ def timed_loop(step, steps, sync, barrier=None):
 def step_stats(ms):
     """Per-step times of a secondary line.  `outlier_steps`: steps of more than three medians (a shared box now and then stalls one step
     of a run for 20 - 60 ms -- seen on three of this round's boxes, on a different line each time; `frames_per_s` of the line is the plain
-    mean and carries it, `frames_per_s_at_median_step` does not)."""
+    mean and carries it, `steps_per_s_at_median_step` does not; a step is one frame except in the C4 / C5 iteration mode)."""
     if not ms:
         return {}
     med = percentile(ms, 0.5)
     return {"median": round(med, 4), "p10": round(percentile(ms, 0.1), 4), "p90": round(percentile(ms, 0.9), 4),
             "min": round(min(ms), 4), "max": round(max(ms), 4), "outlier_steps": sum(1 for x in ms if x > 3.0 * med),
-            "frames_per_s_at_median_step": round(1e3 / med, 1) if med > 0 else None}
+            "steps_per_s_at_median_step": round(1e3 / med, 1) if med > 0 else None}
 
 
 def quick_measure(config, steps, device, use_fs, variant="default", mode=None, with_stats=False, warm=15, cameras=1, graph=False, env=None):

@@ -18,6 +18,7 @@ for r in range(rounds):
             ti.iteration(i, model, cams, env_map, off, state)
         torch.cuda.synchronize()
         clock = ti.StageClock(True)
+        ms0 = torch.cuda.memory_stats()
         t0 = time.perf_counter()
         for i in range(12, 12 + iters):
             ti.iteration(i, model, cams, env_map, clock, state)
@@ -29,6 +30,10 @@ for r in range(rounds):
             where[name] = [round((st["exp_avg"].data_ptr() - p.data_ptr()) / 2**20, 3), round((st["exp_avg_sq"].data_ptr() - p.data_ptr()) / 2**20, 3),
                            hex(p.data_ptr() & 0xfffff)]
         s = clock.summary()
-        print(json.dumps({"adam_in_backward": mode, "ms": round(ms, 4), "backward": s["backward"], "adam": s["adam_gaussians"], "p_m_v_MiB": where}), flush=True)
+        ms1 = torch.cuda.memory_stats()
+        # device allocations (hipMalloc / hipFree by the caching allocator) inside the timed loop: a loop that keeps asking the driver for memory stalls
+        alloc = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("segment.all.allocated", "segment.all.freed", "num_alloc_retries", "num_device_alloc", "num_device_free")}
+        print(json.dumps({"adam_in_backward": mode, "ms": round(ms, 4), "backward": s["backward"], "adam": s["adam_gaussians"], "host_backward": clock.host_summary().get("backward") if hasattr(clock, "host_summary") else None,
+                          "driver_allocations_in_loop": alloc, "reserved_GiB": round(torch.cuda.memory_reserved() / 2**30, 2), "p_m_v_MiB": where}), flush=True)
         del model, cams, env_map, state
         torch.cuda.empty_cache()
