@@ -31,7 +31,7 @@ struct FrameContext {
 	bool bucket_frame_pending;             // the last forward was bucket-binned: its fullest slab is (or will be) in the mailbox
 	long long reruns;                      // forwards whose capacity was too small (binning + blend enqueued twice)
 	int last_order_hint;                   // the last forward was handed a tile order an earlier forward of the same camera and stream left (OrderHints)
-	// Depth-slab bounds of the bucket binning (binning.hip): [MAX_CELLS][SLAB_ROW] device words, the 32-quantiles of every cell's depth keys
+	// Depth-slab bounds of the bucket binning (binning.hip): [MAX_CELLS][SLAB_ROW] device words, the 128-quantiles of every cell's depth keys
 	// as the most recent bucket-binned frame of this thread left them.  Every frame takes its own snapshot in its first kernel and bins
 	// by that; the sort kernels of the frame rewrite the table for the next one.  ANY contents are valid bounds (a torn snapshot beside
 	// another stream's writes, another camera's or another image shape's quantiles: the slab function stays monotone in the depth) --
@@ -776,7 +776,7 @@ static int raster_forward_impl(const ShSource* sh_src, bool training,
 			ADGS_LAUNCH_CHECK(debug, stream);
 			{ StageTimer t(ST_RANGES, stream);
 			  if (launch_tile_ranges((int)cells, d_count, bin.keys, img.cell_ranges, bit >= 32 ? 0xffffffffu : ((1u << bit) - 1u), stream) != 0) return -1;
-			  // a sorted frame teaches the bucket path its depth-slab bounds too (the cells' 32-quantiles, read off the sorted keys)
+			  // a sorted frame teaches the bucket path its depth-slab bounds too (the cells' 128-quantiles, read off the sorted keys)
 			  if (fc->slab_bounds && ncells <= (size_t)MAX_CELLS &&
 			      launch_bounds_from_sorted(bin.keys, img.cell_ranges, (int)ncells, d_count, (uint32_t)std::min<size_t>(cells, 0xffffffffu), fc->slab_bounds, stream) != 0) return -1; }
 			ADGS_LAUNCH_CHECK(debug, stream);

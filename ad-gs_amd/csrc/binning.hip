@@ -1,4 +1,4 @@
-// Bucket binning of the v2 pipeline for gfx950: depth-sorted per-cell Gaussian lists in four short launches, no device-wide sort, no merge.
+// Bucket binning of the v2 pipeline for gfx950: depth-sorted per-cell Gaussian lists in five short launches, no device-wide sort, no merge.
 //
 // What it replaces (RAST/cuda_rasterizer/rasterizer_impl.cu:284-324 in the reference: InclusiveSum, duplicateWithKeys, a device-wide
 // cub radix sort over 64-bit keys, identifyTileRanges; in this library's first v2 pipeline: a 2-launch scan, duplicate_cells, a
@@ -14,13 +14,13 @@
 //                    array, (Gaussian id, rectangle mask) into another -- any order inside a cell;
 //   slab_sort        a cell's list is only ever read front to back, so it is built as the concatenation of 2^lg independently sorted
 //                    DEPTH SLABS: workgroup (cell, slab) streams the cell's depth keys (4 bytes per entry, L2-resident), keeps the
-//                    entries of its slab -- the slab of a depth is a two-step search over the cell's row of 31 bounds; ANY row
+//                    entries of its slab -- the slab of a depth is a search over the cell's row of 127 bounds; ANY row
 //                    contents give a monotone function of the depth, so correctness never depends on the bounds, only the balance
 //                    does --, counts the entries of the slabs below it (= where its output starts: no scan over slabs, no second
 //                    scatter), sorts its <= 4096 entries on (32 depth bits, Gaussian index) inside the CU (a histogram-equalised
 //                    bucket sort; long runs of equal depths: an LSD radix sort) -- exactly the order the reference's stable sort of keys
-//                    emitted in index order produces -- and writes them to their final positions.  The bounds are the 32-quantiles of the
-//                    cell's depth keys in the PREVIOUS frame this thread rendered, read off the sorted output for free.  A slab that holds more
+//                    emitted in index order produces -- and writes them to their final positions.  The bounds are the 128-quantiles of the
+//                    cell's depth keys in the SAME CAMERA's previous render (else: sampled by cell_sample), read off the sorted output.  A slab of more
 //                    than 4096 entries (a thread's first frame, a camera the bounds do not fit at all) is bisected at the median of a
 //                    sample and re-streamed: slower, never wrong.
 //

@@ -146,7 +146,7 @@ struct SlabSortArgs {
 	uint2* ent_f;                       // final (id, mask) entries
 	uint32_t cap;                       // records the binning buffer holds
 	const uint32_t* bounds;             // this frame's snapshot of the slab bounds [ncells][SLAB_ROW]
-	uint32_t* bounds_out;               // the thread's table [MAX_CELLS][SLAB_ROW]: this frame's 32-quantiles per cell, for the next frame (nullptr: none)
+	uint32_t* bounds_out;               // the thread's table [MAX_CELLS][SLAB_ROW]: this frame's 128-quantiles per cell, for the next frame (nullptr: none)
 	uint32_t* bounds_out2;              // ... and the camera's own table (api.hip: OrderHints), for its next render (nullptr: none)
 	uint32_t* slow_list;                // [1 + grid] slabs slab_sort hands to slab_sort_slow, (cell << 8) | slab: [0] = count (zeroed by cell_scatter)
 	uint32_t* d_counts;
@@ -155,7 +155,7 @@ struct SlabSortArgs {
 int launch_slab_sort(const SlabSortArgs& a, hipStream_t stream);
 // this frame's bounds [ncells][SLAB_ROW] from a sample of every cell's keys (frames without bounds of their camera's previous render)
 int launch_cell_sample(const SlabSortArgs& a, uint32_t* bounds, hipStream_t stream);
-// sorted frames (device-wide radix sort): the 32-quantiles of every cell from the sorted (cell | depth) keys
+// sorted frames (device-wide radix sort): the 128-quantiles of every cell from the sorted (cell | depth) keys
 int launch_bounds_from_sorted(const uint64_t* keys, const uint2* cell_ranges, int ncells, const uint32_t* d_total, uint32_t cap, uint32_t* bounds_out, hipStream_t stream);
 
 int launch_duplicate_cells(int P, const uint4* dupinfo, const uint32_t* offsets, uint64_t* keys, uint32_t* vals,
